@@ -1,0 +1,89 @@
+"""Builds the native libraries in-tree.
+
+  liblfdm_hip.so  - the product: hipcc --offload-arch=gfx950 over csrc/*.hip (C ABI in
+                    include/lfdm_hip.h).  Cross-compiles without a GPU.
+  liblfdm_emu.so  - TEST INFRASTRUCTURE: the same kernel sources compiled for x86 against the
+                    fiber emulator in tests/emu/ (index-logic checks on a GPU-less box).
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+HIP_LIB = os.path.join(PKG_DIR, "liblfdm_hip.so")
+EMU_LIB = os.path.join(REPO_ROOT, "tests", "emu", "liblfdm_emu.so")
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps():
+    return _sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(REPO_ROOT, "include", "lfdm_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc -> liblfdm_hip.so (gfx950). One object per source so rebuilds are incremental."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [d for d in _deps() if d.endswith(".h")]
+    objs = []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            out = _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src,
+                        "-o", obj, "-Wno-unused-result"])
+            if verbose and out.strip():
+                print(out)
+    if force or _stale(HIP_LIB, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    return HIP_LIB
+
+
+def build_emu(force=False):
+    """host clang++ -> tests/emu/liblfdm_emu.so (x86, fiber emulator)."""
+    cxx = os.environ.get("LFDM_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    emu_dir = os.path.join(REPO_ROOT, "tests", "emu")
+    deps = _deps() + glob.glob(os.path.join(emu_dir, "hip_emu.*"))
+    if not (force or _stale(EMU_LIB, deps)):
+        return EMU_LIB
+    objdir = os.path.join(emu_dir, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DLFDM_EMU_BUILD", "-I", emu_dir, "-Wno-unused-value",
+             "-Wno-unknown-pragmas", "-Wno-pass-failed"]
+    headers = [d for d in deps if not d.endswith(".hip") and not d.endswith(".cpp")]
+    for src in _sources() + [os.path.join(emu_dir, "hip_emu.cpp")]:
+        obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            _run([cxx] + flags + ["-x", "c++", "-c", src, "-o", obj])
+    _run([cxx, "-shared", "-fPIC", "-o", EMU_LIB] + objs)
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["hip"]
+    if "hip" in which:
+        print(build_hip(force="--force" in which, verbose=True))
+    if "emu" in which:
+        print(build_emu(force="--force" in which))

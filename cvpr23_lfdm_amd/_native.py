@@ -1,0 +1,124 @@
+"""ctypes binding of liblfdm_hip.so (C ABI: include/lfdm_hip.h).
+
+The product path has no fallback: if the library is missing or a tensor is not on the GPU the
+call raises.  (tests/emu/ can inject an x86 emulation build of the same kernels for logic checks
+on a GPU-less box through `_set_library_for_tests`; that library never ships.)
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG_DIR, "liblfdm_hip.so")
+
+f32p = C.c_void_p
+i32 = C.c_int
+i64 = C.c_int64
+f32 = C.c_float
+sz = C.c_size_t
+stream_t = C.c_void_p
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("src0", f32p), ("src1", f32p),
+        ("c0", i32), ("c1", i32), ("ld0", i32), ("ld1", i32),
+        ("n_img", i32), ("hi", i32), ("wi", i32),
+        ("hq", i32), ("wq", i32),
+        ("stride", i32), ("upsample", i32), ("pad_mode", i32),
+        ("kh", i32), ("kw", i32), ("pad_y", i32), ("pad_x", i32),
+        ("weight", f32p),
+        ("cout", i32), ("coutp", i32),
+        ("bias", f32p),
+        ("out", f32p),
+        ("ldo", i32), ("ho", i32), ("wo", i32),
+        ("out_scale", i32), ("out_off_y", i32), ("out_off_x", i32),
+        ("residual", f32p),
+        ("ldr", i32),
+        ("act", i32),
+        ("ksplit", i32),
+        ("partial", f32p),
+    ]
+
+
+class WarpParams(C.Structure):
+    _fields_ = [
+        ("src", f32p), ("prev", f32p), ("out", f32p),
+        ("batch", i32), ("frames", i32), ("h", i32), ("w", i32), ("c", i32),
+        ("ld_src", i32), ("ld_prev", i32), ("ld_out", i32),
+        ("flow_x", f32p), ("flow_y", f32p), ("occ", f32p),
+        ("fh", i32), ("fw", i32),
+        ("fsb", i64), ("fst", i64),
+        ("occ_scale", f32), ("occ_bias", f32),
+        ("prev_is_cl", i32),
+    ]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "lfdm_last_error": (C.c_char_p, []),
+    "lfdm_abi_version": (i32, []),
+    "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
+    "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
+    "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
+    "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32, i32,
+                                        C.c_void_p, sz, stream_t]),
+    "lfdm_layernorm_cl_f32": (i32, [f32p, f32p, i64, i32, f32p, f32, stream_t]),
+    "lfdm_attention_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, stream_t]),
+    "lfdm_linear_attention_ws_bytes": (sz, [i32]),
+    "lfdm_linear_attention_cl_f32": (i32, [f32p, f32p, i32, i32, C.c_void_p, sz, stream_t]),
+    "lfdm_linear_small_f32": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    "lfdm_sinusoidal_f32": (i32, [C.c_void_p, i32, f32p, i32, i32, i32, stream_t]),
+    "lfdm_conv_planar_in_cl_f32": (i32, [f32p, i32, i32, i32, i32, i32, i32, f32p, i32, i32, i32,
+                                        f32p, f32p, f32p, i32, i32, stream_t]),
+    "lfdm_heads_cl_to_planar_f32": (i32, [f32p, f32p, i32, f32p, f32p, f32p, f32p, f32p, i32, i32,
+                                         i32, stream_t]),
+    "lfdm_sampler_ws_bytes": (sz, [i32, i64]),
+    "lfdm_sampler_step_f32": (i32, [f32p, f32p, f32p, f32p, i32, i64, f32p, C.c_void_p, f32, i32,
+                                   C.c_void_p, sz, stream_t]),
+    "lfdm_abs_quantile_f32": (i32, [f32p, i32, i64, f32, f32p, C.c_void_p, sz, stream_t]),
+    "lfdm_warp_cl_f32": (i32, [C.POINTER(WarpParams), stream_t]),
+    "lfdm_warp_planar_f32": (i32, [C.POINTER(WarpParams), stream_t]),
+    "lfdm_affine_act_cl_f32": (i32, [f32p, f32p, i64, i32, i32, i32, f32p, f32p, i32, stream_t]),
+    "lfdm_avgpool2_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
+    "lfdm_planar_to_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
+    "lfdm_cl_to_planar_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class NativeLibrary:
+    def __init__(self, path, kind):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "native library %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'`"
+                " (hipcc --offload-arch=gfx950); there is no fallback path" % path)
+        self.path = path
+        self.kind = kind  # "hip" (product) or "emu" (tests only)
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lfdm_last_error()
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+_active = None
+
+
+def library():
+    """The active native library; loads liblfdm_hip.so on first use, raises if it is absent."""
+    global _active
+    if _active is None:
+        _active = NativeLibrary(HIP_LIB_PATH, "hip")
+    return _active
+
+
+def _set_library_for_tests(lib):
+    global _active
+    _active = lib

@@ -1,0 +1,330 @@
+// Attention kernels of the 3D UNet on channels-last rows (include/lfdm_hip.h).
+//
+// 1. lfdm_attention_cl_f32 - softmax attention over short sequences (temporal: L = T frames per
+//    pixel, with rotary + T5 relative-position bias; mid spatial: L = H*W tokens per frame).
+//    One wavefront owns one (sequence, head): Q/K/V (L x 32 each) are staged in LDS with
+//    coalesced 128-byte row reads (scale and rotary applied on the way in), S = QK^T and O = PV
+//    run on v_mfma_f32_16x16x4_f32, the L x L scores never leave registers/LDS
+//    (the reference materialises a 126 MB qkv re-layout and a 52 MB score tensor per call,
+//    DM/modules/video_flow_diffusion.py:311-361).
+// 2. lfdm_linear_attention_cl_f32 - SpatialLinearAttention core (:256-263): k-softmax over
+//    tokens + context = k v^T (two-pass column reduction), then q-softmax over the 32-dim axis
+//    and out = context^T q.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int QKV_LD = 3 * HEADS * DH;  // 768
+constexpr int OUT_LD = HEADS * DH;      // 256
+
+constexpr int SQ = 34;  // LDS row stride of Q and K
+constexpr int SV = 36;  // LDS row stride of V
+
+template <int LP>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+                                                        float* __restrict__ out, int batch,
+                                                        int frames, int hw, int mode,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ rot_cos,
+                                                        const float* __restrict__ rot_sin) {
+  constexpr int NT = LP / 16;
+  constexpr int SP = LP + 2;                       // LDS row stride of P (aliases Q|K)
+  constexpr int PER_WAVE = LP * (SQ + SQ + SV);
+  __shared__ __attribute__((aligned(16))) float smem[4 * PER_WAVE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Qs = smem + wave * PER_WAVE;
+  float* Ks = Qs + LP * SQ;
+  float* Vs = Ks + LP * SQ;
+  float* Ps = Qs;
+
+  const int L = mode == 0 ? frames : hw;
+  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const bool valid = unit < nseq * HEADS;
+  const int64_t seq = valid ? unit / HEADS : 0;
+  const int head = valid ? (int)(unit - seq * HEADS) : 0;
+  int64_t row0, tstride;
+  if (mode == 0) {
+    const int64_t b = seq / hw, pix = seq - b * hw;
+    row0 = b * frames * hw + pix;
+    tstride = hw;
+  } else {
+    row0 = seq * hw;
+    tstride = 1;
+  }
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+
+  // ---- stage Q, K, V (8 lanes x float4 per 32-float row) ----
+  {
+    const int rr = lane >> 3, c4 = lane & 7;
+    for (int t = rr; t < LP; t += 8) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+      if (valid && t < L) {
+        const float* base = qkv + (row0 + (int64_t)t * tstride) * QKV_LD + head * DH + 4 * c4;
+        q = *reinterpret_cast<const float4*>(base);
+        k = *reinterpret_cast<const float4*>(base + OUT_LD);
+        v = *reinterpret_cast<const float4*>(base + 2 * OUT_LD);
+        q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+        if (rot_cos) {
+          const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
+          const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
+          float4 qr, kr;
+          qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
+          qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
+          kr.x = k.x * c0 - k.y * s0; kr.y = k.y * c0 + k.x * s0;
+          kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
+          q = qr; k = kr;
+        }
+      }
+      float* dq = Qs + t * SQ + 4 * c4;
+      dq[0] = q.x; dq[1] = q.y; dq[2] = q.z; dq[3] = q.w;
+      float* dk = Ks + t * SQ + 4 * c4;
+      dk[0] = k.x; dk[1] = k.y; dk[2] = k.z; dk[3] = k.w;
+      *reinterpret_cast<float4*>(Vs + t * SV + 4 * c4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- S = Q K^T (16x16 tiles, K = 32 in 8 steps of 4) ----
+  const int l15 = lane & 15, lq = lane >> 4;
+  f32x4 s_acc[NT][NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < DH / 4; ++s) {
+        const float a = Qs[(ti * 16 + l15) * SQ + 4 * s + lq];
+        const float b = Ks[(tj * 16 + l15) * SQ + 4 * s + lq];
+        acc = mfma_16x16x4(a, b, acc);
+      }
+      s_acc[ti][tj] = acc;
+    }
+  __syncthreads();  // all lanes done reading Q/K before P overwrites them
+
+  // ---- bias, mask, softmax over columns; write P to LDS ----
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + lq * 4 + r;
+      float m = -3.0e38f;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const int col = tj * 16 + l15;
+        float v = s_acc[ti][tj][r];
+        if (col >= L) v = -3.0e38f;
+        else if (bias && row < L) v += bias[((int64_t)head * L + row) * L + col];
+        s_acc[ti][tj][r] = v;
+        m = fmaxf(m, v);
+      }
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
+      float sum = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const int col = tj * 16 + l15;
+        const float e = col < L ? expf(s_acc[ti][tj][r] - m) : 0.f;
+        s_acc[ti][tj][r] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) sum += __shfl_xor(sum, x);
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) Ps[row * SP + tj * 16 + l15] = s_acc[ti][tj][r] / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- O = P V ----
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    f32x4 o[2];
+    o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o[1] = o[0];
+#pragma unroll
+    for (int s = 0; s < LP / 4; ++s) {
+      const float a = Ps[(ti * 16 + l15) * SP + 4 * s + lq];
+      const float b0 = Vs[(4 * s + lq) * SV + l15];
+      const float b1 = Vs[(4 * s + lq) * SV + 16 + l15];
+      o[0] = mfma_16x16x4(a, b0, o[0]);
+      o[1] = mfma_16x16x4(a, b1, o[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = ti * 16 + lq * 4 + r;
+      if (valid && t < L) {
+        float* dst = out + (row0 + (int64_t)t * tstride) * OUT_LD + head * DH;
+        dst[l15] = o[0][r];
+        dst[16 + l15] = o[1][r];
+      }
+    }
+  }
+}
+
+// ---------------- linear attention ----------------
+// grid (n_frames*8); ctx_out[(f*8+h)][d][e] = sum_n softmax_n(k)[n][d] * v[n][e]
+__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, int hw,
+                                                              float* __restrict__ ctx_out) {
+  __shared__ float red[8][32];
+  __shared__ float kmax[32];
+  __shared__ float ek[64][33];
+  __shared__ __attribute__((aligned(16))) float vv[64][36];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x >> 3, h = blockIdx.x & 7;
+  const float* kbase = qkv + (int64_t)f * hw * QKV_LD + OUT_LD + h * DH;
+  const float* vbase = kbase + OUT_LD;
+
+  {  // pass 1: per-feature max over tokens
+    const int d = tid & 31, part = tid >> 5;
+    float m = -3.0e38f;
+    for (int n = part; n < hw; n += 8) m = fmaxf(m, kbase[(int64_t)n * QKV_LD + d]);
+    red[part][d] = m;
+    __syncthreads();
+    if (tid < 32) {
+      float mm = red[0][tid];
+      for (int p = 1; p < 8; ++p) mm = fmaxf(mm, red[p][tid]);
+      kmax[tid] = mm;
+    }
+    __syncthreads();
+  }
+
+  const int d = tid >> 3, e0 = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;
+  for (int n0 = 0; n0 < hw; n0 += 64) {
+    // stage 64 tokens: exp(k - max) and v
+    for (int i = tid; i < 64 * 8; i += 256) {
+      const int n = i >> 3, c4 = i & 7;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kv;
+      const bool ok = n0 + n < hw;
+      if (ok) {
+        kv = *reinterpret_cast<const float4*>(kbase + (int64_t)(n0 + n) * QKV_LD + 4 * c4);
+        v4 = *reinterpret_cast<const float4*>(vbase + (int64_t)(n0 + n) * QKV_LD + 4 * c4);
+      }
+      ek[n][4 * c4 + 0] = ok ? expf(kv.x - kmax[4 * c4 + 0]) : 0.f;
+      ek[n][4 * c4 + 1] = ok ? expf(kv.y - kmax[4 * c4 + 1]) : 0.f;
+      ek[n][4 * c4 + 2] = ok ? expf(kv.z - kmax[4 * c4 + 2]) : 0.f;
+      ek[n][4 * c4 + 3] = ok ? expf(kv.w - kmax[4 * c4 + 3]) : 0.f;
+      *reinterpret_cast<float4*>(&vv[n][4 * c4]) = v4;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < 64; ++n) {
+      const float e = ek[n][d];
+      const float4 v4 = *reinterpret_cast<const float4*>(&vv[n][e0]);
+      acc[0] = fmaf(e, v4.x, acc[0]);
+      acc[1] = fmaf(e, v4.y, acc[1]);
+      acc[2] = fmaf(e, v4.z, acc[2]);
+      acc[3] = fmaf(e, v4.w, acc[3]);
+      ssum += e;
+    }
+    __syncthreads();
+  }
+  float* dst = ctx_out + ((int64_t)blockIdx.x * DH + d) * DH + e0;
+  dst[0] = acc[0] / ssum;
+  dst[1] = acc[1] / ssum;
+  dst[2] = acc[2] / ssum;
+  dst[3] = acc[3] / ssum;
+}
+
+// grid (ceil(hw/32), n_frames); thread = (token, head)
+__global__ __launch_bounds__(256) void linattn_output_kernel(const float* __restrict__ qkv,
+                                                             const float* __restrict__ ctx, int hw,
+                                                             float* __restrict__ out) {
+  constexpr int CS = DH * DH + 4;  // padded per-head stride
+  __shared__ __attribute__((aligned(16))) float cs[HEADS * CS];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.y;
+  for (int i = tid; i < HEADS * DH * DH; i += 256) {
+    const int h = i / (DH * DH), r = i - h * DH * DH;
+    cs[h * CS + r] = ctx[(int64_t)f * HEADS * DH * DH + i];
+  }
+  __syncthreads();
+  const int tok = blockIdx.x * 32 + (tid >> 3), h = tid & 7;
+  if (tok >= hw) return;
+  const int64_t row = (int64_t)f * hw + tok;
+  const float* qp = qkv + row * QKV_LD + h * DH;
+  float q[DH];
+#pragma unroll
+  for (int i = 0; i < DH / 4; ++i) {
+    const float4 v = reinterpret_cast<const float4*>(qp)[i];
+    q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w;
+  }
+  float m = q[0];
+#pragma unroll
+  for (int i = 1; i < DH; ++i) m = fmaxf(m, q[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < DH; ++i) {
+    q[i] = expf(q[i] - m);
+    sum += q[i];
+  }
+  const float scale = 0.17677669529663687f;
+#pragma unroll
+  for (int i = 0; i < DH; ++i) q[i] = q[i] / sum * scale;
+  float* op = out + row * OUT_LD + h * DH;
+  const float* ch = cs + h * CS;
+#pragma unroll
+  for (int e4 = 0; e4 < DH / 4; ++e4) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) {
+      const float4 c = *reinterpret_cast<const float4*>(ch + dd * DH + 4 * e4);
+      o.x = fmaf(c.x, q[dd], o.x);
+      o.y = fmaf(c.y, q[dd], o.y);
+      o.z = fmaf(c.z, q[dd], o.z);
+      o.w = fmaf(c.w, q[dd], o.w);
+    }
+    reinterpret_cast<float4*>(op)[e4] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int lfdm_attention_cl_f32(const float* qkv, float* out, int batch, int frames, int hw,
+                                     int mode, const float* bias, const float* rot_cos,
+                                     const float* rot_sin, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int L = mode == 0 ? frames : hw;
+  if (!qkv || !out || batch <= 0 || frames <= 0 || hw <= 0 || (mode != 0 && mode != 1) ||
+      L > 64 || ((rot_cos == nullptr) != (rot_sin == nullptr))) {
+    lfdm_set_error("attention: unsupported shape (sequence length must be <= 64)");
+    return LFDM_EINVAL;
+  }
+  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
+  const int64_t units = nseq * HEADS;
+  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+  if (L <= 16) LFDM_LAUNCH((attention_kernel<16>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
+  else if (L <= 32) LFDM_LAUNCH((attention_kernel<32>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
+  else if (L <= 48) LFDM_LAUNCH((attention_kernel<48>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
+  else LFDM_LAUNCH((attention_kernel<64>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
+  return lfdm_check_launch("attention");
+}
+
+extern "C" size_t lfdm_linear_attention_ws_bytes(int n_frames) {
+  return (size_t)n_frames * HEADS * DH * DH * sizeof(float);
+}
+
+extern "C" int lfdm_linear_attention_cl_f32(const float* qkv, float* out, int n_frames, int hw,
+                                            void* ws, size_t ws_bytes, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !out || n_frames <= 0 || hw <= 0) {
+    lfdm_set_error("linear_attention: bad arguments");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_linear_attention_ws_bytes(n_frames)) {
+    lfdm_set_error("linear_attention: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  float* ctx = reinterpret_cast<float*>(ws);
+  LFDM_LAUNCH(linattn_context_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, qkv, hw, ctx);
+  LFDM_LAUNCH(linattn_output_kernel, dim3((hw + 31) / 32, n_frames), dim3(256), 0, stream, qkv,
+              (const float*)ctx, hw, out);
+  return lfdm_check_launch("linear_attention");
+}

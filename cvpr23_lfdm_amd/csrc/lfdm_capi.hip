@@ -1,0 +1,27 @@
+// Error plumbing and ABI version of liblfdm_hip.so (include/lfdm_hip.h).
+#include <string.h>
+
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void lfdm_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+extern "C" const char* lfdm_last_error(void) { return g_err; }
+
+extern "C" int lfdm_abi_version(void) { return 1; }
+
+int lfdm_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[400];
+    snprintf(buf, sizeof(buf), "%s: launch failed: %s", what, hipGetErrorString(e));
+    lfdm_set_error(buf);
+    return LFDM_ELAUNCH;
+  }
+  return LFDM_OK;
+}

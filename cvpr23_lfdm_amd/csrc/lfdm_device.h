@@ -1,0 +1,61 @@
+// Device-side helpers shared by every kernel file: wavefront-64 shuffles, the two fp32 MFMA
+// shapes of gfx950 (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, exact f32 = fmaf chain,
+// cdna_hip_programming.md section 3) and the launch macro.
+//
+// LFDM_EMU_BUILD is a TEST-ONLY switch: tests/emu/ compiles these same kernel sources for x86
+// against a fiber emulator so that index arithmetic can be checked against the CPU oracle in a
+// container without a GPU.  The product library is built by hipcc for gfx950 only.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(LFDM_EMU_BUILD)
+#include "hip_emu.h"
+typedef emu_f32x16 f32x16;
+typedef emu_f32x4 f32x4;
+#define LFDM_LAUNCH(kern, grid, block, smem, stream, ...) \
+  emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
+static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return emu_mfma_32x32x2(a, b, c); }
+static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return emu_mfma_16x16x4(a, b, c); }
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LFDM_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+// lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; D col = l&31, row = (r&3)+8*(r>>2)+4*(l>>5)
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D col = l&15, row = (l>>4)*4 + r
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+#define LFDM_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
+
+// activation codes shared by the C ABI (include/lfdm_hip.h)
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return sigmoidf_(v);
+  if (act == 3) return siluf_(v);
+  return v;
+}
+
+// host-side error plumbing (lfdm_capi.cpp)
+extern "C" void lfdm_set_error(const char* msg);
+int lfdm_check_launch(const char* what);

@@ -1,0 +1,371 @@
+// Normalisation / element-wise kernels on channels-last rows (HBM-bound):
+//   GroupNorm(8) over (C/8, T, H, W) + scale/shift + SiLU   (reference Block.forward :200-211)
+//   channel LayerNorm (gamma only)                          (reference LayerNorm :170-179)
+//   per-channel affine + activation, 2x2 average pool, planar<->channels-last transposes (LFAE).
+// GroupNorm statistics span all frames of a sample, so they are a two-stage reduction:
+// per-workgroup partial (sum, sumsq) via wave shuffles -> a tiny finalize kernel that merges the
+// partials in double and folds mean/rstd/gamma/beta/scale/shift into one per-(b,c) FMA ->
+// a streaming apply pass.  Reduction order is fixed (no float atomics): bit-reproducible.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 256;
+
+__host__ __device__ inline int gn_num_chunks(int pixels) {
+  int n = (pixels + 127) / 128;
+  if (n < 1) n = 1;
+  if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+  return n;
+}
+
+// grid (nchunk, B), 256 threads.  partial[b][chunk][g] = (sum, sumsq)
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int pixels,
+                                                         int channels, int groups,
+                                                         float* __restrict__ partial) {
+  __shared__ float red_s[256], red_q[256];
+  const int tid = threadIdx.x;
+  const int c4n = channels >> 2;
+  const int rows_per_iter = 256 / c4n;
+  const int c4 = tid % c4n, prow = tid / c4n;
+  const int nchunk = gridDim.x, chunk = blockIdx.x, b = blockIdx.y;
+  const int per = (pixels + nchunk - 1) / nchunk;
+  const int p0 = chunk * per;
+  const int p1 = (p0 + per < pixels) ? p0 + per : pixels;
+  const float* xb = x + (int64_t)b * pixels * channels;
+  float s = 0.f, q = 0.f;
+  if (prow < rows_per_iter) {
+    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * channels + 4 * c4);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+  red_s[tid] = s;
+  red_q[tid] = q;
+  __syncthreads();
+  if (tid < groups) {
+    const int cg4 = c4n / groups;  // float4 per group per pixel
+    float ts = 0.f, tq = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r)
+      for (int k = 0; k < cg4; ++k) {
+        const int t = r * c4n + tid * cg4 + k;
+        ts += red_s[t];
+        tq += red_q[t];
+      }
+    float* dst = partial + (((int64_t)b * nchunk + chunk) * groups + tid) * 2;
+    dst[0] = ts;
+    dst[1] = tq;
+  }
+}
+
+// grid (B), 256 threads. ab[b][0][c] = A, ab[b][1][c] = Bc  with  y = x*A + Bc
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                          int nchunk, int pixels, int channels,
+                                                          int groups, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ scale_shift,
+                                                          float eps, float* __restrict__ ab) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < groups) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* src = partial + (((int64_t)b * nchunk + k) * groups + tid) * 2;
+      s += (double)src[0];
+      q += (double)src[1];
+    }
+    const double n = (double)pixels * (double)(channels / groups);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cg = channels / groups;
+  for (int c = tid; c < channels; c += 256) {
+    const int g = c / cg;
+    const float a = s_rstd[g] * gamma[c];
+    float bb = beta[c] - s_mean[g] * a;
+    float aa = a;
+    if (scale_shift) {
+      const float sc = scale_shift[(int64_t)b * 2 * channels + c] + 1.0f;
+      const float sh = scale_shift[(int64_t)b * 2 * channels + channels + c];
+      aa = a * sc;
+      bb = bb * sc + sh;
+    }
+    ab[((int64_t)b * 2 + 0) * channels + c] = aa;
+    ab[((int64_t)b * 2 + 1) * channels + c] = bb;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, int batch,
+                                                       int pixels, int channels,
+                                                       const float* __restrict__ ab, int silu) {
+  const int c4n = channels >> 2;
+  const int64_t per_b = (int64_t)pixels * c4n;
+  const int64_t total = per_b * batch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / per_b);
+    const int c4 = (int)(i % c4n);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(ab + ((int64_t)b * 2 + 0) * channels + 4 * c4);
+    const float4 d = *reinterpret_cast<const float4*>(ab + ((int64_t)b * 2 + 1) * channels + 4 * c4);
+    float4 y;
+    y.x = fmaf(v.x, a.x, d.x);
+    y.y = fmaf(v.y, a.y, d.y);
+    y.z = fmaf(v.z, a.z, d.z);
+    y.w = fmaf(v.w, a.w, d.w);
+    if (silu) {
+      y.x = siluf_(y.x);
+      y.y = siluf_(y.y);
+      y.z = siluf_(y.z);
+      y.w = siluf_(y.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = y;
+  }
+}
+
+// one wavefront per row, 4 rows per workgroup; C % 4 == 0, C <= 1024
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ out, int64_t rows,
+                                                        int channels, const float* __restrict__ gamma,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4n = channels >> 2;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * channels);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = lane + 64 * i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < c4n) {
+        v[i] = xr[f];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) / (float)channels;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = lane + 64 * i;
+      if (f < c4n) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+    const float var = wave_sum(q) / (float)channels;
+    const float denom = sqrtf(var + eps);
+    float4* orow = reinterpret_cast<float4*>(out + row * channels);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = lane + 64 * i;
+      if (f < c4n) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[f];
+        float4 y;
+        y.x = (v[i].x - mean) / denom * g.x;
+        y.y = (v[i].y - mean) / denom * g.y;
+        y.z = (v[i].z - mean) / denom * g.z;
+        y.w = (v[i].w - mean) / denom * g.w;
+        orow[f] = y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, int64_t rows,
+                                                         int channels, int ldx, int ldo,
+                                                         const float* __restrict__ a,
+                                                         const float* __restrict__ b, int act) {
+  const int c4n = channels >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float4 aa = *reinterpret_cast<const float4*>(a + c);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    float4 y;
+    y.x = apply_act(fmaf(v.x, aa.x, bb.x), act);
+    y.y = apply_act(fmaf(v.y, aa.y, bb.y), act);
+    y.z = apply_act(fmaf(v.z, aa.z, bb.z), act);
+    y.w = apply_act(fmaf(v.w, aa.w, bb.w), act);
+    *reinterpret_cast<float4*>(out + r * ldo + c) = y;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, int n_img, int h,
+                                                       int w, int channels) {
+  const int c4n = channels >> 2;
+  const int ho = h >> 1, wo = w >> 1;
+  const int64_t total = (int64_t)n_img * ho * wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t pix = i / c4n;
+    const int ox = (int)(pix % wo);
+    pix /= wo;
+    const int oy = (int)(pix % ho);
+    const int n = (int)(pix / ho);
+    const float* base = x + (((int64_t)n * h + 2 * oy) * w + 2 * ox) * channels + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(base);
+    const float4 v01 = *reinterpret_cast<const float4*>(base + channels);
+    const float4 v10 = *reinterpret_cast<const float4*>(base + (int64_t)w * channels);
+    const float4 v11 = *reinterpret_cast<const float4*>(base + (int64_t)w * channels + channels);
+    float4 y;
+    y.x = ((v00.x + v01.x) + (v10.x + v11.x)) * 0.25f;
+    y.y = ((v00.y + v01.y) + (v10.y + v11.y)) * 0.25f;
+    y.z = ((v00.z + v01.z) + (v10.z + v11.z)) * 0.25f;
+    y.w = ((v00.w + v01.w) + (v10.w + v11.w)) * 0.25f;
+    *reinterpret_cast<float4*>(out + (((int64_t)n * ho + oy) * wo + ox) * channels + c) = y;
+  }
+}
+
+// (n_img, C, hw) planar -> rows (n_img*hw, ldo).  32x32 LDS tile transpose; grid (hw/32, C/32, n)
+__global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ out, int channels,
+                                                           int hw, int ldo) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    tile[i][tx] = (c < channels && p < hw) ? x[((int64_t)n * channels + c) * hw + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    if (p < hw && c < channels) out[((int64_t)n * hw + p) * ldo + c] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void cl_to_planar_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ out, int channels,
+                                                           int hw, int ldx) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    tile[i][tx] = (p < hw && c < channels) ? x[((int64_t)n * hw + p) * ldx + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    if (c < channels && p < hw) out[((int64_t)n * channels + c) * hw + p] = tile[tx][i];
+  }
+}
+
+inline unsigned grid_for(int64_t work_items, unsigned cap = 8192) {
+  int64_t nb = (work_items + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > cap) nb = cap;
+  return (unsigned)nb;
+}
+
+}  // namespace
+
+extern "C" size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels) {
+  const size_t partial = (size_t)batch * gn_num_chunks(pixels) * 64 * 2;
+  const size_t ab = (size_t)batch * 2 * channels;
+  return (partial + ab) * sizeof(float);
+}
+
+extern "C" int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels,
+                                          int channels, int groups, const float* gamma,
+                                          const float* beta, const float* scale_shift, float eps,
+                                          int apply_silu, void* ws, size_t ws_bytes,
+                                          lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || !gamma || !beta || batch <= 0 || pixels <= 0 || channels <= 0 || groups <= 0 ||
+      groups > 64 || channels % groups != 0 || (channels / groups) % 4 != 0 ||
+      256 % (channels / 4) != 0) {
+    lfdm_set_error("groupnorm: unsupported shape (need C%G==0, (C/G)%4==0, 256%(C/4)==0)");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_groupnorm_ws_bytes(batch, pixels, channels)) {
+    lfdm_set_error("groupnorm: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  const int nchunk = gn_num_chunks(pixels);
+  float* partial = reinterpret_cast<float*>(ws);
+  float* ab = partial + (size_t)batch * nchunk * 64 * 2;
+  LFDM_LAUNCH(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, pixels, channels,
+              groups, partial);
+  LFDM_LAUNCH(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const float*)partial, nchunk,
+              pixels, channels, groups, gamma, beta, scale_shift, eps, ab);
+  const int64_t total = (int64_t)batch * pixels * (channels / 4);
+  LFDM_LAUNCH(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, batch, pixels,
+              channels, (const float*)ab, apply_silu);
+  return lfdm_check_launch("groupnorm");
+}
+
+extern "C" int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,
+                                     const float* gamma, float eps, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || !gamma || rows <= 0 || channels <= 0 || channels % 4 != 0 || channels > 1024) {
+    lfdm_set_error("layernorm: unsupported shape (C%4==0, C<=1024)");
+    return LFDM_EINVAL;
+  }
+  int64_t nb = (rows + 3) / 4;
+  if (nb > 16384) nb = 16384;
+  LFDM_LAUNCH(layernorm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, out, rows, channels,
+              gamma, eps);
+  return lfdm_check_launch("layernorm");
+}
+
+extern "C" int lfdm_affine_act_cl_f32(const float* x, float* out, int64_t rows, int channels,
+                                      int ldx, int ldo, const float* a, const float* b, int act,
+                                      lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || !a || !b || rows <= 0 || channels % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0) {
+    lfdm_set_error("affine_act: unsupported shape");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(affine_act_kernel, dim3(grid_for(rows * (channels / 4))), dim3(256), 0, stream, x, out,
+              rows, channels, ldx, ldo, a, b, act);
+  return lfdm_check_launch("affine_act");
+}
+
+extern "C" int lfdm_avgpool2_cl_f32(const float* x, float* out, int n_img, int h, int w,
+                                    int channels, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || n_img <= 0 || (h & 1) || (w & 1) || channels % 4 != 0) {
+    lfdm_set_error("avgpool2: unsupported shape");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)n_img * (h / 2) * (w / 2) * (channels / 4);
+  LFDM_LAUNCH(avgpool2_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, n_img, h, w,
+              channels);
+  return lfdm_check_launch("avgpool2");
+}
+
+extern "C" int lfdm_planar_to_cl_f32(const float* x, float* out, int n_img, int channels, int hw,
+                                     int ldo, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || n_img <= 0 || channels <= 0 || hw <= 0 || ldo < channels) {
+    lfdm_set_error("planar_to_cl: bad arguments");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(planar_to_cl_kernel, dim3((hw + 31) / 32, (channels + 31) / 32, n_img), dim3(256), 0,
+              stream, x, out, channels, hw, ldo);
+  return lfdm_check_launch("planar_to_cl");
+}
+
+extern "C" int lfdm_cl_to_planar_f32(const float* x, float* out, int n_img, int channels, int hw,
+                                     int ldx, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || n_img <= 0 || channels <= 0 || hw <= 0 || ldx < channels) {
+    lfdm_set_error("cl_to_planar: bad arguments");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(cl_to_planar_kernel, dim3((hw + 31) / 32, (channels + 31) / 32, n_img), dim3(256), 0,
+              stream, x, out, channels, hw, ldx);
+  return lfdm_check_launch("cl_to_planar");
+}

@@ -1,0 +1,214 @@
+// Small / boundary kernels of the UNet (include/lfdm_hip.h): conditioning MLPs, sinusoidal
+// timestep embedding (timestep read from device memory for graph replay), the planar-input
+// small-C_in direct convolution (UNet init conv's step-dependent 3 channels, LFAE first conv) and
+// the two 1x1x1 output heads writing the planar (B,3,T,H,W) prediction.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float small_act(float v, int act) {
+  if (act == LFDM_ACT_GELU) return geluf_(v);
+  return apply_act(v, act);
+}
+
+// grid (ceil(N/4), B): one wavefront per output feature
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ y, int k, int n,
+                                                           int ldx, int ldy, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 4 + wave;
+  const int b = blockIdx.y;
+  if (col >= n) return;
+  const float* xr = x + (int64_t)b * ldx;
+  const float* wr = w + (int64_t)col * k;
+  float s = 0.f;
+  for (int i = lane; i < k; i += 64) s = fmaf(small_act(xr[i], act_in), wr[i], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (bias) s += bias[col];
+    y[(int64_t)b * ldy + col] = small_act(s, act_out);
+  }
+}
+
+__global__ __launch_bounds__(64) void sinusoidal_kernel(const int32_t* __restrict__ t_dev,
+                                                        int t_stride, float* __restrict__ out,
+                                                        int dim, int ldo) {
+  const int b = blockIdx.x;
+  const int half = dim / 2;
+  const float tt = (float)t_dev[(int64_t)b * t_stride];
+  const float step = -(float)(9.210340371976184 / (double)(half - 1));  // -ln(1e4)/(half-1)
+  for (int i = threadIdx.x; i < half; i += 64) {
+    const float f = expf((float)i * step);
+    const float a = tt * f;
+    out[(int64_t)b * ldo + i] = sinf(a);
+    out[(int64_t)b * ldo + half + i] = cosf(a);
+  }
+}
+
+// Direct conv, planar input with few channels -> CL rows.  grid (ceil(B*T*H*W/64), cout/64);
+// thread = (pixel = tid&63, 16 output channels = tid>>6).  Weights [K][64-slice] sit in LDS and
+// are read wave-uniformly (broadcast); the planar input is read coalesced along W.
+constexpr int CPI_MAX_K = 7 * 7 * 4;
+__global__ __launch_bounds__(256) void conv_planar_in_kernel(
+    const float* __restrict__ x, int batch, int cin, int cin_total, int frames, int h, int w,
+    const float* __restrict__ wgt, int kh, int kw, int cout, const float* __restrict__ bias,
+    const float* __restrict__ add_term, float* __restrict__ out, int ldo, int act) {
+  __shared__ __attribute__((aligned(16))) float ws[CPI_MAX_K * 64];
+  const int tid = threadIdx.x;
+  const int K = kh * kw * cin;
+  const int co0 = blockIdx.y * 64;
+  for (int i = tid; i < K * 64; i += 256) {
+    const int kk = i >> 6, j = i & 63;
+    ws[i] = wgt[(int64_t)kk * cout + co0 + j];
+  }
+  __syncthreads();
+  const int hw = h * w;
+  const int64_t total = (int64_t)batch * frames * hw;
+  const int64_t gp = (int64_t)blockIdx.x * 64 + (tid & 63);
+  if (gp >= total) return;
+  const int cg = tid >> 6;
+  const int64_t bt = gp / hw;
+  const int pix = (int)(gp - bt * hw);
+  const int b = (int)(bt / frames), t = (int)(bt - (int64_t)b * frames);
+  const int oy = pix / w, ox = pix - oy * w;
+  const int py = kh / 2, px = kw / 2;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int ky = 0; ky < kh; ++ky) {
+    const int iy = oy + ky - py;
+    if (iy < 0 || iy >= h) continue;
+    for (int kx = 0; kx < kw; ++kx) {
+      const int ix = ox + kx - px;
+      if (ix < 0 || ix >= w) continue;
+      for (int c = 0; c < cin; ++c) {
+        const float v = x[(((int64_t)b * cin_total + c) * frames + t) * hw + iy * w + ix];
+        const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * kw + kx) * cin + c) * 64 + cg * 16);
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 ww = wp[j4];
+          acc[4 * j4 + 0] = fmaf(v, ww.x, acc[4 * j4 + 0]);
+          acc[4 * j4 + 1] = fmaf(v, ww.y, acc[4 * j4 + 1]);
+          acc[4 * j4 + 2] = fmaf(v, ww.z, acc[4 * j4 + 2]);
+          acc[4 * j4 + 3] = fmaf(v, ww.w, acc[4 * j4 + 3]);
+        }
+      }
+    }
+  }
+  const int cbase = co0 + cg * 16;
+  float* orow = out + gp * ldo + cbase;
+  const float* arow = add_term ? add_term + ((int64_t)b * hw + pix) * cout + cbase : nullptr;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float v = acc[j];
+    if (bias) v += bias[cbase + j];
+    if (arow) v += arow[j];
+    orow[j] = apply_act(v, act);
+  }
+}
+
+// one thread per pixel row; weights (3 x C) in LDS
+__global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_flow,
+                                                    const float* __restrict__ y_occ, int channels,
+                                                    const float* __restrict__ w_flow,
+                                                    const float* __restrict__ b_flow,
+                                                    const float* __restrict__ w_occ,
+                                                    const float* __restrict__ b_occ,
+                                                    float* __restrict__ out, int batch, int frames,
+                                                    int hw) {
+  __shared__ __attribute__((aligned(16))) float wl[3 * 256];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * channels; i += 256) wl[i] = w_flow[i];
+  for (int i = tid; i < channels; i += 256) wl[2 * channels + i] = w_occ[i];
+  __syncthreads();
+  const int64_t total = (int64_t)batch * frames * hw;
+  const int64_t row = (int64_t)blockIdx.x * 256 + tid;
+  if (row >= total) return;
+  const float4* fr = reinterpret_cast<const float4*>(y_flow + row * channels);
+  const float4* orr = reinterpret_cast<const float4*>(y_occ + row * channels);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < channels / 4; ++i) {
+    const float4 a = fr[i];
+    const float4 o = orr[i];
+    const float4 w0 = reinterpret_cast<const float4*>(wl)[i];
+    const float4 w1 = reinterpret_cast<const float4*>(wl + channels)[i];
+    const float4 w2 = reinterpret_cast<const float4*>(wl + 2 * channels)[i];
+    s0 += (a.x * w0.x + a.y * w0.y) + (a.z * w0.z + a.w * w0.w);
+    s1 += (a.x * w1.x + a.y * w1.y) + (a.z * w1.z + a.w * w1.w);
+    s2 += (o.x * w2.x + o.y * w2.y) + (o.z * w2.z + o.w * w2.w);
+  }
+  const int64_t bt = row / hw;
+  const int pix = (int)(row - bt * hw);
+  const int b = (int)(bt / frames), t = (int)(bt - (int64_t)b * frames);
+  const int64_t fhw = (int64_t)frames * hw;
+  float* ob = out + (int64_t)b * 3 * fhw + (int64_t)t * hw + pix;
+  ob[0] = s0 + b_flow[0];
+  ob[fhw] = s1 + b_flow[1];
+  ob[2 * fhw] = s2 + b_occ[0];
+}
+
+}  // namespace
+
+extern "C" int lfdm_linear_small_f32(const float* x, const float* w, const float* bias, float* y,
+                                     int batch, int k, int n, int ldx, int ldy, int act_in,
+                                     int act_out, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !w || !y || batch <= 0 || k <= 0 || n <= 0 || ldx < k || ldy < n) {
+    lfdm_set_error("linear_small: bad arguments");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(linear_small_kernel, dim3((n + 3) / 4, batch), dim3(256), 0, stream, x, w, bias, y, k,
+              n, ldx, ldy, act_in, act_out);
+  return lfdm_check_launch("linear_small");
+}
+
+extern "C" int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, float* out, int batch,
+                                   int dim, int ldo, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!t_dev || !out || batch <= 0 || dim < 4 || (dim & 1) || ldo < dim) {
+    lfdm_set_error("sinusoidal: bad arguments");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(sinusoidal_kernel, dim3(batch), dim3(64), 0, stream, t_dev, t_stride, out, dim, ldo);
+  return lfdm_check_launch("sinusoidal");
+}
+
+extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, int cin_total,
+                                          int frames, int h, int w, const float* wgt, int kh,
+                                          int kw, int cout, const float* bias,
+                                          const float* add_term, float* out, int ldo, int act,
+                                          lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wgt || !out || batch <= 0 || cin <= 0 || cin > cin_total || frames <= 0 || h <= 0 ||
+      w <= 0 || kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1) || cout <= 0 || cout % 64 != 0 ||
+      kh * kw * cin > CPI_MAX_K || ldo < cout) {
+    lfdm_set_error("conv_planar_in: unsupported shape (odd kernel, kh*kw*cin<=196, cout%64==0)");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)batch * frames * h * w;
+  LFDM_LAUNCH(conv_planar_in_kernel, dim3((unsigned)((total + 63) / 64), cout / 64), dim3(256), 0,
+              stream, x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout, bias, add_term, out,
+              ldo, act);
+  return lfdm_check_launch("conv_planar_in");
+}
+
+extern "C" int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels,
+                                           const float* w_flow, const float* b_flow,
+                                           const float* w_occ, const float* b_occ, float* out,
+                                           int batch, int frames, int hw, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!y_flow || !y_occ || !w_flow || !b_flow || !w_occ || !b_occ || !out || channels <= 0 ||
+      channels > 256 || channels % 4 != 0 || batch <= 0 || frames <= 0 || hw <= 0) {
+    lfdm_set_error("heads: bad arguments");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)batch * frames * hw;
+  LFDM_LAUNCH(heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow,
+              y_occ, channels, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw);
+  return lfdm_check_launch("heads");
+}

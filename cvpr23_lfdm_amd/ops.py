@@ -1,0 +1,364 @@
+"""Python face of the C ABI (include/lfdm_hip.h): one thin function per entry point.
+
+Tensors are torch fp32 tensors used only as device memory (data_ptr + current HIP stream);
+all arithmetic happens in the HIP kernels of liblfdm_hip.so.  "CL" activations are 2-D tensors
+(rows, C): rows = N*H*W pixels in (n, y, x) order, UNet frames n = b*T + t.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native
+from ._native import ConvParams, WarpParams
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_GELU = 0, 1, 2, 3, 4
+
+
+def _lib():
+    return _native.library()
+
+
+def _stream(lib):
+    if lib.kind == "hip":
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(lib, *tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if t.dtype not in (torch.float32, torch.int32):
+            raise TypeError("lfdm ops take float32/int32 tensors, got %s" % t.dtype)
+        if lib.kind == "hip" and not t.is_cuda:
+            raise RuntimeError("lfdm ops need tensors on the GPU (no CPU fallback exists)")
+        if lib.kind == "emu" and t.is_cuda:
+            raise RuntimeError("emulation library needs CPU tensors")
+
+
+def empty(shape, like=None, device=None, dtype=torch.float32):
+    dev = device if device is not None else like.device
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (one-time, load-time plumbing)
+# ---------------------------------------------------------------------------------------------
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_conv_weight(w):
+    """(Cout, Cin, kh, kw) [or (Cout, Cin, 1, kh, kw)] -> packed [kh*kw][Cin][coutp], coutp = ceil32."""
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    coutp = round_up(cout, 32)
+    packed = torch.zeros(kh * kw, cin, coutp, dtype=torch.float32, device=w.device)
+    packed[:, :, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    return packed.contiguous()
+
+
+def pack_deconv_weight(w):
+    """ConvTranspose3d weight (Cin, Cout, 1, 4, 4), stride 2, padding 1 -> four parity packs
+    [(py, px, packed[4][Cin][coutp])]: output pixel (2q+py, 2q'+px) = 2x2 conv with pad (1-py, 1-px);
+    tap ky' uses kernel row ky = 3 - 2ky' (py = 0) or 2 - 2ky' (py = 1)."""
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    cin, cout, kh, kw = w.shape
+    assert kh == 4 and kw == 4
+    coutp = round_up(cout, 32)
+    packs = []
+    for py in (0, 1):
+        for px in (0, 1):
+            kys = [3, 1] if py == 0 else [2, 0]
+            kxs = [3, 1] if px == 0 else [2, 0]
+            packed = torch.zeros(4, cin, coutp, dtype=torch.float32, device=w.device)
+            for a, ky in enumerate(kys):
+                for b, kx in enumerate(kxs):
+                    packed[a * 2 + b, :, :cout] = w[:, :, ky, kx]
+            packs.append((py, px, packed.contiguous()))
+    return packs
+
+
+def pack_planar_in_weight(w):
+    """(Cout, Cin, kh, kw) -> [kh*kw*Cin][Cout] (tap-major, then channel) for conv_planar_in_cl."""
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    cout, cin, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# ops
+# ---------------------------------------------------------------------------------------------
+
+def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
+              upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
+              ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=1, partial=None):
+    lib = _lib()
+    _chk(lib, src0, src1, weight, bias, residual, out, partial)
+    cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
+    assert weight.shape[0] == kh * kw and weight.shape[1] == cin, (weight.shape, kh, kw, cin)
+    coutp = weight.shape[2]
+    pad_y, pad_x = (kh // 2, kw // 2) if pad is None else pad
+    h_in = hi * 2 if upsample else hi
+    w_in = wi * 2 if upsample else wi
+    if hq is None:
+        hq = (h_in + 2 * pad_y - kh) // stride + 1
+        wq = (w_in + 2 * pad_x - kw) // stride + 1
+    if ho is None:
+        ho, wo = hq * out_scale, wq * out_scale
+    if out is None:
+        out = torch.empty(n_img * ho * wo, cout, dtype=torch.float32, device=src0.device)
+    p = ConvParams()
+    p.src0, p.src1 = _p(src0), _p(src1)
+    p.c0, p.c1 = src0.shape[1], (src1.shape[1] if src1 is not None else 0)
+    p.ld0, p.ld1 = src0.stride(0), (src1.stride(0) if src1 is not None else 0)
+    p.n_img, p.hi, p.wi, p.hq, p.wq = n_img, hi, wi, hq, wq
+    p.stride, p.upsample, p.pad_mode = stride, int(upsample), int(reflect)
+    p.kh, p.kw, p.pad_y, p.pad_x = kh, kw, pad_y, pad_x
+    p.weight, p.cout, p.coutp, p.bias = _p(weight), cout, coutp, _p(bias)
+    p.out, p.ldo, p.ho, p.wo = _p(out), out.stride(0), ho, wo
+    p.out_scale, p.out_off_y, p.out_off_x = out_scale, out_off[0], out_off[1]
+    p.residual, p.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
+    p.act, p.ksplit, p.partial = act, ksplit, _p(partial)
+    if ksplit > 1 and partial is None:
+        need = lib.lfdm_conv2d_partial_bytes(C.byref(p))
+        partial = torch.empty(need // 4, dtype=torch.float32, device=src0.device)
+        p.partial = _p(partial)
+    lib.check(lib.lfdm_conv2d_cl_f32(C.byref(p), _stream(lib)), "lfdm_conv2d_cl_f32")
+    return out
+
+
+def deconv4x4s2_cl(src, packs, cout, n_img, hi, wi, *, bias=None, out=None):
+    """ConvTranspose (1,4,4) stride (1,2,2) pad (0,1,1) as four parity 2x2 convolutions."""
+    if out is None:
+        out = torch.empty(n_img * 4 * hi * wi, cout, dtype=torch.float32, device=src.device)
+    for py, px, w in packs:
+        conv2d_cl(src, w, cout, 2, 2, n_img, hi, wi, bias=bias, pad=(1 - py, 1 - px), out=out,
+                  hq=hi, wq=wi, ho=2 * hi, wo=2 * wi, out_scale=2, out_off=(py, px))
+    return out
+
+
+def groupnorm_silu_cl(x, batch, gamma, beta, *, groups=8, scale_shift=None, eps=1e-5, silu=True,
+                      out=None, ws=None):
+    lib = _lib()
+    rows, ch = x.shape
+    pixels = rows // batch
+    _chk(lib, x, gamma, beta, scale_shift, out, ws)
+    if out is None:
+        out = torch.empty_like(x)
+    need = lib.lfdm_groupnorm_ws_bytes(batch, pixels, ch)
+    if ws is None:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_groupnorm_silu_cl_f32(_p(x), _p(out), batch, pixels, ch, groups, _p(gamma),
+                                             _p(beta), _p(scale_shift), eps, int(silu), _p(ws),
+                                             ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_silu_cl_f32")
+    return out
+
+
+def layernorm_cl(x, gamma, eps=1e-5, out=None):
+    lib = _lib()
+    _chk(lib, x, gamma, out)
+    if out is None:
+        out = torch.empty_like(x)
+    lib.check(lib.lfdm_layernorm_cl_f32(_p(x), _p(out), x.shape[0], x.shape[1], _p(gamma), eps,
+                                        _stream(lib)), "lfdm_layernorm_cl_f32")
+    return out
+
+
+def attention_cl(qkv, batch, frames, hw, mode, *, bias=None, rot_cos=None, rot_sin=None, out=None):
+    lib = _lib()
+    _chk(lib, qkv, bias, rot_cos, rot_sin, out)
+    assert qkv.shape[1] == 768 and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(qkv.shape[0], 256, dtype=torch.float32, device=qkv.device)
+    lib.check(lib.lfdm_attention_cl_f32(_p(qkv), _p(out), batch, frames, hw, mode, _p(bias),
+                                        _p(rot_cos), _p(rot_sin), _stream(lib)), "lfdm_attention_cl_f32")
+    return out
+
+
+def linear_attention_cl(qkv, n_frames, hw, *, out=None, ws=None):
+    lib = _lib()
+    _chk(lib, qkv, out, ws)
+    assert qkv.shape[1] == 768 and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty(qkv.shape[0], 256, dtype=torch.float32, device=qkv.device)
+    need = lib.lfdm_linear_attention_ws_bytes(n_frames)
+    if ws is None:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=qkv.device)
+    lib.check(lib.lfdm_linear_attention_cl_f32(_p(qkv), _p(out), n_frames, hw, _p(ws), ws.numel() * 4,
+                                               _stream(lib)), "lfdm_linear_attention_cl_f32")
+    return out
+
+
+def linear_small(x, w, bias=None, *, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    lib = _lib()
+    _chk(lib, x, w, bias, out)
+    batch, k = x.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and w.is_contiguous()
+    if out is None:
+        out = torch.empty(batch, n, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_linear_small_f32(_p(x), _p(w), _p(bias), _p(out), batch, k, n, x.stride(0),
+                                        out.stride(0), act_in, act_out, _stream(lib)), "lfdm_linear_small_f32")
+    return out
+
+
+def sinusoidal(t_dev, batch, dim, *, t_stride=1, out=None):
+    lib = _lib()
+    _chk(lib, t_dev, out)
+    assert t_dev.dtype == torch.int32
+    if out is None:
+        out = torch.empty(batch, dim, dtype=torch.float32, device=t_dev.device)
+    lib.check(lib.lfdm_sinusoidal_f32(_p(t_dev), t_stride, _p(out), batch, dim, out.stride(0),
+                                      _stream(lib)), "lfdm_sinusoidal_f32")
+    return out
+
+
+def conv_planar_in_cl(x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout, *, bias=None,
+                      add_term=None, act=ACT_NONE, out=None):
+    lib = _lib()
+    _chk(lib, x, wgt, bias, add_term, out)
+    if out is None:
+        out = torch.empty(batch * frames * h * w, cout, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_conv_planar_in_cl_f32(_p(x), batch, cin, cin_total, frames, h, w, _p(wgt), kh, kw,
+                                             cout, _p(bias), _p(add_term), _p(out), out.stride(0), act,
+                                             _stream(lib)), "lfdm_conv_planar_in_cl_f32")
+    return out
+
+
+def heads_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, batch, frames, hw, *, out=None):
+    lib = _lib()
+    _chk(lib, y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, out)
+    ch = y_flow.shape[1]
+    if out is None:
+        out = torch.empty(batch, 3, frames, hw, dtype=torch.float32, device=y_flow.device)
+    lib.check(lib.lfdm_heads_cl_to_planar_f32(_p(y_flow), _p(y_occ), ch, _p(w_flow), _p(b_flow),
+                                              _p(w_occ), _p(b_occ), _p(out), batch, frames, hw,
+                                              _stream(lib)), "lfdm_heads_cl_to_planar_f32")
+    return out
+
+
+def sampler_ws(batch, n, device):
+    lib = _lib()
+    return torch.empty(lib.lfdm_sampler_ws_bytes(batch, n) // 4, dtype=torch.float32, device=device)
+
+
+def sampler_step(x, eps, noise, coef, step_dev, *, quantile=0.9, advance=True, x0_out=None, ws=None):
+    lib = _lib()
+    _chk(lib, x, eps, noise, coef, step_dev, x0_out, ws)
+    batch = x.shape[0]
+    n = x.numel() // batch
+    if ws is None:
+        ws = sampler_ws(batch, n, x.device)
+    lib.check(lib.lfdm_sampler_step_f32(_p(x), _p(eps), _p(noise), _p(x0_out), batch, n, _p(coef),
+                                        _p(step_dev), quantile, int(advance), _p(ws), ws.numel() * 4,
+                                        _stream(lib)), "lfdm_sampler_step_f32")
+    return x
+
+
+def abs_quantile(x, quantile=0.9, ws=None):
+    lib = _lib()
+    batch = x.shape[0]
+    n = x.numel() // batch
+    _chk(lib, x, ws)
+    if ws is None:
+        ws = sampler_ws(batch, n, x.device)
+    out = torch.empty(batch, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_abs_quantile_f32(_p(x), batch, n, quantile, _p(out), _p(ws), ws.numel() * 4,
+                                        _stream(lib)), "lfdm_abs_quantile_f32")
+    return out
+
+
+def _warp_params(src, out, batch, frames, h, w, c, flow_x, flow_y, occ, fh, fw, fsb, fst, prev,
+                 occ_scale, occ_bias, ld_src, ld_prev, ld_out, prev_is_cl):
+    p = WarpParams()
+    p.src, p.prev, p.out = _p(src), _p(prev), _p(out)
+    p.batch, p.frames, p.h, p.w, p.c = batch, frames, h, w, c
+    p.ld_src, p.ld_prev, p.ld_out = ld_src, ld_prev, ld_out
+    p.flow_x, p.flow_y, p.occ = _p(flow_x), _p(flow_y), _p(occ)
+    p.fh, p.fw, p.fsb, p.fst = fh, fw, fsb, fst
+    p.occ_scale, p.occ_bias, p.prev_is_cl = occ_scale, occ_bias, int(prev_is_cl)
+    return p
+
+
+def warp_cl(src, batch, frames, h, w, flow_x, flow_y, occ, fh, fw, fsb, fst, *, prev=None,
+            occ_scale=1.0, occ_bias=0.0, out=None):
+    """src: CL (batch*h*w, C); out/prev: CL (batch*frames*h*w, C). flow_x/flow_y/occ: tensors whose
+    data_ptr is the map base (element (b,t,y,x) at b*fsb + t*fst + y*fw + x)."""
+    lib = _lib()
+    _chk(lib, src, flow_x, flow_y, occ, prev, out)
+    c = src.shape[1]
+    if out is None:
+        out = torch.empty(batch * frames * h * w, c, dtype=torch.float32, device=src.device)
+    p = _warp_params(src, out, batch, frames, h, w, c, flow_x, flow_y, occ, fh, fw, fsb, fst, prev,
+                     occ_scale, occ_bias, src.stride(0), prev.stride(0) if prev is not None else 0,
+                     out.stride(0), True)
+    lib.check(lib.lfdm_warp_cl_f32(C.byref(p), _stream(lib)), "lfdm_warp_cl_f32")
+    return out
+
+
+def warp_planar(src, frames, flow_x, flow_y, occ, fh, fw, fsb, fst, *, prev=None, prev_is_cl=False,
+                occ_scale=1.0, occ_bias=0.0, out=None):
+    """src: planar (B, C, H, W); out: planar (B, C, frames, H, W)."""
+    lib = _lib()
+    _chk(lib, src, flow_x, flow_y, occ, prev, out)
+    b, c, h, w = src.shape
+    assert src.is_contiguous()
+    if out is None:
+        out = torch.empty(b, c, frames, h, w, dtype=torch.float32, device=src.device)
+    ld_prev = prev.stride(0) if (prev is not None and prev_is_cl) else 0
+    p = _warp_params(src, out, b, frames, h, w, c, flow_x, flow_y, occ, fh, fw, fsb, fst, prev,
+                     occ_scale, occ_bias, 0, ld_prev, 0, prev_is_cl)
+    lib.check(lib.lfdm_warp_planar_f32(C.byref(p), _stream(lib)), "lfdm_warp_planar_f32")
+    return out
+
+
+def affine_act_cl(x, a, b, act=ACT_RELU, out=None):
+    lib = _lib()
+    _chk(lib, x, a, b, out)
+    if out is None:
+        out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_affine_act_cl_f32(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0),
+                                         out.stride(0), _p(a), _p(b), act, _stream(lib)), "lfdm_affine_act_cl_f32")
+    return out
+
+
+def avgpool2_cl(x, n_img, h, w, out=None):
+    lib = _lib()
+    _chk(lib, x, out)
+    assert x.is_contiguous()
+    c = x.shape[1]
+    if out is None:
+        out = torch.empty(n_img * (h // 2) * (w // 2), c, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_avgpool2_cl_f32(_p(x), _p(out), n_img, h, w, c, _stream(lib)), "lfdm_avgpool2_cl_f32")
+    return out
+
+
+def planar_to_cl(x, n_img, channels, hw, out=None):
+    lib = _lib()
+    _chk(lib, x, out)
+    if out is None:
+        out = torch.empty(n_img * hw, channels, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_planar_to_cl_f32(_p(x), _p(out), n_img, channels, hw, out.stride(0), _stream(lib)),
+              "lfdm_planar_to_cl_f32")
+    return out
+
+
+def cl_to_planar(x, n_img, channels, hw, out=None):
+    lib = _lib()
+    _chk(lib, x, out)
+    if out is None:
+        out = torch.empty(n_img, channels, hw, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_cl_to_planar_f32(_p(x), _p(out), n_img, channels, hw, x.stride(0), _stream(lib)),
+              "lfdm_cl_to_planar_f32")
+    return out

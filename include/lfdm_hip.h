@@ -1,0 +1,222 @@
+/* lfdm_hip.h - C ABI of liblfdm_hip.so, the MI355X (gfx950) kernels of the LFDM hot path.
+ *
+ * The reference (nihaomiao/CVPR23_LFDM) has no native/FFI layer: its hot path is a chain of
+ * PyTorch ATen calls.  Each entry point below replaces one family of
+ * those call sites; the reference file:line it stands in for is cited per function
+ * (paths relative to the reference root).  The Python host side (cvpr23_lfdm_amd/) binds these
+ * with ctypes - see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (unless stated) owned by the caller;
+ *  - "CL" = channels-last rows: a tensor (N, H, W, C) stored as N*H*W rows of C floats with a
+ *    row stride `ld` >= C (so a kernel can read/write a channel slice of a wider buffer);
+ *    UNet activations use N = B*T (frame-major: row = ((b*T + t)*H + y)*W + x);
+ *  - "planar" = the reference layout (B, C, T, H, W) / (B, C, H, W), contiguous;
+ *  - no allocation, no synchronisation, no hidden state: every call only enqueues kernels on
+ *    `stream` (hipGraph-capturable); scratch memory is passed in by the caller;
+ *  - return value 0 on success, negative LFDM_E* otherwise; lfdm_last_error() describes it.
+ */
+#ifndef LFDM_HIP_H
+#define LFDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lfdm_stream_t; /* hipStream_t */
+
+#define LFDM_OK 0
+#define LFDM_EINVAL (-1)
+#define LFDM_ELAUNCH (-2)
+#define LFDM_EWORKSPACE (-3)
+
+#define LFDM_ACT_NONE 0
+#define LFDM_ACT_RELU 1
+#define LFDM_ACT_SIGMOID 2
+#define LFDM_ACT_SILU 3
+#define LFDM_ACT_GELU 4
+
+const char* lfdm_last_error(void);
+int lfdm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as fp32-MFMA implicit GEMM (M = N*hq*wq pixels, N = cout, K = kh*kw*cin).
+ * Replaces: Conv3d k=(1,3,3) Block.proj  DM/modules/video_flow_diffusion.py:199
+ *           Conv3d 1x1x1 res_conv :224, final heads :495,508; Linear to_qkv/to_out :300-301;
+ *           Conv2d 1x1 SpatialLinearAttention :246-247; Downsample :167; Upsample :158,160-163;
+ *           init_conv fea term :410; LFAE Conv2d blocks LFAE/modules/util.py:70-150,
+ *           LFAE/modules/generator.py:54 (with eval-BatchNorm folded into weight/bias).
+ * Input = channel concat of src0 (c0 ch) and optional src1 (c1 ch)  -> torch.cat :580,587.
+ * Tap (ky,kx) reads input pixel (qy*stride + ky - pad_y, qx*stride + kx - pad_x) of the
+ * (optionally x2 nearest-upsampled) input; out pixel = (qy*out_scale + out_off_y, ...), which
+ * expresses ConvTranspose3d k4 s2 p1 as four 2x2 parity convolutions.
+ * weight is packed [kh*kw][c0+c1][coutp] (coutp = cout rounded up to 32, zero filled).
+ * out = act(acc + bias + residual).
+ */
+typedef struct lfdm_conv_params {
+  const float* src0;
+  const float* src1;
+  int c0, c1, ld0, ld1;
+  int n_img, hi, wi;      /* physical input size */
+  int hq, wq;             /* iteration grid per image */
+  int stride;             /* input stride */
+  int upsample;           /* 1: read the input through a virtual nearest x2 upsample */
+  int pad_mode;           /* 0 zeros, 1 reflect */
+  int kh, kw, pad_y, pad_x;
+  const float* weight;
+  int cout, coutp;
+  const float* bias;      /* [cout] or NULL */
+  float* out;
+  int ldo, ho, wo;
+  int out_scale, out_off_y, out_off_x;
+  const float* residual;  /* NULL or rows indexed like out */
+  int ldr;
+  int act;                /* LFDM_ACT_* (NONE/RELU/SIGMOID/SILU) */
+  /* split-K: ksplit > 1 writes raw partial sums to `partial` ([ksplit][M][coutp]) and the
+     epilogue (bias/residual/act) is applied by lfdm_conv2d_cl_f32 in a reduce pass */
+  int ksplit;
+  float* partial;
+} lfdm_conv_params;
+
+int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
+/* bytes of `partial` needed for a given ksplit */
+size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm(G) over (C/G, T, H, W) + optional (scale+1, shift) + SiLU, channels-last.
+ * Replaces Block.forward norm/scale-shift/act: DM/modules/video_flow_diffusion.py:200-211.
+ * x, out: (B, P, C) rows (P = T*H*W pixels per sample), may alias.
+ * scale_shift: NULL or (B, 2*C) = [scale | shift]  (ResnetBlock.mlp output chunked, :230-232).
+ * ws: caller scratch of lfdm_groupnorm_ws_bytes(B, P, C) bytes.
+ */
+size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels);
+int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels, int channels,
+                               int groups, const float* gamma, const float* beta,
+                               const float* scale_shift, float eps, int apply_silu,
+                               void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
+int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,
+                          const float* gamma, float eps, lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Softmax attention over short sequences (L <= 64), 8 heads x 32, fp32 MFMA for QK^T / PV.
+ * Replaces Attention.forward (video_flow_diffusion.py:303-363) incl. rotary (:329-331),
+ * relative position bias (:339-340) and the einops re-layouts (:270-283).
+ * qkv: rows of 768 floats [q(8x32) | k | v] in UNet CL row order (B*T*HW rows).
+ * mode 0 (temporal): one sequence per (b, pixel), tokens = frames  (needs rot_cos/rot_sin
+ *        (T,16) tables and bias (8,T,T)); mode 1 (spatial): one sequence per (b, frame),
+ *        tokens = pixels (no rotary, no bias).
+ * out: rows of 256 floats (heads merged), same row order.
+ */
+int lfdm_attention_cl_f32(const float* qkv, float* out, int batch, int frames, int hw, int mode,
+                          const float* bias, const float* rot_cos, const float* rot_sin,
+                          lfdm_stream_t stream);
+
+/* Linear attention of SpatialLinearAttention.forward (video_flow_diffusion.py:249-265),
+ * between the two 1x1 convolutions.  qkv rows of 768, out rows of 256; n_frames = B*T, hw tokens
+ * per frame.  ws: n_frames*8*32*32 floats. */
+size_t lfdm_linear_attention_ws_bytes(int n_frames);
+int lfdm_linear_attention_cl_f32(const float* qkv, float* out, int n_frames, int hw,
+                                 void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small dense layers of the conditioning path (time_mlp :423-428, ResnetBlock.mlp :217-220).
+ * y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ),  w row-major (N, K). */
+int lfdm_linear_small_f32(const float* x, const float* w, const float* bias, float* y,
+                          int batch, int k, int n, int ldx, int ldy, int act_in, int act_out,
+                          lfdm_stream_t stream);
+
+/* SinusoidalPosEmb (:141-153): emb[b] = [sin(t*f_i) | cos(t*f_i)], f_i = exp(-ln(1e4)*i/(dim/2-1)).
+ * The timestep is read from DEVICE memory (int32) so a captured graph can be replayed per step. */
+int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, float* out, int batch, int dim,
+                        int ldo, lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-C_in convolution from a PLANAR input into CL output (direct, VALU):
+ *   UNet init_conv's step-dependent 3-channel part (video_flow_diffusion.py:410,547) with the
+ *   per-video precomputed `fea` term added (exact split of the 259-channel conv by linearity);
+ *   LFAE `first` 7x7 conv (LFAE/modules/generator.py:34, BN folded).
+ * x: (B, cin_total, T, H, W) planar, only channels [0, cin) are read; w: [kh*kw*cin][cout]
+ * (tap-major, then channel); add_term: NULL or (B, H, W, cout) CL broadcast over T.
+ */
+int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, int cin_total, int frames,
+                               int h, int w, const float* wgt, int kh, int kw, int cout,
+                               const float* bias, const float* add_term, float* out, int ldo,
+                               int act, lfdm_stream_t stream);
+
+/* Output heads: the two 1x1x1 convs (video_flow_diffusion.py:495,508,588) from CL features to the
+ * PLANAR 3-channel prediction (B, 3, T, H, W): ch 0,1 from y_flow (w_flow (2,C)), ch 2 from y_occ. */
+int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels,
+                                const float* w_flow, const float* b_flow, const float* w_occ,
+                                const float* b_occ, float* out, int batch, int frames, int hw,
+                                lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler step (GaussianDiffusion.ddim_sample :791-827 / p_sample :737-746): predict x0
+ * (:697-701), dynamic threshold = per-sample 0.9-quantile of |x0| with linear interpolation,
+ * clamp and divide (:805-818), then the DDIM or DDPM update.  Coefficients come from a device
+ * table indexed by a device step counter, so the whole step can be replayed from a hipGraph:
+ *   coef[step] = { c_x (sqrt_recip_alphas_cumprod), c_eps (sqrt_recipm1_alphas_cumprod),
+ *                  k_x0, k_eps, k_x, k_noise }:  x <- k_x0*x0 + k_eps*eps + k_x*x + k_noise*noise
+ * x (in/out), eps, noise: planar (B, n) with n = 3*T*S*S. x0_out optional (B, n).
+ * ws: lfdm_sampler_ws_bytes(batch, n).  advance != 0 increments *step_dev at the end.
+ */
+size_t lfdm_sampler_ws_bytes(int batch, int64_t n);
+int lfdm_sampler_step_f32(float* x, const float* eps, const float* noise, float* x0_out,
+                          int batch, int64_t n, const float* coef, int32_t* step_dev,
+                          float quantile, int advance, void* ws, size_t ws_bytes,
+                          lfdm_stream_t stream);
+/* stand-alone |x| quantile (torch.quantile semantics, :722-726) for tests: q_out[b] */
+int lfdm_abs_quantile_f32(const float* x, int batch, int64_t n, float quantile, float* q_out,
+                          void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LFAE warp: Generator.deform_input + apply_optical (LFAE/modules/generator.py:59-88):
+ * bilinear resize of the low-res sampling grid / occlusion map to the feature resolution
+ * (F.interpolate align_corners=False, :65,:80) fused with grid_sample (bilinear, zeros,
+ * align_corners=False, :67) and the occlusion blend out = w*occ + prev*(1-occ) (:82-84).
+ * flow_x/flow_y/occ: low-res maps addressed as  base[b*sb + t*st + y*fw + x]  so the planar
+ * DM prediction (B,3,T,S,S) is read in place (occ_scale/occ_bias map it to [0,1]: 0.5/0.5 for
+ * the raw prediction, 1/0 for a ready occlusion map; occ may be NULL = no masking).
+ */
+typedef struct lfdm_warp_params {
+  const float* src;      /* CL (B, H, W, C) rows (ld_src) or planar (B, C, H, W) */
+  const float* prev;     /* NULL or rows (B*T, H, W, C) (ld_prev) / planar like out */
+  float* out;            /* CL (B*T, H, W, C) rows (ld_out) or planar (B, C, T, H, W) */
+  int batch, frames, h, w, c;
+  int ld_src, ld_prev, ld_out;
+  const float* flow_x;
+  const float* flow_y;
+  const float* occ;
+  int fh, fw;            /* low-res map size */
+  int64_t fsb, fst;      /* batch / frame strides (floats) of the maps */
+  float occ_scale, occ_bias;
+  int prev_is_cl;        /* planar kernel only: prev given as CL rows (ld_prev) */
+} lfdm_warp_params;
+
+int lfdm_warp_cl_f32(const lfdm_warp_params* p, lfdm_stream_t stream);
+int lfdm_warp_planar_f32(const lfdm_warp_params* p, lfdm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / layout helpers of the LFAE decode path.
+ * affine_act: y = act(x*a[c] + b[c])  (eval BatchNorm + ReLU of ResBlock2d, util.py:84-90)
+ * avgpool2:   2x2 average pool (DownBlock2d, util.py:124)
+ */
+int lfdm_affine_act_cl_f32(const float* x, float* out, int64_t rows, int channels, int ldx,
+                           int ldo, const float* a, const float* b, int act,
+                           lfdm_stream_t stream);
+int lfdm_avgpool2_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels,
+                         lfdm_stream_t stream);
+int lfdm_planar_to_cl_f32(const float* x, float* out, int n_img, int channels, int hw, int ldo,
+                          lfdm_stream_t stream);
+int lfdm_cl_to_planar_f32(const float* x, float* out, int n_img, int channels, int hw, int ldx,
+                          lfdm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFDM_HIP_H */

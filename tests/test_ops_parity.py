@@ -1,0 +1,378 @@
+"""Per-op parity: every C-ABI entry point (include/lfdm_hip.h) against the CPU oracle
+(oracle/lfdm_oracle.py / the ATen op the reference calls) on the same seeded inputs.
+
+Runs twice: backend=hip on the MI355X (`-m gpu`, the parity tests proper, at C2-like shapes) and
+backend=emu (the kernel sources under the x86 fiber emulator, tiny shapes - index-logic check).
+Tolerance: 1e-4 relative to the output scale per op (fp32 kernels with a different summation
+order than ATen; the north-star budget for the whole chain is 1e-3)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lfdm_oracle as O
+from cvpr23_lfdm_amd import ops
+from util import assert_close, from_cl, to_cl, unet_from_cl, unet_to_cl
+
+TOL = 1e-4
+
+
+def big(dev):
+    return dev == "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(cin=32, cout=64, k=3, n=2, h=8, w=8),
+    dict(cin=64, cout=64, k=3, n=3, h=6, w=10),           # ragged M (180 rows)
+    dict(cin=32, cout=96, k=1, n=2, h=8, w=8),            # 1x1 / linear, cout not /64
+    dict(cin=3, cout=64, k=7, n=1, h=12, w=12),           # generic path, tiny C_in
+    dict(cin=64, cout=3, k=7, n=1, h=10, w=10, act=2),    # LFAE final conv + sigmoid
+    dict(cin=32, cout=32, k=4, n=2, h=8, w=8, stride=2, pad=1),   # Downsample
+    dict(cin=32, cout=32, k=3, n=2, h=4, w=4, upsample=True, reflect=True),  # upconv variant
+    dict(cin=32, cout=64, k=3, n=2, h=4, w=4, upsample=True, act=1),         # UpBlock2d
+    dict(cin=64, cout=64, k=3, n=2, h=8, w=8, split_src=32, residual=True),  # fused concat + residual
+    dict(cin=64, cout=64, k=3, n=2, h=8, w=8, ksplit=3, residual=True, act=1),
+    dict(cin=256, cout=256, k=3, n=2, h=4, w=4, ksplit=4),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv2d(backend, case):
+    dev = backend
+    cin, cout, k, n, h, w = (case[x] for x in ("cin", "cout", "k", "n", "h", "w"))
+    stride, pad = case.get("stride", 1), case.get("pad", k // 2)
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    bias = rnd(cout, seed=3)
+    xin = x
+    if case.get("upsample"):
+        xin = F.interpolate(x, scale_factor=2, mode="nearest")
+    if case.get("reflect"):
+        ref = F.conv2d(F.pad(xin, (pad,) * 4, mode="reflect"), wt, bias, stride=stride)
+    else:
+        ref = F.conv2d(xin, wt, bias, stride=stride, padding=pad)
+    res = None
+    if case.get("residual"):
+        res = rnd(*ref.shape, seed=4)
+        ref = ref + res
+    act = case.get("act", 0)
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = torch.sigmoid(ref)
+    xs = to_cl(x).to(dev)
+    src0, src1 = xs, None
+    if case.get("split_src"):
+        s = case["split_src"]
+        src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
+    out = ops.conv2d_cl(src0, ops.pack_conv_weight(wt).to(dev), cout, k, k, n, h, w, src1=src1,
+                        bias=bias.to(dev), pad=(pad, pad), stride=stride,
+                        upsample=bool(case.get("upsample")), reflect=bool(case.get("reflect")),
+                        residual=None if res is None else to_cl(res).to(dev), act=act,
+                        ksplit=case.get("ksplit", 1))
+    assert_close(from_cl(out.cpu(), n, ref.shape[2], ref.shape[3]), ref, TOL, "conv2d")
+
+
+def test_conv2d_c2_shapes(backend):
+    """C2-sized contractions - GPU only."""
+    if not big(backend):
+        pytest.skip("full-size shapes run on the GPU")
+    dev = backend
+    for (cin, cout, s, frames) in [(64, 64, 32, 40), (128, 64, 32, 40), (512, 512, 4, 40), (1024, 256, 4, 40),
+                                   (64, 768, 32, 8)]:
+        k = 3 if cout != 768 else 1
+        x = rnd(frames, cin, s, s, seed=5)
+        wt = rnd(cout, cin, k, k, seed=6, scale=1.0 / math.sqrt(cin * k * k))
+        bias = rnd(cout, seed=7)
+        ref = F.conv2d(x, wt, bias, padding=k // 2)
+        out = ops.conv2d_cl(to_cl(x).to(dev), ops.pack_conv_weight(wt).to(dev), cout, k, k, frames, s, s,
+                            bias=bias.to(dev))
+        assert_close(from_cl(out.cpu(), frames, s, s), ref, TOL, "conv %s" % ((cin, cout, s),))
+
+
+def test_deconv(backend):
+    dev = backend
+    n, c, h, w = 2, 32, 4, 4
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, c, 4, 4, seed=2, scale=0.1)
+    bias = rnd(c, seed=3)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2, padding=1)
+    packs = [(py, px, p.to(dev)) for py, px, p in ops.pack_deconv_weight(wt)]
+    out = ops.deconv4x4s2_cl(to_cl(x).to(dev), packs, c, n, h, w, bias=bias.to(dev))
+    assert_close(from_cl(out.cpu(), n, 2 * h, 2 * w), ref, TOL, "deconv")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c,with_ss", [(64, True), (128, False), (512, True)])
+def test_groupnorm_silu(backend, c, with_ss):
+    dev = backend
+    b, t, s = (2, 40, 32) if (big(dev) and c == 64) else (2, 3, 4)
+    x = rnd(b, c, t, s, s, seed=1) * 2 + 0.5
+    gamma, beta = rnd(c, seed=2) + 1.0, rnd(c, seed=3)
+    ss = rnd(b, 2 * c, seed=4) * 0.5 if with_ss else None
+    ref = F.group_norm(x, 8, gamma, beta, eps=1e-5)
+    if with_ss:
+        sc, sh = ss[:, :c], ss[:, c:]
+        ref = ref * (sc.view(b, c, 1, 1, 1) + 1) + sh.view(b, c, 1, 1, 1)
+    ref = F.silu(ref)
+    out = ops.groupnorm_silu_cl(unet_to_cl(x).to(dev), b, gamma.to(dev), beta.to(dev),
+                                scale_shift=None if ss is None else ss.to(dev))
+    assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
+
+
+@pytest.mark.parametrize("c", [64, 128, 512])
+def test_layernorm(backend, c):
+    dev = backend
+    x = rnd(2, c, 2, 4, 4, seed=1) * 3 + 1
+    gamma = rnd(1, c, 1, 1, 1, seed=2) + 1
+    ref = O.channel_layernorm(x, gamma)
+    out = ops.layernorm_cl(unet_to_cl(x).to(dev), gamma.reshape(-1).contiguous().to(dev))
+    assert_close(unet_from_cl(out.cpu(), 2, 2, 4, 4), ref, TOL, "layernorm")
+
+
+# ------------------------------------------------------------------------------------------
+def _attention_ref(qkv_tokens, bias, rotary):
+    """qkv_tokens (..., n, 768) -> (..., n, 256) following Attention.forward semantics."""
+    q, k, v = qkv_tokens.chunk(3, dim=-1)
+
+    def heads(z):
+        return z.reshape(*z.shape[:-1], 8, 32).transpose(-2, -3)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    q = q * (32 ** -0.5)
+    if rotary is not None:
+        q, k = O.apply_rotary(q, *rotary), O.apply_rotary(k, *rotary)
+    sim = q @ k.transpose(-1, -2)
+    if bias is not None:
+        sim = sim + bias
+    sim = sim - sim.amax(dim=-1, keepdim=True)
+    out = sim.softmax(dim=-1) @ v
+    return out.transpose(-2, -3).reshape(*qkv_tokens.shape[:-1], 256)
+
+
+@pytest.mark.parametrize("frames", [4, 40])
+def test_attention_temporal(backend, frames):
+    dev = backend
+    b, s = (1, 32) if (big(dev) and frames == 40) else (2, 2)
+    hw = s * s
+    qkv = rnd(b, frames, hw, 768, seed=1)                   # CL row order (b, t, pix)
+    emb = rnd(32, 8, seed=2)
+    bias = O.rel_pos_bias(emb, frames)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    cos, sin = O.rotary_tables(freqs, frames)
+    tokens = qkv.permute(0, 2, 1, 3)                       # (b, pix, t, 768)
+    ref = _attention_ref(tokens, bias, (cos, sin)).permute(0, 2, 1, 3).reshape(-1, 256)
+    out = ops.attention_cl(qkv.reshape(-1, 768).to(dev), b, frames, hw, 0, bias=bias.contiguous().to(dev),
+                           rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
+    assert_close(out.cpu(), ref, TOL, "temporal attention")
+
+
+@pytest.mark.parametrize("hw", [16, 64])
+def test_attention_spatial(backend, hw):
+    dev = backend
+    b, frames = 1, 3
+    qkv = rnd(b, frames, hw, 768, seed=3)
+    ref = _attention_ref(qkv, None, None).reshape(-1, 256)
+    out = ops.attention_cl(qkv.reshape(-1, 768).to(dev), b, frames, hw, 1)
+    assert_close(out.cpu(), ref, TOL, "spatial attention")
+
+
+@pytest.mark.parametrize("hw", [16, 80])
+def test_linear_attention(backend, hw):
+    dev = backend
+    nf = 3
+    if big(dev) and hw == 80:
+        nf, hw = 40, 1024
+    qkv = rnd(nf, hw, 768, seed=4)
+    q, k, v = [z.reshape(nf, hw, 8, 32).permute(0, 2, 3, 1) for z in qkv.chunk(3, dim=-1)]  # b h d n
+    q = q.softmax(dim=-2) * (32 ** -0.5)
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(nf * hw, 256)
+    out = ops.linear_attention_cl(qkv.reshape(-1, 768).to(dev), nf, hw)
+    assert_close(out.cpu(), ref, TOL, "linear attention")
+
+
+# ------------------------------------------------------------------------------------------
+def test_linear_small_and_sinusoidal(backend):
+    dev = backend
+    b = 3
+    t = torch.tensor([999, 500, 0], dtype=torch.int32)
+    emb = ops.sinusoidal(t.to(dev), b, 64)
+    half = 32
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = t.long()[:, None] * freq[None, :]
+    ref = torch.cat((e.sin(), e.cos()), dim=-1)
+    assert_close(emb.cpu(), ref, 2e-5, "sinusoidal")
+    w1, b1 = rnd(256, 64, seed=1, scale=0.1), rnd(256, seed=2)
+    y = ops.linear_small(ref.to(dev), w1.to(dev), b1.to(dev), act_out=ops.ACT_GELU)
+    assert_close(y.cpu(), F.gelu(F.linear(ref, w1, b1)), TOL, "linear+gelu")
+    x = rnd(b, 1024, seed=3)
+    w2, b2 = rnd(130, 1024, seed=4, scale=0.05), rnd(130, seed=5)
+    y2 = ops.linear_small(x.to(dev), w2.to(dev), b2.to(dev), act_in=ops.ACT_SILU)
+    assert_close(y2.cpu(), F.linear(F.silu(x), w2, b2), TOL, "silu+linear")
+
+
+def test_conv_planar_in_and_heads(backend):
+    dev = backend
+    b, t, s = (1, 40, 32) if big(dev) else (2, 2, 6)
+    x = rnd(b, 7, t, s, s, seed=1)                          # only the first 3 channels are read
+    wt = rnd(64, 3, 1, 7, 7, seed=2, scale=0.1)
+    bias = rnd(64, seed=3)
+    add = rnd(b, 64, s, s, seed=4)
+    ref = F.conv3d(x[:, :3], wt, bias, padding=(0, 3, 3)) + add.unsqueeze(2)
+    out = ops.conv_planar_in_cl(x.to(dev), b, 3, 7, t, s, s, ops.pack_planar_in_weight(wt).to(dev), 7, 7, 64,
+                                bias=bias.to(dev), add_term=to_cl(add).to(dev))
+    assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "conv_planar_in")
+    # heads
+    yf, yo = rnd(b, 64, t, s, s, seed=5), rnd(b, 64, t, s, s, seed=6)
+    wf, bf, wo, bo = rnd(2, 64, seed=7, scale=0.2), rnd(2, seed=8), rnd(1, 64, seed=9, scale=0.2), rnd(1, seed=10)
+    ref = torch.cat((F.conv3d(yf, wf.view(2, 64, 1, 1, 1), bf), F.conv3d(yo, wo.view(1, 64, 1, 1, 1), bo)), dim=1)
+    out = ops.heads_cl_to_planar(unet_to_cl(yf).to(dev), unet_to_cl(yo).to(dev), wf.to(dev), bf.to(dev),
+                                 wo.to(dev), bo.to(dev), b, t, s * s)
+    assert_close(out.cpu().reshape(b, 3, t, s, s), ref, TOL, "heads")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [97, 3 * 4 * 8 * 8, 122880])
+def test_abs_quantile(backend, n):
+    dev = backend
+    if n > 10000 and not big(dev):
+        n = 5000
+    x = rnd(3, n, seed=n) * 1.7
+    x[1, : n // 3] = 0.25                                   # heavy duplicates
+    x[2] = x[2].abs() * 1e-3
+    ref = torch.quantile(x.abs(), 0.9, dim=-1)
+    assert torch.equal(O.abs_quantile(x, 0.9), ref), "oracle quantile must equal torch.quantile bit for bit"
+    out = ops.abs_quantile(x.to(dev), 0.9)
+    assert torch.equal(out.cpu(), ref), (out.cpu(), ref)
+
+
+@pytest.mark.parametrize("mode", ["ddim", "ddim_last", "ddpm"])
+def test_sampler_step(backend, mode):
+    dev = backend
+    b, shape = 2, (3, 4, 8, 8)
+    if big(dev):
+        shape = (3, 40, 32, 32)
+    x, eps, noise = rnd(b, *shape, seed=1), rnd(b, *shape, seed=2), rnd(b, *shape, seed=3)
+    sd = O.make_schedule(1000)
+    time = 640
+    cx, ce = sd["sqrt_recip_alphas_cumprod"][time], sd["sqrt_recipm1_alphas_cumprod"][time]
+    x0 = O.dynamic_threshold(cx * x - ce * eps)
+    if mode.startswith("ddim"):
+        time_next = 0 if mode == "ddim_last" else 630
+        a, an = sd["alphas_cumprod_prev"][time], sd["alphas_cumprod_prev"][time_next]
+        sigma = 1.0 * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+        c = ((1 - an) - sigma ** 2).sqrt()
+        coefs = [cx, ce, an.sqrt(), c, torch.tensor(0.0), sigma if time_next > 0 else torch.tensor(0.0)]
+        ref = x0 * an.sqrt() + c * eps + (sigma * noise if time_next > 0 else 0.0)
+    else:
+        p1, p2 = sd["posterior_mean_coef1"][time], sd["posterior_mean_coef2"][time]
+        std = (0.5 * sd["posterior_log_variance_clipped"][time]).exp()
+        coefs = [cx, ce, p1, torch.tensor(0.0), p2, std]
+        ref = p1 * x0 + p2 * x + std * noise
+    table = torch.zeros(3, 6)
+    table[1] = torch.stack([torch.as_tensor(v, dtype=torch.float32) for v in coefs])
+    step = torch.tensor([1], dtype=torch.int32).to(dev)
+    xd = x.clone().to(dev)
+    x0_out = torch.empty_like(xd)
+    ops.sampler_step(xd, eps.to(dev), noise.to(dev), table.to(dev), step, x0_out=x0_out)
+    assert int(step.cpu()[0]) == 2
+    assert_close(x0_out.cpu(), x0, 1e-5, "x0")
+    assert_close(xd.cpu(), ref, 1e-5, "sampler update")
+
+
+# ------------------------------------------------------------------------------------------
+def _flow_case(b, t, fs, seed, spread=1.3):
+    g = torch.Generator().manual_seed(seed)
+    ident = F.affine_grid(torch.eye(2, 3).unsqueeze(0), (1, 1, fs, fs), align_corners=True)  # (1,fs,fs,2)
+    flow = ident.unsqueeze(1).repeat(b, t, 1, 1, 1) + 0.25 * torch.randn(b, t, fs, fs, 2, generator=g)
+    flow = (flow * spread).clamp(-1.4, 1.4)
+    flow[0, 0, 0, 0] = torch.tensor([-1.0, -1.0])           # exact borders
+    flow[0, 0, 0, 1] = torch.tensor([1.0, 1.0])
+    pred = torch.empty(b, 3, t, fs, fs)
+    pred[:, 0] = flow[..., 0]
+    pred[:, 1] = flow[..., 1]
+    pred[:, 2] = torch.rand(b, t, fs, fs, generator=g) * 2 - 1
+    return pred.contiguous()
+
+
+@pytest.mark.parametrize("c,res,fs", [(8, 8, 8), (16, 16, 8), (4, 32, 8)])
+def test_warp_cl(backend, c, res, fs):
+    dev = backend
+    b, t = 2, 3
+    if big(dev):
+        c, res, fs = {8: (256, 32, 32), 16: (128, 64, 32), 4: (64, 128, 32)}[c]
+        t = 5
+    pred = _flow_case(b, t, fs, seed=c)
+    src = rnd(b, c, res, res, seed=1)
+    prev = rnd(b * t, c, res, res, seed=2)
+    occ = (pred[:, 2:3] + 1) * 0.5
+    refs = []
+    for bi in range(b):
+        for ti in range(t):
+            flow = pred[bi:bi + 1, :2, ti].permute(0, 2, 3, 1)
+            refs.append(O.apply_optical(prev[bi * t + ti:bi * t + ti + 1], src[bi:bi + 1], flow, occ[bi:bi + 1, :, ti]))
+    ref = torch.cat(refs, dim=0)
+    # the oracle's formula-level restatement must agree with ATen first
+    flow0 = pred[0:1, :2, 0].permute(0, 2, 3, 1)
+    if fs != res:
+        flow0 = F.interpolate(flow0.permute(0, 3, 1, 2), size=(res, res), mode="bilinear").permute(0, 2, 3, 1)
+    assert_close(O.grid_sample_bilinear_zeros(src[0:1], flow0), F.grid_sample(src[0:1], flow0, align_corners=False),
+                 1e-5, "oracle grid_sample vs ATen")
+    pd = pred.to(dev)
+    fsb, fst = 3 * t * fs * fs, fs * fs
+    out = ops.warp_cl(to_cl(src).to(dev), b, t, res, res, pd[:, 0], pd[:, 1], pd[:, 2], fs, fs, fsb, fst,
+                      prev=to_cl(prev).to(dev), occ_scale=0.5, occ_bias=0.5)
+    assert_close(from_cl(out.cpu(), b * t, res, res), ref, TOL, "warp_cl blend")
+    out2 = ops.warp_cl(to_cl(src).to(dev), b, t, res, res, pd[:, 0], pd[:, 1], pd[:, 2], fs, fs, fsb, fst,
+                       occ_scale=0.5, occ_bias=0.5)
+    ref2 = torch.cat([O.apply_optical(None, src[bi:bi + 1], pred[bi:bi + 1, :2, ti].permute(0, 2, 3, 1),
+                                      occ[bi:bi + 1, :, ti]) for bi in range(b) for ti in range(t)], dim=0)
+    assert_close(from_cl(out2.cpu(), b * t, res, res), ref2, TOL, "warp_cl mask only")
+
+
+@pytest.mark.parametrize("res,fs", [(16, 8), (8, 8)])
+def test_warp_planar(backend, res, fs):
+    dev = backend
+    b, t, c = 2, 3, 3
+    if big(dev):
+        res, fs, t = 128, 32, 40
+    pred = _flow_case(b, t, fs, seed=res)
+    src = torch.rand(b, c, res, res, generator=torch.Generator().manual_seed(5))
+    occ = (pred[:, 2:3] + 1) * 0.5
+    pd = pred.to(dev)
+    fsb, fst = 3 * t * fs * fs, fs * fs
+    # pure deform (Generator.deform_input)
+    out = ops.warp_planar(src.to(dev), t, pd[:, 0], pd[:, 1], None, fs, fs, fsb, fst)
+    ref = torch.stack([O.deform_input(src, pred[:, :2, ti].permute(0, 2, 3, 1)) for ti in range(t)], dim=2)
+    assert_close(out.cpu(), ref, TOL, "warp_planar deform")
+    # final blend with a CL 'prev' (sigmoid output of the last conv, ld = 4)
+    prev = torch.rand(b * t * res * res, 4, generator=torch.Generator().manual_seed(6))
+    prev_nchw = from_cl(prev[:, :3].contiguous(), b * t, res, res).reshape(b, t, 3, res, res)
+    ref2 = torch.stack([O.apply_optical(prev_nchw[:, ti], src, pred[:, :2, ti].permute(0, 2, 3, 1), occ[:, :, ti])
+                        for ti in range(t)], dim=2)
+    out2 = ops.warp_planar(src.to(dev), t, pd[:, 0], pd[:, 1], pd[:, 2], fs, fs, fsb, fst, prev=prev.to(dev),
+                           prev_is_cl=True, occ_scale=0.5, occ_bias=0.5)
+    assert_close(out2.cpu(), ref2, TOL, "warp_planar blend")
+
+
+# ------------------------------------------------------------------------------------------
+def test_elementwise_and_layout(backend):
+    dev = backend
+    n, c, h, w = 2, 32, 6, 6
+    x = rnd(n, c, h, w, seed=1)
+    a, bb = rnd(c, seed=2), rnd(c, seed=3)
+    out = ops.affine_act_cl(to_cl(x).to(dev), a.to(dev), bb.to(dev), ops.ACT_RELU)
+    assert_close(from_cl(out.cpu(), n, h, w), F.relu(x * a.view(1, c, 1, 1) + bb.view(1, c, 1, 1)), TOL, "affine")
+    out = ops.avgpool2_cl(to_cl(x).to(dev), n, h, w)
+    assert_close(from_cl(out.cpu(), n, h // 2, w // 2), F.avg_pool2d(x, 2), TOL, "avgpool")
+    y = rnd(n, 40, 7 * 5, seed=4)
+    cl = ops.planar_to_cl(y.to(dev), n, 40, 35)
+    assert torch.equal(cl.cpu(), y.permute(0, 2, 1).reshape(n * 35, 40))
+    back = ops.cl_to_planar(cl, n, 40, 35)
+    assert torch.equal(back.cpu(), y)
