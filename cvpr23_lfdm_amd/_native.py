@@ -60,14 +60,15 @@ _SIGNATURES = {
     "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
     "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
     "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
-    "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32, i32,
-                                        C.c_void_p, sz, stream_t]),
+    "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
+                                        f32, i32, C.c_void_p, sz, stream_t]),
     "lfdm_layernorm_cl_f32": (i32, [f32p, f32p, i64, i32, f32p, f32, stream_t]),
     "lfdm_attention_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, stream_t]),
     "lfdm_linear_attention_ws_bytes": (sz, [i32]),
     "lfdm_linear_attention_cl_f32": (i32, [f32p, f32p, i32, i32, C.c_void_p, sz, stream_t]),
-    "lfdm_linear_small_f32": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, stream_t]),
-    "lfdm_sinusoidal_f32": (i32, [C.c_void_p, i32, f32p, i32, i32, i32, stream_t]),
+    "lfdm_linear_small_f32": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    "lfdm_step_cond_f32": (i32, [f32p, f32p, C.c_void_p, f32p, i32, i32, stream_t]),
+    "lfdm_sinusoidal_f32": (i32, [C.c_void_p, i32, f32p, f32p, i32, i32, i32, stream_t]),
     "lfdm_conv_planar_in_cl_f32": (i32, [f32p, i32, i32, i32, i32, i32, i32, f32p, i32, i32, i32,
                                         f32p, f32p, f32p, i32, i32, stream_t]),
     "lfdm_heads_cl_to_planar_f32": (i32, [f32p, f32p, i32, f32p, f32p, f32p, f32p, f32p, i32, i32,
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "lfdm_sampler_ws_bytes": (sz, [i32, i64]),
     "lfdm_sampler_step_f32": (i32, [f32p, f32p, f32p, f32p, i32, i64, f32p, C.c_void_p, f32, i32,
                                    C.c_void_p, sz, stream_t]),
+    "lfdm_cfg_combine_f32": (i32, [f32p, f32p, f32, f32p, i64, stream_t]),
     "lfdm_abs_quantile_f32": (i32, [f32p, i32, i64, f32, f32p, C.c_void_p, sz, stream_t]),
     "lfdm_warp_cl_f32": (i32, [C.POINTER(WarpParams), stream_t]),
     "lfdm_warp_planar_f32": (i32, [C.POINTER(WarpParams), stream_t]),

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           int groups, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ scale_shift,
-                                                          float eps, float* __restrict__ ab) {
+                                                          int ss_ld, float eps, float* __restrict__ ab) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < groups) {
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     float bb = beta[c] - s_mean[g] * a;
     float aa = a;
     if (scale_shift) {
-      const float sc = scale_shift[(int64_t)b * 2 * channels + c] + 1.0f;
-      const float sh = scale_shift[(int64_t)b * 2 * channels + channels + c];
+      const float sc = scale_shift[(int64_t)b * ss_ld + c] + 1.0f;
+      const float sh = scale_shift[(int64_t)b * ss_ld + channels + c];
       aa = a * sc;
       bb = bb * sc + sh;
     }
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
                                                        float* __restrict__ out, int batch,
                                                        int pixels, int channels,
-                                                       const float* __restrict__ ab, int silu) {
+                                                       const float* __restrict__ ab, int silu,
+                                                       const float* __restrict__ residual) {
   const int c4n = channels >> 2;
   const int64_t per_b = (int64_t)pixels * c4n;
   const int64_t total = per_b * batch;
@@ -124,6 +125,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       y.y = siluf_(y.y);
       y.z = siluf_(y.z);
       y.w = siluf_(y.w);
+    }
+    if (residual) {
+      const float4 r = reinterpret_cast<const float4*>(residual)[i];
+      y.x += r.x;
+      y.y += r.y;
+      y.z += r.z;
+      y.w += r.w;
     }
     reinterpret_cast<float4*>(out)[i] = y;
   }
@@ -279,12 +287,12 @@ extern "C" size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels) {
 
 extern "C" int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels,
                                           int channels, int groups, const float* gamma,
-                                          const float* beta, const float* scale_shift, float eps,
-                                          int apply_silu, void* ws, size_t ws_bytes,
-                                          lfdm_stream_t stream_) {
+                                          const float* beta, const float* scale_shift, int ss_ld,
+                                          const float* residual, float eps, int apply_silu, void* ws,
+                                          size_t ws_bytes, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !out || !gamma || !beta || batch <= 0 || pixels <= 0 || channels <= 0 || groups <= 0 ||
-      groups > 64 || channels % groups != 0 || (channels / groups) % 4 != 0 ||
+      groups > 64 || (scale_shift && ss_ld < 2 * channels) || channels % groups != 0 || (channels / groups) % 4 != 0 ||
       256 % (channels / 4) != 0) {
     lfdm_set_error("groupnorm: unsupported shape (need C%G==0, (C/G)%4==0, 256%(C/4)==0)");
     return LFDM_EINVAL;
@@ -299,10 +307,10 @@ extern "C" int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch,
   LFDM_LAUNCH(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, pixels, channels,
               groups, partial);
   LFDM_LAUNCH(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const float*)partial, nchunk,
-              pixels, channels, groups, gamma, beta, scale_shift, eps, ab);
+              pixels, channels, groups, gamma, beta, scale_shift, ss_ld, eps, ab);
   const int64_t total = (int64_t)batch * pixels * (channels / 4);
   LFDM_LAUNCH(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, batch, pixels,
-              channels, (const float*)ab, apply_silu);
+              channels, (const float*)ab, apply_silu, residual);
   return lfdm_check_launch("groupnorm");
 }
 

@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
   }
 }
 
+// classifier-free guidance: out = null + (cond - null) * scale   (reference :525-526)
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ cond_eps,
+                                                          const float* __restrict__ null_eps,
+                                                          float scale, float* __restrict__ out,
+                                                          int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = null_eps[i];
+    out[i] = a + (cond_eps[i] - a) * scale;
+  }
+}
+
 __global__ void advance_step_kernel(int32_t* step_dev) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_dev += 1;
 }
@@ -213,6 +224,20 @@ int run_select(const float* v, int batch, int64_t n, Ranks rk, unsigned* hists, 
 }
 
 }  // namespace
+
+extern "C" int lfdm_cfg_combine_f32(const float* cond_eps, const float* null_eps, float scale,
+                                    float* out, int64_t n, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cond_eps || !null_eps || !out || n <= 0) {
+    lfdm_set_error("cfg_combine: bad arguments");
+    return LFDM_EINVAL;
+  }
+  int64_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  LFDM_LAUNCH(cfg_combine_kernel, dim3((unsigned)nb), dim3(256), 0, stream, cond_eps, null_eps, scale,
+              out, n);
+  return lfdm_check_launch("cfg_combine");
+}
 
 extern "C" size_t lfdm_sampler_ws_bytes(int batch, int64_t n) {
   return (size_t)batch * HIST_PER_SAMPLE * sizeof(unsigned) + (size_t)batch * (size_t)n * sizeof(float);

@@ -19,13 +19,14 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ y, int k, int n,
-                                                           int ldx, int ldy, int act_in, int act_out) {
+                                                           int ldx, int ldw, int ldy, int act_in,
+                                                           int act_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 4 + wave;
   const int b = blockIdx.y;
   if (col >= n) return;
   const float* xr = x + (int64_t)b * ldx;
-  const float* wr = w + (int64_t)col * k;
+  const float* wr = w + (int64_t)col * ldw;
   float s = 0.f;
   for (int i = lane; i < k; i += 64) s = fmaf(small_act(xr[i], act_in), wr[i], s);
   s = wave_sum(s);
@@ -36,15 +37,13 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(64) void sinusoidal_kernel(const int32_t* __restrict__ t_dev,
-                                                        int t_stride, float* __restrict__ out,
-                                                        int dim, int ldo) {
+                                                        int t_stride, const float* __restrict__ freqs,
+                                                        float* __restrict__ out, int dim, int ldo) {
   const int b = blockIdx.x;
   const int half = dim / 2;
   const float tt = (float)t_dev[(int64_t)b * t_stride];
-  const float step = -(float)(9.210340371976184 / (double)(half - 1));  // -ln(1e4)/(half-1)
   for (int i = threadIdx.x; i < half; i += 64) {
-    const float f = expf((float)i * step);
-    const float a = tt * f;
+    const float a = tt * freqs[i];
     out[(int64_t)b * ldo + i] = sinf(a);
     out[(int64_t)b * ldo + half + i] = cosf(a);
   }
@@ -152,29 +151,57 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_
   ob[2 * fhw] = s2 + b_occ[0];
 }
 
+// out[b][i] = step_table[*step][i] + batch_base[b][i]
+__global__ __launch_bounds__(256) void step_cond_kernel(const float* __restrict__ step_table,
+                                                        const float* __restrict__ batch_base,
+                                                        const int32_t* __restrict__ step_dev,
+                                                        float* __restrict__ out, int batch, int n) {
+  const float* row = step_table + (int64_t)(*step_dev) * n;
+  const int64_t total = (int64_t)batch * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % n);
+    out[i] = row[c] + batch_base[i];
+  }
+}
+
 }  // namespace
 
-extern "C" int lfdm_linear_small_f32(const float* x, const float* w, const float* bias, float* y,
-                                     int batch, int k, int n, int ldx, int ldy, int act_in,
-                                     int act_out, lfdm_stream_t stream_) {
+extern "C" int lfdm_step_cond_f32(const float* step_table, const float* batch_base,
+                                  const int32_t* step_dev, float* out, int batch, int n,
+                                  lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !w || !y || batch <= 0 || k <= 0 || n <= 0 || ldx < k || ldy < n) {
+  if (!step_table || !batch_base || !step_dev || !out || batch <= 0 || n <= 0) {
+    lfdm_set_error("step_cond: bad arguments");
+    return LFDM_EINVAL;
+  }
+  int64_t nb = ((int64_t)batch * n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  LFDM_LAUNCH(step_cond_kernel, dim3((unsigned)nb), dim3(256), 0, stream, step_table, batch_base,
+              step_dev, out, batch, n);
+  return lfdm_check_launch("step_cond");
+}
+
+extern "C" int lfdm_linear_small_f32(const float* x, const float* w, const float* bias, float* y,
+                                     int batch, int k, int n, int ldx, int ldw, int ldy,
+                                     int act_in, int act_out, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !w || !y || batch <= 0 || k <= 0 || n <= 0 || ldx < k || ldw < k || ldy < n) {
     lfdm_set_error("linear_small: bad arguments");
     return LFDM_EINVAL;
   }
   LFDM_LAUNCH(linear_small_kernel, dim3((n + 3) / 4, batch), dim3(256), 0, stream, x, w, bias, y, k,
-              n, ldx, ldy, act_in, act_out);
+              n, ldx, ldw, ldy, act_in, act_out);
   return lfdm_check_launch("linear_small");
 }
 
-extern "C" int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, float* out, int batch,
-                                   int dim, int ldo, lfdm_stream_t stream_) {
+extern "C" int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, const float* freqs,
+                                   float* out, int batch, int dim, int ldo, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!t_dev || !out || batch <= 0 || dim < 4 || (dim & 1) || ldo < dim) {
+  if (!t_dev || !freqs || !out || batch <= 0 || dim < 4 || (dim & 1) || ldo < dim) {
     lfdm_set_error("sinusoidal: bad arguments");
     return LFDM_EINVAL;
   }
-  LFDM_LAUNCH(sinusoidal_kernel, dim3(batch), dim3(64), 0, stream, t_dev, t_stride, out, dim, ldo);
+  LFDM_LAUNCH(sinusoidal_kernel, dim3(batch), dim3(64), 0, stream, t_dev, t_stride, freqs, out, dim, ldo);
   return lfdm_check_launch("sinusoidal");
 }
 

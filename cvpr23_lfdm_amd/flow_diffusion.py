@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference pipeline wrapper `FlowDiffusion`
+(DM/modules/video_flow_diffusion_model.py:17-253): same constructor keywords, attributes,
+setters and `sample_one_video`, so demo_*.py / test_*.py style callers can switch over.
+The sampling path (a28) is fully native: LFAE encoder once per video -> hipGraph-replayed
+DDIM/DDPM loop -> batched LFAE decode of all T frames.
+The DM *training* step (a29: pseudo-GT LFAE forward + UNet backward + Adam) is the next row to
+be built; `forward()` / `optimize_parameters()` say so loudly instead of
+silently running something else.
+"""
+import torch
+import yaml
+from torch import nn
+
+from .diffusion import GaussianDiffusion
+from .generator import Generator
+from .params import ParamTree, bg_predictor_spec, build_tree, region_predictor_spec
+from .unet import Unet3D
+
+
+class RegionPredictor(ParamTree):
+    """Parameter holder (checkpoint compatibility) for LFAE/modules/region_predictor.py; only the
+    training pseudo-GT path evaluates it (not built yet)."""
+
+    def __init__(self, num_regions, num_channels, estimate_affine=True, **params):
+        super().__init__()
+        build_tree(self, region_predictor_spec(num_regions=num_regions, num_channels=num_channels, **params))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("RegionPredictor.forward: training pseudo-GT path, SURVEY.md 8(f).1")
+
+
+class BGMotionPredictor(ParamTree):
+    """Parameter holder for LFAE/modules/bg_motion_predictor.py."""
+
+    def __init__(self, num_channels, **params):
+        super().__init__()
+        build_tree(self, bg_predictor_spec(num_channels=num_channels, **params))
+        with torch.no_grad():   # reference initialises fc to the identity affine (bg_motion_predictor.py:33-39)
+            self.get("fc.bias").copy_(torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("BGMotionPredictor.forward: training pseudo-GT path, SURVEY.md 8(f).1")
+
+
+class FlowDiffusion(nn.Module):
+    def __init__(self, img_size=32, num_frames=40, sampling_timesteps=250, null_cond_prob=0.1,
+                 ddim_sampling_eta=1., timesteps=1000, dim_mults=(1, 2, 4, 8), lr=1e-4,
+                 adam_betas=(0.9, 0.99), is_train=True, only_use_flow=True, use_residual_flow=False,
+                 learn_null_cond=False, use_deconv=True, padding_mode="zeros", pretrained_pth="",
+                 config_pth=""):
+        super().__init__()
+        self.use_residual_flow = use_residual_flow
+        self.only_use_flow = only_use_flow
+        checkpoint = torch.load(pretrained_pth, map_location="cpu") if pretrained_pth != "" else None
+        with open(config_pth) as f:
+            mp = yaml.safe_load(f)['model_params']
+        self.generator = Generator(num_regions=mp['num_regions'], num_channels=mp['num_channels'],
+                                   revert_axis_swap=mp['revert_axis_swap'], **mp['generator_params'])
+        self.region_predictor = RegionPredictor(num_regions=mp['num_regions'], num_channels=mp['num_channels'],
+                                                estimate_affine=mp['estimate_affine'],
+                                                **mp['region_predictor_params'])
+        self.bg_predictor = BGMotionPredictor(num_channels=mp['num_channels'], **mp['bg_predictor_params'])
+        for name in ('generator', 'region_predictor', 'bg_predictor'):
+            net = getattr(self, name)
+            if checkpoint is not None:
+                net.load_state_dict(checkpoint[name])
+                net.eval()
+                self.set_requires_grad(net, False)
+        self.unet = Unet3D(dim=64, channels=3 + 256, out_grid_dim=2, out_conf_dim=1, dim_mults=dim_mults,
+                           use_bert_text_cond=True, learn_null_cond=learn_null_cond,
+                           use_final_activation=False, use_deconv=use_deconv, padding_mode=padding_mode)
+        self.diffusion = GaussianDiffusion(self.unet, image_size=img_size, num_frames=num_frames,
+                                           sampling_timesteps=sampling_timesteps, timesteps=timesteps,
+                                           loss_type='l2', use_dynamic_thres=True,
+                                           null_cond_prob=null_cond_prob, ddim_sampling_eta=ddim_sampling_eta)
+        for attr in ('ref_img', 'ref_img_fea', 'real_vid', 'real_out_vid', 'real_warped_vid', 'real_vid_grid',
+                     'real_vid_conf', 'fake_out_vid', 'fake_warped_vid', 'fake_vid_grid', 'fake_vid_conf',
+                     'sample_out_vid', 'sample_warped_vid', 'sample_vid_grid', 'sample_vid_conf'):
+            setattr(self, attr, None)
+        self.is_train = is_train
+        if self.is_train:
+            self.unet.train()
+            self.diffusion.train()
+            self.lr = lr
+            self.loss = torch.tensor(0.0)
+            self.rec_loss = torch.tensor(0.0)
+            self.rec_warp_loss = torch.tensor(0.0)
+            self.optimizer_diff = torch.optim.Adam(self.diffusion.parameters(), lr=lr, betas=adam_betas)
+
+    # ------------------------------------------------------------------ sampling (a28)
+    def sample_one_video(self, cond_scale):
+        """Reference :190-216.  Results land in sample_vid_grid (B,2,T,S,S), sample_vid_conf (B,1,T,S,S),
+        sample_out_vid / sample_warped_vid (B,3,T,H,W)."""
+        gen = self.generator
+        with torch.no_grad():
+            img = self.sample_img.float().contiguous()
+            skips = gen.encode(img)                                   # encoder ONCE per video
+            b, _, h, w = img.shape
+            d = 2 ** gen.num_down_blocks
+            fea_cl = skips[-1]
+            fea = gen.compute_fea_from_skips(skips, b, h // d, w // d)
+            self.sample_img_fea = fea
+            pred = self.diffusion.sample(fea, cond=self.sample_text, batch_size=1, cond_scale=cond_scale)
+            nf, s = pred.shape[2], pred.shape[3]
+            if self.use_residual_flow:
+                grid = pred[:, :2] + self.get_grid(b, nf, s, s, normalize=True).to(pred.device)
+                maps = torch.cat((grid, pred[:, 2:3]), dim=1).contiguous()
+            else:
+                maps = pred
+            self.sample_vid_grid = maps[:, :2]
+            self.sample_vid_conf = (pred[:, 2, :, :, :].unsqueeze(dim=1) + 1) * 0.5
+            out, warped = gen.decode_video(img, skips, maps[:, 0], maps[:, 1], maps[:, 2], nf, s, s,
+                                           3 * nf * s * s, s * s, occ_scale=0.5, occ_bias=0.5)
+            self.sample_out_vid = out
+            self.sample_warped_vid = warped
+
+    def set_sample_input(self, sample_img, sample_text):
+        dev = next(self.unet.parameters()).device
+        self.sample_img = sample_img.to(dev)
+        self.sample_text = sample_text
+
+    # ------------------------------------------------------------------ training (a29) - next row
+    def set_train_input(self, ref_img, real_vid, ref_text):
+        dev = next(self.unet.parameters()).device
+        self.ref_img = ref_img.to(dev)
+        self.real_vid = real_vid.to(dev)
+        self.ref_text = ref_text
+
+    def forward(self):
+        raise NotImplementedError(
+            "FlowDiffusion.forward (DM training step: pseudo-GT LFAE forward + UNet loss) is not built yet; "
+            "SURVEY.md 8(f).1 / DESIGN.md 'what comes next'")
+
+    def optimize_parameters(self):
+        self.forward()
+
+    # ------------------------------------------------------------------ misc (reference :227-253)
+    def print_learning_rate(self):
+        lr = self.optimizer_diff.param_groups[0]['lr']
+        assert lr > 0
+        print('lr= %.7f' % lr)
+
+    def get_grid(self, b, nf, H, W, normalize=True):
+        """linspace(-1,1) identity grid in (x, y) order, (B, 2, nf, H, W) (:232-240)."""
+        ys = torch.linspace(-1, 1, H) if normalize else torch.arange(0, H).float()
+        xs = torch.linspace(-1, 1, W) if normalize else torch.arange(0, W).float()
+        gy, gx = ys.view(H, 1).expand(H, W), xs.view(1, W).expand(H, W)
+        grid = torch.stack((gx, gy), dim=0).float()
+        return grid.view(1, 2, 1, H, W).repeat(b, 1, nf, 1, 1)
+
+    def set_requires_grad(self, nets, requires_grad=False):
+        if not isinstance(nets, list):
+            nets = [nets]
+        for net in nets:
+            if net is not None:
+                for p in net.parameters():
+                    p.requires_grad = requires_grad

@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference LFAE `Generator` (LFAE/modules/generator.py:17-166): same
+constructor, same state-dict keys, same `compute_fea` / `forward_with_flow` signatures and outputs.
+
+MI355X-first re-plan of the decode step:
+  * the source-image encoder is evaluated ONCE per video (the reference re-runs it for each of the
+    T frames, generator.py:137-141 - the source image does not depend on the frame);
+  * all T frames of a video batch are decoded together (N = B*T images per kernel launch) on
+    channels-last rows, with eval-BatchNorm folded into the adjacent convolution;
+  * every `deform_input` + `apply_optical` pair is one fused warp kernel that reads the 32x32 flow /
+    occlusion prediction of the diffusion model in place (no up-sampled grid is materialised).
+"""
+import torch
+
+from . import ops
+from .params import ParamTree, build_tree, generator_spec
+
+BN_EPS = 1e-5
+
+
+class Generator(ParamTree):
+    def __init__(self, num_channels, num_regions, block_expansion, max_features, num_down_blocks,
+                 num_bottleneck_blocks, pixelwise_flow_predictor_params=None, skips=False,
+                 revert_axis_swap=True):
+        super().__init__()
+        fp = pixelwise_flow_predictor_params or {}
+        build_tree(self, generator_spec(
+            num_channels=num_channels, block_expansion=block_expansion, max_features=max_features,
+            num_down_blocks=num_down_blocks, num_bottleneck_blocks=num_bottleneck_blocks,
+            num_regions=num_regions, with_flow_predictor=pixelwise_flow_predictor_params is not None,
+            fp_block_expansion=fp.get("block_expansion", 64), fp_max_features=fp.get("max_features", 1024),
+            fp_num_blocks=fp.get("num_blocks", 5)))
+        if not skips:
+            raise NotImplementedError("Generator(skips=False): every LFDM config sets skips: True")
+        self.num_channels = num_channels
+        self.num_down_blocks = num_down_blocks
+        self.num_bottleneck_blocks = num_bottleneck_blocks
+        self.block_expansion = block_expansion
+        self.max_features = max_features
+        self.skips = skips
+        self.frames_per_chunk = 160      # decode working set bound (images per launch)
+        self._pk = None
+        self._pk_sig = None
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._pk = None
+        self._bufs = {}
+        return out
+
+    def _buf(self, name, rows, ch):
+        need = rows * ch
+        cur = self._bufs.get(name)
+        dev = next(self.parameters()).device
+        if cur is None or cur.numel() < need or cur.device != dev:
+            cur = torch.empty(need, dtype=torch.float32, device=dev)
+            self._bufs[name] = cur
+        return cur[:need].view(rows, ch)
+
+    def packed(self):
+        sig = (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
+               next(self.parameters()).device)
+        if self._pk is None or self._pk_sig != sig:
+            with torch.no_grad():
+                self._pk = self._pack()
+            self._pk_sig = sig
+        return self._pk
+
+    def _pack(self):
+        g = lambda k: self.get(k).detach().float()
+        pk = {}
+
+        def bn_affine(prefix):
+            a = g(prefix + "weight") / torch.sqrt(g(prefix + "running_var") + BN_EPS)
+            return a, g(prefix + "bias") - g(prefix + "running_mean") * a
+
+        def conv_bn(cprefix, nprefix):
+            """conv followed by eval BatchNorm -> one conv (util.py:107-150)."""
+            a, b = bn_affine(nprefix)
+            w = g(cprefix + "weight") * a.view(-1, 1, 1, 1)
+            return w.contiguous(), (g(cprefix + "bias") * a + b).contiguous()
+
+        w, b = conv_bn("first.conv.", "first.norm.")
+        pk["first.w"], pk["first.b"] = ops.pack_planar_in_weight(w), b
+        for i in range(self.num_down_blocks):
+            w, b = conv_bn("down_blocks.%d.conv." % i, "down_blocks.%d.norm." % i)
+            pk["down%d.w" % i], pk["down%d.b" % i] = ops.pack_conv_weight(w), b
+        for i in range(self.num_down_blocks):
+            w, b = conv_bn("up_blocks.%d.conv." % i, "up_blocks.%d.norm." % i)
+            pk["up%d.w" % i], pk["up%d.b" % i] = ops.pack_conv_weight(w), b
+        for i in range(self.num_bottleneck_blocks):
+            p = "bottleneck.r%d." % i
+            a1, b1 = bn_affine(p + "norm1.")                 # pre-activation BN + ReLU (util.py:85-86)
+            pk["r%d.a1" % i], pk["r%d.b1" % i] = a1.contiguous(), b1.contiguous()
+            w, b = conv_bn(p + "conv1.", p + "norm2.")       # conv1 -> norm2 folded, ReLU in the epilogue
+            pk["r%d.w1" % i], pk["r%d.bb1" % i] = ops.pack_conv_weight(w), b
+            pk["r%d.w2" % i] = ops.pack_conv_weight(g(p + "conv2.weight").contiguous())
+            pk["r%d.b2" % i] = g(p + "conv2.bias").contiguous()
+        pk["final.w"] = ops.pack_conv_weight(g("final.weight").contiguous())
+        pk["final.b"] = g("final.bias").contiguous()
+        return pk
+
+    def _feat(self, i):
+        return min(self.max_features, self.block_expansion * (2 ** i))
+
+    # ------------------------------------------------------------------ encoder (once per video)
+    def encode(self, source_image):
+        """first + down blocks (generator.py:137-141): returns CL skips
+        [(B*H*W, 64), (B*H/2*W/2, 128), (B*H/4*W/4, 256)] for a 128^2 MUG config."""
+        pk = self.packed()
+        img = source_image.float().contiguous()
+        b, c, h, w = img.shape
+        out = ops.conv_planar_in_cl(img, b, c, c, 1, h, w, pk["first.w"], 7, 7, self._feat(0), bias=pk["first.b"],
+                                    act=ops.ACT_RELU, out=self._buf("enc0", b * h * w, self._feat(0)))
+        skips = [out]
+        res_h, res_w = h, w
+        for i in range(self.num_down_blocks):
+            co = self._feat(i + 1)
+            y = ops.conv2d_cl(out, pk["down%d.w" % i], co, 3, 3, b, res_h, res_w, bias=pk["down%d.b" % i],
+                              act=ops.ACT_RELU, out=self._buf("enc.t", b * res_h * res_w, co))
+            res_h, res_w = res_h // 2, res_w // 2
+            out = ops.avgpool2_cl(y, b, res_h * 2, res_w * 2, out=self._buf("enc%d" % (i + 1), b * res_h * res_w, co))
+            skips.append(out)
+        return skips
+
+    def compute_fea_from_skips(self, skips, b, lh, lw):
+        co = self._feat(self.num_down_blocks)
+        return ops.cl_to_planar(skips[-1], b, co, lh * lw).view(b, co, lh, lw)
+
+    def compute_fea(self, source_image):
+        """Reference :130-134 -> planar (B, 256, H/4, W/4)."""
+        with torch.no_grad():
+            skips = self.encode(source_image)
+            b, _, h, w = source_image.shape
+            d = 2 ** self.num_down_blocks
+            return self.compute_fea_from_skips(skips, b, h // d, w // d)
+
+    # ------------------------------------------------------------------ decode
+    def decode_video(self, source_image, skips, flow_x, flow_y, occ, frames, fh, fw, fsb, fst,
+                     occ_scale=1.0, occ_bias=0.0):
+        """All frames of a video batch: returns planar (prediction, deformed) of shape (B, C, T, H, W).
+        flow_x/flow_y/occ are base tensors of low-res maps addressed b*fsb + t*fst + y*fw + x."""
+        pk = self.packed()
+        img = source_image.float().contiguous()
+        b, c, h, w = img.shape
+        n = b * frames
+        wk = dict(fh=fh, fw=fw, fsb=fsb, fst=fst, occ_scale=occ_scale, occ_bias=occ_bias)
+        deformed = ops.warp_planar(img, frames, flow_x, flow_y, None, fh, fw, fsb, fst)
+        d = 2 ** self.num_down_blocks
+        lh, lw = h // d, w // d
+        cb = self._feat(self.num_down_blocks)
+        # bottleneck input: warped + masked latent (generator.py:149)
+        out = ops.warp_cl(skips[-1], b, frames, lh, lw, flow_x, flow_y, occ, out=self._buf("dec.x", n * lh * lw, cb), **wk)
+        for i in range(self.num_bottleneck_blocks):          # ResBlock2d (util.py:84-92)
+            t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
+                                   out=self._buf("dec.t0", n * lh * lw, cb))
+            t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
+                               out=self._buf("dec.t1", n * lh * lw, cb))
+            out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
+                                out=out)
+        res_h, res_w = lh, lw
+        for i in range(self.num_down_blocks):                # apply_optical(skip, prev) + UpBlock2d (:152-155)
+            skip = skips[-(i + 1)]
+            ci = skip.shape[1]
+            blended = ops.warp_cl(skip, b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
+                                  out=self._buf("dec.w%d" % i, n * res_h * res_w, ci), **wk)
+            co = self._feat(self.num_down_blocks - i - 1)
+            out = ops.conv2d_cl(blended, pk["up%d.w" % i], co, 3, 3, n, res_h, res_w, bias=pk["up%d.b" % i],
+                                upsample=True, act=ops.ACT_RELU,
+                                out=self._buf("dec.u%d" % i, n * 4 * res_h * res_w, co))
+            res_h, res_w = res_h * 2, res_w * 2
+        blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
+                              out=self._buf("dec.wf", n * res_h * res_w, skips[0].shape[1]), **wk)
+        rgb = ops.conv2d_cl(blended, pk["final.w"], c, 7, 7, n, res_h, res_w, bias=pk["final.b"],
+                            act=ops.ACT_SIGMOID, out=self._buf("dec.rgb", n * res_h * res_w, 4)[:, :c])
+        prediction = ops.warp_planar(img, frames, flow_x, flow_y, occ, fh, fw, fsb, fst, prev=rgb, prev_is_cl=True,
+                                     occ_scale=occ_scale, occ_bias=occ_bias)
+        return prediction, deformed
+
+    def forward_with_flow(self, source_image, optical_flow, occlusion_map):
+        """Reference :136-166.  optical_flow (B, h, w, 2) absolute sampling grid, occlusion_map
+        (B, 1, h, w) in [0,1]  ->  {'prediction', 'deformed'} (B, C, H, W)."""
+        with torch.no_grad():
+            b = source_image.shape[0]
+            fh, fw = optical_flow.shape[1], optical_flow.shape[2]
+            maps = torch.empty(b, 3, fh, fw, dtype=torch.float32, device=source_image.device)
+            maps[:, 0] = optical_flow[..., 0]
+            maps[:, 1] = optical_flow[..., 1]
+            maps[:, 2] = occlusion_map[:, 0]
+            skips = self.encode(source_image)
+            pred, deformed = self.decode_video(source_image, skips, maps[:, 0], maps[:, 1], maps[:, 2], 1, fh, fw,
+                                               3 * fh * fw, 0)
+            return {"prediction": pred[:, :, 0], "deformed": deformed[:, :, 0]}
+
+    def forward(self, source_image, driving_region_params, source_region_params, bg_params=None):
+        raise NotImplementedError(
+            "Generator.forward (pseudo ground-truth flow for DM training, needs PixelwiseFlowPredictor) is "
+            "the next widening step (SURVEY.md 8(f).1); sampling uses forward_with_flow / decode_video")

@@ -148,19 +148,21 @@ def deconv4x4s2_cl(src, packs, cout, n_img, hi, wi, *, bias=None, out=None):
     return out
 
 
-def groupnorm_silu_cl(x, batch, gamma, beta, *, groups=8, scale_shift=None, eps=1e-5, silu=True,
-                      out=None, ws=None):
+def groupnorm_silu_cl(x, batch, gamma, beta, *, groups=8, scale_shift=None, residual=None, eps=1e-5,
+                      silu=True, out=None, ws=None):
     lib = _lib()
     rows, ch = x.shape
     pixels = rows // batch
-    _chk(lib, x, gamma, beta, scale_shift, out, ws)
+    _chk(lib, x, gamma, beta, scale_shift, residual, out, ws)
     if out is None:
         out = torch.empty_like(x)
     need = lib.lfdm_groupnorm_ws_bytes(batch, pixels, ch)
     if ws is None:
         ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     lib.check(lib.lfdm_groupnorm_silu_cl_f32(_p(x), _p(out), batch, pixels, ch, groups, _p(gamma),
-                                             _p(beta), _p(scale_shift), eps, int(silu), _p(ws),
+                                             _p(beta), _p(scale_shift),
+                                             scale_shift.stride(0) if scale_shift is not None else 0,
+                                             _p(residual), eps, int(silu), _p(ws),
                                              ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_silu_cl_f32")
     return out
 
@@ -205,21 +207,38 @@ def linear_small(x, w, bias=None, *, act_in=ACT_NONE, act_out=ACT_NONE, out=None
     _chk(lib, x, w, bias, out)
     batch, k = x.shape
     n = w.shape[0]
-    assert w.shape[1] == k and w.is_contiguous()
+    assert w.shape[1] == k and w.stride(1) == 1
     if out is None:
         out = torch.empty(batch, n, dtype=torch.float32, device=x.device)
     lib.check(lib.lfdm_linear_small_f32(_p(x), _p(w), _p(bias), _p(out), batch, k, n, x.stride(0),
-                                        out.stride(0), act_in, act_out, _stream(lib)), "lfdm_linear_small_f32")
+                                        w.stride(0), out.stride(0), act_in, act_out, _stream(lib)),
+              "lfdm_linear_small_f32")
     return out
 
 
-def sinusoidal(t_dev, batch, dim, *, t_stride=1, out=None):
+def step_cond(step_table, batch_base, step_dev, out):
     lib = _lib()
-    _chk(lib, t_dev, out)
+    _chk(lib, step_table, batch_base, step_dev, out)
+    batch, n = batch_base.shape
+    lib.check(lib.lfdm_step_cond_f32(_p(step_table), _p(batch_base), _p(step_dev), _p(out), batch, n,
+                                     _stream(lib)), "lfdm_step_cond_f32")
+    return out
+
+
+def sinusoidal_freqs(dim, device):
+    """fp32 frequency table, computed with the reference's expression (video_flow_diffusion.py:148-150)."""
+    import math
+    half = dim // 2
+    return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(device)
+
+
+def sinusoidal(t_dev, freqs, batch, dim, *, t_stride=1, out=None):
+    lib = _lib()
+    _chk(lib, t_dev, freqs, out)
     assert t_dev.dtype == torch.int32
     if out is None:
         out = torch.empty(batch, dim, dtype=torch.float32, device=t_dev.device)
-    lib.check(lib.lfdm_sinusoidal_f32(_p(t_dev), t_stride, _p(out), batch, dim, out.stride(0),
+    lib.check(lib.lfdm_sinusoidal_f32(_p(t_dev), t_stride, _p(freqs), _p(out), batch, dim, out.stride(0),
                                       _stream(lib)), "lfdm_sinusoidal_f32")
     return out
 
@@ -264,6 +283,14 @@ def sampler_step(x, eps, noise, coef, step_dev, *, quantile=0.9, advance=True, x
                                         _p(step_dev), quantile, int(advance), _p(ws), ws.numel() * 4,
                                         _stream(lib)), "lfdm_sampler_step_f32")
     return x
+
+
+def cfg_combine(cond_eps, null_eps, scale, out):
+    lib = _lib()
+    _chk(lib, cond_eps, null_eps, out)
+    lib.check(lib.lfdm_cfg_combine_f32(_p(cond_eps), _p(null_eps), float(scale), _p(out), cond_eps.numel(),
+                                       _stream(lib)), "lfdm_cfg_combine_f32")
+    return out
 
 
 def abs_quantile(x, quantile=0.9, ws=None):

@@ -1,0 +1,423 @@
+"""Host-side mirror of the reference `Unet3D` (DM/modules/video_flow_diffusion.py:368-588):
+same constructor arguments, same state-dict keys, same `forward` / `forward_with_cond_scale`
+signatures - but the forward pass is a static launch plan over the HIP kernels of
+liblfdm_hip.so (channels-last activations, weights repacked once, skip concatenation /
+residual adds / GroupNorm affine fused into kernel arguments).  No torch compute op runs on the
+activation path; torch only provides device memory and the stream.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .params import ParamTree, build_tree, unet_spec
+
+BERT_MODEL_DIM = 768
+
+
+def prob_mask_like(shape, prob, device):
+    """Reference prob_mask_like (:55-61): consumes the RNG only for 0 < prob < 1."""
+    if prob == 1:
+        return torch.ones(shape, device=device, dtype=torch.bool)
+    if prob == 0:
+        return torch.zeros(shape, device=device, dtype=torch.bool)
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
+def rel_pos_bias_table(emb_weight, n, num_buckets=32, max_distance=32):
+    """RelativePositionBias (:72-111) evaluated once per (weights, n): (heads, n, n).
+    Input independent, so it is precomputed at plan time instead of on every forward."""
+    import math
+    dev = emb_weight.device
+    pos = torch.arange(n, device=dev)
+    rel = pos[None, :] - pos[:, None]
+    neg = -rel
+    half = num_buckets // 2
+    ret = (neg < 0).long() * half
+    a = neg.abs()
+    max_exact = half // 2
+    large = max_exact + (torch.log(a.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (half - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, half - 1))
+    bucket = ret + torch.where(a < max_exact, a, large)
+    return emb_weight[bucket].permute(2, 0, 1).contiguous()
+
+
+class Unet3D(ParamTree):
+    def __init__(self, dim, cond_dim=None, out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2, 4, 8),
+                 channels=3, attn_heads=8, attn_dim_head=32, use_bert_text_cond=False, init_dim=None,
+                 init_kernel_size=7, use_sparse_linear_attn=True, resnet_groups=8,
+                 use_final_activation=False, learn_null_cond=False, use_deconv=True,
+                 padding_mode="zeros"):
+        super().__init__()
+        if attn_heads != 8 or attn_dim_head != 32 or resnet_groups != 8 or not use_sparse_linear_attn \
+                or use_final_activation or init_dim not in (None, dim) or init_kernel_size != 7:
+            raise NotImplementedError("Unet3D: only the configuration the LFDM scripts use is built "
+                                      "(heads=8, dim_head=32, groups=8, sparse linear attention)")
+        self.null_cond_mask = None
+        self.channels = channels
+        self.dim = dim
+        self.dim_mults = tuple(dim_mults)
+        self.out_grid_dim, self.out_conf_dim = out_grid_dim, out_conf_dim
+        self.has_cond = (cond_dim is not None) or use_bert_text_cond
+        self.cond_dim = BERT_MODEL_DIM if use_bert_text_cond else cond_dim
+        self.learn_null_cond = learn_null_cond
+        self.use_deconv = use_deconv
+        self.padding_mode = padding_mode
+        if not use_deconv and padding_mode not in ("zeros", "reflect"):
+            raise NotImplementedError("padding_mode %r" % padding_mode)
+        spec = unet_spec(dim=dim, dim_mults=self.dim_mults, channels=channels, out_grid_dim=out_grid_dim,
+                         out_conf_dim=out_conf_dim, cond_dim=self.cond_dim or 0,
+                         learn_null_cond=learn_null_cond and self.has_cond, use_deconv=use_deconv)
+        build_tree(self, spec)
+        if self.has_cond and not learn_null_cond:
+            # a plain tensor in the reference too (not in the state dict, :440)
+            self.null_cond_emb = torch.zeros(1, self.cond_dim)
+        self._pk = None
+        self._pk_sig = None
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if isinstance(getattr(self, "null_cond_emb", None), torch.Tensor) and not isinstance(
+                self.null_cond_emb, nn.Parameter):
+            self.null_cond_emb = fn(self.null_cond_emb)
+        self._pk = None
+        self._bufs = {}
+        return out
+
+    def _signature(self):
+        sig = 0
+        for p in self.parameters():
+            sig += p._version
+        return (sig, next(self.parameters()).device)
+
+    def _buf(self, name, rows, ch, dtype=torch.float32):
+        need = rows * ch
+        cur = self._bufs.get(name)
+        dev = next(self.parameters()).device
+        if cur is None or cur.numel() < need or cur.device != dev or cur.dtype != dtype:
+            cur = torch.empty(need, dtype=dtype, device=dev)
+            self._bufs[name] = cur
+        return cur[:need].view(rows, ch)
+
+    @property
+    def levels(self):
+        dims = [self.dim] + [self.dim * m for m in self.dim_mults]
+        return list(zip(dims[:-1], dims[1:]))
+
+    # ------------------------------------------------------------------ weight packing
+    def packed(self):
+        sig = self._signature()
+        if self._pk is not None and self._pk_sig == sig:
+            return self._pk
+        with torch.no_grad():
+            self._pk = self._pack()
+        self._pk_sig = sig
+        return self._pk
+
+    def _pack(self):
+        g = lambda k: self.get(k).detach().float().contiguous()
+        pk = {}
+
+        def block(prefix):
+            pk[prefix + "proj.w"] = ops.pack_conv_weight(g(prefix + "proj.weight"))
+            pk[prefix + "proj.b"] = g(prefix + "proj.bias")
+            pk[prefix + "norm.w"] = g(prefix + "norm.weight")
+            pk[prefix + "norm.b"] = g(prefix + "norm.bias")
+
+        cond_w, cond_b, off = [], [], 0
+
+        def resblock(prefix):
+            nonlocal off
+            block(prefix + "block1.")
+            block(prefix + "block2.")
+            if self.has(prefix + "res_conv.weight"):
+                pk[prefix + "res.w"] = ops.pack_conv_weight(g(prefix + "res_conv.weight"))
+                pk[prefix + "res.b"] = g(prefix + "res_conv.bias")
+            if self.has(prefix + "mlp.1.weight"):
+                w = g(prefix + "mlp.1.weight")
+                cond_w.append(w)
+                cond_b.append(g(prefix + "mlp.1.bias"))
+                pk[prefix + "ss_off"] = off
+                off += w.shape[0]
+
+        def temporal(prefix):
+            pk[prefix + "gamma"] = g(prefix + "fn.norm.gamma").reshape(-1).contiguous()
+            pk[prefix + "qkv.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_qkv.weight"))
+            pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
+
+        def spatial_linear(prefix):
+            pk[prefix + "gamma"] = g(prefix + "fn.norm.gamma").reshape(-1).contiguous()
+            pk[prefix + "qkv.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_qkv.weight"))
+            pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
+            pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
+
+        w0 = g("init_conv.weight")                      # (dim, 3+256, 1, 7, 7)
+        n_dyn = self.channels - 256 if self.channels > 256 else self.channels
+        pk["n_dyn"] = n_dyn
+        pk["init.dyn_w"] = ops.pack_planar_in_weight(w0[:, :n_dyn].contiguous())
+        if self.channels > n_dyn:
+            pk["init.fea_w"] = ops.pack_conv_weight(w0[:, n_dyn:].contiguous())
+        pk["init.b"] = g("init_conv.bias")
+        temporal("init_temporal_attn.")
+        pk["time.w1"], pk["time.b1"] = g("time_mlp.1.weight"), g("time_mlp.1.bias")
+        pk["time.w3"], pk["time.b3"] = g("time_mlp.3.weight"), g("time_mlp.3.bias")
+        pk["time.freqs"] = ops.sinusoidal_freqs(self.dim, w0.device)
+        nl = len(self.levels)
+        for lvl in range(nl):
+            p = "downs.%d." % lvl
+            resblock(p + "0.")
+            resblock(p + "1.")
+            spatial_linear(p + "2.")
+            temporal(p + "3.")
+            if lvl < nl - 1:
+                pk[p + "4.w"] = ops.pack_conv_weight(g(p + "4.weight"))
+                pk[p + "4.b"] = g(p + "4.bias")
+        resblock("mid_block1.")
+        pk["mid_spatial_attn.gamma"] = g("mid_spatial_attn.fn.norm.gamma").reshape(-1).contiguous()
+        pk["mid_spatial_attn.qkv.w"] = ops.pack_conv_weight(g("mid_spatial_attn.fn.fn.fn.to_qkv.weight"))
+        pk["mid_spatial_attn.out.w"] = ops.pack_conv_weight(g("mid_spatial_attn.fn.fn.fn.to_out.weight"))
+        temporal("mid_temporal_attn.")
+        resblock("mid_block2.")
+        for lvl in range(nl):
+            p = "ups.%d." % lvl
+            resblock(p + "0.")
+            resblock(p + "1.")
+            spatial_linear(p + "2.")
+            temporal(p + "3.")
+            if lvl < nl - 1:
+                if self.use_deconv:
+                    pk[p + "4.packs"] = ops.pack_deconv_weight(g(p + "4.weight"))
+                    pk[p + "4.b"] = g(p + "4.bias")
+                else:
+                    pk[p + "4.w"] = ops.pack_conv_weight(g(p + "4.1.weight"))
+                    pk[p + "4.b"] = g(p + "4.1.bias")
+        for head in ("final_conv.", "occlusion_map."):
+            resblock(head + "0.")
+            pk[head + "1.w"] = g(head + "1.weight").reshape(-1, self.dim).contiguous()
+            pk[head + "1.b"] = g(head + "1.bias")
+        pk["cond.w"] = torch.cat(cond_w, dim=0).contiguous()     # (sum 2C, time_dim + cond_dim)
+        pk["cond.b"] = torch.cat(cond_b, dim=0).contiguous()
+        pk["cond.n"] = off
+        pk["rel_emb"] = g("time_rel_pos_bias.relative_attention_bias.weight")
+        pk["freqs"] = g("init_temporal_attn.fn.fn.fn.rotary_emb.freqs")
+        pk["tables"] = {}
+        return pk
+
+    def _tables(self, pk, frames):
+        t = pk["tables"].get(frames)
+        if t is None:
+            bias = rel_pos_bias_table(pk["rel_emb"], frames)
+            ang = torch.arange(frames, device=bias.device).float()[:, None] * pk["freqs"][None, :]
+            t = (bias, ang.cos().contiguous(), ang.sin().contiguous())
+            pk["tables"][frames] = t
+        return t
+
+    # ------------------------------------------------------------------ conditioning
+    def time_embedding(self, pk, t_dev, batch, t_stride=1):
+        """SinusoidalPosEmb + time_mlp (:141-153, :423-428); t_dev int32 on device."""
+        e = ops.sinusoidal(t_dev, pk["time.freqs"], batch, self.dim, t_stride=t_stride)
+        e = ops.linear_small(e, pk["time.w1"], pk["time.b1"], act_out=ops.ACT_GELU)
+        return ops.linear_small(e, pk["time.w3"], pk["time.b3"])
+
+    def merge_cond(self, cond, null_mask):
+        """where(null_mask, null_cond_emb, cond) (:556-561)."""
+        null = self.null_cond_emb.to(cond.device, cond.dtype)
+        return torch.where(null_mask.view(-1, 1), null, cond).contiguous()
+
+    def cond_scale_shift(self, pk, temb, cond):
+        """All ResnetBlock.mlp projections in one launch: Linear(SiLU(cat(temb, cond)))."""
+        tc = torch.cat((temb, cond), dim=-1).contiguous()
+        return ops.linear_small(tc, pk["cond.w"], pk["cond.b"], act_in=ops.ACT_SILU)
+
+    def cond_tables(self, pk, temb_steps, cond):
+        """Split form for graph replay: (per-step part, per-sample part incl. bias)."""
+        td = temb_steps.shape[1]
+        w = pk["cond.w"]
+        step_part = ops.linear_small(temb_steps, w[:, :td], None, act_in=ops.ACT_SILU)
+        sample_part = ops.linear_small(cond, w[:, td:], pk["cond.b"], act_in=ops.ACT_SILU)
+        return step_part, sample_part
+
+    # ------------------------------------------------------------------ building blocks
+    def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, **kw):
+        """conv2d_cl with an occupancy-driven split-K choice for the low-resolution levels."""
+        m = n_img * s * s
+        cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
+        ksplit = 1
+        if "stride" not in kw and "upsample" not in kw and "out_scale" not in kw:
+            coutp = w.shape[2]
+            small = m * ((coutp + 63) // 64) < 128 * 512
+            tiles = ((m + 63) // 64) * ((coutp + 63) // 64) if small else ((m + 127) // 128) * ((coutp + 63) // 64)
+            nchunks = k * k * max(cin // 32, 1)
+            if tiles < 256 and nchunks >= 8:
+                ksplit = max(1, min(512 // tiles, nchunks // 4, 16))
+        partial = None
+        if ksplit > 1:
+            partial = self._buf("splitk", ksplit * m, w.shape[2])
+        return ops.conv2d_cl(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
+                             out=out, ksplit=ksplit, partial=partial, **kw)
+
+    def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
+        n_img, rows = batch * frames, batch * frames * s * s
+        h1 = self._buf("rb.h1", rows, cout)
+        self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
+                   bias=pk[prefix + "block1.proj.b"], out=h1)
+        sshift = None
+        if ss is not None and (prefix + "ss_off") in pk:
+            o = pk[prefix + "ss_off"]
+            sshift = ss[:, o:o + 2 * cout]
+        gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
+        ops.groupnorm_silu_cl(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"],
+                              scale_shift=sshift, out=h1, ws=gws)
+        out = self._buf(outname, rows, cout)
+        self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"], out=out)
+        has_res = (prefix + "res.w") in pk
+        ops.groupnorm_silu_cl(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"],
+                              residual=None if has_res else x, out=out, ws=gws)
+        if has_res:
+            self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"],
+                       residual=out, out=out)
+        return out
+
+    def _attn_common(self, pk, prefix, x, n_img, s, c):
+        rows = n_img * s * s
+        ln = self._buf("at.ln", rows, c)
+        ops.layernorm_cl(x, pk[prefix + "gamma"], out=ln)
+        qkv = self._buf("at.qkv", rows, 768)
+        self._conv(ln, pk[prefix + "qkv.w"], 768, 1, n_img, s, out=qkv)
+        return qkv, self._buf("at.o", rows, 256)
+
+    def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables):
+        qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
+        bias, cos, sin = tables
+        ops.attention_cl(qkv, batch, frames, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=att)
+        out = self._buf(outname, x.shape[0], c)
+        return self._conv(att, pk[prefix + "out.w"], c, 1, batch * frames, s, residual=x, out=out)
+
+    def _spatial_attn(self, pk, prefix, x, batch, frames, s, c, outname):
+        qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
+        ops.attention_cl(qkv, batch, frames, s * s, 1, out=att)
+        out = self._buf(outname, x.shape[0], c)
+        return self._conv(att, pk[prefix + "out.w"], c, 1, batch * frames, s, residual=x, out=out)
+
+    def _linear_attn(self, pk, prefix, x, batch, frames, s, c, outname):
+        n_img = batch * frames
+        qkv, att = self._attn_common(pk, prefix, x, n_img, s, c)
+        ws = self._buf("la.ws", n_img, 8 * 32 * 32)
+        ops.linear_attention_cl(qkv, n_img, s * s, out=att, ws=ws)
+        out = self._buf(outname, x.shape[0], c)
+        return self._conv(att, pk[prefix + "out.w"], c, 1, n_img, s, bias=pk[prefix + "out.b"], residual=x, out=out)
+
+    # ------------------------------------------------------------------ the network
+    def fea_term(self, pk, fea_cl, batch, s):
+        """Step-invariant part of init_conv: conv7x7 over the 256 `fea` channels + bias,
+        (B*S*S, dim) CL; exact split of the 259-channel convolution by linearity (:410, :713, :789)."""
+        return self._conv(fea_cl, pk["init.fea_w"], self.dim, 7, batch, s, bias=pk["init.b"],
+                          out=self._buf("fea_term", batch * s * s, self.dim))
+
+    def stem(self, pk, x_dyn, add_term, batch, frames, s):
+        """Step-dependent part of init_conv: x_dyn planar (B, >=n_dyn, T, S, S) (first n_dyn channels
+        are read) + add_term ((B*S*S, dim) CL, broadcast over T, already holding the bias) -> r."""
+        r = self._buf("r", batch * frames * s * s, self.dim)
+        return ops.conv_planar_in_cl(x_dyn, batch, pk["n_dyn"], x_dyn.shape[1], frames, s, s, pk["init.dyn_w"],
+                                     7, 7, self.dim, bias=None if add_term is not None else pk["init.b"],
+                                     add_term=add_term, out=r)
+
+    def run_trunk(self, pk, r, ss, batch, frames, s, out):
+        """r: init_conv output (B*T*S*S, dim) CL; ss: (B, sum 2C) scale/shift rows;
+        out: planar (B, 3, T, S, S)."""
+        n_img = batch * frames
+        tables = self._tables(pk, frames)
+        dim = self.dim
+        x = self._temporal_attn(pk, "init_temporal_attn.", r, batch, frames, s, dim, "x.init", tables)
+        skips = []
+        res = s
+        nl = len(self.levels)
+        for lvl, (ci, co) in enumerate(self.levels):
+            p = "downs.%d." % lvl
+            x = self._resblock(pk, p + "0.", x, None, batch, frames, res, ss, co, "d%d.a" % lvl)
+            x = self._resblock(pk, p + "1.", x, None, batch, frames, res, ss, co, "d%d.b" % lvl)
+            x = self._linear_attn(pk, p + "2.", x, batch, frames, res, co, "d%d.c" % lvl)
+            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, co, "d%d.skip" % lvl, tables)
+            skips.append(x)
+            if lvl < nl - 1:
+                out_d = self._buf("d%d.down" % lvl, n_img * (res // 2) ** 2, co)
+                x = ops.conv2d_cl(x, pk[p + "4.w"], co, 4, 4, n_img, res, res, bias=pk[p + "4.b"], pad=(1, 1),
+                                  stride=2, out=out_d)
+                res //= 2
+        mid = self.levels[-1][1]
+        x = self._resblock(pk, "mid_block1.", x, None, batch, frames, res, ss, mid, "m.a")
+        x = self._spatial_attn(pk, "mid_spatial_attn.", x, batch, frames, res, mid, "m.b")
+        x = self._temporal_attn(pk, "mid_temporal_attn.", x, batch, frames, res, mid, "m.c", tables)
+        x = self._resblock(pk, "mid_block2.", x, None, batch, frames, res, ss, mid, "m.d")
+        for lvl, (ci, co) in enumerate(reversed(self.levels)):
+            p = "ups.%d." % lvl
+            x = self._resblock(pk, p + "0.", x, skips.pop(), batch, frames, res, ss, ci, "u%d.a" % lvl)
+            x = self._resblock(pk, p + "1.", x, None, batch, frames, res, ss, ci, "u%d.b" % lvl)
+            x = self._linear_attn(pk, p + "2.", x, batch, frames, res, ci, "u%d.c" % lvl)
+            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, ci, "u%d.d" % lvl, tables)
+            if lvl < nl - 1:
+                out_u = self._buf("u%d.up" % lvl, n_img * (res * 2) ** 2, ci)
+                if self.use_deconv:
+                    x = ops.deconv4x4s2_cl(x, pk[p + "4.packs"], ci, n_img, res, res, bias=pk[p + "4.b"], out=out_u)
+                else:
+                    x = ops.conv2d_cl(x, pk[p + "4.w"], ci, 3, 3, n_img, res, res, bias=pk[p + "4.b"],
+                                      upsample=True, reflect=(self.padding_mode == "reflect"), out=out_u)
+                res *= 2
+        yf = self._resblock(pk, "final_conv.0.", x, r, batch, frames, res, None, dim, "h.flow")
+        yo = self._resblock(pk, "occlusion_map.0.", x, r, batch, frames, res, None, dim, "h.occ")
+        ops.heads_cl_to_planar(yf, yo, pk["final_conv.1.w"], pk["final_conv.1.b"], pk["occlusion_map.1.w"],
+                               pk["occlusion_map.1.b"], batch, frames, res * res, out=out)
+        return out
+
+    # ------------------------------------------------------------------ reference-compatible API
+    def forward_with_cond_scale(self, *args, cond_scale=2., **kwargs):
+        """:511-526."""
+        if cond_scale == 0:
+            return self.forward(*args, null_cond_prob=1., **kwargs)
+        logits = self.forward(*args, null_cond_prob=0., **kwargs)
+        if cond_scale == 1 or not self.has_cond:
+            return logits
+        null_logits = self.forward(*args, null_cond_prob=1., **kwargs)
+        return null_logits + (logits - null_logits) * cond_scale
+
+    def forward(self, x, time, cond=None, null_cond_prob=0., none_cond_mask=None, focus_present_mask=None,
+                prob_focus_present=0.):
+        """Reference signature (:528-538).  x: (B, channels, T, S, S) planar = [noisy 3 | fea 256]
+        (fea may differ per frame here; the samplers use the cheaper split path where it is constant)."""
+        if self.has_cond and cond is None:
+            raise AssertionError("cond must be passed in if cond_dim specified")
+        if prob_focus_present != 0 or (focus_present_mask is not None and bool(focus_present_mask.any())):
+            raise NotImplementedError("focus_present_mask: the LFDM scripts never enable it")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError(
+                "Unet3D.forward under autograd: the native backward kernels are not built yet "
+                "(SURVEY.md 8(f)); call under torch.no_grad() / .eval() for inference")
+        pk = self.packed()
+        x = x.contiguous().float()
+        batch, _, frames, s, _ = x.shape
+        dev = x.device
+        self.null_cond_mask = prob_mask_like((batch,), null_cond_prob, device=dev)
+        if none_cond_mask is not None:
+            self.null_cond_mask = torch.logical_or(self.null_cond_mask,
+                                                   torch.as_tensor(none_cond_mask, device=dev))
+        temb = self.time_embedding(pk, time.to(torch.int32).contiguous(), batch)
+        if self.has_cond:
+            ss = self.cond_scale_shift(pk, temb, self.merge_cond(cond.float(), self.null_cond_mask))
+        else:
+            ss = ops.linear_small(temb, pk["cond.w"], pk["cond.b"], act_in=ops.ACT_SILU)
+        n_dyn = pk["n_dyn"]
+        out = torch.empty(batch, self.out_grid_dim + self.out_conf_dim, frames, s, s, device=dev)
+        if self.channels > n_dyn:
+            # general case: the fea channels may differ per frame -> evaluate their 7x7 conv on all
+            # B*T frames and run the 3-channel part with (B*T) folded into the batch axis
+            nf = self.channels - n_dyn
+            fea = x[:, n_dyn:].permute(0, 2, 1, 3, 4).reshape(batch * frames, nf, s * s).contiguous()
+            fea_cl = ops.planar_to_cl(fea, batch * frames, nf, s * s)
+            term = self._conv(fea_cl, pk["init.fea_w"], self.dim, 7, batch * frames, s, bias=pk["init.b"])
+            xd = x[:, :n_dyn].permute(0, 2, 1, 3, 4).reshape(batch * frames, n_dyn, 1, s, s).contiguous()
+            r = self.stem(pk, xd, term, batch * frames, 1, s)
+        else:
+            r = self.stem(pk, x, None, batch, frames, s)
+        return self.run_trunk(pk, r, ss, batch, frames, s, out)

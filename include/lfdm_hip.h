@@ -89,14 +89,17 @@ size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
  * GroupNorm(G) over (C/G, T, H, W) + optional (scale+1, shift) + SiLU, channels-last.
  * Replaces Block.forward norm/scale-shift/act: DM/modules/video_flow_diffusion.py:200-211.
  * x, out: (B, P, C) rows (P = T*H*W pixels per sample), may alias.
- * scale_shift: NULL or (B, 2*C) = [scale | shift]  (ResnetBlock.mlp output chunked, :230-232).
+ * scale_shift: NULL or B rows [scale(C) | shift(C)] with row stride ss_ld (ResnetBlock.mlp output
+ * chunked, :230-232).  residual: NULL or rows like x, added AFTER the activation
+ * (ResnetBlock: block2(h) + x when res_conv is Identity, :237).
  * ws: caller scratch of lfdm_groupnorm_ws_bytes(B, P, C) bytes.
  */
 size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels);
 int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels, int channels,
                                int groups, const float* gamma, const float* beta,
-                               const float* scale_shift, float eps, int apply_silu,
-                               void* ws, size_t ws_bytes, lfdm_stream_t stream);
+                               const float* scale_shift, int ss_ld, const float* residual,
+                               float eps, int apply_silu, void* ws, size_t ws_bytes,
+                               lfdm_stream_t stream);
 
 /* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
 int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,
@@ -125,15 +128,23 @@ int lfdm_linear_attention_cl_f32(const float* qkv, float* out, int n_frames, int
 
 /* ------------------------------------------------------------------------------------------
  * Small dense layers of the conditioning path (time_mlp :423-428, ResnetBlock.mlp :217-220).
- * y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ),  w row-major (N, K). */
+ * y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ),  w rows of stride ldw. */
 int lfdm_linear_small_f32(const float* x, const float* w, const float* bias, float* y,
-                          int batch, int k, int n, int ldx, int ldy, int act_in, int act_out,
-                          lfdm_stream_t stream);
+                          int batch, int k, int n, int ldx, int ldw, int ldy, int act_in,
+                          int act_out, lfdm_stream_t stream);
 
-/* SinusoidalPosEmb (:141-153): emb[b] = [sin(t*f_i) | cos(t*f_i)], f_i = exp(-ln(1e4)*i/(dim/2-1)).
+/* Per-step conditioning for graph replay: out[b][i] = step_table[*step_dev][i] + batch_base[b][i].
+ * (The ResnetBlock.mlp input is cat(time_emb, cond), :562,:230: its Linear splits exactly into a
+ * time part that depends only on the step and a cond part that depends only on the sample.) */
+int lfdm_step_cond_f32(const float* step_table, const float* batch_base, const int32_t* step_dev,
+                       float* out, int batch, int n, lfdm_stream_t stream);
+
+/* SinusoidalPosEmb (:141-153): emb[b] = [sin(t*f_i) | cos(t*f_i)]; freqs[i] = exp(-ln(1e4)*i/(dim/2-1))
+ * is a (dim/2) table prepared once by the host (a 1-ulp difference in exp is amplified ~1000x by
+ * t, so the table is computed with the same fp32 expression the reference uses).
  * The timestep is read from DEVICE memory (int32) so a captured graph can be replayed per step. */
-int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, float* out, int batch, int dim,
-                        int ldo, lfdm_stream_t stream);
+int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, const float* freqs, float* out,
+                        int batch, int dim, int ldo, lfdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small-C_in convolution from a PLANAR input into CL output (direct, VALU):
@@ -170,6 +181,10 @@ int lfdm_sampler_step_f32(float* x, const float* eps, const float* noise, float*
                           int batch, int64_t n, const float* coef, int32_t* step_dev,
                           float quantile, int advance, void* ws, size_t ws_bytes,
                           lfdm_stream_t stream);
+/* classifier-free guidance combine of Unet3D.forward_with_cond_scale (:525-526):
+ * out = null_eps + (cond_eps - null_eps) * scale   (out may alias an input) */
+int lfdm_cfg_combine_f32(const float* cond_eps, const float* null_eps, float scale, float* out,
+                         int64_t n, lfdm_stream_t stream);
 /* stand-alone |x| quantile (torch.quantile semantics, :722-726) for tests: q_out[b] */
 int lfdm_abs_quantile_f32(const float* x, int batch, int64_t n, float quantile, float* q_out,
                           void* ws, size_t ws_bytes, lfdm_stream_t stream);

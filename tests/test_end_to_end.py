@@ -1,0 +1,85 @@
+"""End-to-end parity of the drop-in classes against the CPU oracle on a synthetic checkpoint:
+Unet3D.forward, Generator.compute_fea / forward_with_flow, FlowDiffusion.sample_one_video
+(DDIM and DDPM, noise replayed from a tape so CPU oracle and HIP path see identical draws).
+Tolerance: north-star 1e-3 (fp32) for the sampled latent and the decoded frames."""
+import os
+
+import pytest
+import torch
+
+import lfdm_oracle as O
+import synth
+from util import assert_close
+
+
+def _skip_slow_emu(dev):
+    """A whole UNet forward under the fiber emulator takes minutes: opt in with LFDM_EMU_E2E=1."""
+    if dev == "cpu" and os.environ.get("LFDM_EMU_E2E", "0") != "1":
+        pytest.skip("end-to-end under the emulator is opt-in (LFDM_EMU_E2E=1); it runs on the GPU")
+
+
+def _tiny(dev):
+    return dict(b=2, t=4, s=8) if dev == "cpu" else dict(b=2, t=8, s=16)
+
+
+@pytest.mark.parametrize("variant", ["deconv", "upconv_lnc"])
+def test_unet_forward(backend, variant):
+    dev = backend
+    _skip_slow_emu(dev)
+    if dev == "cpu" and variant == "upconv_lnc":
+        pytest.skip("second UNet variant is exercised on the GPU (emulator time)")
+    kw = {} if variant == "deconv" else dict(learn_null_cond=True, use_deconv=False, padding_mode="reflect")
+    z = _tiny(dev)
+    m, dsd, _ = synth.build_flow_diffusion(dev, img_size=z["s"], num_frames=z["t"], sampling_timesteps=5, **kw)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(z["b"], 259, z["t"], z["s"], z["s"], generator=g)
+    x[:, 3:] = x[:, 3:, :1]                               # fea is constant over frames on the real path
+    time = torch.tensor([999, 17][: z["b"]])
+    cond = torch.randn(z["b"], 768, generator=g)
+    for null_prob in (0.0, 1.0):
+        mask = torch.full((z["b"],), bool(null_prob), dtype=torch.bool)
+        ref = O.unet_forward(dsd, x, time, cond, mask)
+        with torch.no_grad():
+            out = m.unet.forward(x.to(dev), time.to(dev), cond=cond.to(dev), null_cond_prob=null_prob)
+        assert_close(out.cpu(), ref, 2e-4, "unet forward (%s, null=%s)" % (variant, null_prob))
+
+
+def test_generator(backend):
+    dev = backend
+    _skip_slow_emu(dev)
+    hw = 32 if dev == "cpu" else 128
+    m, _, gsd = synth.build_flow_diffusion(dev, img_size=hw // 4, num_frames=2, sampling_timesteps=5)
+    img, _ = synth.inputs(2, hw)
+    g = torch.Generator().manual_seed(5)
+    s = hw // 4
+    ident = torch.nn.functional.affine_grid(torch.eye(2, 3).unsqueeze(0), (1, 1, s, s), align_corners=True)
+    flow = (ident.repeat(2, 1, 1, 1) + 0.3 * torch.randn(2, s, s, 2, generator=g)).clamp(-1.3, 1.3)
+    occ = torch.rand(2, 1, s, s, generator=g)
+    fea = m.generator.compute_fea(img.to(dev))
+    assert_close(fea.cpu(), O.generator_compute_fea(gsd, img), 2e-4, "compute_fea")
+    ref = O.generator_forward_with_flow(gsd, img, flow, occ)
+    out = m.generator.forward_with_flow(img.to(dev), flow.to(dev), occ.to(dev))
+    assert_close(out["deformed"].cpu(), ref["deformed"], 2e-4, "deformed")
+    assert_close(out["prediction"].cpu(), ref["prediction"], 5e-4, "prediction")
+
+
+@pytest.mark.parametrize("sampler", ["ddim", "ddpm"])
+def test_sample_one_video(backend, sampler):
+    dev = backend
+    _skip_slow_emu(dev)
+    z = dict(b=1, t=2, s=8, hw=32) if dev == "cpu" else dict(b=2, t=8, s=16, hw=64)
+    steps, total = (3, 1000) if sampler == "ddim" else (6, 6)
+    m, dsd, gsd = synth.build_flow_diffusion(dev, img_size=z["s"], num_frames=z["t"], sampling_timesteps=steps,
+                                             timesteps=total)
+    img, cond = synth.inputs(z["b"], z["hw"])
+    sd = dict(dsd)
+    sd.update(O.make_schedule(total))
+    ref = O.sample_one_video(sd, gsd, img, cond, z["t"], z["s"], steps, timesteps=total,
+                             noise_fn=synth.NoiseTape(11))
+    m.diffusion.noise_source = synth.NoiseTape(11)
+    m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
+    m.sample_one_video(cond_scale=1.0)
+    assert_close(m.sample_vid_grid.cpu(), ref["sample_vid_grid"], 1e-3, "sample_vid_grid")
+    assert_close(m.sample_vid_conf.cpu(), ref["sample_vid_conf"], 1e-3, "sample_vid_conf")
+    assert_close(m.sample_warped_vid.cpu(), ref["sample_warped_vid"], 1e-3, "sample_warped_vid")
+    assert_close(m.sample_out_vid.cpu(), ref["sample_out_vid"], 1e-3, "sample_out_vid")

@@ -202,7 +202,7 @@ def test_linear_small_and_sinusoidal(backend):
     dev = backend
     b = 3
     t = torch.tensor([999, 500, 0], dtype=torch.int32)
-    emb = ops.sinusoidal(t.to(dev), b, 64)
+    emb = ops.sinusoidal(t.to(dev), ops.sinusoidal_freqs(64, dev), b, 64)
     half = 32
     freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
     e = t.long()[:, None] * freq[None, :]
