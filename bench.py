@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py - headline metric of BASELINE.json on MI355X.
+
+  metric   : 40-frame 128x128 videos/sec (DDIM-100)          [BASELINE.json "metric"]
+  workload : configs[1] = MUG 128x128, 40-frame DDIM-100 sample, batch=1 per GPU
+  a "step" : one FlowDiffusion.sample_one_video() call = LFAE encode + 100 UNet/sampler steps
+             + 40-frame LFAE decode, on synthetic random-init weights / inputs (no network).
+
+`python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
+torch.distributed.run (sampling shards by video: no data-path collective, "weak" scaling).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = fp32-MFMA implicit-GEMM conv) and
+`cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO_ROOT)
+sys.path.insert(0, os.path.join(REPO_ROOT, "tests"))
+
+WORKLOAD = dict(name="MUG 128x128, 40-frame DDIM-100 sample, batch=1 per GPU (BASELINE.json configs[1])",
+                batch=1, frames=40, latent=32, image=128, sampling_timesteps=100, timesteps=1000)
+# fp32 matrix peak of MI355X (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+# reference-dataflow algorithmic work per C2 video: 100*235.10 + 5.14 + 40*24.78 GFLOP
+GFLOP_PER_VIDEO_REFERENCE = 24506.0
+
+
+def dist_setup(n_gpus):
+    """One process per GPU; returns (rank, world, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def timed_region(run_step, steps, warmup, world, device_sync):
+    """W untimed + exactly K timed steps, bracketed by barrier + device sync; returns max-over-ranks seconds."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        run_step()
+    device_sync()
+    if world > 1:
+        dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    device_sync()
+    if world > 1:
+        dist.barrier()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def conv_roofline(model, img, cond):
+    """One instrumented eager UNet step: every lfdm_conv2d_cl_f32 launch is bracketed by HIP events on the
+    launch stream; achieved = sum(algorithmic 2*M*N*K) / sum(kernel time)."""
+    from cvpr23_lfdm_amd import ops
+    records = []
+    orig = ops.conv2d_cl
+
+    def timed_conv(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
+        e1.record()
+        cin = src0.shape[1] + (kw_["src1"].shape[1] if kw_.get("src1") is not None else 0)
+        rows = out.shape[0] if kw_.get("out_scale", 1) == 1 else out.shape[0] // (kw_["out_scale"] ** 2)
+        records.append((2.0 * rows * cout * cin * kh * kw, e0, e1))
+        return out
+
+    unet = model.unet
+    b, t, s = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"]
+    x = torch.randn(b, 259, t, s, s, device=img.device)
+    x[:, 3:] = x[:, 3:, :1]
+    tt = torch.full((b,), 500, device=img.device)
+    with torch.no_grad():
+        unet.forward(x, tt, cond=cond)          # warm
+        torch.cuda.synchronize()
+        ops.conv2d_cl = timed_conv
+        try:
+            unet.forward(x, tt, cond=cond)
+        finally:
+            ops.conv2d_cl = orig
+        torch.cuda.synchronize()
+    flops = sum(r[0] for r in records)
+    ms = sum(r[1].elapsed_time(r[2]) for r in records)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one UNet step, eager)",
+            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": len(records), "gflop_per_step": round(flops / 1e9, 2), "ms_per_step_in_kernel": round(ms, 3)}
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/lfdm_oracle.py, a port of the reference dataflow) on this host, bounded sample:
+    2 UNet forwards at the C2 shape + compute_fea + 2 decoded frames, extrapolated linearly to one video
+    (per-step cost is step independent)."""
+    sys.path.insert(0, os.path.join(REPO_ROOT, "oracle"))
+    import lfdm_oracle as O
+    import synth
+    torch.manual_seed(0)
+    dsd = {"denoise_fn." + k: v for k, v in synth.unet_state().items()}
+    gsd = synth.generator_state()
+    b, t, s, hw = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"], WORKLOAD["image"]
+    img, cond = synth.inputs(b, hw)
+    x = torch.randn(b, 259, t, s, s)
+    tt = torch.full((b,), 500, dtype=torch.long)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        fea = O.generator_compute_fea(gsd, img)
+        t_fea = time.perf_counter() - t0
+        O.unet_forward(dsd, x, tt, cond)        # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        n_unet = 2
+        for _ in range(n_unet):
+            O.unet_forward(dsd, x, tt, cond)
+        t_unet = (time.perf_counter() - t0) / n_unet
+        flow = torch.rand(b, s, s, 2) * 2 - 1
+        occ = torch.rand(b, 1, s, s)
+        t0 = time.perf_counter()
+        n_dec = 2
+        for _ in range(n_dec):
+            O.generator_forward_with_flow(gsd, img, flow, occ)
+        t_dec = (time.perf_counter() - t0) / n_dec
+    per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t * t_dec
+    return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/lfdm_oracle.py on host CPU: %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each, compute_fea %.3f s, "
+                      "%d decode frames = %.3f s each; extrapolated to %d steps + %d frames"
+                      % (n_unet, b, t, s, s, t_unet, t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = dist_setup(args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+
+    import synth
+    torch.manual_seed(1234)
+    model, _, _ = synth.build_flow_diffusion(dev, img_size=WORKLOAD["latent"], num_frames=WORKLOAD["frames"],
+                                             sampling_timesteps=WORKLOAD["sampling_timesteps"],
+                                             timesteps=WORKLOAD["timesteps"])
+    img, cond = synth.inputs(WORKLOAD["batch"], WORKLOAD["image"], seed=7 + rank)
+    img, cond = img.to(dev), cond.to(dev)
+    torch.manual_seed(1237 + rank)          # sampling noise seed
+    model.set_sample_input(sample_img=img, sample_text=cond)
+
+    def run_step():
+        model.sample_one_video(cond_scale=1.0)
+
+    elapsed = timed_region(run_step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    videos = args.steps * WORKLOAD["batch"] * world
+    value = videos / elapsed
+
+    if rank == 0:
+        line = {
+            "metric": "40-frame 128x128 videos/sec (DDIM-100)",
+            "value": round(value, 4), "unit": "videos/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (random-init weights, rand image, randn cond; seeds 1234/7/1237)",
+            "config": {"workload": WORKLOAD["name"], "global_batch": WORKLOAD["batch"] * world,
+                       "frames": WORKLOAD["frames"], "latent": WORKLOAD["latent"], "image": WORKLOAD["image"],
+                       "sampler": "DDIM-100 eta=1, cond_scale=1", "parallelism": "replicas x%d (videos sharded, no collective)" % world},
+            "gflop_per_video_reference_dataflow": GFLOP_PER_VIDEO_REFERENCE,
+            "whole_job_tflops_reference_dataflow": round(value * GFLOP_PER_VIDEO_REFERENCE / 1e3, 2),
+        }
+        if not args.no_roofline:
+            line["roofline"] = conv_roofline(model, img, cond)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

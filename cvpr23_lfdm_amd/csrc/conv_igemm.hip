@@ -327,9 +327,11 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   const int nchunks = fast ? p.kh * p.kw * (cin / 32) : (p.kh * p.kw * cin + 31) / 32;
   if (p.ksplit > nchunks) p.ksplit = nchunks;
-  // tile choice: wide N tile when there are enough output channels and rows to fill the chip
+  // tile choice (measured on MI355X, tools/bench_conv.py): 128x128 tiles only when they still give
+  // >= 256 workgroups; otherwise 64x64 tiles (more, smaller workgroups balance the 256 CUs better
+  // than 128-row tiles at the UNet's M = 40*S*S) and split-K (caller) for the low-resolution levels.
   const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
-  const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;  // few tiles: use BM=64
+  const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
   dim3 block(256);
   if (wide) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 127) / 128), p.ksplit);

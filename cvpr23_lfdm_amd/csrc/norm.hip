@@ -69,19 +69,31 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           int ss_ld, float eps, float* __restrict__ ab) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < groups) {
+  // 32 lanes per group, 8 groups per pass; partials are merged in double with a fixed order
+  const int sub = tid & 31;
+  for (int g0 = 0; g0 < groups; g0 += 8) {
+    const int g = g0 + (tid >> 5);
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* src = partial + (((int64_t)b * nchunk + k) * groups + tid) * 2;
-      s += (double)src[0];
-      q += (double)src[1];
+    if (g < groups) {
+      for (int k = sub; k < nchunk; k += 32) {
+        const float* src = partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
+        s += (double)src[0];
+        q += (double)src[1];
+      }
     }
-    const double n = (double)pixels * (double)(channels / groups);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[tid] = (float)mean;
-    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      s += __shfl_xor(s, m);
+      q += __shfl_xor(q, m);
+    }
+    if (g < groups && sub == 0) {
+      const double n = (double)pixels * (double)(channels / groups);
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   const int cg = channels / groups;

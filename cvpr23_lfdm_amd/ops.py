@@ -100,6 +100,20 @@ def pack_planar_in_weight(w):
 # ops
 # ---------------------------------------------------------------------------------------------
 
+def conv_ksplit(m, coutp, nchunks, n_cu=256):
+    """Split-K factor for lfdm_conv2d_cl_f32 (mirrors the kernel's tile choice): when the output tiles
+    cannot fill the 256 CUs (low-resolution UNet levels at B=1), split the K loop so that about two
+    workgroups per CU exist, keeping >= 4 K-chunks per slice."""
+    small = m * ((coutp + 63) // 64) < 128 * 512
+    if small:
+        tiles = ((m + 63) // 64) * ((coutp + 63) // 64)
+    else:
+        tiles = ((m + 127) // 128) * ((coutp + 63) // 64)
+    if tiles >= n_cu or nchunks < 8:
+        return 1
+    return max(1, min(2 * n_cu // tiles, nchunks // 4, 16))
+
+
 def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
               upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
               ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=1, partial=None):

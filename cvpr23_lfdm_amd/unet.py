@@ -246,12 +246,7 @@ class Unet3D(ParamTree):
         cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
         ksplit = 1
         if "stride" not in kw and "upsample" not in kw and "out_scale" not in kw:
-            coutp = w.shape[2]
-            small = m * ((coutp + 63) // 64) < 128 * 512
-            tiles = ((m + 63) // 64) * ((coutp + 63) // 64) if small else ((m + 127) // 128) * ((coutp + 63) // 64)
-            nchunks = k * k * max(cin // 32, 1)
-            if tiles < 256 and nchunks >= 8:
-                ksplit = max(1, min(512 // tiles, nchunks // 4, 16))
+            ksplit = ops.conv_ksplit(m, w.shape[2], k * k * max(cin // 32, 1))
         partial = None
         if ksplit > 1:
             partial = self._buf("splitk", ksplit * m, w.shape[2])

@@ -1,0 +1,134 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE - generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference, imported on CPU through oracle/ref_shims) on synthetic checkpoints and inputs
+that every consumer can regenerate bit-for-bit from seeds (tests/synth.py: numpy PCG64).
+
+The reference has no tests / golden vectors of its own, so these fixtures are
+what pins the oracle (tests/test_oracle_golden.py) and the HIP path (tests/test_golden_gpu.py).
+Only OUTPUTS are stored; inputs and weights are re-derived from the seeds recorded in each file.
+
+    python oracle/make_golden.py            # small cases (seconds)
+    python oracle/make_golden.py --c2       # + one C2-shape UNet forward and a full C2 DDIM-100 video (minutes)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import reference_loader  # noqa: E402
+
+ref = reference_loader.load_reference()
+sys.path.append(REPO)
+sys.path.append(os.path.join(REPO, "tests"))
+import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+class patched_noise:
+    """Routes torch.randn / randn_like of the reference's samplers to a NoiseTape."""
+
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.randn, self.randn_like = torch.randn, torch.randn_like
+        torch.randn = lambda *shape, **kw: self.tape(tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape))
+        torch.randn_like = lambda t, **kw: self.tape(tuple(t.shape))
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like = self.randn, self.randn_like
+
+
+def reference_model(img_size, num_frames, sampling_timesteps, timesteps=1000, **variant):
+    m = ref.vfdm.FlowDiffusion(img_size=img_size, num_frames=num_frames, sampling_timesteps=sampling_timesteps,
+                               timesteps=timesteps, is_train=False, config_pth=synth.CONFIG, pretrained_pth="",
+                               **variant)
+    spec_kw = dict(learn_null_cond=variant.get("learn_null_cond", False), use_deconv=variant.get("use_deconv", True))
+    m.unet.load_state_dict(synth.unet_state(**spec_kw))
+    m.generator.load_state_dict(synth.generator_state())
+    m.eval()
+    return m
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def unet_case(name, b, t, s, **variant):
+    m = reference_model(s, t, 5, **variant)
+    x, time, cond = synth.unet_inputs(b, t, s)
+    outs = {}
+    with torch.no_grad():
+        for tag, prob in (("cond", 0.0), ("null", 1.0)):
+            outs[tag] = m.unet(x, time, cond=cond, null_cond_prob=prob)
+        outs["scale2"] = m.unet.forward_with_cond_scale(x, time, cond=cond, cond_scale=2.0)
+    save(name, b=b, t=t, s=s, **outs)
+
+
+def sampler_case(name, b, t, s, hw, steps, timesteps):
+    m = reference_model(s, t, steps, timesteps)
+    img, cond = synth.inputs(b, hw)
+    m.set_sample_input(sample_img=img, sample_text=cond)
+    with patched_noise(synth.NoiseTape(11)), torch.no_grad():
+        m.sample_one_video(cond_scale=1.0)
+    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=timesteps, noise_seed=11,
+         sample_vid_grid=m.sample_vid_grid, sample_vid_conf=m.sample_vid_conf,
+         sample_out_vid=m.sample_out_vid, sample_warped_vid=m.sample_warped_vid)
+
+
+def generator_case(name, b, hw):
+    m = reference_model(hw // 4, 2, 5)
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    with torch.no_grad():
+        fea = m.generator.compute_fea(img)
+        out = m.generator.forward_with_flow(img, flow, occ)
+    save(name, b=b, hw=hw, fea=fea, prediction=out["prediction"], deformed=out["deformed"])
+
+
+def op_cases():
+    g = torch.Generator().manual_seed(21)
+    emb = torch.randn(32, 8, generator=g)
+    rpb = ref.vfd.RelativePositionBias(heads=8, max_distance=32)
+    with torch.no_grad():
+        rpb.relative_attention_bias.weight.copy_(emb)
+        bias40 = rpb(40, device="cpu")
+    import rotary_embedding_torch as rot
+    q = torch.randn(2, 3, 8, 40, 32, generator=g)
+    rq = rot.RotaryEmbedding(32).rotate_queries_or_keys(q)
+    x = torch.randn(3, 7000, generator=g) * 2
+    quant = torch.quantile(x.abs(), 0.9, dim=-1)
+    gd = ref.vfd.GaussianDiffusion(torch.nn.Identity(), image_size=8, num_frames=4, timesteps=1000, sampling_timesteps=100)
+    sched = {k: v for k, v in gd.state_dict().items()}
+    times = torch.linspace(0., 1000, steps=102)[:-1].int()
+    save("ops", emb=emb, bias40=bias40, rot_q=q, rot_out=rq, quant_in=x, quant_out=quant, ddim100_times=times, **sched)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c2", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    op_cases()
+    unet_case("unet_tiny_deconv", 2, 4, 8)
+    unet_case("unet_tiny_upconv_lnc", 2, 4, 8, learn_null_cond=True, use_deconv=False, padding_mode="reflect")
+    generator_case("generator_32", 2, 32)
+    sampler_case("sample_ddim5_tiny", 2, 4, 8, 32, 5, 1000)
+    sampler_case("sample_ddpm8_tiny", 1, 4, 8, 32, 8, 8)
+    if args.c2:
+        unet_case("unet_c2_deconv", 1, 40, 32)
+        generator_case("generator_128", 1, 128)
+        sampler_case("sample_ddim100_c2", 1, 40, 32, 128, 100, 1000)
+
+
+if __name__ == "__main__":
+    main()

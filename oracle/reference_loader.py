@@ -42,6 +42,7 @@ def load_reference():
     sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != repo_root]
     sys.path.insert(0, REFERENCE_ROOT)
     sys.path.insert(0, _SHIMS)
+    sys.path.append(repo_root)          # the product package stays importable, behind the reference
 
     if not torch.cuda.is_available():
         # the reference hard-codes .cuda() (video_flow_diffusion.py:440,560,

@@ -50,3 +50,24 @@ def build_flow_diffusion(device, *, img_size, num_frames, sampling_timesteps, ti
     m.to(device)
     dsd = {"denoise_fn." + k: v for k, v in usd.items()}
     return m, dsd, gsd
+
+
+def unet_inputs(batch, frames, s, seed=3):
+    """(x (B,259,T,S,S) with frame-constant fea channels, time (B,), cond (B,768))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = torch.from_numpy(rng.standard_normal((batch, 259, frames, s, s)).astype(np.float32))
+    x[:, 3:] = x[:, 3:, :1]
+    time = torch.tensor([999, 17, 500, 3][:batch] if batch <= 4 else list(range(batch)))
+    cond = torch.from_numpy(rng.standard_normal((batch, 768)).astype(np.float32))
+    return x, time, cond
+
+
+def flow_inputs(batch, s, seed=5):
+    """Sampling grid (B,s,s,2) around the align_corners=True identity (incl. out-of-range samples) + occlusion."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lin = torch.linspace(-1, 1, s)
+    ident = torch.stack((lin.view(1, s).expand(s, s), lin.view(s, 1).expand(s, s)), dim=-1)
+    flow = ident.unsqueeze(0).repeat(batch, 1, 1, 1) + 0.3 * torch.from_numpy(
+        rng.standard_normal((batch, s, s, 2)).astype(np.float32))
+    occ = torch.from_numpy(rng.random((batch, 1, s, s), dtype=np.float32))
+    return flow.clamp(-1.3, 1.3).contiguous(), occ

@@ -1,0 +1,74 @@
+"""HIP path against the fixtures produced by the unmodified reference (tests/golden/, see
+oracle/make_golden.py) - including the full-size C2 case: one (1,259,40,32,32) UNet forward and a
+complete 40-frame 128x128 DDIM-100 video with replayed noise.  Tolerance: the north-star 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from util import assert_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+pytestmark = pytest.mark.gpu
+
+
+def gold(name):
+    path = os.path.join(GOLD, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % name)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(path).items()}
+
+
+@pytest.fixture(autouse=True)
+def _hip():
+    from cvpr23_lfdm_amd import _native
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _native._set_library_for_tests(None)
+    assert _native.library().kind == "hip"
+
+
+@pytest.mark.parametrize("name,variant", [
+    ("unet_tiny_deconv", {}),
+    ("unet_tiny_upconv_lnc", dict(learn_null_cond=True, use_deconv=False, padding_mode="reflect")),
+    ("unet_c2_deconv", {}),
+])
+def test_unet_forward(name, variant):
+    g = gold(name)
+    b, t, s = int(g["b"]), int(g["t"]), int(g["s"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=5, **variant)
+    x, time, cond = synth.unet_inputs(b, t, s)
+    x, time, cond = x.cuda(), time.cuda(), cond.cuda()
+    with torch.no_grad():
+        assert_close(m.unet(x, time, cond=cond, null_cond_prob=0.).cpu(), g["cond"], 1e-3, "cond")
+        assert_close(m.unet(x, time, cond=cond, null_cond_prob=1.).cpu(), g["null"], 1e-3, "null")
+        assert_close(m.unet.forward_with_cond_scale(x, time, cond=cond, cond_scale=2.0).cpu(), g["scale2"], 1e-3, "scale2")
+
+
+@pytest.mark.parametrize("name", ["generator_32", "generator_128"])
+def test_generator(name):
+    g = gold(name)
+    b, hw = int(g["b"]), int(g["hw"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=hw // 4, num_frames=2, sampling_timesteps=5)
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    assert_close(m.generator.compute_fea(img.cuda()).cpu(), g["fea"], 1e-3, "fea")
+    out = m.generator.forward_with_flow(img.cuda(), flow.cuda(), occ.cuda())
+    assert_close(out["deformed"].cpu(), g["deformed"], 1e-3, "deformed")
+    assert_close(out["prediction"].cpu(), g["prediction"], 1e-3, "prediction")
+
+
+@pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny", "sample_ddim100_c2"])
+def test_sample_one_video(name):
+    g = gold(name)
+    b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=int(g["steps"]),
+                                         timesteps=int(g["timesteps"]))
+    img, cond = synth.inputs(b, hw)
+    m.diffusion.noise_source = synth.NoiseTape(int(g["noise_seed"]))
+    m.set_sample_input(sample_img=img.cuda(), sample_text=cond.cuda())
+    m.sample_one_video(cond_scale=1.0)
+    for k in ("sample_vid_grid", "sample_vid_conf", "sample_warped_vid", "sample_out_vid"):
+        assert_close(getattr(m, k).cpu(), g[k], 1e-3, k)

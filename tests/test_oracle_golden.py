@@ -1,0 +1,73 @@
+"""Pins the CPU oracle (oracle/lfdm_oracle.py) against fixtures produced by the UNMODIFIED reference
+(oracle/make_golden.py ran /root/reference on CPU).  Runs anywhere (no GPU, no reference tree)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lfdm_oracle as O
+import synth
+from util import assert_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    path = os.path.join(GOLD, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % name)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(path).items()}
+
+
+def test_ops_against_reference_fixtures():
+    g = gold("ops")
+    assert torch.equal(O.rel_pos_bias(g["emb"], 40), g["bias40"])
+    cos, sin = O.rotary_tables(1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)), 40)
+    assert_close(O.apply_rotary(g["rot_q"], cos, sin), g["rot_out"], 1e-6, "rotary")
+    assert torch.equal(O.abs_quantile(g["quant_in"], 0.9), g["quant_out"])
+    sched = O.make_schedule(1000)
+    for k in O.SCHEDULE_KEYS:
+        assert torch.equal(sched[k], g[k]), k
+    pairs = O.ddim_time_pairs(1000, 100)
+    assert [p[0] for p in pairs] == list(reversed(g["ddim100_times"].tolist()))[:-1]
+    assert pairs[0] == (990, 980) and pairs[-1] == (9, 0) and len(pairs) == 100
+
+
+@pytest.mark.parametrize("name,variant", [("unet_tiny_deconv", {}),
+                                          ("unet_tiny_upconv_lnc", dict(learn_null_cond=True, use_deconv=False))])
+def test_unet_forward(name, variant):
+    g = gold(name)
+    b, t, s = int(g["b"]), int(g["t"]), int(g["s"])
+    dsd = {"denoise_fn." + k: v for k, v in synth.unet_state(**variant).items()}
+    x, time, cond = synth.unet_inputs(b, t, s)
+    ones = torch.ones(b, dtype=torch.bool)
+    assert_close(O.unet_forward(dsd, x, time, cond, ~ones), g["cond"], 1e-5, "cond")
+    assert_close(O.unet_forward(dsd, x, time, cond, ones), g["null"], 1e-5, "null")
+    assert_close(O.unet_forward_with_cond_scale(dsd, x, time, cond, 2.0), g["scale2"], 1e-5, "scale2")
+
+
+def test_generator():
+    g = gold("generator_32")
+    b, hw = int(g["b"]), int(g["hw"])
+    gsd = synth.generator_state()
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    assert_close(O.generator_compute_fea(gsd, img), g["fea"], 1e-5, "fea")
+    out = O.generator_forward_with_flow(gsd, img, flow, occ)
+    assert_close(out["deformed"], g["deformed"], 1e-5, "deformed")
+    assert_close(out["prediction"], g["prediction"], 1e-5, "prediction")
+
+
+@pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny"])
+def test_sample_one_video(name):
+    g = gold(name)
+    b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
+    steps, total = int(g["steps"]), int(g["timesteps"])
+    sd = {"denoise_fn." + k: v for k, v in synth.unet_state().items()}
+    sd.update(O.make_schedule(total))
+    img, cond = synth.inputs(b, hw)
+    out = O.sample_one_video(sd, synth.generator_state(), img, cond, t, s, steps, timesteps=total,
+                             noise_fn=synth.NoiseTape(int(g["noise_seed"])))
+    for k in ("sample_vid_grid", "sample_vid_conf", "sample_out_vid", "sample_warped_vid"):
+        assert_close(out[k], g[k], 2e-5, k)

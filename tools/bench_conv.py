@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of lfdm_conv2d_cl_f32 on the contraction shapes of one C2 UNet step
+ and of the LFAE decode; prints TFLOP/s per shape.  GPU only."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvpr23_lfdm_amd import ops  # noqa: E402
+
+FRAMES = int(os.environ.get("FRAMES", "40"))
+SHAPES = [
+    # (name, cin, cout, k, s, count_per_step)
+    ("3x3 64->64 @32", 64, 64, 3, 32, 9), ("3x3 128->64 @32", 128, 64, 3, 32, 3), ("1x1 64->768 @32", 64, 768, 1, 32, 5),
+    ("1x1 256->64 @32", 256, 64, 1, 32, 5), ("1x1 128->64 @32", 128, 64, 1, 32, 2),
+    ("3x3 64->128 @16", 64, 128, 3, 16, 1), ("3x3 128->128 @16", 128, 128, 3, 16, 5), ("3x3 256->128 @16", 256, 128, 3, 16, 1),
+    ("1x1 128->768 @16", 128, 768, 1, 16, 4), ("1x1 256->128 @16", 256, 128, 1, 16, 4),
+    ("3x3 128->256 @8", 128, 256, 3, 8, 1), ("3x3 256->256 @8", 256, 256, 3, 8, 5), ("3x3 512->256 @8", 512, 256, 3, 8, 1),
+    ("1x1 256->768 @8", 256, 768, 1, 8, 4), ("1x1 256->256 @8", 256, 256, 1, 8, 4),
+    ("3x3 256->512 @4", 256, 512, 3, 4, 1), ("3x3 512->512 @4", 512, 512, 3, 4, 7), ("3x3 1024->256 @4", 1024, 256, 3, 4, 1),
+    ("1x1 512->768 @4", 512, 768, 1, 4, 5), ("1x1 256->512 @4", 256, 512, 1, 4, 5),
+    ("dec 3x3 256->256 @32", 256, 256, 3, 32, 0), ("dec 3x3 128->64 @128(8f)", 128, 64, 3, 128, 0),
+]
+
+
+def main():
+    dev = "cuda"
+    import importlib
+    unet_mod = importlib.import_module("cvpr23_lfdm_amd.unet")
+    helper = unet_mod.Unet3D.__new__(unet_mod.Unet3D)      # only for the split-K heuristic
+    tot_ms = 0.0
+    tot_gf = 0.0
+    print("%-28s %9s %8s %8s %8s" % ("shape", "GFLOP", "us", "TF/s", "ksplit"))
+    for name, cin, cout, k, s, count in SHAPES:
+        n_img = FRAMES if "8f" not in name else 8
+        m = n_img * s * s
+        x = torch.randn(m, cin, device=dev)
+        w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device=dev) * 0.05)
+        b = torch.randn(cout, device=dev)
+        out = torch.empty(m, cout, device=dev)
+        coutp = w.shape[2]
+        ksplit = ops.conv_ksplit(m, coutp, k * k * max(cin // 32, 1))
+        ksplit = int(os.environ.get("KSPLIT", ksplit))
+        partial = torch.empty(ksplit * m * coutp, device=dev) if ksplit > 1 else None
+        run = lambda: ops.conv2d_cl(x, w, cout, k, k, n_img, s, s, bias=b, out=out, ksplit=ksplit, partial=partial)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        gf = 2.0 * m * cout * cin * k * k / 1e9
+        print("%-28s %9.2f %8.1f %8.1f %8d" % (name, gf, us, gf / us * 1e3, ksplit))
+        tot_ms += us * count / 1e3
+        tot_gf += gf * count
+    print("weighted per UNet step: %.1f GFLOP in %.3f ms -> %.1f TF/s" % (tot_gf, tot_ms, tot_gf / tot_ms))
+
+
+if __name__ == "__main__":
+    main()
