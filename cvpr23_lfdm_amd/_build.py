@@ -50,7 +50,7 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            out = _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src,
+            out = _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
                         "-o", obj, "-Wno-unused-result"])
             if verbose and out.strip():
                 print(out)

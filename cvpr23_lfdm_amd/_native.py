@@ -37,6 +37,8 @@ class ConvParams(C.Structure):
         ("act", i32),
         ("ksplit", i32),
         ("partial", f32p),
+        ("gn_partial", f32p),
+        ("gn_groups", i32), ("gn_pixels", i32),
     ]
 
 
@@ -59,9 +61,12 @@ _SIGNATURES = {
     "lfdm_abi_version": (i32, []),
     "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
     "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
+    "lfdm_conv2d_tile_rows": (i32, [C.POINTER(ConvParams)]),
     "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
     "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
                                         f32, i32, C.c_void_p, sz, stream_t]),
+    "lfdm_groupnorm_apply_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32, i32,
+                                         f32p, i32, C.c_void_p, sz, stream_t]),
     "lfdm_layernorm_cl_f32": (i32, [f32p, f32p, i64, i32, f32p, f32, stream_t]),
     "lfdm_attention_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, stream_t]),
     "lfdm_linear_attention_ws_bytes": (sz, [i32]),

@@ -3,22 +3,25 @@
 // v_mfma_f32_32x32x2_f32; K is walked in 32-wide chunks (one filter tap x 32 input channels on
 // the fast path, a flattened (tap, channel) index on the generic path for tiny C_in).
 //
-//  - A tile (pixels x k) lives in LDS as [BM][33] so the MFMA A-operand read
-//    (lane -> row l&31, k = 2s + (l>>5)) touches 32 distinct banks per 32-lane group;
-//  - B tile (k x cout) is [32][BN], read along cout -> conflict free;
-//  - global->LDS staging is register double-buffered: chunk c+1 is fetched into VGPRs before the
-//    MFMAs of chunk c are issued, and written to LDS after them;
-//  - D layout: col = lane&31 is the output channel, so every store instruction writes two
-//    128-byte row segments of the channels-last output.
+// What keeps the non-MFMA instruction count per MFMA low (the fp32 MFMA is slow enough - 64
+// cycles - that address arithmetic and LDS traffic, not the matrix pipe, bound a naive kernel):
+//  - both tiles sit in LDS k-contiguous ([row][32+4]): one ds_read_b128 feeds FOUR MFMA k-steps.
+//    MFMA step 4q+e takes k = 8q + 4*kh + e from lane half kh (any k pairing is legal as long as A
+//    and B agree), so each lane's four steps are 4 consecutive floats; the 36-float row stride
+//    makes the 16-lane b128 groups conflict-free;
+//  - weights are packed [chunk][cout][32] so the B tile is a coalesced 128-byte-row copy;
+//  - staging is float4 in, ds_write_b128 out, register double-buffered (chunk c+1 is fetched
+//    before the MFMAs of chunk c);
+//  - for stride-1 zero-padded convolutions every output row keeps a 64-bit tap-validity mask and
+//    a base pixel index computed once per tile: per chunk the source address is one add;
+//  - the epilogue transposes each 32x32 accumulator tile through LDS so that global stores are
+//    float4 per lane (8 x 128-byte row segments per instruction) with bias / residual /
+//    activation applied vectorised; optionally it also emits the per-tile GroupNorm partial sums
+//    (sum, sum of squares per group) so the following GroupNorm needs no statistics pass.
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
 namespace {
-
-struct RowInfo {
-  int img;   // -1 = row beyond M
-  int qy, qx;
-};
 
 __device__ __forceinline__ bool src_pixel(const lfdm_conv_params& p, int img, int qy, int qx,
                                           int tap, int64_t& pix) {
@@ -43,21 +46,29 @@ __device__ __forceinline__ bool src_pixel(const lfdm_conv_params& p, int img, in
   return true;
 }
 
-template <int BM, int BN, bool FAST>
+// FAST: every source has a multiple of 32 channels (chunk = one tap x 32 channels, float4 loads)
+// SIMPLE: stride 1, zero padding, no up-sampling, <= 64 taps: mask-based addressing
+template <int BM, int BN, bool FAST, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   constexpr int BK = 32;
-  constexpr int LDA = BK + 1;
+  constexpr int LD = BK + 4;         // LDS row stride of both tiles (floats)
   constexpr int WM = BM / 2;         // rows per wave
   constexpr int WN = BN / 2;         // cols per wave
   constexpr int TM = WM / 32;        // 32x32 tiles per wave along M
   constexpr int TN = WN / 32;        // and along N
   constexpr int A_F4 = BM * BK / 4 / 256;   // float4 per thread (fast path)
   constexpr int A_F1 = BM * BK / 256;       // floats per thread (generic path)
-  constexpr int B_F4 = BK * BN / 4 / 256;
+  constexpr int B_F4 = BN * BK / 4 / 256;
 
-  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  // one array: A tile | B tile; the epilogue reuses it as 4 wave-private 32 x LD transpose scratches
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LD];
+  static_assert((BM + BN) * LD >= 4 * 32 * LD, "epilogue scratch does not fit");
+  float* const As = smem;
+  float* const Bs = smem + BM * LD;
   __shared__ int s_img[BM], s_qy[BM], s_qx[BM];
+  __shared__ int s_pix[BM];
+  __shared__ unsigned long long s_mask[BM];
+  __shared__ float s_gn[2][2][BN];   // [sum|sumsq][wm][col]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -72,17 +83,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
 
   for (int r = tid; r < BM; r += 256) {
     int64_t m = m0 + r;
+    int img = -1, qy = 0, qx = 0;
     if (m < M) {
-      int img = (int)(m / hqwq);
-      int rem = (int)(m - (int64_t)img * hqwq);
-      int qy = rem / p.wq;
-      s_img[r] = img;
-      s_qy[r] = qy;
-      s_qx[r] = rem - qy * p.wq;
-    } else {
-      s_img[r] = -1;
-      s_qy[r] = 0;
-      s_qx[r] = 0;
+      img = (int)(m / hqwq);
+      const int rem = (int)(m - (int64_t)img * hqwq);
+      qy = rem / p.wq;
+      qx = rem - qy * p.wq;
+    }
+    s_img[r] = img;
+    s_qy[r] = qy;
+    s_qx[r] = qx;
+    if (SIMPLE) {
+      unsigned long long mask = 0ull;
+      if (img >= 0) {
+        for (int t = 0; t < ntaps; ++t) {
+          const int ky = t / p.kw, kx = t - ky * p.kw;
+          const int iy = qy + ky - p.pad_y, ix = qx + kx - p.pad_x;
+          if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi) mask |= 1ull << t;
+        }
+      }
+      s_mask[r] = mask;
+      s_pix[r] = (img * p.hi + qy - p.pad_y) * p.wi + qx - p.pad_x;   // pixel index of tap (0,0)
     }
   }
   __syncthreads();
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nchunks_all = FAST ? ntaps * (cin / BK) : (ktotal + BK - 1) / BK;
+  const int nchunks_all = (ktotal + BK - 1) / BK;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
   const int kc_begin = (int)((int64_t)nchunks_all * blockIdx.z / ksplit);
   const int kc_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / ksplit);
@@ -103,6 +124,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   float4 ra4[FAST ? A_F4 : 1];
   float ra1[FAST ? 1 : A_F1];
   float4 rb[B_F4];
+
+  // per-thread constants of the fast path
+  int a_pix[FAST ? A_F4 : 1];
+  unsigned long long a_mask[FAST ? A_F4 : 1];
+  if (FAST && SIMPLE) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      a_pix[i] = s_pix[r];
+      a_mask[i] = s_mask[r];
+    }
+  }
 
   auto fetch = [&](int kc) {
     if (FAST) {
@@ -117,14 +150,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         ld = p.ld1;
       }
       const int cq = tid & 7;
+      int tap_off = 0;
+      if (SIMPLE) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        tap_off = ky * p.wi + kx;
+      }
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
-        const int r = (tid >> 3) + 32 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int img = s_img[r];
-        int64_t pix;
-        if (img >= 0 && src_pixel(p, img, s_qy[r], s_qx[r], tap, pix))
-          v = *reinterpret_cast<const float4*>(src + pix * ld + cc + 4 * cq);
+        if (SIMPLE) {
+          if ((a_mask[i] >> tap) & 1ull)
+            v = *reinterpret_cast<const float4*>(src + (int64_t)(a_pix[i] + tap_off) * ld + cc + 4 * cq);
+        } else {
+          const int r = (tid >> 3) + 32 * i;
+          const int img = s_img[r];
+          int64_t pix;
+          if (img >= 0 && src_pixel(p, img, s_qy[r], s_qx[r], tap, pix))
+            v = *reinterpret_cast<const float4*>(src + pix * ld + cc + 4 * cq);
+        }
         ra4[i] = v;
       }
     } else {
@@ -149,16 +192,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         ra1[i] = v;
       }
     }
-    const int krow0 = kc * BK;
+    const float* wchunk = p.weight + (int64_t)kc * p.coutp * BK;
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       const int f = tid + 256 * i;
-      const int row = f / (BN / 4);
-      const int c4 = f - row * (BN / 4);
+      const int n = f >> 3, k4 = f & 7;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int col = n0 + 4 * c4;
-      if (krow0 + row < ktotal && col < p.coutp)
-        v = *reinterpret_cast<const float4*>(p.weight + (int64_t)(krow0 + row) * p.coutp + col);
+      if (n0 + n < p.coutp) v = *reinterpret_cast<const float4*>(wchunk + (int64_t)(n0 + n) * BK + 4 * k4);
       rb[i] = v;
     }
   };
@@ -169,23 +209,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         const int r = (tid >> 3) + 32 * i;
-        float* d = As + r * LDA + 4 * cq;
-        d[0] = ra4[i].x;
-        d[1] = ra4[i].y;
-        d[2] = ra4[i].z;
-        d[3] = ra4[i].w;
+        *reinterpret_cast<float4*>(As + r * LD + 4 * cq) = ra4[i];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < A_F1; ++i) {
         const int r = (tid >> 5) + 8 * i;
-        As[r * LDA + (tid & 31)] = ra1[i];
+        As[r * LD + (tid & 31)] = ra1[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       const int f = tid + 256 * i;
-      *reinterpret_cast<float4*>(Bs + 4 * f) = rb[i];
+      *reinterpret_cast<float4*>(Bs + (f >> 3) * LD + 4 * (f & 7)) = rb[i];
     }
   };
 
@@ -203,17 +239,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     const bool more = kc + 1 < kc_end;
     if (more) fetch(kc + 1);
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      const int kk = 2 * s + khalf;
-      float a[TM], b[TN];
+    for (int q = 0; q < BK / 8; ++q) {
+      float4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(arow + 32 * i) * LDA + kk];
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const float4*>(As + (arow + 32 * i) * LD + 8 * q + 4 * khalf);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[kk * BN + bcol + 32 * j];
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const float4*>(Bs + (bcol + 32 * j) * LD + 8 * q + 4 * khalf);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_32x32x2(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = mfma_32x32x2(a[i].x, b[j].x, acc[i][j]);
+          acc[i][j] = mfma_32x32x2(a[i].y, b[j].y, acc[i][j]);
+          acc[i][j] = mfma_32x32x2(a[i].z, b[j].z, acc[i][j]);
+          acc[i][j] = mfma_32x32x2(a[i].w, b[j].w, acc[i][j]);
+        }
     }
     __syncthreads();
     if (more) {
@@ -222,36 +264,121 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     }
   }
 
-  // epilogue
+  // ------------------------------------------------------------------ epilogue
+  if (ksplit > 1) {
+    // raw partial sums, reduced (with bias / residual / activation) by conv_splitk_reduce_kernel
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int img = s_img[row];
-      if (img < 0) continue;
-      if (ksplit > 1) {
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (s_img[row] < 0) continue;
         float* dst = p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = n0 + wn * WN + 32 * j + (lane & 31);
           if (col < p.coutp) dst[col] = acc[i][j][r];
         }
-      } else {
+      }
+    return;
+  }
+
+  // transpose each 32x32 accumulator tile through a wave-private LDS scratch (aliases the A tile)
+  float* scratch = smem + wave * (32 * LD);
+  const bool vec_ok = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)p.out) & 15) == 0) &&
+                      (!p.residual || ((p.ldr % 4 == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
+  const int c4 = lane & 7, rsub = lane >> 3;
+  float gs[TN][4], gq[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gs[j][e] = gq[j][e] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LD + (lane & 31)] = acc[i][j][r];
+      __syncthreads();
+      const int colbase = n0 + wn * WN + 32 * j + 4 * c4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int trow = it * 8 + rsub;
+        const int row = wm * WM + 32 * i + trow;
+        const int img = s_img[row];
+        if (img < 0 || colbase >= p.cout) continue;
+        float4 v = *reinterpret_cast<const float4*>(scratch + trow * LD + 4 * c4);
         const int oy = s_qy[row] * p.out_scale + p.out_off_y;
         const int ox = s_qx[row] * p.out_scale + p.out_off_x;
         const int64_t orow = ((int64_t)img * p.ho + oy) * p.wo + ox;
+        if (vec_ok) {
+          if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          if (p.gn_partial) {
+            gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
+            gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
+          }
+          if (p.residual) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+          v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+          *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
+        } else {
+          const float vals[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = n0 + wn * WN + 32 * j + (lane & 31);
-          if (col < p.cout) {
-            float v = acc[i][j][r];
-            if (p.bias) v += p.bias[col];
-            if (p.residual) v += p.residual[orow * p.ldr + col];
-            p.out[orow * p.ldo + col] = apply_act(v, p.act);
+          for (int e = 0; e < 4; ++e) {
+            const int col = colbase + e;
+            if (col < p.cout) {
+              float t = vals[e];
+              if (p.bias) t += p.bias[col];
+              if (p.residual) t += p.residual[orow * p.ldr + col];
+              p.out[orow * p.ldo + col] = apply_act(t, p.act);
+            }
           }
         }
       }
+    }
+  }
+
+  if (p.gn_partial) {
+    // per-tile GroupNorm partial sums: lanes with equal c4 hold the same 4 columns
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = gs[j][e], q = gq[j][e];
+#pragma unroll
+        for (int m = 8; m <= 32; m <<= 1) {
+          s += __shfl_xor(s, m);
+          q += __shfl_xor(q, m);
+        }
+        if (lane < 8) {
+          const int col = wn * WN + 32 * j + 4 * c4 + e;
+          s_gn[0][wm][col] = s;
+          s_gn[1][wm][col] = q;
+        }
+      }
+    __syncthreads();
+    const int cg = p.cout / p.gn_groups;              // channels per group
+    const int gpt = BN / cg;                          // groups covered by this N tile (BN % cg == 0)
+    if (tid < gpt && n0 + tid * cg < p.cout) {
+      float s = 0.f, q = 0.f;
+      for (int c = 0; c < cg; ++c) {
+        s += s_gn[0][0][tid * cg + c] + s_gn[0][1][tid * cg + c];
+        q += s_gn[1][0][tid * cg + c] + s_gn[1][1][tid * cg + c];
+      }
+      const int64_t tile = m0 / BM;                   // gn_pixels % BM == 0: one sample per tile
+      float* dst = p.gn_partial + (tile * p.gn_groups + (n0 / cg + tid)) * 2;
+      dst[0] = s;
+      dst[1] = q;
     }
   }
 }
@@ -293,11 +420,33 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_param
   }
 }
 
+template <int BM, int BN>
+void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, hipStream_t stream) {
+  dim3 block(256);
+  if (fast && simple) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, true>), grid, block, 0, stream, p);
+  else if (fast) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, false>), grid, block, 0, stream, p);
+  else LFDM_LAUNCH((conv_igemm_kernel<BM, BN, false, false>), grid, block, 0, stream, p);
+}
+
+// the tile choice (the caller needs it to size gn_partial)
+int conv_block_m(const lfdm_conv_params& p) {
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
+  if (wide) return 128;
+  const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
+  return small_m ? 64 : 128;
+}
+
 }  // namespace
 
 extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p || p->ksplit <= 1) return 0;
   return (size_t)p->ksplit * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
+}
+
+extern "C" int lfdm_conv2d_tile_rows(const lfdm_conv_params* p) {
+  if (!p) return 0;
+  return conv_block_m(*p);
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
@@ -324,27 +473,32 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   const bool fast = (p.c0 % 32 == 0) && (p.c1 % 32 == 0) && (p.ld0 % 4 == 0) &&
                     (p.c1 == 0 || p.ld1 % 4 == 0) &&
                     (((uintptr_t)p.src0 & 15) == 0) && (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0);
+  const bool simple = p.stride == 1 && !p.upsample && p.pad_mode == 0 && p.kh * p.kw <= 64 &&
+                      (int64_t)p.n_img * p.hi * p.wi < (1ll << 31) - (1 << 20);
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
-  const int nchunks = fast ? p.kh * p.kw * (cin / 32) : (p.kh * p.kw * cin + 31) / 32;
+  const int nchunks = (p.kh * p.kw * cin + 31) / 32;
   if (p.ksplit > nchunks) p.ksplit = nchunks;
   // tile choice (measured on MI355X, tools/bench_conv.py): 128x128 tiles only when they still give
   // >= 256 workgroups; otherwise 64x64 tiles (more, smaller workgroups balance the 256 CUs better
   // than 128-row tiles at the UNet's M = 40*S*S) and split-K (caller) for the low-resolution levels.
   const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
-  const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
-  dim3 block(256);
+  const int bm = conv_block_m(p);
+  if (p.gn_partial) {
+    const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;
+    if (p.ksplit > 1 || p.gn_groups <= 0 || p.cout % p.gn_groups != 0 || cg % 4 != 0 ||
+        (wide ? 128 : 64) % cg != 0 || p.gn_pixels <= 0 || p.gn_pixels % bm != 0 || p.cout % 4 != 0 ||
+        p.ldo % 4 != 0 || (((uintptr_t)p.out) & 15) != 0) {
+      lfdm_set_error("conv2d: fused GroupNorm statistics need ksplit==1, pixels % tile_rows == 0, "
+                     "group size dividing the 64/128 column tile");
+      return LFDM_EINVAL;
+    }
+  }
   if (wide) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 127) / 128), p.ksplit);
-    if (fast) LFDM_LAUNCH((conv_igemm_kernel<128, 128, true>), grid, block, 0, stream, p);
-    else LFDM_LAUNCH((conv_igemm_kernel<128, 128, false>), grid, block, 0, stream, p);
-  } else if (small_m) {
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((p.coutp + 63) / 64), p.ksplit);
-    if (fast) LFDM_LAUNCH((conv_igemm_kernel<64, 64, true>), grid, block, 0, stream, p);
-    else LFDM_LAUNCH((conv_igemm_kernel<64, 64, false>), grid, block, 0, stream, p);
+    launch_conv<128, 128>(p, fast, simple, dim3((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 127) / 128), p.ksplit), stream);
+  } else if (bm == 64) {
+    launch_conv<64, 64>(p, fast, simple, dim3((unsigned)((M + 63) / 64), (unsigned)((p.coutp + 63) / 64), p.ksplit), stream);
   } else {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 63) / 64), p.ksplit);
-    if (fast) LFDM_LAUNCH((conv_igemm_kernel<128, 64, true>), grid, block, 0, stream, p);
-    else LFDM_LAUNCH((conv_igemm_kernel<128, 64, false>), grid, block, 0, stream, p);
+    launch_conv<128, 64>(p, fast, simple, dim3((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 63) / 64), p.ksplit), stream);
   }
   int rc = lfdm_check_launch("conv_igemm");
   if (rc) return rc;
@@ -352,7 +506,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     const int64_t total = M * (p.coutp / 4);
     unsigned nb = (unsigned)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    LFDM_LAUNCH(conv_splitk_reduce_kernel, dim3(nb), block, 0, stream, p);
+    LFDM_LAUNCH(conv_splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, p);
     rc = lfdm_check_launch("conv_splitk_reduce");
   }
   return rc;

@@ -326,6 +326,32 @@ extern "C" int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch,
   return lfdm_check_launch("groupnorm");
 }
 
+extern "C" int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch, int pixels,
+                                           int channels, int groups, const float* gamma,
+                                           const float* beta, const float* scale_shift, int ss_ld,
+                                           const float* residual, float eps, int apply_silu,
+                                           const float* partial, int nchunk, void* ws,
+                                           size_t ws_bytes, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || !gamma || !beta || !partial || nchunk <= 0 || batch <= 0 || pixels <= 0 ||
+      channels <= 0 || groups <= 0 || groups > 64 || channels % groups != 0 || channels % 4 != 0 ||
+      (scale_shift && ss_ld < 2 * channels)) {
+    lfdm_set_error("groupnorm_apply: bad arguments");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < (size_t)batch * 2 * channels * sizeof(float)) {
+    lfdm_set_error("groupnorm_apply: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  float* ab = reinterpret_cast<float*>(ws);
+  LFDM_LAUNCH(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, partial, nchunk, pixels, channels,
+              groups, gamma, beta, scale_shift, ss_ld, eps, ab);
+  const int64_t total = (int64_t)batch * pixels * (channels / 4);
+  LFDM_LAUNCH(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, batch, pixels,
+              channels, (const float*)ab, apply_silu, residual);
+  return lfdm_check_launch("groupnorm_apply");
+}
+
 extern "C" int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,
                                      const float* gamma, float eps, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -53,38 +53,41 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def _pack_k_major(wk, cout):
+    """(K, cout) rows in k order -> [ceil(K/32)][coutp][32] (k contiguous per output channel)."""
+    k = wk.shape[0]
+    kp, coutp = round_up(k, 32), round_up(cout, 32)
+    full = torch.zeros(kp, coutp, dtype=torch.float32, device=wk.device)
+    full[:k, :cout] = wk
+    return full.view(kp // 32, 32, coutp).permute(0, 2, 1).contiguous()
+
+
 def pack_conv_weight(w):
-    """(Cout, Cin, kh, kw) [or (Cout, Cin, 1, kh, kw)] -> packed [kh*kw][Cin][coutp], coutp = ceil32."""
+    """(Cout, Cin, kh, kw) [or (Cout, Cin, 1, kh, kw) / (Cout, Cin)] -> lfdm_conv2d_cl_f32 layout:
+    [ceil(K/32)][coutp][32], K = kh*kw*Cin flattened tap-major then channel."""
     if w.dim() == 5:
         w = w[:, :, 0]
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin, kh, kw = w.shape
-    coutp = round_up(cout, 32)
-    packed = torch.zeros(kh * kw, cin, coutp, dtype=torch.float32, device=w.device)
-    packed[:, :, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
-    return packed.contiguous()
+    return _pack_k_major(w.permute(2, 3, 1, 0).reshape(kh * kw * cin, cout), cout)
 
 
 def pack_deconv_weight(w):
     """ConvTranspose3d weight (Cin, Cout, 1, 4, 4), stride 2, padding 1 -> four parity packs
-    [(py, px, packed[4][Cin][coutp])]: output pixel (2q+py, 2q'+px) = 2x2 conv with pad (1-py, 1-px);
+    [(py, px, packed)]: output pixel (2q+py, 2q'+px) = 2x2 conv with pad (1-py, 1-px);
     tap ky' uses kernel row ky = 3 - 2ky' (py = 0) or 2 - 2ky' (py = 1)."""
     if w.dim() == 5:
         w = w[:, :, 0]
     cin, cout, kh, kw = w.shape
     assert kh == 4 and kw == 4
-    coutp = round_up(cout, 32)
     packs = []
     for py in (0, 1):
         for px in (0, 1):
             kys = [3, 1] if py == 0 else [2, 0]
             kxs = [3, 1] if px == 0 else [2, 0]
-            packed = torch.zeros(4, cin, coutp, dtype=torch.float32, device=w.device)
-            for a, ky in enumerate(kys):
-                for b, kx in enumerate(kxs):
-                    packed[a * 2 + b, :, :cout] = w[:, :, ky, kx]
-            packs.append((py, px, packed.contiguous()))
+            taps = [w[:, :, ky, kx] for ky in kys for kx in kxs]          # each (Cin, Cout)
+            packs.append((py, px, _pack_k_major(torch.cat(taps, dim=0), cout)))
     return packs
 
 
@@ -116,12 +119,13 @@ def conv_ksplit(m, coutp, nchunks, n_cu=256):
 
 def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
               upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
-              ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=1, partial=None):
+              ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=1, partial=None, gn_partial=None,
+              gn_groups=8, gn_pixels=0):
     lib = _lib()
-    _chk(lib, src0, src1, weight, bias, residual, out, partial)
+    _chk(lib, src0, src1, weight, bias, residual, out, partial, gn_partial)
     cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
-    assert weight.shape[0] == kh * kw and weight.shape[1] == cin, (weight.shape, kh, kw, cin)
-    coutp = weight.shape[2]
+    assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
+    coutp = weight.shape[1]
     pad_y, pad_x = (kh // 2, kw // 2) if pad is None else pad
     h_in = hi * 2 if upsample else hi
     w_in = wi * 2 if upsample else wi
@@ -144,6 +148,7 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None
     p.out_scale, p.out_off_y, p.out_off_x = out_scale, out_off[0], out_off[1]
     p.residual, p.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     p.act, p.ksplit, p.partial = act, ksplit, _p(partial)
+    p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
     if ksplit > 1 and partial is None:
         need = lib.lfdm_conv2d_partial_bytes(C.byref(p))
         partial = torch.empty(need // 4, dtype=torch.float32, device=src0.device)
@@ -178,6 +183,31 @@ def groupnorm_silu_cl(x, batch, gamma, beta, *, groups=8, scale_shift=None, resi
                                              scale_shift.stride(0) if scale_shift is not None else 0,
                                              _p(residual), eps, int(silu), _p(ws),
                                              ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_silu_cl_f32")
+    return out
+
+
+def conv_tile_rows(m, coutp):
+    """Output-tile rows lfdm_conv2d_cl_f32 uses (mirror of lfdm_conv2d_tile_rows)."""
+    if coutp >= 128 and (m // 128) * (coutp // 128) >= 256:
+        return 128
+    return 64 if m * ((coutp + 63) // 64) < 128 * 512 else 128
+
+
+def groupnorm_apply_cl(x, batch, gamma, beta, partial, nchunk, *, groups=8, scale_shift=None, residual=None,
+                       eps=1e-5, silu=True, out=None, ws=None):
+    """GroupNorm whose statistics came from the producing convolution (gn_partial)."""
+    lib = _lib()
+    rows, ch = x.shape
+    _chk(lib, x, gamma, beta, partial, scale_shift, residual, out, ws)
+    if out is None:
+        out = torch.empty_like(x)
+    if ws is None:
+        ws = torch.empty(batch * 2 * ch, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_groupnorm_apply_cl_f32(_p(x), _p(out), batch, rows // batch, ch, groups, _p(gamma), _p(beta),
+                                              _p(scale_shift),
+                                              scale_shift.stride(0) if scale_shift is not None else 0,
+                                              _p(residual), eps, int(silu), _p(partial), nchunk, _p(ws),
+                                              ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_apply_cl_f32")
     return out
 
 

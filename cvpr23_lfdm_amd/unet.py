@@ -240,36 +240,53 @@ class Unet3D(ParamTree):
         return step_part, sample_part
 
     # ------------------------------------------------------------------ building blocks
-    def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, **kw):
-        """conv2d_cl with an occupancy-driven split-K choice for the low-resolution levels."""
+    def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, gn=None, **kw):
+        """conv2d_cl with an occupancy-driven split-K choice for the low-resolution levels.
+        gn = (batch,) asks for fused GroupNorm statistics; returns (out, (partial, nchunk) or None)."""
         m = n_img * s * s
         cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
         ksplit = 1
         if "stride" not in kw and "upsample" not in kw and "out_scale" not in kw:
-            ksplit = ops.conv_ksplit(m, w.shape[2], k * k * max(cin // 32, 1))
+            ksplit = ops.conv_ksplit(m, w.shape[1], k * k * max(cin // 32, 1))
         partial = None
         if ksplit > 1:
-            partial = self._buf("splitk", ksplit * m, w.shape[2])
-        return ops.conv2d_cl(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
-                             out=out, ksplit=ksplit, partial=partial, **kw)
+            partial = self._buf("splitk", ksplit * m, w.shape[1])
+        stats = None
+        if gn is not None:
+            batch = gn[0]
+            rows_per_tile = ops.conv_tile_rows(m, w.shape[1])
+            pixels = m // batch
+            cg = cout // 8
+            if ksplit == 1 and pixels % rows_per_tile == 0 and cg % 4 == 0 and 64 % cg == 0:
+                nchunk = pixels // rows_per_tile
+                stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
+                kw = dict(kw, gn_partial=stats[0], gn_groups=8, gn_pixels=pixels)
+        y = ops.conv2d_cl(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
+                          out=out, ksplit=ksplit, partial=partial, **kw)
+        return (y, stats) if gn is not None else y
+
+    def _gn(self, x, batch, gamma, beta, stats, **kw):
+        gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
+        if stats is not None:
+            return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, **kw)
+        return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, **kw)
 
     def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
         n_img, rows = batch * frames, batch * frames * s * s
         h1 = self._buf("rb.h1", rows, cout)
-        self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
-                   bias=pk[prefix + "block1.proj.b"], out=h1)
+        _, st = self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
+                           bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,))
         sshift = None
         if ss is not None and (prefix + "ss_off") in pk:
             o = pk[prefix + "ss_off"]
             sshift = ss[:, o:o + 2 * cout]
-        gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
-        ops.groupnorm_silu_cl(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"],
-                              scale_shift=sshift, out=h1, ws=gws)
+        self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
         out = self._buf(outname, rows, cout)
-        self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"], out=out)
+        _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
+                           out=out, gn=(batch,))
         has_res = (prefix + "res.w") in pk
-        ops.groupnorm_silu_cl(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"],
-                              residual=None if has_res else x, out=out, ws=gws)
+        self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st,
+                 residual=None if has_res else x)
         if has_res:
             self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"],
                        residual=out, out=out)

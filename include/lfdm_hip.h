@@ -53,8 +53,13 @@ int lfdm_abi_version(void);
  * Tap (ky,kx) reads input pixel (qy*stride + ky - pad_y, qx*stride + kx - pad_x) of the
  * (optionally x2 nearest-upsampled) input; out pixel = (qy*out_scale + out_off_y, ...), which
  * expresses ConvTranspose3d k4 s2 p1 as four 2x2 parity convolutions.
- * weight is packed [kh*kw][c0+c1][coutp] (coutp = cout rounded up to 32, zero filled).
+ * weight is packed [ceil(K/32)][coutp][32] with K = kh*kw*(c0+c1) flattened tap-major then
+ * channel (k = tap*cin + c), zero padded (coutp = cout rounded up to 32).
  * out = act(acc + bias + residual).
+ * Optional fused GroupNorm statistics (ksplit == 1): when gn_partial != NULL the kernel also writes, per
+ * output row tile, the (sum, sum of squares) of (acc + bias) per channel group:
+ * gn_partial[(tile*gn_groups + g)*2 + {0,1}], tile = first_row / lfdm_conv2d_tile_rows(p); it requires
+ * gn_pixels (rows per sample) to be a multiple of the tile rows so no tile straddles two samples.
  */
 typedef struct lfdm_conv_params {
   const float* src0;
@@ -79,9 +84,13 @@ typedef struct lfdm_conv_params {
      epilogue (bias/residual/act) is applied by lfdm_conv2d_cl_f32 in a reduce pass */
   int ksplit;
   float* partial;
+  float* gn_partial;      /* NULL or fused GroupNorm partial sums (see above) */
+  int gn_groups, gn_pixels;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
+/* rows of the output tile the kernel will use for this geometry (64 or 128) */
+int lfdm_conv2d_tile_rows(const lfdm_conv_params* p);
 /* bytes of `partial` needed for a given ksplit */
 size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
 
@@ -100,6 +109,15 @@ int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels
                                const float* scale_shift, int ss_ld, const float* residual,
                                float eps, int apply_silu, void* ws, size_t ws_bytes,
                                lfdm_stream_t stream);
+
+/* Same normalisation when the statistics were already produced by the preceding convolution
+ * (lfdm_conv_params.gn_partial): partial = [batch][nchunk][groups][2] (sum, sum of squares),
+ * nchunk = pixels / lfdm_conv2d_tile_rows.  ws: batch*2*channels floats. */
+int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch, int pixels, int channels,
+                                int groups, const float* gamma, const float* beta,
+                                const float* scale_shift, int ss_ld, const float* residual,
+                                float eps, int apply_silu, const float* partial, int nchunk,
+                                void* ws, size_t ws_bytes, lfdm_stream_t stream);
 
 /* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
 int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,

@@ -74,15 +74,17 @@ def unet_case(name, b, t, s, **variant):
     save(name, b=b, t=t, s=s, **outs)
 
 
-def sampler_case(name, b, t, s, hw, steps, timesteps):
+def sampler_case(name, b, t, s, hw, steps, timesteps, video_frames=None):
+    """video_frames: keep only these frame indices of the image-resolution outputs (fixture size)."""
     m = reference_model(s, t, steps, timesteps)
     img, cond = synth.inputs(b, hw)
     m.set_sample_input(sample_img=img, sample_text=cond)
     with patched_noise(synth.NoiseTape(11)), torch.no_grad():
         m.sample_one_video(cond_scale=1.0)
-    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=timesteps, noise_seed=11,
+    vf = np.arange(t) if video_frames is None else np.asarray(video_frames)
+    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=timesteps, noise_seed=11, video_frames=vf,
          sample_vid_grid=m.sample_vid_grid, sample_vid_conf=m.sample_vid_conf,
-         sample_out_vid=m.sample_out_vid, sample_warped_vid=m.sample_warped_vid)
+         sample_out_vid=m.sample_out_vid[:, :, vf], sample_warped_vid=m.sample_warped_vid[:, :, vf])
 
 
 def generator_case(name, b, hw):
@@ -127,7 +129,7 @@ def main():
     if args.c2:
         unet_case("unet_c2_deconv", 1, 40, 32)
         generator_case("generator_128", 1, 128)
-        sampler_case("sample_ddim100_c2", 1, 40, 32, 128, 100, 1000)
+        sampler_case("sample_ddim100_c2", 1, 40, 32, 128, 100, 1000, video_frames=[0, 13, 26, 39])
 
 
 if __name__ == "__main__":

@@ -124,6 +124,31 @@ def test_groupnorm_silu(backend, c, with_ss):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
 
 
+def test_conv_fused_groupnorm_stats(backend):
+    """conv epilogue emits the GroupNorm partial sums; finalize+apply must equal conv -> group_norm."""
+    dev = backend
+    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 2, 8, 32, 64)
+    x = rnd(b, cin, t, s, s, seed=1)
+    wt = rnd(cout, cin, 1, 3, 3, seed=2, scale=0.06)
+    bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
+    ss = rnd(b, 2 * cout, seed=6) * 0.3
+    res = rnd(b, cout, t, s, s, seed=7)
+    ref = F.group_norm(F.conv3d(x, wt, bias, padding=(0, 1, 1)), 8, gamma, beta, eps=1e-5)
+    ref = F.silu(ref * (ss[:, :cout].view(b, cout, 1, 1, 1) + 1) + ss[:, cout:].view(b, cout, 1, 1, 1)) + res
+    m = b * t * s * s
+    w = ops.pack_conv_weight(wt).to(dev)
+    rows_per_tile = ops.conv_tile_rows(m, w.shape[1])
+    pixels = t * s * s
+    assert pixels % rows_per_tile == 0
+    nchunk = pixels // rows_per_tile
+    partial = torch.zeros(b * nchunk, 16, device=dev)
+    h = ops.conv2d_cl(unet_to_cl(x).to(dev), w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), gn_partial=partial,
+                      gn_groups=8, gn_pixels=pixels)
+    out = ops.groupnorm_apply_cl(h, b, gamma.to(dev), beta.to(dev), partial, nchunk, scale_shift=ss.to(dev),
+                                 residual=unet_to_cl(res).to(dev))
+    assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
+
+
 @pytest.mark.parametrize("c", [64, 128, 512])
 def test_layernorm(backend, c):
     dev = backend

@@ -39,7 +39,7 @@ def main():
         w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device=dev) * 0.05)
         b = torch.randn(cout, device=dev)
         out = torch.empty(m, cout, device=dev)
-        coutp = w.shape[2]
+        coutp = w.shape[1]
         ksplit = ops.conv_ksplit(m, coutp, k * k * max(cin // 32, 1))
         ksplit = int(os.environ.get("KSPLIT", ksplit))
         partial = torch.empty(ksplit * m * coutp, device=dev) if ksplit > 1 else None
