@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG_DIR, "liblfdm_hip.so")
+HIP_LIB_PATH = os.environ.get("LFDM_HIP_LIB", os.path.join(_PKG_DIR, "liblfdm_hip.so"))   # override: kernel probes only
 
 f32p = C.c_void_p
 i32 = C.c_int
@@ -61,7 +61,7 @@ _SIGNATURES = {
     "lfdm_abi_version": (i32, []),
     "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
     "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
-    "lfdm_conv2d_tile_rows": (i32, [C.POINTER(ConvParams)]),
+    "lfdm_conv2d_plan": (i32, [C.POINTER(ConvParams), C.POINTER(i32), C.POINTER(i32)]),
     "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
     "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
                                         f32, i32, C.c_void_p, sz, stream_t]),

@@ -18,6 +18,8 @@
 //    float4 per lane (8 x 128-byte row segments per instruction) with bias / residual /
 //    activation applied vectorised; optionally it also emits the per-tile GroupNorm partial sums
 //    (sum, sum of squares per group) so the following GroupNorm needs no statistics pass.
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -47,7 +49,7 @@ __device__ __forceinline__ bool src_pixel(const lfdm_conv_params& p, int img, in
 }
 
 // FAST: every source has a multiple of 32 channels (chunk = one tap x 32 channels, float4 loads)
-// SIMPLE: stride 1, zero padding, no up-sampling, <= 64 taps: mask-based addressing
+// SIMPLE: zero padding, no up-sampling, <= 64 taps: mask-based addressing
 template <int BM, int BN, bool FAST, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   constexpr int BK = 32;
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   constexpr int B_F4 = BN * BK / 4 / 256;
 
   // one array: A tile | B tile; the epilogue reuses it as 4 wave-private 32 x LD transpose scratches
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LD];
-  static_assert((BM + BN) * LD >= 4 * 32 * LD, "epilogue scratch does not fit");
-  float* const As = smem;
-  float* const Bs = smem + BM * LD;
+  // (an LDS double-buffered variant of this loop measured 6 % slower on MI355X and was dropped)
+  constexpr int STAGE = (BM + BN) * LD;
+  __shared__ __attribute__((aligned(16))) float smem[STAGE];
+  static_assert(STAGE >= 4 * 32 * LD, "epilogue scratch does not fit");
   __shared__ int s_img[BM], s_qy[BM], s_qx[BM];
   __shared__ int s_pix[BM];
   __shared__ unsigned long long s_mask[BM];
@@ -98,12 +100,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
       if (img >= 0) {
         for (int t = 0; t < ntaps; ++t) {
           const int ky = t / p.kw, kx = t - ky * p.kw;
-          const int iy = qy + ky - p.pad_y, ix = qx + kx - p.pad_x;
+          const int iy = qy * p.stride + ky - p.pad_y, ix = qx * p.stride + kx - p.pad_x;
           if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi) mask |= 1ull << t;
         }
       }
       s_mask[r] = mask;
-      s_pix[r] = (img * p.hi + qy - p.pad_y) * p.wi + qx - p.pad_x;   // pixel index of tap (0,0)
+      s_pix[r] = (img * p.hi + qy * p.stride - p.pad_y) * p.wi + qx * p.stride - p.pad_x;   // tap (0,0)
     }
   }
   __syncthreads();
@@ -204,6 +206,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   };
 
   auto stage = [&]() {
+    float* const As = smem;
+    float* const Bs = As + BM * LD;
     if (FAST) {
       const int cq = tid & 7;
 #pragma unroll
@@ -225,19 +229,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     }
   };
 
-  if (kc_begin < kc_end) {
+  const int arow = wm * WM + (lane & 31);
+  const int bcol = wn * WN + (lane & 31);
+  const int khalf = lane >> 5;
+  const int nk = kc_end - kc_begin;
+
+  if (nk > 0) {
     fetch(kc_begin);
     stage();
   }
   __syncthreads();
 
-  const int arow = wm * WM + (lane & 31);
-  const int bcol = wn * WN + (lane & 31);
-  const int khalf = lane >> 5;
-
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end;
-    if (more) fetch(kc + 1);
+  for (int c = 0; c < nk; ++c) {
+    const bool more = c + 1 < nk;
+#ifndef LFDM_PROBE_NOFETCH
+    if (more) fetch(kc_begin + c + 1);
+#endif
+    const float* const As = smem;
+    const float* const Bs = As + BM * LD;
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) {
       float4 a[TM], b[TN];
@@ -251,10 +260,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+#ifdef LFDM_PROBE_NOMFMA
+          acc[i][j][0] += a[i].x * b[j].x + a[i].y * b[j].y + a[i].z * b[j].z + a[i].w * b[j].w;
+#else
           acc[i][j] = mfma_32x32x2(a[i].x, b[j].x, acc[i][j]);
           acc[i][j] = mfma_32x32x2(a[i].y, b[j].y, acc[i][j]);
           acc[i][j] = mfma_32x32x2(a[i].z, b[j].z, acc[i][j]);
           acc[i][j] = mfma_32x32x2(a[i].w, b[j].w, acc[i][j]);
+#endif
         }
     }
     __syncthreads();
@@ -428,35 +441,105 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
   else LFDM_LAUNCH((conv_igemm_kernel<BM, BN, false, false>), grid, block, 0, stream, p);
 }
 
-// the tile choice (the caller needs it to size gn_partial)
-int conv_block_m(const lfdm_conv_params& p) {
+}  // namespace
+
+int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
+
+namespace {
+
+struct ConvPlan {
+  int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip)
+  int bm, bn, ksplit;
+  bool fast, simple;
+};
+
+int conv_force() {   // debugging aid for tools/bench_conv.py: LFDM_CONV_FORCE=igemm|ksw
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("LFDM_CONV_FORCE");
+    v = !e ? -1 : (e[0] == 'k' ? 1 : 0);
+  }
+  return v;
+}
+
+// One place decides tile shape and split-K (measured on MI355X with tools/bench_conv.py):
+//  - K >= 256, zero padding, C_in % 32 == 0  -> 160-row K-split-across-waves tiles; 160x64 when that
+//    already yields >= 224 workgroups, else 160x32, else additionally split K over blockIdx.z so that
+//    about 256 workgroups (one per CU) exist;
+//  - otherwise the 2x2-wave kernel: 128x128 tiles when they give >= 256 workgroups, else 64x64, with
+//    split-K for the low-resolution levels.
+ConvPlan make_plan(const lfdm_conv_params& p) {
+  ConvPlan pl;
+  const int cin = p.c0 + p.c1;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
-  const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
-  if (wide) return 128;
-  const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
-  return small_m ? 64 : 128;
+  const int nchunks = (p.kh * p.kw * cin + 31) / 32;
+  pl.fast = (p.c0 % 32 == 0) && (p.c1 % 32 == 0) && (p.ld0 % 4 == 0) && (p.c1 == 0 || p.ld1 % 4 == 0) &&
+            (((uintptr_t)p.src0 & 15) == 0) && (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0);
+  pl.simple = !p.upsample && p.pad_mode == 0 && p.kh * p.kw <= 64 &&
+              (int64_t)p.n_img * p.hi * p.wi < (1ll << 31) - (1 << 20);
+  const int user_k = p.ksplit;                       // 0 = choose
+  bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160;
+  if (conv_force() == 0) ksw = false;
+  if (conv_force() == 1 && pl.fast && pl.simple) ksw = true;
+  if (ksw) {
+    pl.kind = 1;
+    pl.bm = 160;
+    const int64_t mt = (M + 159) / 160;
+    const int64_t t64 = mt * ((p.coutp + 63) / 64), t32 = mt * ((p.coutp + 31) / 32);
+    pl.bn = t64 >= 224 ? 64 : 32;
+    if (const char* e = getenv("LFDM_KSW_BN")) pl.bn = atoi(e);   // experiment knob
+    int k = 1;
+    if (t64 < 224 && t32 < 224) {
+      k = (int)(256 / t32);
+      if (k > nchunks / 4) k = nchunks / 4;
+      if (k < 1) k = 1;
+    }
+    pl.ksplit = user_k >= 1 ? user_k : k;
+  } else {
+    pl.kind = 0;
+    const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
+    const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
+    pl.bm = wide ? 128 : (small_m ? 64 : 128);
+    pl.bn = wide ? 128 : 64;
+    int k = 1;
+    const int64_t tiles = ((M + pl.bm - 1) / pl.bm) * ((p.coutp + pl.bn - 1) / pl.bn);
+    if (tiles < 256 && nchunks >= 8) {
+      k = (int)(512 / tiles);
+      if (k > nchunks / 4) k = nchunks / 4;
+      if (k > 16) k = 16;
+      if (k < 1) k = 1;
+    }
+    pl.ksplit = user_k >= 1 ? user_k : k;
+  }
+  if (pl.ksplit > nchunks) pl.ksplit = nchunks;
+  if (pl.ksplit < 1) pl.ksplit = 1;
+  return pl;
 }
 
 }  // namespace
 
-extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
-  if (!p || p->ksplit <= 1) return 0;
-  return (size_t)p->ksplit * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
+extern "C" int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit) {
+  if (!p) return LFDM_EINVAL;
+  const ConvPlan pl = make_plan(*p);
+  if (tile_rows) *tile_rows = pl.bm;
+  if (ksplit) *ksplit = pl.ksplit;
+  return LFDM_OK;
 }
 
-extern "C" int lfdm_conv2d_tile_rows(const lfdm_conv_params* p) {
+extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p) return 0;
-  return conv_block_m(*p);
+  const ConvPlan pl = make_plan(*p);
+  if (pl.ksplit <= 1) return 0;
+  return (size_t)pl.ksplit * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!pp) { lfdm_set_error("conv2d: null params"); return LFDM_EINVAL; }
   lfdm_conv_params p = *pp;
-  const int cin = p.c0 + p.c1;
   if (!p.src0 || !p.weight || !p.out || p.c0 <= 0 || p.c1 < 0 || (p.c1 > 0 && !p.src1) ||
       p.n_img <= 0 || p.hq <= 0 || p.wq <= 0 || p.kh <= 0 || p.kw <= 0 || p.cout <= 0 ||
-      p.coutp < p.cout || (p.coutp % 32) != 0 || p.stride <= 0 || p.out_scale <= 0 ||
+      p.coutp < p.cout || (p.coutp % 32) != 0 || p.stride <= 0 || p.out_scale <= 0 || p.ksplit < 0 ||
       p.ld0 < p.c0 || (p.c1 > 0 && p.ld1 < p.c1) || p.ldo < p.cout) {
     lfdm_set_error("conv2d: invalid geometry");
     return LFDM_EINVAL;
@@ -468,39 +551,30 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
       return LFDM_EINVAL;
     }
   }
-  if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: ksplit without partial buffer"); return LFDM_EWORKSPACE; }
-  if (p.ksplit < 1) p.ksplit = 1;
-  const bool fast = (p.c0 % 32 == 0) && (p.c1 % 32 == 0) && (p.ld0 % 4 == 0) &&
-                    (p.c1 == 0 || p.ld1 % 4 == 0) &&
-                    (((uintptr_t)p.src0 & 15) == 0) && (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0);
-  const bool simple = p.stride == 1 && !p.upsample && p.pad_mode == 0 && p.kh * p.kw <= 64 &&
-                      (int64_t)p.n_img * p.hi * p.wi < (1ll << 31) - (1 << 20);
+  const ConvPlan pl = make_plan(p);
+  p.ksplit = pl.ksplit;
+  if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
-  const int nchunks = (p.kh * p.kw * cin + 31) / 32;
-  if (p.ksplit > nchunks) p.ksplit = nchunks;
-  // tile choice (measured on MI355X, tools/bench_conv.py): 128x128 tiles only when they still give
-  // >= 256 workgroups; otherwise 64x64 tiles (more, smaller workgroups balance the 256 CUs better
-  // than 128-row tiles at the UNet's M = 40*S*S) and split-K (caller) for the low-resolution levels.
-  const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
-  const int bm = conv_block_m(p);
   if (p.gn_partial) {
     const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;
-    if (p.ksplit > 1 || p.gn_groups <= 0 || p.cout % p.gn_groups != 0 || cg % 4 != 0 ||
-        (wide ? 128 : 64) % cg != 0 || p.gn_pixels <= 0 || p.gn_pixels % bm != 0 || p.cout % 4 != 0 ||
-        p.ldo % 4 != 0 || (((uintptr_t)p.out) & 15) != 0) {
-      lfdm_set_error("conv2d: fused GroupNorm statistics need ksplit==1, pixels % tile_rows == 0, "
-                     "group size dividing the 64/128 column tile");
+    if (p.ksplit > 1 || p.gn_groups <= 0 || p.cout % p.gn_groups != 0 || cg % 4 != 0 || pl.bn % cg != 0 ||
+        p.gn_pixels <= 0 || p.gn_pixels % pl.bm != 0 || p.cout % 4 != 0 || p.ldo % 4 != 0 ||
+        (((uintptr_t)p.out) & 15) != 0) {
+      lfdm_set_error("conv2d: fused GroupNorm statistics need ksplit==1, pixels % tile_rows == 0 and a "
+                     "group size dividing the column tile (see lfdm_conv2d_plan)");
       return LFDM_EINVAL;
     }
   }
-  if (wide) {
-    launch_conv<128, 128>(p, fast, simple, dim3((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 127) / 128), p.ksplit), stream);
-  } else if (bm == 64) {
-    launch_conv<64, 64>(p, fast, simple, dim3((unsigned)((M + 63) / 64), (unsigned)((p.coutp + 63) / 64), p.ksplit), stream);
+  int rc;
+  if (pl.kind == 1) {
+    rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else {
-    launch_conv<128, 64>(p, fast, simple, dim3((unsigned)((M + 127) / 128), (unsigned)((p.coutp + 63) / 64), p.ksplit), stream);
+    const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit);
+    if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);
+    else if (pl.bm == 64) launch_conv<64, 64>(p, pl.fast, pl.simple, grid, stream);
+    else launch_conv<128, 64>(p, pl.fast, pl.simple, grid, stream);
+    rc = lfdm_check_launch("conv_igemm");
   }
-  int rc = lfdm_check_launch("conv_igemm");
   if (rc) return rc;
   if (p.ksplit > 1) {
     const int64_t total = M * (p.coutp / 4);

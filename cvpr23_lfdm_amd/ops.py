@@ -103,26 +103,13 @@ def pack_planar_in_weight(w):
 # ops
 # ---------------------------------------------------------------------------------------------
 
-def conv_ksplit(m, coutp, nchunks, n_cu=256):
-    """Split-K factor for lfdm_conv2d_cl_f32 (mirrors the kernel's tile choice): when the output tiles
-    cannot fill the 256 CUs (low-resolution UNet levels at B=1), split the K loop so that about two
-    workgroups per CU exist, keeping >= 4 K-chunks per slice."""
-    small = m * ((coutp + 63) // 64) < 128 * 512
-    if small:
-        tiles = ((m + 63) // 64) * ((coutp + 63) // 64)
-    else:
-        tiles = ((m + 127) // 128) * ((coutp + 63) // 64)
-    if tiles >= n_cu or nchunks < 8:
-        return 1
-    return max(1, min(2 * n_cu // tiles, nchunks // 4, 16))
-
-
-def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
-              upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
-              ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=1, partial=None, gn_partial=None,
-              gn_groups=8, gn_pixels=0):
+def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
+                upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
+                ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0):
+    """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
+    ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
-    _chk(lib, src0, src1, weight, bias, residual, out, partial, gn_partial)
+    _chk(lib, src0, src1, weight, bias, residual, out)
     cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
     assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
     coutp = weight.shape[1]
@@ -147,13 +134,40 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None
     p.out, p.ldo, p.ho, p.wo = _p(out), out.stride(0), ho, wo
     p.out_scale, p.out_off_y, p.out_off_x = out_scale, out_off[0], out_off[1]
     p.residual, p.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
-    p.act, p.ksplit, p.partial = act, ksplit, _p(partial)
-    p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
-    if ksplit > 1 and partial is None:
-        need = lib.lfdm_conv2d_partial_bytes(C.byref(p))
-        partial = torch.empty(need // 4, dtype=torch.float32, device=src0.device)
-        p.partial = _p(partial)
+    p.act, p.ksplit, p.partial = act, ksplit, None
+    p.gn_partial, p.gn_groups, p.gn_pixels = None, 0, 0
+    p._keep = (src0, src1, weight, bias, residual, out)      # keep the tensors alive with the struct
+    return p, out
+
+
+def conv_plan(p):
+    """(tile_rows, ksplit) the library will use for these params (lfdm_conv2d_plan)."""
+    lib = _lib()
+    rows, ks = C.c_int(0), C.c_int(0)
+    lib.check(lib.lfdm_conv2d_plan(C.byref(p), C.byref(rows), C.byref(ks)), "lfdm_conv2d_plan")
+    return rows.value, ks.value
+
+
+def conv_launch(p):
+    lib = _lib()
     lib.check(lib.lfdm_conv2d_cl_f32(C.byref(p), _stream(lib)), "lfdm_conv2d_cl_f32")
+
+
+def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_partial=None, gn_groups=8,
+              gn_pixels=0, **kw_):
+    """One convolution (see conv_params for the keywords).  Split-K scratch is allocated on demand."""
+    lib = _lib()
+    _chk(lib, partial, gn_partial)
+    p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
+    _, ks = conv_plan(p)
+    if ks > 1:
+        need = ks * n_img * p.hq * p.wq * p.coutp
+        if partial is None or partial.numel() < need:
+            partial = torch.empty(need, dtype=torch.float32, device=src0.device)
+        p.partial = _p(partial)
+    if gn_partial is not None:
+        p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
+    conv_launch(p)
     return out
 
 
@@ -184,13 +198,6 @@ def groupnorm_silu_cl(x, batch, gamma, beta, *, groups=8, scale_shift=None, resi
                                              _p(residual), eps, int(silu), _p(ws),
                                              ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_silu_cl_f32")
     return out
-
-
-def conv_tile_rows(m, coutp):
-    """Output-tile rows lfdm_conv2d_cl_f32 uses (mirror of lfdm_conv2d_tile_rows)."""
-    if coutp >= 128 and (m // 128) * (coutp // 128) >= 256:
-        return 128
-    return 64 if m * ((coutp + 63) // 64) < 128 * 512 else 128
 
 
 def groupnorm_apply_cl(x, batch, gamma, beta, partial, nchunk, *, groups=8, scale_shift=None, residual=None,

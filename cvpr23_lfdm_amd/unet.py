@@ -241,28 +241,25 @@ class Unet3D(ParamTree):
 
     # ------------------------------------------------------------------ building blocks
     def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, gn=None, **kw):
-        """conv2d_cl with an occupancy-driven split-K choice for the low-resolution levels.
-        gn = (batch,) asks for fused GroupNorm statistics; returns (out, (partial, nchunk) or None)."""
-        m = n_img * s * s
-        cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
-        ksplit = 1
-        if "stride" not in kw and "upsample" not in kw and "out_scale" not in kw:
-            ksplit = ops.conv_ksplit(m, w.shape[1], k * k * max(cin // 32, 1))
-        partial = None
+        """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
+        gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
+        p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
+                               out=out, **kw)
+        tile_rows, ksplit = ops.conv_plan(p)
+        m = n_img * p.hq * p.wq
         if ksplit > 1:
-            partial = self._buf("splitk", ksplit * m, w.shape[1])
+            part = self._buf("splitk", ksplit * m, w.shape[1])
+            p.partial = part.data_ptr()
         stats = None
         if gn is not None:
             batch = gn[0]
-            rows_per_tile = ops.conv_tile_rows(m, w.shape[1])
             pixels = m // batch
             cg = cout // 8
-            if ksplit == 1 and pixels % rows_per_tile == 0 and cg % 4 == 0 and 64 % cg == 0:
-                nchunk = pixels // rows_per_tile
+            if ksplit == 1 and pixels % tile_rows == 0 and cg % 4 == 0 and 32 % cg == 0:
+                nchunk = pixels // tile_rows
                 stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
-                kw = dict(kw, gn_partial=stats[0], gn_groups=8, gn_pixels=pixels)
-        y = ops.conv2d_cl(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
-                          out=out, ksplit=ksplit, partial=partial, **kw)
+                p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), 8, pixels
+        ops.conv_launch(p)
         return (y, stats) if gn is not None else y
 
     def _gn(self, x, batch, gamma, beta, stats, **kw):

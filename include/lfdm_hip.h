@@ -58,7 +58,7 @@ int lfdm_abi_version(void);
  * out = act(acc + bias + residual).
  * Optional fused GroupNorm statistics (ksplit == 1): when gn_partial != NULL the kernel also writes, per
  * output row tile, the (sum, sum of squares) of (acc + bias) per channel group:
- * gn_partial[(tile*gn_groups + g)*2 + {0,1}], tile = first_row / lfdm_conv2d_tile_rows(p); it requires
+ * gn_partial[(tile*gn_groups + g)*2 + {0,1}], tile = first_row / tile_rows (lfdm_conv2d_plan); it requires
  * gn_pixels (rows per sample) to be a multiple of the tile rows so no tile straddles two samples.
  */
 typedef struct lfdm_conv_params {
@@ -80,8 +80,9 @@ typedef struct lfdm_conv_params {
   const float* residual;  /* NULL or rows indexed like out */
   int ldr;
   int act;                /* LFDM_ACT_* (NONE/RELU/SIGMOID/SILU) */
-  /* split-K: ksplit > 1 writes raw partial sums to `partial` ([ksplit][M][coutp]) and the
-     epilogue (bias/residual/act) is applied by lfdm_conv2d_cl_f32 in a reduce pass */
+  /* split-K: 0 = let the library choose (lfdm_conv2d_plan reports the choice), >= 1 = forced.
+     With a factor > 1 raw partial sums go to `partial` ([ksplit][M][coutp], size from
+     lfdm_conv2d_partial_bytes) and a reduce pass applies bias/residual/act. */
   int ksplit;
   float* partial;
   float* gn_partial;      /* NULL or fused GroupNorm partial sums (see above) */
@@ -89,9 +90,10 @@ typedef struct lfdm_conv_params {
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
-/* rows of the output tile the kernel will use for this geometry (64 or 128) */
-int lfdm_conv2d_tile_rows(const lfdm_conv_params* p);
-/* bytes of `partial` needed for a given ksplit */
+/* the schedule the library will use for this geometry: rows of the output tile (64 / 128 / 160) and the
+ * split-K factor (the given one if p->ksplit >= 1) */
+int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit);
+/* bytes of `partial` needed (0 when the plan does not split K) */
 size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
 
 /* ------------------------------------------------------------------------------------------
@@ -112,7 +114,7 @@ int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch, int pixels
 
 /* Same normalisation when the statistics were already produced by the preceding convolution
  * (lfdm_conv_params.gn_partial): partial = [batch][nchunk][groups][2] (sum, sum of squares),
- * nchunk = pixels / lfdm_conv2d_tile_rows.  ws: batch*2*channels floats. */
+ * nchunk = pixels / tile_rows (lfdm_conv2d_plan).  ws: batch*2*channels floats. */
 int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch, int pixels, int channels,
                                 int groups, const float* gamma, const float* beta,
                                 const float* scale_shift, int ss_ld, const float* residual,

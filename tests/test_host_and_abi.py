@@ -76,13 +76,6 @@ def test_state_dict_layout_and_roundtrip():
         m.optimize_parameters()                             # the training row is not built yet: say so
 
 
-def test_split_k_heuristic():
-    from cvpr23_lfdm_amd import ops
-    assert ops.conv_ksplit(40960, 64, 18) == 1              # full-resolution level fills the chip
-    k = ops.conv_ksplit(640, 512, 144)                      # 4x4 level at B=1
-    assert 2 <= k <= 16
-
-
 def test_bench_timing_protocol_gloo_world2(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(

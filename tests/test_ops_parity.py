@@ -40,6 +40,10 @@ def rnd(*shape, seed=0, scale=1.0):
     dict(cin=64, cout=64, k=3, n=2, h=8, w=8, split_src=32, residual=True),  # fused concat + residual
     dict(cin=64, cout=64, k=3, n=2, h=8, w=8, ksplit=3, residual=True, act=1),
     dict(cin=256, cout=256, k=3, n=2, h=4, w=4, ksplit=4),
+    dict(cin=64, cout=64, k=3, n=5, h=8, w=8, residual=True, act=1),            # K-split-across-waves 160x32/64
+    dict(cin=96, cout=128, k=3, n=3, h=8, w=10, split_src=32, ksplit=2),         # ksw + split-K, ragged M
+    dict(cin=256, cout=64, k=1, n=5, h=8, w=8),                                  # ksw on a 1x1 (K = 256)
+    dict(cin=32, cout=32, k=4, n=5, h=16, w=16, stride=2, pad=1),                # ksw, strided
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
 def test_conv2d(backend, case):
     dev = backend
@@ -127,7 +131,7 @@ def test_groupnorm_silu(backend, c, with_ss):
 def test_conv_fused_groupnorm_stats(backend):
     """conv epilogue emits the GroupNorm partial sums; finalize+apply must equal conv -> group_norm."""
     dev = backend
-    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 2, 8, 32, 64)
+    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 5, 8, 32, 64)
     x = rnd(b, cin, t, s, s, seed=1)
     wt = rnd(cout, cin, 1, 3, 3, seed=2, scale=0.06)
     bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
@@ -135,15 +139,16 @@ def test_conv_fused_groupnorm_stats(backend):
     res = rnd(b, cout, t, s, s, seed=7)
     ref = F.group_norm(F.conv3d(x, wt, bias, padding=(0, 1, 1)), 8, gamma, beta, eps=1e-5)
     ref = F.silu(ref * (ss[:, :cout].view(b, cout, 1, 1, 1) + 1) + ss[:, cout:].view(b, cout, 1, 1, 1)) + res
-    m = b * t * s * s
     w = ops.pack_conv_weight(wt).to(dev)
-    rows_per_tile = ops.conv_tile_rows(m, w.shape[1])
+    xs = unet_to_cl(x).to(dev)
+    pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=1)
+    rows_per_tile, ks = ops.conv_plan(pp)
     pixels = t * s * s
-    assert pixels % rows_per_tile == 0
+    assert ks == 1 and pixels % rows_per_tile == 0, (ks, rows_per_tile)
     nchunk = pixels // rows_per_tile
     partial = torch.zeros(b * nchunk, 16, device=dev)
-    h = ops.conv2d_cl(unet_to_cl(x).to(dev), w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), gn_partial=partial,
-                      gn_groups=8, gn_pixels=pixels)
+    h = ops.conv2d_cl(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), gn_partial=partial,
+                      gn_groups=8, gn_pixels=pixels, ksplit=1)
     out = ops.groupnorm_apply_cl(h, b, gamma.to(dev), beta.to(dev), partial, nchunk, scale_shift=ss.to(dev),
                                  residual=unet_to_cl(res).to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")

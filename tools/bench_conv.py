@@ -31,7 +31,7 @@ def main():
     helper = unet_mod.Unet3D.__new__(unet_mod.Unet3D)      # only for the split-K heuristic
     tot_ms = 0.0
     tot_gf = 0.0
-    print("%-28s %9s %8s %8s %8s" % ("shape", "GFLOP", "us", "TF/s", "ksplit"))
+    print("%-28s %9s %8s %8s %8s %5s" % ("shape", "GFLOP", "us", "TF/s", "ksplit", "rows"))
     for name, cin, cout, k, s, count in SHAPES:
         n_img = FRAMES if "8f" not in name else 8
         m = n_img * s * s
@@ -39,11 +39,12 @@ def main():
         w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device=dev) * 0.05)
         b = torch.randn(cout, device=dev)
         out = torch.empty(m, cout, device=dev)
-        coutp = w.shape[1]
-        ksplit = ops.conv_ksplit(m, coutp, k * k * max(cin // 32, 1))
-        ksplit = int(os.environ.get("KSPLIT", ksplit))
-        partial = torch.empty(ksplit * m * coutp, device=dev) if ksplit > 1 else None
-        run = lambda: ops.conv2d_cl(x, w, cout, k, k, n_img, s, s, bias=b, out=out, ksplit=ksplit, partial=partial)
+        pp, _ = ops.conv_params(x, w, cout, k, k, n_img, s, s, bias=b, out=out, ksplit=int(os.environ.get("KSPLIT", "0")))
+        rows_per_tile, ksplit = ops.conv_plan(pp)
+        if ksplit > 1:
+            partial = torch.empty(ksplit * m * w.shape[1], device=dev)
+            pp.partial = partial.data_ptr()
+        run = lambda: ops.conv_launch(pp)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -56,7 +57,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         gf = 2.0 * m * cout * cin * k * k / 1e9
-        print("%-28s %9.2f %8.1f %8.1f %8d" % (name, gf, us, gf / us * 1e3, ksplit))
+        print("%-28s %9.2f %8.1f %8.1f %8d %5d" % (name, gf, us, gf / us * 1e3, ksplit, rows_per_tile))
         tot_ms += us * count / 1e3
         tot_gf += gf * count
     print("weighted per UNet step: %.1f GFLOP in %.3f ms -> %.1f TF/s" % (tot_gf, tot_ms, tot_gf / tot_ms))
