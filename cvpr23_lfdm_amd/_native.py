@@ -39,6 +39,7 @@ class ConvParams(C.Structure):
         ("partial", f32p),
         ("gn_partial", f32p),
         ("gn_groups", i32), ("gn_pixels", i32),
+        ("ln_wsum", f32p), ("ln_eps", f32),
     ]
 
 

@@ -50,7 +50,7 @@ __device__ __forceinline__ bool src_pixel(const lfdm_conv_params& p, int img, in
 
 // FAST: every source has a multiple of 32 channels (chunk = one tap x 32 channels, float4 loads)
 // SIMPLE: zero padding, no up-sampling, <= 64 taps: mask-based addressing
-template <int BM, int BN, bool FAST, bool SIMPLE>
+template <int BM, int BN, bool FAST, bool SIMPLE, bool LN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   constexpr int BK = 32;
   constexpr int LD = BK + 4;         // LDS row stride of both tiles (floats)
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   __shared__ int s_pix[BM];
   __shared__ unsigned long long s_mask[BM];
   __shared__ float s_gn[2][2][BN];   // [sum|sumsq][wm][col]
+  __shared__ float s_lnm[BM], s_lnr[BM];   // fused channel-LayerNorm: per-row mean, 1/sqrt(var+eps)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     int64_t m = m0 + r;
     int img = -1, qy = 0, qx = 0;
     if (m < M) {
-      img = (int)(m / hqwq);
-      const int rem = (int)(m - (int64_t)img * hqwq);
+      const int mi = (int)m;                       // M < 2^31 (checked on the host)
+      img = mi / hqwq;
+      const int rem = mi - img * hqwq;
       qy = rem / p.wq;
       qx = rem - qy * p.wq;
     }
@@ -98,10 +100,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     if (SIMPLE) {
       unsigned long long mask = 0ull;
       if (img >= 0) {
-        for (int t = 0; t < ntaps; ++t) {
-          const int ky = t / p.kw, kx = t - ky * p.kw;
-          const int iy = qy * p.stride + ky - p.pad_y, ix = qx * p.stride + kx - p.pad_x;
-          if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi) mask |= 1ull << t;
+        int t = 0;
+        for (int ky = 0; ky < p.kh; ++ky) {
+          const int iy = qy * p.stride + ky - p.pad_y;
+          const bool yok = iy >= 0 && iy < p.hi;
+          for (int kx = 0; kx < p.kw; ++kx, ++t) {
+            const int ix = qx * p.stride + kx - p.pad_x;
+            if (yok && ix >= 0 && ix < p.wi) mask |= 1ull << t;
+          }
         }
       }
       s_mask[r] = mask;
@@ -139,6 +145,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     }
   }
 
+  float ln_s[FAST ? A_F4 : 1], ln_q[FAST ? A_F4 : 1];
+#pragma unroll
+  for (int i = 0; i < (FAST ? A_F4 : 1); ++i) ln_s[i] = ln_q[i] = 0.f;
+
   auto fetch = [&](int kc) {
     if (FAST) {
       const int cpt = cin / BK;
@@ -171,6 +181,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
             v = *reinterpret_cast<const float4*>(src + pix * ld + cc + 4 * cq);
         }
         ra4[i] = v;
+        if (LN) {
+          ln_s[i] += (v.x + v.y) + (v.z + v.w);
+          ln_q[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
       }
     } else {
       const int k = kc * BK + (tid & 31);
@@ -277,6 +291,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
     }
   }
 
+  if (FAST && LN) {
+    // channel-LayerNorm statistics of every row of the tile (the 1x1 conv streamed all C channels)
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      float sv = ln_s[i], qv = ln_q[i];
+#pragma unroll
+      for (int m = 1; m <= 4; m <<= 1) {
+        sv += __shfl_xor(sv, m);
+        qv += __shfl_xor(qv, m);
+      }
+      if ((tid & 7) == 0) {
+        const float inv_c = 1.0f / (float)cin;
+        const float mean = sv * inv_c;
+        float var = qv * inv_c - mean * mean;
+        if (var < 0.f) var = 0.f;
+        const int r = (tid >> 3) + 32 * i;
+        s_lnm[r] = mean;
+        s_lnr[r] = 1.0f / sqrtf(var + p.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
+
   // ------------------------------------------------------------------ epilogue
   if (ksplit > 1) {
     // raw partial sums, reduced (with bias / residual / activation) by conv_splitk_reduce_kernel
@@ -328,6 +365,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         const int ox = s_qx[row] * p.out_scale + p.out_off_x;
         const int64_t orow = ((int64_t)img * p.ho + oy) * p.wo + ox;
         if (vec_ok) {
+          if (FAST && LN) {      // y = rstd * (x.W' - mean * sum_c W')
+            const float4 ws = *reinterpret_cast<const float4*>(p.ln_wsum + colbase);
+            const float mu = s_lnm[row], rs = s_lnr[row];
+            v.x = rs * (v.x - mu * ws.x); v.y = rs * (v.y - mu * ws.y);
+            v.z = rs * (v.z - mu * ws.z); v.w = rs * (v.w - mu * ws.w);
+          }
           if (p.bias) {
             const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -396,26 +439,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   }
 }
 
-// split-K epilogue: out = act(sum_z partial[z] + bias + residual)
+// split-K epilogue: out = act(sum_z partial[z] + bias + residual).  One workgroup owns SPLITK_ROWS
+// consecutive output rows (all channels), so it can also emit the GroupNorm partial sums of its rows
+// (gn_partial[(rowblock*groups + g)*2]); gn_pixels % SPLITK_ROWS == 0 keeps a block inside one sample.
+constexpr int SPLITK_ROWS = 16;
+// grid (row blocks, column chunks): blockIdx.y owns float4 columns [y*cw, (y+1)*cw), cw = c4n / gridDim.y
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_params p) {
+  __shared__ float red_s[256], red_q[256];
+  const int tid = threadIdx.x;
   const int hqwq = p.hq * p.wq;
-  const int64_t M = (int64_t)p.n_img * hqwq;
+  const int M = p.n_img * hqwq;
   const int c4n = p.coutp / 4;
-  const int64_t total = M * c4n;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * 256) {
-    const int64_t m = idx / c4n;
-    const int col = (int)(idx - m * c4n) * 4;
+  const int cw = c4n / gridDim.y;                  // float4 columns of this block
+  const int cq0 = blockIdx.y * cw;
+  const int m0 = blockIdx.x * SPLITK_ROWS;
+  const int items = SPLITK_ROWS * cw;
+  float gs = 0.f, gq = 0.f;           // with 256 % cw == 0 a thread always sees the same column quad
+  for (int it = tid; it < items; it += 256) {
+    const int r = it / cw;
+    const int col = (cq0 + it - r * cw) * 4;
+    const int m = m0 + r;
+    if (m >= M) continue;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < p.ksplit; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)z * M + m) * p.coutp + col);
+    const float* pp = p.partial + (int64_t)m * p.coutp + col;
+    const int64_t zs = (int64_t)M * p.coutp;
+    int z = 0;
+    for (; z + 4 <= p.ksplit; z += 4) {            // four independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(pp + (z + 0) * zs);
+      const float4 v1 = *reinterpret_cast<const float4*>(pp + (z + 1) * zs);
+      const float4 v2 = *reinterpret_cast<const float4*>(pp + (z + 2) * zs);
+      const float4 v3 = *reinterpret_cast<const float4*>(pp + (z + 3) * zs);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x);
+      s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z);
+      s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; z < p.ksplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(pp + z * zs);
       s.x += v.x;
       s.y += v.y;
       s.z += v.z;
       s.w += v.w;
     }
-    const int img = (int)(m / hqwq);
-    const int rem = (int)(m - (int64_t)img * hqwq);
+    const int img = m / hqwq;
+    const int rem = m - img * hqwq;
     const int qy = rem / p.wq, qx = rem - qy * p.wq;
     const int64_t orow = ((int64_t)img * p.ho + qy * p.out_scale + p.out_off_y) * p.wo +
                          qx * p.out_scale + p.out_off_x;
@@ -426,19 +493,61 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_param
       if (c < p.cout) {
         float v = vals[e];
         if (p.bias) v += p.bias[c];
+        gs += v;
+        gq += v * v;
         if (p.residual) v += p.residual[orow * p.ldr + c];
         p.out[orow * p.ldo + c] = apply_act(v, p.act);
       }
     }
   }
+  if (p.gn_partial) {
+    red_s[tid] = gs;
+    red_q[tid] = gq;
+    __syncthreads();
+    const int cg4 = (p.cout / p.gn_groups) / 4;      // float4 columns per group
+    const int gpb = cw / cg4;                        // groups owned by this block (cw % cg4 == 0)
+    if (tid < gpb) {
+      float ts = 0.f, tq = 0.f;
+      // thread t touched local column quad t % cw (256 % cw == 0): local group tid owns [tid*cg4, +cg4)
+      for (int rep = 0; rep < 256; rep += cw)
+        for (int k = 0; k < cg4; ++k) {
+          ts += red_s[rep + tid * cg4 + k];
+          tq += red_q[rep + tid * cg4 + k];
+        }
+      float* dst = p.gn_partial + ((int64_t)blockIdx.x * p.gn_groups + cq0 / cg4 + tid) * 2;
+      dst[0] = ts;
+      dst[1] = tq;
+    }
+  }
+}
+
+// column chunks for the reduce grid: enough workgroups to cover the chip, chunks of >= 16 float4 that
+// divide the row and (with fused GroupNorm statistics) hold whole groups and divide 256
+int splitk_col_chunks(const lfdm_conv_params& p, int64_t M) {
+  const int c4n = p.coutp / 4;
+  const int64_t rowblocks = (M + SPLITK_ROWS - 1) / SPLITK_ROWS;
+  int gy = 1;
+  while (rowblocks * gy < 256 && gy < 16) {
+    const int cand = gy * 2;
+    if (c4n % cand != 0) break;
+    const int cw = c4n / cand;
+    if (cw < 16) break;
+    if (p.gn_partial) {
+      const int cg4 = (p.cout / p.gn_groups) / 4;
+      if (cw % cg4 != 0 || 256 % cw != 0) break;
+    }
+    gy = cand;
+  }
+  return gy;
 }
 
 template <int BM, int BN>
 void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, hipStream_t stream) {
   dim3 block(256);
-  if (fast && simple) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, true>), grid, block, 0, stream, p);
-  else if (fast) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, false>), grid, block, 0, stream, p);
-  else LFDM_LAUNCH((conv_igemm_kernel<BM, BN, false, false>), grid, block, 0, stream, p);
+  if (fast && simple && p.ln_wsum) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, true, true>), grid, block, 0, stream, p);
+  else if (fast && simple) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, true, false>), grid, block, 0, stream, p);
+  else if (fast) LFDM_LAUNCH((conv_igemm_kernel<BM, BN, true, false, false>), grid, block, 0, stream, p);
+  else LFDM_LAUNCH((conv_igemm_kernel<BM, BN, false, false, false>), grid, block, 0, stream, p);
 }
 
 }  // namespace
@@ -478,9 +587,15 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   pl.simple = !p.upsample && p.pad_mode == 0 && p.kh * p.kw <= 64 &&
               (int64_t)p.n_img * p.hi * p.wi < (1ll << 31) - (1 << 20);
   const int user_k = p.ksplit;                       // 0 = choose
-  bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160;
+  const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+  const bool fits32 = in_rows * p.ld0 * 4 < (1ll << 32) - 64 && in_rows * (p.c1 ? p.ld1 : 1) * 4 < (1ll << 32) - 64 &&
+                      (int64_t)nchunks * p.coutp * 128 < (1ll << 32) - 64;      // buffer descriptors: 32-bit offsets
+  const bool vec_ok = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)p.out) & 15) == 0) &&
+                      (!p.residual || ((p.ldr % 4 == 0) && ((((uintptr_t)p.residual) & 15) == 0))) &&
+                      (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+  bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160 && !p.ln_wsum && fits32 && vec_ok;
   if (conv_force() == 0) ksw = false;
-  if (conv_force() == 1 && pl.fast && pl.simple) ksw = true;
+  if (conv_force() == 1 && pl.fast && pl.simple && !p.ln_wsum && fits32 && vec_ok) ksw = true;
   if (ksw) {
     pl.kind = 1;
     pl.bm = 160;
@@ -521,7 +636,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
 extern "C" int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit) {
   if (!p) return LFDM_EINVAL;
   const ConvPlan pl = make_plan(*p);
-  if (tile_rows) *tile_rows = pl.bm;
+  if (tile_rows) *tile_rows = pl.ksplit > 1 ? SPLITK_ROWS : pl.bm;   // granularity of gn_partial
   if (ksplit) *ksplit = pl.ksplit;
   return LFDM_OK;
 }
@@ -539,7 +654,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   lfdm_conv_params p = *pp;
   if (!p.src0 || !p.weight || !p.out || p.c0 <= 0 || p.c1 < 0 || (p.c1 > 0 && !p.src1) ||
       p.n_img <= 0 || p.hq <= 0 || p.wq <= 0 || p.kh <= 0 || p.kw <= 0 || p.cout <= 0 ||
-      p.coutp < p.cout || (p.coutp % 32) != 0 || p.stride <= 0 || p.out_scale <= 0 || p.ksplit < 0 ||
+      (int64_t)p.n_img * p.hq * p.wq >= (1ll << 31) || p.coutp < p.cout || (p.coutp % 32) != 0 || p.stride <= 0 || p.out_scale <= 0 || p.ksplit < 0 ||
       p.ld0 < p.c0 || (p.c1 > 0 && p.ld1 < p.c1) || p.ldo < p.cout) {
     lfdm_set_error("conv2d: invalid geometry");
     return LFDM_EINVAL;
@@ -557,11 +672,21 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (p.gn_partial) {
     const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;
-    if (p.ksplit > 1 || p.gn_groups <= 0 || p.cout % p.gn_groups != 0 || cg % 4 != 0 || pl.bn % cg != 0 ||
-        p.gn_pixels <= 0 || p.gn_pixels % pl.bm != 0 || p.cout % 4 != 0 || p.ldo % 4 != 0 ||
-        (((uintptr_t)p.out) & 15) != 0) {
-      lfdm_set_error("conv2d: fused GroupNorm statistics need ksplit==1, pixels % tile_rows == 0 and a "
-                     "group size dividing the column tile (see lfdm_conv2d_plan)");
+    const int rows = p.ksplit > 1 ? SPLITK_ROWS : pl.bm;
+    const bool ok = p.gn_groups > 0 && p.cout % p.gn_groups == 0 && cg % 4 == 0 && p.gn_pixels > 0 &&
+                    p.gn_pixels % rows == 0 && p.cout % 4 == 0 && p.ldo % 4 == 0 &&
+                    (((uintptr_t)p.out) & 15) == 0 &&
+                    (p.ksplit > 1 ? (256 % (p.coutp / 4) == 0 && p.cout == p.coutp) : (pl.bn % cg == 0));
+    if (!ok) {
+      lfdm_set_error("conv2d: fused GroupNorm statistics need pixels % tile_rows == 0 and a group size dividing "
+                     "the column tile (see lfdm_conv2d_plan)");
+      return LFDM_EINVAL;
+    }
+  }
+  if (p.ln_wsum) {
+    if (!pl.fast || !pl.simple || p.kh != 1 || p.kw != 1 || p.c1 != 0 || p.ksplit != 1 || p.stride != 1 || p.cout % 4 != 0 ||
+        p.ldo % 4 != 0 || (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.ln_wsum) & 15) != 0) {
+      lfdm_set_error("conv2d: fused LayerNorm needs a 1x1 convolution over one source, C % 32 == 0, ksplit == 1");
       return LFDM_EINVAL;
     }
   }
@@ -577,10 +702,9 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   }
   if (rc) return rc;
   if (p.ksplit > 1) {
-    const int64_t total = M * (p.coutp / 4);
-    unsigned nb = (unsigned)((total + 255) / 256);
-    if (nb > 4096) nb = 4096;
-    LFDM_LAUNCH(conv_splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, p);
+    LFDM_LAUNCH(conv_splitk_reduce_kernel,
+                dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M)), dim3(256), 0,
+                stream, p);
     rc = lfdm_check_launch("conv_splitk_reduce");
   }
   return rc;

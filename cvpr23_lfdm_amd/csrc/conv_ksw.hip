@@ -45,14 +45,19 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     int img = -1, qy = 0, qx = 0;
     unsigned long long mask = 0ull;
     if (m < M) {
-      img = (int)(m / hqwq);
-      const int rem = (int)(m - (int64_t)img * hqwq);
+      const int mi = (int)m;                       // M < 2^31 (checked on the host)
+      img = mi / hqwq;
+      const int rem = mi - img * hqwq;
       qy = rem / p.wq;
       qx = rem - qy * p.wq;
-      for (int t = 0; t < ntaps; ++t) {
-        const int ky = t / p.kw, kx = t - ky * p.kw;
-        const int iy = qy * p.stride + ky - p.pad_y, ix = qx * p.stride + kx - p.pad_x;
-        if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi) mask |= 1ull << t;
+      int t = 0;
+      for (int ky = 0; ky < p.kh; ++ky) {
+        const int iy = qy * p.stride + ky - p.pad_y;
+        const bool yok = iy >= 0 && iy < p.hi;
+        for (int kx = 0; kx < p.kw; ++kx, ++t) {
+          const int ix = qx * p.stride + kx - p.pad_x;
+          if (yok && ix >= 0 && ix < p.wi) mask |= 1ull << t;
+        }
       }
     }
     s_img[r] = img;
@@ -77,46 +82,50 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   const int kc_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / ksplit);
   const int nk = kc_end - kc_begin;
 
+  // Branch-free main loop: every load goes through a buffer descriptor and an invalid tap is an
+  // out-of-range offset (returns 0); chunk indices are clamped instead of guarded, so the loop body is
+  // one basic block and the 16*TM*TN accumulator registers stay where they are.
   const int cq = tid & 7;
-  int a_pix[A_F4];
+  const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+  const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
+  const lfdm_buf buf1 = p.c1 > 0 ? lfdm_make_buf(p.src1, (uint32_t)(((in_rows - 1) * p.ld1 + p.c1) * 4)) : buf0;
+  const lfdm_buf bufw = lfdm_make_buf(p.weight, (uint32_t)((int64_t)nchunks_all * p.coutp * BK * 4));
+  uint32_t a_off0[A_F4], a_off1[A_F4];
   unsigned long long a_mask[A_F4];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     const int r = (tid >> 3) + 32 * i;
-    a_pix[i] = s_pix[r];
+    a_off0[i] = ((uint32_t)s_pix[r] * (uint32_t)p.ld0 + 4u * cq) * 4u;     // wraps; valid taps un-wrap it
+    a_off1[i] = ((uint32_t)s_pix[r] * (uint32_t)p.ld1 + 4u * cq) * 4u;
     a_mask[i] = s_mask[r];
   }
+  uint32_t b_off[B_F4];
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int f = tid + 256 * i;
+    b_off[i] = (n0 + (f >> 3) < p.coutp) ? (uint32_t)(((n0 + (f >> 3)) * BK + 4 * (f & 7)) * 4) : LFDM_BUF_OOB;
+  }
   float4 ra[A_F4], rb[B_F4];
+  const int cpt = cin / BK;
+  const uint32_t wchunk_bytes = (uint32_t)p.coutp * BK * 4;
 
   auto fetch = [&](int kc) {
-    const int cpt = cin / BK;
     const int tap = kc / cpt;
     int cc = (kc - tap * cpt) * BK;
-    const float* src = p.src0;
-    int ld = p.ld0;
-    if (cc >= p.c0) {
-      cc -= p.c0;
-      src = p.src1;
-      ld = p.ld1;
-    }
+    const bool second = cc >= p.c0;
+    if (second) cc -= p.c0;
     const int ky = tap / p.kw, kx = tap - ky * p.kw;
-    const int tap_off = ky * p.wi + kx;
+    const uint32_t chunk_off = (uint32_t)(((ky * p.wi + kx) * (second ? p.ld1 : p.ld0) + cc) * 4);
+    const lfdm_buf buf = second ? buf1 : buf0;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((a_mask[i] >> tap) & 1ull)
-        v = *reinterpret_cast<const float4*>(src + (int64_t)(a_pix[i] + tap_off) * ld + cc + 4 * cq);
-      ra[i] = v;
+      const uint32_t base = second ? a_off1[i] : a_off0[i];
+      const uint32_t off = ((a_mask[i] >> tap) & 1ull) ? base + chunk_off : LFDM_BUF_OOB;
+      ra[i] = lfdm_buf_load_f4(buf, off);
     }
-    const float* wchunk = p.weight + (int64_t)kc * p.coutp * BK;
+    const uint32_t wbase = (uint32_t)kc * wchunk_bytes;
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      const int f = tid + 256 * i;
-      const int n = f >> 3;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + n < p.coutp) v = *reinterpret_cast<const float4*>(wchunk + (int64_t)(n0 + n) * BK + 4 * (f & 7));
-      rb[i] = v;
-    }
+    for (int i = 0; i < B_F4; ++i) rb[i] = lfdm_buf_load_f4(bufw, b_off[i] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[i]);
   };
   auto stage = [&](int buf) {
     float* const As = smem + buf * STAGE;
@@ -131,20 +140,21 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     }
   };
 
-  if (nk > 0) {
-    fetch(kc_begin);
-    stage(0);
-  }
+  fetch(kc_begin);                                  // nk >= 1 (host clamps ksplit to the chunk count)
+  stage(0);
   __syncthreads();
-  if (nk > 1) fetch(kc_begin + 1);
+  fetch(kc_begin + (nk > 1 ? 1 : 0));
 
   const int koff = 8 * wave + 4 * (lane >> 5);   // this wave's k slice of a chunk, this lane half's quad
   const int l31 = lane & 31;
   for (int c = 0; c < nk; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nk) stage(cur ^ 1);               // registers hold chunk c+1
+    stage(cur ^ 1);                                 // registers hold chunk min(c+1, nk-1); idle buffer
 #ifndef LFDM_PROBE_NOFETCH
-    if (c + 2 < nk) fetch(kc_begin + c + 2);
+    {
+      const int nxt = c + 2 < nk ? c + 2 : nk - 1;
+      fetch(kc_begin + nxt);
+    }
 #endif
     const float* const As = smem + cur * STAGE;
     const float* const Bs = As + BM * LD;
@@ -172,8 +182,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   // ---- cross-wave reduction + epilogue, one 32x32 tile at a time ----
   float* const scratch = smem;                     // [4 waves][32][LD]
   const int trow = tid >> 3, c4 = tid & 7;
-  const bool vec_ok = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)p.out) & 15) == 0) &&
-                      (!p.residual || ((p.ldr % 4 == 0) && ((((uintptr_t)p.residual) & 15) == 0)));
+  // (the host only selects this kernel when float4 epilogue accesses are legal)
   float gs[TN][4], gq[TN][4];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -205,35 +214,21 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
           const int oy = s_qy[row] * p.out_scale + p.out_off_y;
           const int ox = s_qx[row] * p.out_scale + p.out_off_x;
           const int64_t orow = ((int64_t)img * p.ho + oy) * p.wo + ox;
-          if (vec_ok) {
-            if (p.bias) {
-              const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
-              v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            }
-            if (p.gn_partial) {
-              gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
-              gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
-            }
-            if (p.residual) {
-              const float4 rr = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
-              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-            *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
-          } else {
-            const float vals[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int col = colbase + e;
-              if (col < p.cout) {
-                float t = vals[e];
-                if (p.bias) t += p.bias[col];
-                if (p.residual) t += p.residual[orow * p.ldr + col];
-                p.out[orow * p.ldo + col] = apply_act(t, p.act);
-              }
-            }
+          if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
+          if (p.gn_partial) {
+            gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
+            gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
+          }
+          if (p.residual) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+          v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+          *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
         }
       }
       __syncthreads();

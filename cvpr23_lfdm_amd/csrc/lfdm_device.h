@@ -35,6 +35,38 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 
 #define LFDM_WAVE 64
 
+// Buffer-descriptor loads: an out-of-range byte offset returns zeros, which turns "is this filter tap
+// inside the image" into one v_cndmask on the offset instead of a divergent branch around the load
+// (branches inside the MFMA loop also made hipcc copy all accumulator registers every iteration).
+#if defined(LFDM_EMU_BUILD)
+struct lfdm_buf {
+  const char* base;
+  uint32_t bytes;
+};
+static inline lfdm_buf lfdm_make_buf(const void* p, uint32_t bytes) { return lfdm_buf{(const char*)p, bytes}; }
+static inline float4 lfdm_buf_load_f4(lfdm_buf b, uint32_t off) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((uint64_t)off + 16u <= (uint64_t)b.bytes) memcpy(&v, b.base + off, 16);
+  return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t lfdm_buf;
+typedef int lfdm_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lfdm_buf lfdm_make_buf(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 lfdm_buf_load_f4(lfdm_buf b, uint32_t off) {
+  const lfdm_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0);
+  float4 f;
+  f.x = __int_as_float(v.x);
+  f.y = __int_as_float(v.y);
+  f.z = __int_as_float(v.z);
+  f.w = __int_as_float(v.w);
+  return f;
+}
+#endif
+#define LFDM_BUF_OOB 0xFFFFFFF0u
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -14,7 +14,9 @@ namespace {
 constexpr int GN_MAX_CHUNKS = 256;
 
 __host__ __device__ inline int gn_num_chunks(int pixels) {
-  int n = (pixels + 127) / 128;
+  // >= 16 pixels per workgroup; small tensors (low-resolution UNet levels) still get tens of
+  // workgroups instead of a handful of long serial loops
+  int n = (pixels + 15) / 16;
   if (n < 1) n = 1;
   if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
   return n;
@@ -60,16 +62,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-// grid (B), 256 threads. ab[b][0][c] = A, ab[b][1][c] = Bc  with  y = x*A + Bc
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                          int nchunk, int pixels, int channels,
-                                                          int groups, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          const float* __restrict__ scale_shift,
-                                                          int ss_ld, float eps, float* __restrict__ ab) {
+// Finalize + apply in one launch.  grid (blocks_per_sample, B).  Every workgroup first merges the
+// (sum, sumsq) partials of its sample in double (fixed order -> bit reproducible) and folds
+// mean / rstd / gamma / beta / (scale+1, shift) into one FMA per channel kept in LDS, then streams its
+// slice:  y = silu(x * A[c] + Bc[c]) (+ residual).
+constexpr int GN_MAX_C = 1024;
+__global__ __launch_bounds__(256) void gn_apply_kernel(
+    const float* __restrict__ x, float* __restrict__ out, int pixels, int channels, int groups,
+    const float* __restrict__ partial, int nchunk, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale_shift, int ss_ld, float eps, int silu,
+    const float* __restrict__ residual) {
   __shared__ float s_mean[64], s_rstd[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  // 32 lanes per group, 8 groups per pass; partials are merged in double with a fixed order
+  __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C], s_b[GN_MAX_C];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int sub = tid & 31;
   for (int g0 = 0; g0 < groups; g0 += 8) {
     const int g = g0 + (tid >> 5);
@@ -108,25 +113,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
       aa = a * sc;
       bb = bb * sc + sh;
     }
-    ab[((int64_t)b * 2 + 0) * channels + c] = aa;
-    ab[((int64_t)b * 2 + 1) * channels + c] = bb;
+    s_a[c] = aa;
+    s_b[c] = bb;
   }
-}
-
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x,
-                                                       float* __restrict__ out, int batch,
-                                                       int pixels, int channels,
-                                                       const float* __restrict__ ab, int silu,
-                                                       const float* __restrict__ residual) {
+  __syncthreads();
   const int c4n = channels >> 2;
   const int64_t per_b = (int64_t)pixels * c4n;
-  const int64_t total = per_b * batch;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int b = (int)(i / per_b);
+  const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)b * per_b;
+  float4* ob = reinterpret_cast<float4*>(out) + (int64_t)b * per_b;
+  const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < per_b; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % c4n);
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 a = *reinterpret_cast<const float4*>(ab + ((int64_t)b * 2 + 0) * channels + 4 * c4);
-    const float4 d = *reinterpret_cast<const float4*>(ab + ((int64_t)b * 2 + 1) * channels + 4 * c4);
+    const float4 v = xb[i];
+    const float4 a = *reinterpret_cast<const float4*>(s_a + 4 * c4);
+    const float4 d = *reinterpret_cast<const float4*>(s_b + 4 * c4);
     float4 y;
     y.x = fmaf(v.x, a.x, d.x);
     y.y = fmaf(v.y, a.y, d.y);
@@ -138,14 +138,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       y.z = siluf_(y.z);
       y.w = siluf_(y.w);
     }
-    if (residual) {
-      const float4 r = reinterpret_cast<const float4*>(residual)[i];
+    if (rb) {
+      const float4 r = rb[i];
       y.x += r.x;
       y.y += r.y;
       y.z += r.z;
       y.w += r.w;
     }
-    reinterpret_cast<float4*>(out)[i] = y;
+    ob[i] = y;
   }
 }
 
@@ -289,6 +289,18 @@ inline unsigned grid_for(int64_t work_items, unsigned cap = 8192) {
   return (unsigned)nb;
 }
 
+void launch_gn_apply(const float* x, float* out, int batch, int pixels, int channels, int groups,
+                     const float* partial, int nchunk, const float* gamma, const float* beta,
+                     const float* scale_shift, int ss_ld, float eps, int silu, const float* residual,
+                     hipStream_t stream) {
+  const int64_t per_b = (int64_t)pixels * (channels / 4);
+  int64_t nb = (per_b + 256 * 4 - 1) / (256 * 4);       // ~4 float4 per thread
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  LFDM_LAUNCH(gn_apply_kernel, dim3((unsigned)nb, batch), dim3(256), 0, stream, x, out, pixels, channels,
+              groups, partial, nchunk, gamma, beta, scale_shift, ss_ld, eps, silu, residual);
+}
+
 }  // namespace
 
 extern "C" size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels) {
@@ -315,14 +327,10 @@ extern "C" int lfdm_groupnorm_silu_cl_f32(const float* x, float* out, int batch,
   }
   const int nchunk = gn_num_chunks(pixels);
   float* partial = reinterpret_cast<float*>(ws);
-  float* ab = partial + (size_t)batch * nchunk * 64 * 2;
   LFDM_LAUNCH(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, stream, x, pixels, channels,
               groups, partial);
-  LFDM_LAUNCH(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const float*)partial, nchunk,
-              pixels, channels, groups, gamma, beta, scale_shift, ss_ld, eps, ab);
-  const int64_t total = (int64_t)batch * pixels * (channels / 4);
-  LFDM_LAUNCH(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, batch, pixels,
-              channels, (const float*)ab, apply_silu, residual);
+  launch_gn_apply(x, out, batch, pixels, channels, groups, (const float*)partial, nchunk, gamma, beta,
+                  scale_shift, ss_ld, eps, apply_silu, residual, stream);
   return lfdm_check_launch("groupnorm");
 }
 
@@ -334,21 +342,15 @@ extern "C" int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch
                                            size_t ws_bytes, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !out || !gamma || !beta || !partial || nchunk <= 0 || batch <= 0 || pixels <= 0 ||
-      channels <= 0 || groups <= 0 || groups > 64 || channels % groups != 0 || channels % 4 != 0 ||
-      (scale_shift && ss_ld < 2 * channels)) {
+      channels <= 0 || channels > GN_MAX_C || groups <= 0 || groups > 64 || channels % groups != 0 ||
+      channels % 4 != 0 || (scale_shift && ss_ld < 2 * channels)) {
     lfdm_set_error("groupnorm_apply: bad arguments");
     return LFDM_EINVAL;
   }
-  if (!ws || ws_bytes < (size_t)batch * 2 * channels * sizeof(float)) {
-    lfdm_set_error("groupnorm_apply: workspace too small");
-    return LFDM_EWORKSPACE;
-  }
-  float* ab = reinterpret_cast<float*>(ws);
-  LFDM_LAUNCH(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, partial, nchunk, pixels, channels,
-              groups, gamma, beta, scale_shift, ss_ld, eps, ab);
-  const int64_t total = (int64_t)batch * pixels * (channels / 4);
-  LFDM_LAUNCH(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, out, batch, pixels,
-              channels, (const float*)ab, apply_silu, residual);
+  (void)ws;
+  (void)ws_bytes;
+  launch_gn_apply(x, out, batch, pixels, channels, groups, partial, nchunk, gamma, beta, scale_shift,
+                  ss_ld, eps, apply_silu, residual, stream);
   return lfdm_check_launch("groupnorm_apply");
 }
 

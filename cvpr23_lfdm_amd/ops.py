@@ -91,6 +91,16 @@ def pack_deconv_weight(w):
     return packs
 
 
+def pack_ln_conv_weight(w, gamma):
+    """1x1 conv / linear weight (Cout, Cin[,1,1]) preceded by a channel LayerNorm with scale gamma (Cin,):
+    returns (packed W' = W*gamma, ln_wsum (coutp,) = sum_c W'[o][c]) for lfdm_conv_params.ln_wsum."""
+    w2 = w.reshape(w.shape[0], -1).float() * gamma.reshape(1, -1).float()
+    packed = pack_conv_weight(w2)
+    wsum = torch.zeros(packed.shape[1], dtype=torch.float32, device=w.device)
+    wsum[: w2.shape[0]] = w2.double().sum(dim=1).float()
+    return packed, wsum
+
+
 def pack_planar_in_weight(w):
     """(Cout, Cin, kh, kw) -> [kh*kw*Cin][Cout] (tap-major, then channel) for conv_planar_in_cl."""
     if w.dim() == 5:
@@ -105,11 +115,11 @@ def pack_planar_in_weight(w):
 
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
-                ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0):
+                ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
-    _chk(lib, src0, src1, weight, bias, residual, out)
+    _chk(lib, src0, src1, weight, bias, residual, out, ln_wsum)
     cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
     assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
     coutp = weight.shape[1]
@@ -136,7 +146,10 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     p.residual, p.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     p.act, p.ksplit, p.partial = act, ksplit, None
     p.gn_partial, p.gn_groups, p.gn_pixels = None, 0, 0
-    p._keep = (src0, src1, weight, bias, residual, out)      # keep the tensors alive with the struct
+    p.ln_wsum, p.ln_eps = _p(ln_wsum), ln_eps
+    if ln_wsum is not None:
+        p.ksplit = 1
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum)      # keep the tensors alive with the struct
     return p, out
 
 

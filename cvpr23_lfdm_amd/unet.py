@@ -143,13 +143,13 @@ class Unet3D(ParamTree):
                 off += w.shape[0]
 
         def temporal(prefix):
-            pk[prefix + "gamma"] = g(prefix + "fn.norm.gamma").reshape(-1).contiguous()
-            pk[prefix + "qkv.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_qkv.weight"))
+            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(
+                g(prefix + "fn.fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma"))
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
 
         def spatial_linear(prefix):
-            pk[prefix + "gamma"] = g(prefix + "fn.norm.gamma").reshape(-1).contiguous()
-            pk[prefix + "qkv.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_qkv.weight"))
+            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(
+                g(prefix + "fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma"))
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
             pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
 
@@ -175,8 +175,8 @@ class Unet3D(ParamTree):
                 pk[p + "4.w"] = ops.pack_conv_weight(g(p + "4.weight"))
                 pk[p + "4.b"] = g(p + "4.bias")
         resblock("mid_block1.")
-        pk["mid_spatial_attn.gamma"] = g("mid_spatial_attn.fn.norm.gamma").reshape(-1).contiguous()
-        pk["mid_spatial_attn.qkv.w"] = ops.pack_conv_weight(g("mid_spatial_attn.fn.fn.fn.to_qkv.weight"))
+        pk["mid_spatial_attn.qkv.w"], pk["mid_spatial_attn.qkv.wsum"] = ops.pack_ln_conv_weight(
+            g("mid_spatial_attn.fn.fn.fn.to_qkv.weight"), g("mid_spatial_attn.fn.norm.gamma"))
         pk["mid_spatial_attn.out.w"] = ops.pack_conv_weight(g("mid_spatial_attn.fn.fn.fn.to_out.weight"))
         temporal("mid_temporal_attn.")
         resblock("mid_block2.")
@@ -255,7 +255,8 @@ class Unet3D(ParamTree):
             batch = gn[0]
             pixels = m // batch
             cg = cout // 8
-            if ksplit == 1 and pixels % tile_rows == 0 and cg % 4 == 0 and 32 % cg == 0:
+            if pixels % tile_rows == 0 and cg % 4 == 0 and 32 % cg == 0 and (
+                    ksplit == 1 or (256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout)):
                 nchunk = pixels // tile_rows
                 stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), 8, pixels
@@ -290,11 +291,11 @@ class Unet3D(ParamTree):
         return out
 
     def _attn_common(self, pk, prefix, x, n_img, s, c):
+        """PreNorm + to_qkv as ONE kernel: the channel LayerNorm is folded into the 1x1 projection
+        (lfdm_conv_params.ln_wsum), so the normalised tensor is never written."""
         rows = n_img * s * s
-        ln = self._buf("at.ln", rows, c)
-        ops.layernorm_cl(x, pk[prefix + "gamma"], out=ln)
         qkv = self._buf("at.qkv", rows, 768)
-        self._conv(ln, pk[prefix + "qkv.w"], 768, 1, n_img, s, out=qkv)
+        self._conv(x, pk[prefix + "qkv.w"], 768, 1, n_img, s, out=qkv, ln_wsum=pk[prefix + "qkv.wsum"])
         return qkv, self._buf("at.o", rows, 256)
 
     def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables):

@@ -87,6 +87,12 @@ typedef struct lfdm_conv_params {
   float* partial;
   float* gn_partial;      /* NULL or fused GroupNorm partial sums (see above) */
   int gn_groups, gn_pixels;
+  /* Optional fused channel-LayerNorm of the INPUT rows (1x1 convolutions only; PreNorm + to_qkv,
+     video_flow_diffusion.py:176-179,189 + :311 / :253): with W' = W*gamma packed as `weight` and
+     ln_wsum[o] = sum_c W'[o][c], the kernel accumulates each row's mean / variance while it streams
+     the row and writes rstd*(x.W' - mean*ln_wsum) - algebraically LayerNorm(x)*gamma followed by W. */
+  const float* ln_wsum;
+  float ln_eps;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);

@@ -128,8 +128,10 @@ def test_groupnorm_silu(backend, c, with_ss):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
 
 
-def test_conv_fused_groupnorm_stats(backend):
-    """conv epilogue emits the GroupNorm partial sums; finalize+apply must equal conv -> group_norm."""
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_conv_fused_groupnorm_stats(backend, ksplit):
+    """conv epilogue (or the split-K reduce) emits the GroupNorm partial sums; finalize+apply must equal
+    conv -> group_norm."""
     dev = backend
     b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 5, 8, 32, 64)
     x = rnd(b, cin, t, s, s, seed=1)
@@ -141,17 +143,31 @@ def test_conv_fused_groupnorm_stats(backend):
     ref = F.silu(ref * (ss[:, :cout].view(b, cout, 1, 1, 1) + 1) + ss[:, cout:].view(b, cout, 1, 1, 1)) + res
     w = ops.pack_conv_weight(wt).to(dev)
     xs = unet_to_cl(x).to(dev)
-    pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=1)
+    pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=ksplit)
     rows_per_tile, ks = ops.conv_plan(pp)
     pixels = t * s * s
-    assert ks == 1 and pixels % rows_per_tile == 0, (ks, rows_per_tile)
+    assert ks == ksplit and pixels % rows_per_tile == 0, (ks, rows_per_tile)
     nchunk = pixels // rows_per_tile
     partial = torch.zeros(b * nchunk, 16, device=dev)
     h = ops.conv2d_cl(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), gn_partial=partial,
-                      gn_groups=8, gn_pixels=pixels, ksplit=1)
+                      gn_groups=8, gn_pixels=pixels, ksplit=ksplit)
     out = ops.groupnorm_apply_cl(h, b, gamma.to(dev), beta.to(dev), partial, nchunk, scale_shift=ss.to(dev),
                                  residual=unet_to_cl(res).to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
+
+
+@pytest.mark.parametrize("c", [64, 512])
+def test_conv_fused_layernorm(backend, c):
+    """PreNorm (channel LayerNorm) folded into the 1x1 qkv projection."""
+    dev = backend
+    b, t, s = (1, 40, 32) if (big(dev) and c == 64) else (2, 3, 4)
+    x = rnd(b, c, t, s, s, seed=1) * 2 + 0.7
+    gamma = rnd(1, c, 1, 1, 1, seed=2) * 0.3 + 1
+    w = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
+    ref = torch.einsum("oc,bcthw->bothw", w, O.channel_layernorm(x, gamma))
+    packed, wsum = ops.pack_ln_conv_weight(w, gamma.reshape(-1))
+    out = ops.conv2d_cl(unet_to_cl(x).to(dev), packed.to(dev), 768, 1, 1, b * t, s, s, ln_wsum=wsum.to(dev))
+    assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused layernorm + qkv")
 
 
 @pytest.mark.parametrize("c", [64, 128, 512])
