@@ -133,15 +133,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   float ra1[FAST ? 1 : A_F1];
   float4 rb[B_F4];
 
-  // per-thread constants of the fast path
-  int a_pix[FAST ? A_F4 : 1];
+  // per-thread constants of the fast path.  FAST && SIMPLE loads go through buffer descriptors: an
+  // invalid tap becomes an out-of-range offset (returns 0) instead of a branch, and chunk indices are
+  // clamped instead of guarded, so the MFMA loop is one basic block (no accumulator copies).
+  uint32_t a_off0[FAST ? A_F4 : 1], a_off1[FAST ? A_F4 : 1];
   unsigned long long a_mask[FAST ? A_F4 : 1];
+  uint32_t b_off[B_F4];
+  const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+  const bool use_buf = FAST && SIMPLE;
+  const lfdm_buf buf0 = lfdm_make_buf(p.src0, use_buf ? (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4) : 0u);
+  const lfdm_buf buf1 = (use_buf && p.c1 > 0) ? lfdm_make_buf(p.src1, (uint32_t)(((in_rows - 1) * p.ld1 + p.c1) * 4)) : buf0;
+  const lfdm_buf bufw = lfdm_make_buf(p.weight, use_buf ? (uint32_t)((int64_t)((ktotal + BK - 1) / BK) * p.coutp * BK * 4) : 0u);
   if (FAST && SIMPLE) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int r = (tid >> 3) + 32 * i;
-      a_pix[i] = s_pix[r];
+      a_off0[i] = ((uint32_t)s_pix[r] * (uint32_t)p.ld0 + 4u * (tid & 7)) * 4u;   // wraps; valid taps un-wrap
+      a_off1[i] = ((uint32_t)s_pix[r] * (uint32_t)p.ld1 + 4u * (tid & 7)) * 4u;
       a_mask[i] = s_mask[r];
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int f = tid + 256 * i;
+      b_off[i] = (n0 + (f >> 3) < p.coutp) ? (uint32_t)(((n0 + (f >> 3)) * BK + 4 * (f & 7)) * 4) : LFDM_BUF_OOB;
     }
   }
 
@@ -149,7 +163,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
 #pragma unroll
   for (int i = 0; i < (FAST ? A_F4 : 1); ++i) ln_s[i] = ln_q[i] = 0.f;
 
-  auto fetch = [&](int kc) {
+  auto fetch = [&](int kc, float lnw) {
+    if (FAST && SIMPLE) {
+      const int cpt = cin / BK;
+      const int tap = kc / cpt;
+      int cc = (kc - tap * cpt) * BK;
+      const bool second = cc >= p.c0;
+      if (second) cc -= p.c0;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const uint32_t chunk_off = (uint32_t)(((ky * p.wi + kx) * (second ? p.ld1 : p.ld0) + cc) * 4);
+      const lfdm_buf buf = second ? buf1 : buf0;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        const uint32_t base = second ? a_off1[i] : a_off0[i];
+        const uint32_t off = ((a_mask[i] >> tap) & 1ull) ? base + chunk_off : LFDM_BUF_OOB;
+        const float4 v = lfdm_buf_load_f4(buf, off);
+        ra4[i] = v;
+        if (LN) {
+          ln_s[i] += lnw * ((v.x + v.y) + (v.z + v.w));
+          ln_q[i] += lnw * ((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        }
+      }
+      const uint32_t wbase = (uint32_t)kc * (uint32_t)p.coutp * BK * 4;
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i)
+        rb[i] = lfdm_buf_load_f4(bufw, b_off[i] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[i]);
+      return;
+    }
     if (FAST) {
       const int cpt = cin / BK;
       const int tap = kc / cpt;
@@ -162,29 +202,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         ld = p.ld1;
       }
       const int cq = tid & 7;
-      int tap_off = 0;
-      if (SIMPLE) {
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        tap_off = ky * p.wi + kx;
-      }
 #pragma unroll
       for (int i = 0; i < A_F4; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (SIMPLE) {
-          if ((a_mask[i] >> tap) & 1ull)
-            v = *reinterpret_cast<const float4*>(src + (int64_t)(a_pix[i] + tap_off) * ld + cc + 4 * cq);
-        } else {
-          const int r = (tid >> 3) + 32 * i;
-          const int img = s_img[r];
-          int64_t pix;
-          if (img >= 0 && src_pixel(p, img, s_qy[r], s_qx[r], tap, pix))
-            v = *reinterpret_cast<const float4*>(src + pix * ld + cc + 4 * cq);
-        }
+        const int r = (tid >> 3) + 32 * i;
+        const int img = s_img[r];
+        int64_t pix;
+        if (img >= 0 && src_pixel(p, img, s_qy[r], s_qx[r], tap, pix))
+          v = *reinterpret_cast<const float4*>(src + pix * ld + cc + 4 * cq);
         ra4[i] = v;
-        if (LN) {
-          ln_s[i] += (v.x + v.y) + (v.z + v.w);
-          ln_q[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        }
       }
     } else {
       const int k = kc * BK + (tid & 31);
@@ -249,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   const int nk = kc_end - kc_begin;
 
   if (nk > 0) {
-    fetch(kc_begin);
+    fetch(kc_begin, 1.f);
     stage();
   }
   __syncthreads();
@@ -257,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   for (int c = 0; c < nk; ++c) {
     const bool more = c + 1 < nk;
 #ifndef LFDM_PROBE_NOFETCH
-    if (more) fetch(kc_begin + c + 1);
+    fetch(kc_begin + (more ? c + 1 : c), more ? 1.f : 0.f);     // clamped: the last iteration re-reads its chunk
 #endif
     const float* const As = smem;
     const float* const Bs = As + BM * LD;
@@ -285,10 +311,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         }
     }
     __syncthreads();
-    if (more) {
-      stage();
-      __syncthreads();
-    }
+    stage();                          // unconditional (harmless after the last chunk): no branch in the loop
+    __syncthreads();
   }
 
   if (FAST && LN) {
@@ -593,6 +617,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   const bool vec_ok = (p.cout % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)p.out) & 15) == 0) &&
                       (!p.residual || ((p.ldr % 4 == 0) && ((((uintptr_t)p.residual) & 15) == 0))) &&
                       (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+  pl.simple = pl.simple && fits32;      // the mask/buffer-descriptor path uses 32-bit byte offsets
   bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160 && !p.ln_wsum && fits32 && vec_ok;
   if (conv_force() == 0) ksw = false;
   if (conv_force() == 1 && pl.fast && pl.simple && !p.ln_wsum && fits32 && vec_ok) ksw = true;
