@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restric
   }
 }
 
+// Histogram clear.  NOT hipMemsetAsync: a memset node inside a captured hipGraph stopped writing zeros
+// after a few replays on ROCm 7.2 / gfx950 (it filled a stale 32-bit pattern instead), which silently
+// corrupted every quantile of the second video onwards; a plain kernel node replays correctly.
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+
 __global__ void advance_step_kernel(int32_t* step_dev) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_dev += 1;
 }
@@ -255,7 +262,11 @@ extern "C" int lfdm_abs_quantile_f32(const float* x, int batch, int64_t n, float
     return LFDM_EWORKSPACE;
   }
   unsigned* hists = reinterpret_cast<unsigned*>(ws);
-  (void)hipMemsetAsync(hists, 0, (size_t)batch * HIST_PER_SAMPLE * sizeof(unsigned), stream);
+  {
+    const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
+    LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream,
+                hists, nz);
+  }
   const Ranks rk = make_ranks(n, quantile);
   LFDM_LAUNCH(quantile_pass0_kernel, dim3(blocks_for(n), batch), dim3(256), 0, stream, x,
               (const float*)nullptr, (float*)nullptr, n, (const float*)nullptr,
@@ -280,7 +291,11 @@ extern "C" int lfdm_sampler_step_f32(float* x, const float* eps, const float* no
   }
   unsigned* hists = reinterpret_cast<unsigned*>(ws);
   float* x0buf = reinterpret_cast<float*>(hists + (size_t)batch * HIST_PER_SAMPLE);
-  (void)hipMemsetAsync(hists, 0, (size_t)batch * HIST_PER_SAMPLE * sizeof(unsigned), stream);
+  {
+    const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
+    LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream,
+                hists, nz);
+  }
   const Ranks rk = make_ranks(n, quantile);
   const dim3 grid(blocks_for(n), batch), block(256);
   LFDM_LAUNCH(quantile_pass0_kernel, grid, block, 0, stream, (const float*)x, eps, x0buf, n, coef,

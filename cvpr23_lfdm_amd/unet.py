@@ -353,8 +353,7 @@ class Unet3D(ParamTree):
             skips.append(x)
             if lvl < nl - 1:
                 out_d = self._buf("d%d.down" % lvl, n_img * (res // 2) ** 2, co)
-                x = ops.conv2d_cl(x, pk[p + "4.w"], co, 4, 4, n_img, res, res, bias=pk[p + "4.b"], pad=(1, 1),
-                                  stride=2, out=out_d)
+                x = self._conv(x, pk[p + "4.w"], co, 4, n_img, res, bias=pk[p + "4.b"], pad=(1, 1), stride=2, out=out_d)
                 res //= 2
         mid = self.levels[-1][1]
         x = self._resblock(pk, "mid_block1.", x, None, batch, frames, res, ss, mid, "m.a")
@@ -369,11 +368,14 @@ class Unet3D(ParamTree):
             x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, ci, "u%d.d" % lvl, tables)
             if lvl < nl - 1:
                 out_u = self._buf("u%d.up" % lvl, n_img * (res * 2) ** 2, ci)
-                if self.use_deconv:
-                    x = ops.deconv4x4s2_cl(x, pk[p + "4.packs"], ci, n_img, res, res, bias=pk[p + "4.b"], out=out_u)
+                if self.use_deconv:      # ConvTranspose (1,4,4) s2 p1 = four 2x2 parity convolutions
+                    for py, px, wpk in pk[p + "4.packs"]:
+                        self._conv(x, wpk, ci, 2, n_img, res, bias=pk[p + "4.b"], pad=(1 - py, 1 - px), out=out_u,
+                                   hq=res, wq=res, ho=2 * res, wo=2 * res, out_scale=2, out_off=(py, px))
+                    x = out_u
                 else:
-                    x = ops.conv2d_cl(x, pk[p + "4.w"], ci, 3, 3, n_img, res, res, bias=pk[p + "4.b"],
-                                      upsample=True, reflect=(self.padding_mode == "reflect"), out=out_u)
+                    x = self._conv(x, pk[p + "4.w"], ci, 3, n_img, res, bias=pk[p + "4.b"], upsample=True,
+                                   reflect=(self.padding_mode == "reflect"), out=out_u)
                 res *= 2
         yf = self._resblock(pk, "final_conv.0.", x, r, batch, frames, res, None, dim, "h.flow")
         yo = self._resblock(pk, "occlusion_map.0.", x, r, batch, frames, res, None, dim, "h.occ")

@@ -516,15 +516,25 @@ def generator_forward_with_flow(gsd, img, flow, occ, n_down=2, n_bottleneck=6):
     return {"prediction": out, "deformed": deformed}
 
 
+def identity_grid(b, nf, h, w):
+    """FlowDiffusion.get_grid(normalize=True) (video_flow_diffusion_model.py:232-240): linspace(-1,1)
+    meshgrid in (x, y) order, (B, 2, nf, H, W)."""
+    ys, xs = torch.linspace(-1, 1, h), torch.linspace(-1, 1, w)
+    grid = torch.stack((xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w)), dim=0)
+    return grid.view(1, 2, 1, h, w).repeat(b, 1, nf, 1, 1)
+
+
 def sample_one_video(dsd, gsd, img, cond, num_frames, latent_size, sampling_timesteps,
-                     timesteps=1000, eta=1.0, cond_scale=1.0, noise_fn=None, record=None):
-    """FlowDiffusion.sample_one_video (video_flow_diffusion_model.py:190-216),
-    use_residual_flow=False."""
+                     timesteps=1000, eta=1.0, cond_scale=1.0, noise_fn=None, record=None,
+                     use_residual_flow=False):
+    """FlowDiffusion.sample_one_video (video_flow_diffusion_model.py:190-216)."""
     fea = generator_compute_fea(gsd, img)
     b = cond.shape[0]
     pred = sample(dsd, fea, cond, (b, 3, num_frames, latent_size, latent_size),
                   sampling_timesteps, timesteps, eta, cond_scale, noise_fn, record)
     grid = pred[:, :2]
+    if use_residual_flow:
+        grid = grid + identity_grid(b, num_frames, latent_size, latent_size)
     conf = (pred[:, 2:3] + 1) * 0.5
     outs, warps = [], []
     for f in range(num_frames):

@@ -83,3 +83,42 @@ def test_sample_one_video(backend, sampler):
     assert_close(m.sample_vid_conf.cpu(), ref["sample_vid_conf"], 1e-3, "sample_vid_conf")
     assert_close(m.sample_warped_vid.cpu(), ref["sample_warped_vid"], 1e-3, "sample_warped_vid")
     assert_close(m.sample_out_vid.cpu(), ref["sample_out_vid"], 1e-3, "sample_out_vid")
+
+
+@pytest.mark.parametrize("mode", ["cfg2", "cfg0", "residual_flow"])
+def test_sample_variants(backend, mode):
+    """Classifier-free guidance (cond_scale 2 = two UNet passes + combine, cond_scale 0 = null only,
+    reference :511-526) and use_residual_flow (:195-198) against the oracle."""
+    dev = backend
+    _skip_slow_emu(dev)
+    z = dict(b=1, t=2, s=8, hw=32) if dev == "cpu" else dict(b=2, t=4, s=8, hw=32)
+    kw = dict(use_residual_flow=True) if mode == "residual_flow" else {}
+    m, dsd, gsd = synth.build_flow_diffusion(dev, img_size=z["s"], num_frames=z["t"], sampling_timesteps=3, **kw)
+    img, cond = synth.inputs(z["b"], z["hw"])
+    scale = {"cfg2": 2.0, "cfg0": 0.0}.get(mode, 1.0)
+    sd = dict(dsd)
+    sd.update(O.make_schedule(1000))
+    ref = O.sample_one_video(sd, gsd, img, cond, z["t"], z["s"], 3, cond_scale=scale, noise_fn=synth.NoiseTape(5),
+                             use_residual_flow=(mode == "residual_flow"))
+    m.diffusion.noise_source = synth.NoiseTape(5)
+    m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
+    m.sample_one_video(cond_scale=scale)
+    for k in ("sample_vid_grid", "sample_vid_conf", "sample_warped_vid", "sample_out_vid"):
+        assert_close(getattr(m, k).cpu(), ref[k], 1e-3, "%s (%s)" % (k, mode))
+
+
+def test_second_call_reuses_graph(backend):
+    """A second sample() with the same shapes replays the captured hipGraph with refreshed tables: the result
+    must follow the new inputs (new image / cond / noise), not the first call's."""
+    dev = backend
+    _skip_slow_emu(dev)
+    m, dsd, gsd = synth.build_flow_diffusion(dev, img_size=8, num_frames=4, sampling_timesteps=3)
+    sd = dict(dsd)
+    sd.update(O.make_schedule(1000))
+    for seed in (7, 8):
+        img, cond = synth.inputs(1, 32, seed=seed)
+        ref = O.sample_one_video(sd, gsd, img, cond, 4, 8, 3, noise_fn=synth.NoiseTape(seed))
+        m.diffusion.noise_source = synth.NoiseTape(seed)
+        m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
+        m.sample_one_video(cond_scale=1.0)
+        assert_close(m.sample_out_vid.cpu(), ref["sample_out_vid"], 1e-3, "call with seed %d" % seed)
