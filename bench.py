@@ -73,17 +73,15 @@ def conv_roofline(model, img, cond):
     launch stream; achieved = sum(algorithmic 2*M*N*K) / sum(kernel time)."""
     from cvpr23_lfdm_amd import ops
     records = []
-    orig = ops.conv2d_cl
+    orig = ops.conv_launch
 
-    def timed_conv(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_):
+    def timed_launch(p):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
+        orig(p)
         e1.record()
-        cin = src0.shape[1] + (kw_["src1"].shape[1] if kw_.get("src1") is not None else 0)
-        rows = out.shape[0] if kw_.get("out_scale", 1) == 1 else out.shape[0] // (kw_["out_scale"] ** 2)
-        records.append((2.0 * rows * cout * cin * kh * kw, e0, e1))
-        return out
+        rows = p.n_img * p.hq * p.wq
+        records.append((2.0 * rows * p.cout * (p.c0 + p.c1) * p.kh * p.kw, e0, e1))
 
     unet = model.unet
     b, t, s = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"]
@@ -93,16 +91,16 @@ def conv_roofline(model, img, cond):
     with torch.no_grad():
         unet.forward(x, tt, cond=cond)          # warm
         torch.cuda.synchronize()
-        ops.conv2d_cl = timed_conv
+        ops.conv_launch = timed_launch
         try:
             unet.forward(x, tt, cond=cond)
         finally:
-            ops.conv2d_cl = orig
+            ops.conv_launch = orig
         torch.cuda.synchronize()
     flops = sum(r[0] for r in records)
     ms = sum(r[1].elapsed_time(r[2]) for r in records)
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of one UNet step, eager)",
+    return {"bound": "mfma", "kernel": "lfdm_conv2d_cl_f32 = conv_ksw_kernel + conv_igemm_kernel (+ split-K reduce), all launches of one eager UNet step",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "launches": len(records), "gflop_per_step": round(flops / 1e9, 2), "ms_per_step_in_kernel": round(ms, 3)}
@@ -177,6 +175,9 @@ def main():
     elapsed = timed_region(run_step, args.steps, args.warmup, world, torch.cuda.synchronize)
     videos = args.steps * WORKLOAD["batch"] * world
     value = videos / elapsed
+    out = model.sample_out_vid
+    assert out.shape == (WORKLOAD["batch"], 3, WORKLOAD["frames"], WORKLOAD["image"], WORKLOAD["image"])
+    assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0, "bad sample"
 
     if rank == 0:
         line = {

@@ -59,32 +59,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const float scale = 0.17677669529663687f;  // 32^-0.5
 
   // ---- stage Q, K, V (8 lanes x float4 per 32-float row) ----
+  // All global loads of the wave are issued before the first use (LP/8 x 3 independent float4 per lane):
+  // with the loads inside the rotary / LDS-store loop the kernel was bound by 6 serial memory latencies.
   {
+    constexpr int NR = LP / 8;
     const int rr = lane >> 3, c4 = lane & 7;
-    for (int t = rr; t < LP; t += 8) {
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+    float4 qv[NR], kv[NR], vv[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int t = rr + 8 * i;
+      qv[i] = kv[i] = vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid && t < L) {
         const float* base = qkv + (row0 + (int64_t)t * tstride) * QKV_LD + head * DH + 4 * c4;
-        q = *reinterpret_cast<const float4*>(base);
-        k = *reinterpret_cast<const float4*>(base + OUT_LD);
-        v = *reinterpret_cast<const float4*>(base + 2 * OUT_LD);
-        q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
-        if (rot_cos) {
-          const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
-          const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
-          float4 qr, kr;
-          qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
-          qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
-          kr.x = k.x * c0 - k.y * s0; kr.y = k.y * c0 + k.x * s0;
-          kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
-          q = qr; k = kr;
-        }
+        qv[i] = *reinterpret_cast<const float4*>(base);
+        kv[i] = *reinterpret_cast<const float4*>(base + OUT_LD);
+        vv[i] = *reinterpret_cast<const float4*>(base + 2 * OUT_LD);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int t = rr + 8 * i;
+      float4 q = qv[i], k = kv[i];
+      q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+      if (rot_cos && t < L) {
+        const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
+        const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
+        float4 qr, kr;
+        qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
+        qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
+        kr.x = k.x * c0 - k.y * s0; kr.y = k.y * c0 + k.x * s0;
+        kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
+        q = qr; k = kr;
       }
       float* dq = Qs + t * SQ + 4 * c4;
       dq[0] = q.x; dq[1] = q.y; dq[2] = q.z; dq[3] = q.w;
       float* dk = Ks + t * SQ + 4 * c4;
       dk[0] = k.x; dk[1] = k.y; dk[2] = k.z; dk[3] = k.w;
-      *reinterpret_cast<float4*>(Vs + t * SV + 4 * c4) = v;
+      *reinterpret_cast<float4*>(Vs + t * SV + 4 * c4) = vv[i];
     }
   }
   __syncthreads();
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // grid (n_frames*8); ctx_out[(f*8+h)][d][e] = sum_n softmax_n(k)[n][d] * v[n][e]
 __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, int hw,
                                                               float* __restrict__ ctx_out) {
-  __shared__ float red[8][32];
+  __shared__ float red[4][32];
   __shared__ float kmax[32];
   __shared__ float ek[64][33];
   __shared__ __attribute__((aligned(16))) float vv[64][36];
@@ -180,40 +191,67 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
   const float* kbase = qkv + (int64_t)f * hw * QKV_LD + OUT_LD + h * DH;
   const float* vbase = kbase + OUT_LD;
 
-  {  // pass 1: per-feature max over tokens
-    const int d = tid & 31, part = tid >> 5;
-    float m = -3.0e38f;
-    for (int n = part; n < hw; n += 8) m = fmaxf(m, kbase[(int64_t)n * QKV_LD + d]);
-    red[part][d] = m;
-    __syncthreads();
-    if (tid < 32) {
-      float mm = red[0][tid];
-      for (int p = 1; p < 8; ++p) mm = fmaxf(mm, red[p][tid]);
-      kmax[tid] = mm;
+  {  // pass 1: per-feature max over tokens (float4 per lane, 4 independent rows in flight)
+    const int c4 = tid & 7, part = tid >> 3;          // 32 parts x 8 float4 columns
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    for (int n = part; n < hw; n += 128) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + 32 * u;
+        v[u] = nn < hw ? *reinterpret_cast<const float4*>(kbase + (int64_t)nn * QKV_LD + 4 * c4) : m;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+      }
     }
+    // reduce over the 8 parts that share a wave-local (lane>>3), then across waves through LDS
+#pragma unroll
+    for (int x = 8; x <= 32; x <<= 1) {
+      m.x = fmaxf(m.x, __shfl_xor(m.x, x)); m.y = fmaxf(m.y, __shfl_xor(m.y, x));
+      m.z = fmaxf(m.z, __shfl_xor(m.z, x)); m.w = fmaxf(m.w, __shfl_xor(m.w, x));
+    }
+    if ((tid & 63) < 8) {
+      const int w = tid >> 6;
+      red[w][4 * c4 + 0] = m.x; red[w][4 * c4 + 1] = m.y; red[w][4 * c4 + 2] = m.z; red[w][4 * c4 + 3] = m.w;
+    }
+    __syncthreads();
+    if (tid < 32) kmax[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
     __syncthreads();
   }
 
   const int d = tid >> 3, e0 = (tid & 7) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   float ssum = 0.f;
-  for (int n0 = 0; n0 < hw; n0 += 64) {
-    // stage 64 tokens: exp(k - max) and v
-    for (int i = tid; i < 64 * 8; i += 256) {
-      const int n = i >> 3, c4 = i & 7;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kv;
-      const bool ok = n0 + n < hw;
-      if (ok) {
-        kv = *reinterpret_cast<const float4*>(kbase + (int64_t)(n0 + n) * QKV_LD + 4 * c4);
-        v4 = *reinterpret_cast<const float4*>(vbase + (int64_t)(n0 + n) * QKV_LD + 4 * c4);
+  // pass 2: 64-token tiles, next tile's global loads in flight while this tile is accumulated
+  const int ln = tid >> 3, lc4 = tid & 7;              // loader: token ln (+32), float4 column lc4
+  float4 rk[2], rv[2];
+  auto load_tile = [&](int n0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + ln + 32 * u;
+      rk[u] = rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < hw) {
+        rk[u] = *reinterpret_cast<const float4*>(kbase + (int64_t)n * QKV_LD + 4 * lc4);
+        rv[u] = *reinterpret_cast<const float4*>(vbase + (int64_t)n * QKV_LD + 4 * lc4);
       }
-      ek[n][4 * c4 + 0] = ok ? expf(kv.x - kmax[4 * c4 + 0]) : 0.f;
-      ek[n][4 * c4 + 1] = ok ? expf(kv.y - kmax[4 * c4 + 1]) : 0.f;
-      ek[n][4 * c4 + 2] = ok ? expf(kv.z - kmax[4 * c4 + 2]) : 0.f;
-      ek[n][4 * c4 + 3] = ok ? expf(kv.w - kmax[4 * c4 + 3]) : 0.f;
-      *reinterpret_cast<float4*>(&vv[n][4 * c4]) = v4;
+    }
+  };
+  load_tile(0);
+  for (int n0 = 0; n0 < hw; n0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int nl = ln + 32 * u;
+      const bool ok = n0 + nl < hw;
+      ek[nl][4 * lc4 + 0] = ok ? expf(rk[u].x - kmax[4 * lc4 + 0]) : 0.f;
+      ek[nl][4 * lc4 + 1] = ok ? expf(rk[u].y - kmax[4 * lc4 + 1]) : 0.f;
+      ek[nl][4 * lc4 + 2] = ok ? expf(rk[u].z - kmax[4 * lc4 + 2]) : 0.f;
+      ek[nl][4 * lc4 + 3] = ok ? expf(rk[u].w - kmax[4 * lc4 + 3]) : 0.f;
+      *reinterpret_cast<float4*>(&vv[nl][4 * lc4]) = rv[u];
     }
     __syncthreads();
+    if (n0 + 64 < hw) load_tile(n0 + 64);
 #pragma unroll 8
     for (int n = 0; n < 64; ++n) {
       const float e = ek[n][d];
