@@ -81,7 +81,10 @@ def conv_roofline(model, img, cond):
         orig(p)
         e1.record()
         rows = p.n_img * p.hq * p.wq
-        records.append((2.0 * rows * p.cout * (p.c0 + p.c1) * p.kh * p.kw, e0, e1))
+        kdim = (p.c0 + p.c1) * p.kh * p.kw
+        # algorithmic bytes: input once + packed weights once + output once (fp32)
+        nbytes = 4.0 * (p.n_img * p.hi * p.wi * (p.c0 + p.c1) + kdim * p.cout + p.n_img * p.ho * p.wo * p.cout)
+        records.append((2.0 * rows * p.cout * kdim, e0, e1, nbytes))
 
     unet = model.unet
     b, t, s = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"]
@@ -100,10 +103,71 @@ def conv_roofline(model, img, cond):
     flops = sum(r[0] for r in records)
     ms = sum(r[1].elapsed_time(r[2]) for r in records)
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    tf = os.path.join(REPO_ROOT, "profiles", "r01_e_traffic.json")
+    if os.path.exists(tf):          # PMC counters cannot be read from inside the process: committed rocprofv3 pass
+        with open(tf) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj["conv_bytes_per_step"], tj["source"]
     return {"bound": "mfma", "kernel": "lfdm_conv2d_cl_f32 = conv_ksw_kernel + conv_igemm_kernel (+ split-K reduce), all launches of one eager UNet step",
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per UNet step summed over the same launches (rocprofv3 PMC, not live)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_step": round(sum(r[3] for r in records)),
             "launches": len(records), "gflop_per_step": round(flops / 1e9, 2), "ms_per_step_in_kernel": round(ms, 3)}
+
+
+def warp_bench(model, img, iters=20):
+    """BASELINE.json's second metric, "LFAE warp Gpix/s": the six deform_input/apply_optical launches of one
+    40-frame decode (flow = identity + 0.1 randn clipped to [-1.2,1.2], occ = rand).
+    Gpix/s = 1e-9 * sum(C*H*W*frames) / time (channel-pixels); HBM roofline on the algorithmic bytes of 8d:
+    8 B/elem for a pure warp (gathered input counted once + output), 12 B/elem for warp+blend (prev read)."""
+    from cvpr23_lfdm_amd import ops
+    gen = model.generator
+    b, t, s = img.shape[0], WORKLOAD["frames"], WORKLOAD["latent"]
+    g = torch.Generator(device="cpu").manual_seed(99)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, s), torch.linspace(-1, 1, s), indexing="ij")
+    ident = torch.stack((xs, ys), 0).view(1, 2, 1, s, s)
+    flow = (ident + 0.1 * torch.randn(b, 2, t, s, s, generator=g)).clamp_(-1.2, 1.2)
+    maps = torch.cat((flow, torch.rand(b, 1, t, s, s, generator=g)), 1).contiguous().to(img.device)
+    fx, fy, occ = maps[:, 0], maps[:, 1], maps[:, 2]
+    wk = dict(fh=s, fw=s, fsb=3 * t * s * s, fst=s * s)
+    with torch.no_grad():
+        skips = gen.encode(img)
+    n = b * t
+    h = img.shape[2]
+    prevs = {k: torch.rand(n * r * r, c, device=img.device) for k, (r, c) in
+             {"u0": (h // 2, skips[1].shape[1]), "u1": (h, skips[0].shape[1]), "rgb": (h, 4)}.items()}
+    outs = {"lat": torch.empty(n * s * s, skips[2].shape[1], device=img.device),
+            "u0": torch.empty_like(prevs["u0"]), "u1": torch.empty_like(prevs["u1"]),
+            "def": torch.empty(b, 3, t, h, h, device=img.device), "pred": torch.empty(b, 3, t, h, h, device=img.device)}
+
+    def one_decode_warps():
+        ops.warp_planar(img, t, fx, fy, None, s, s, wk["fsb"], wk["fst"], out=outs["def"])
+        ops.warp_cl(skips[2], b, t, s, s, fx, fy, occ, out=outs["lat"], **wk)
+        ops.warp_cl(skips[1], b, t, h // 2, h // 2, fx, fy, occ, prev=prevs["u0"], out=outs["u0"], **wk)
+        ops.warp_cl(skips[0], b, t, h, h, fx, fy, occ, prev=prevs["u1"], out=outs["u1"], **wk)
+        ops.warp_planar(img, t, fx, fy, occ, s, s, wk["fsb"], wk["fst"], prev=prevs["rgb"][:, :3], prev_is_cl=True,
+                        out=outs["pred"])
+
+    # reference frame count: deform_input x6 per frame (the (3,128,128) source warp appears twice in a34)
+    pure = n * (3 * h * h + skips[2].shape[1] * s * s)
+    blend = n * (skips[1].shape[1] * (h // 2) ** 2 + skips[0].shape[1] * h * h + 3 * h * h)
+    elems, nbytes = pure + blend, 8 * pure + 12 * blend
+    one_decode_warps()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        one_decode_warps()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    gbs = nbytes / sec / 1e9
+    return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 5 launches = all warps of one 40-frame decode)",
+            "us_per_video": round(sec * 1e6, 1), "elements": elems,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
 
 
 def cpu_baseline():
@@ -151,19 +215,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="videos per GPU per step; 1 = BASELINE.json configs[1] (latency mode), >1 = throughput mode")
     args = ap.parse_args()
 
     rank, world, local = dist_setup(args.gpus)
+    if args.batch != 1:
+        WORKLOAD["batch"] = args.batch
+        WORKLOAD["name"] = WORKLOAD["name"].replace("batch=1 per GPU (BASELINE.json configs[1])",
+                                                    "batch=%d per GPU (throughput mode, NOT configs[1])" % args.batch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
+    import contextlib
     import synth
     torch.manual_seed(1234)
-    model, _, _ = synth.build_flow_diffusion(dev, img_size=WORKLOAD["latent"], num_frames=WORKLOAD["frames"],
-                                             sampling_timesteps=WORKLOAD["sampling_timesteps"],
-                                             timesteps=WORKLOAD["timesteps"])
+    with contextlib.redirect_stdout(sys.stderr):      # the reference-compatible ctor prints; stdout = ONE json line
+        model, _, _ = synth.build_flow_diffusion(dev, img_size=WORKLOAD["latent"], num_frames=WORKLOAD["frames"],
+                                                 sampling_timesteps=WORKLOAD["sampling_timesteps"],
+                                                 timesteps=WORKLOAD["timesteps"])
     img, cond = synth.inputs(WORKLOAD["batch"], WORKLOAD["image"], seed=7 + rank)
     img, cond = img.to(dev), cond.to(dev)
     torch.manual_seed(1237 + rank)          # sampling noise seed
@@ -194,6 +266,7 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = conv_roofline(model, img, cond)
+            line["warp"] = warp_bench(model, img)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

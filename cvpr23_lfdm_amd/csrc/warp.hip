@@ -87,51 +87,66 @@ __device__ __forceinline__ PixelTaps pixel_taps(const lfdm_warp_params& p, int b
 }
 
 // ---------------- channels-last ----------------
+// A pixel is served by G = C/(4*R) adjacent lanes; lane j owns the float4 chunks j, j+G, ... (R of
+// them), so the taps / occlusion (12 low-res map reads + the bilinear set-up) are computed once per
+// 4*R channels and every access of the G lanes is one contiguous G*16-byte segment.
+template <int R>
 __global__ __launch_bounds__(256) void warp_cl_kernel(lfdm_warp_params p) {
-  const int c4n = p.c >> 2;
+  const int g = (p.c >> 2) / R;             // lanes per pixel
   const int hw = p.h * p.w;
-  const int64_t total = (int64_t)p.batch * p.frames * hw * c4n;
+  const int64_t total = (int64_t)p.batch * p.frames * hw * g;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % c4n) * 4;
-    const int64_t gp = i / c4n;             // output pixel row
+    const int c = (int)(i % g) * 4;
+    const int64_t gp = i / g;               // output pixel row
     const int64_t n = gp / hw;              // frame index b*T + t
     const int pix = (int)(gp - n * hw);
     const int b = (int)(n / p.frames), t = (int)(n - (int64_t)b * p.frames);
     const int oy = pix / p.w, ox = pix - oy * p.w;
     const PixelTaps tp = pixel_taps(p, b, t, oy, ox);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* sb = p.src + (int64_t)b * hw * p.ld_src + c;
+    // tap offsets/weights (weight 0 + clamped address for out-of-range taps: zeros padding)
+    float wgt[4];
+    int64_t off[4];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int yy = tp.y0 + dy;
-      if (yy < 0 || yy >= p.h) continue;
-      const float wy = dy ? tp.wy1 : tp.wy0;
+    for (int k = 0; k < 4; ++k) {
+      const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+      const bool in = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+      wgt[k] = in ? ((k & 1) ? tp.wx1 : tp.wx0) * ((k >> 1) ? tp.wy1 : tp.wy0) : 0.f;
+      off[k] = in ? (int64_t)(yy * p.w + xx) * p.ld_src : 0;
+    }
+    float4 pv[R];
+    if (p.prev) {
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int xx = tp.x0 + dx;
-        if (xx < 0 || xx >= p.w) continue;
-        const float wgt = (dx ? tp.wx1 : tp.wx0) * wy;
-        const float4 v = *reinterpret_cast<const float4*>(sb + (int64_t)(yy * p.w + xx) * p.ld_src);
-        acc.x = fmaf(v.x, wgt, acc.x);
-        acc.y = fmaf(v.y, wgt, acc.y);
-        acc.z = fmaf(v.z, wgt, acc.z);
-        acc.w = fmaf(v.w, wgt, acc.w);
-      }
+      for (int r = 0; r < R; ++r) pv[r] = *reinterpret_cast<const float4*>(p.prev + gp * p.ld_prev + c + r * 4 * g);
     }
-    if (p.occ) {
-      const float o = tp.occ;
-      if (p.prev) {
-        const float4 pv = *reinterpret_cast<const float4*>(p.prev + gp * p.ld_prev + c);
-        const float om = 1.f - o;
-        acc.x = acc.x * o + pv.x * om;
-        acc.y = acc.y * o + pv.y * om;
-        acc.z = acc.z * o + pv.z * om;
-        acc.w = acc.w * o + pv.w * om;
-      } else {
-        acc.x *= o; acc.y *= o; acc.z *= o; acc.w *= o;
+    float4 v[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[r][k] = *reinterpret_cast<const float4*>(sb + off[k] + r * 4 * g);
+    const float o = tp.occ, om = 1.f - o;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {       // same tap order as before: (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+        acc.x = fmaf(v[r][k].x, wgt[k], acc.x);
+        acc.y = fmaf(v[r][k].y, wgt[k], acc.y);
+        acc.z = fmaf(v[r][k].z, wgt[k], acc.z);
+        acc.w = fmaf(v[r][k].w, wgt[k], acc.w);
       }
+      if (p.occ) {
+        if (p.prev) {
+          acc.x = acc.x * o + pv[r].x * om;
+          acc.y = acc.y * o + pv[r].y * om;
+          acc.z = acc.z * o + pv[r].z * om;
+          acc.w = acc.w * o + pv[r].w * om;
+        } else {
+          acc.x *= o; acc.y *= o; acc.z *= o; acc.w *= o;
+        }
+      }
+      *reinterpret_cast<float4*>(p.out + gp * p.ld_out + c + r * 4 * g) = acc;
     }
-    *reinterpret_cast<float4*>(p.out + gp * p.ld_out + c) = acc;
   }
 }
 
@@ -187,6 +202,48 @@ __global__ __launch_bounds__(256) void warp_planar_kernel(lfdm_warp_params p, in
   }
 }
 
+// Few source planes (the RGB image, C = 3): one thread per output pixel computes the taps once and
+// produces up to 4 channels; the 196 KB source stays in L1/L2, outputs are coalesced plane rows.
+// grid (ceil(hw/256), ceil(C/4), B*T).
+__global__ __launch_bounds__(256) void warp_planar_pixel_kernel(lfdm_warp_params p) {
+  const int hw = p.h * p.w;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= hw) return;
+  const int n = blockIdx.z;
+  const int b = n / p.frames, t = n - b * p.frames;
+  const int oy = pix / p.w, ox = pix - oy * p.w;
+  const PixelTaps tp = pixel_taps(p, b, t, oy, ox);
+  float wgt[4];
+  int off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+    const bool in = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+    wgt[k] = in ? ((k & 1) ? tp.wx1 : tp.wx0) * ((k >> 1) ? tp.wy1 : tp.wy0) : 0.f;
+    off[k] = in ? yy * p.w + xx : 0;
+  }
+  const int c0 = blockIdx.y * 4;
+  const int c1 = c0 + 4 < p.c ? c0 + 4 : p.c;
+  const float o = tp.occ;
+  for (int c = c0; c < c1; ++c) {
+    const float* S = p.src + ((int64_t)b * p.c + c) * hw;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = fmaf(S[off[k]], wgt[k], acc);
+    const int64_t obase = (((int64_t)b * p.c + c) * p.frames + t) * hw;
+    if (p.occ) {
+      if (p.prev) {
+        const float pv = p.prev_is_cl ? p.prev[(((int64_t)b * p.frames + t) * hw + pix) * p.ld_prev + c]
+                                      : p.prev[obase + pix];
+        acc = acc * o + pv * (1.f - o);
+      } else {
+        acc *= o;
+      }
+    }
+    p.out[obase + pix] = acc;
+  }
+}
+
 }  // namespace
 
 static int check_warp(const lfdm_warp_params* p, const char* who) {
@@ -208,10 +265,13 @@ extern "C" int lfdm_warp_cl_f32(const lfdm_warp_params* pp, lfdm_stream_t stream
     lfdm_set_error("warp_cl: channels and row strides must be multiples of 4");
     return LFDM_EINVAL;
   }
-  const int64_t total = (int64_t)p.batch * p.frames * p.h * p.w * (p.c / 4);
+  const int r = (p.c % 16 == 0) ? 4 : (p.c % 8 == 0 ? 2 : 1);
+  const int64_t total = (int64_t)p.batch * p.frames * p.h * p.w * (p.c / (4 * r));
   int64_t nb = (total + 255) / 256;
-  if (nb > 65536) nb = 65536;
-  LFDM_LAUNCH(warp_cl_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  if (nb > 262144) nb = 262144;
+  if (r == 4) LFDM_LAUNCH((warp_cl_kernel<4>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  else if (r == 2) LFDM_LAUNCH((warp_cl_kernel<2>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  else LFDM_LAUNCH((warp_cl_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, p);
   return lfdm_check_launch("warp_cl");
 }
 
@@ -225,6 +285,11 @@ extern "C" int lfdm_warp_planar_f32(const lfdm_warp_params* pp, lfdm_stream_t st
   int fpb = (int)(((int64_t)p.frames * p.c * p.batch) / 512);
   if (fpb < 1) fpb = 1;
   if (fpb > 8) fpb = 8;
+  if ((int64_t)p.c * p.batch * p.frames < 2048 && (int64_t)p.batch * p.frames <= 65535) {
+    const dim3 pgrid((hw + 255) / 256, (p.c + 3) / 4, p.batch * p.frames);
+    LFDM_LAUNCH(warp_planar_pixel_kernel, pgrid, dim3(256), 0, stream, p);
+    return lfdm_check_launch("warp_planar");
+  }
   const dim3 grid((p.frames + fpb - 1) / fpb, p.c, p.batch), block(256);
   const bool staged = hw <= PLANE_MAX && (hw % 4) == 0 && (((uintptr_t)p.src & 15) == 0);
   if (staged) LFDM_LAUNCH((warp_planar_kernel<true>), grid, block, 0, stream, p, fpb);

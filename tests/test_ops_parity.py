@@ -382,11 +382,12 @@ def test_warp_cl(backend, c, res, fs):
     assert_close(from_cl(out2.cpu(), b * t, res, res), ref2, TOL, "warp_cl mask only")
 
 
-@pytest.mark.parametrize("res,fs", [(16, 8), (8, 8)])
-def test_warp_planar(backend, res, fs):
+@pytest.mark.parametrize("res,fs,c", [(16, 8, 3), (8, 8, 3), (8, 4, 400)])
+def test_warp_planar(backend, res, fs, c):
+    """c = 3: per-pixel kernel (image planes); c = 400: LDS-staged plane kernel (many planes)."""
     dev = backend
-    b, t, c = 2, 3, 3
-    if big(dev):
+    b, t = 2, 3
+    if big(dev) and c == 3:
         res, fs, t = 128, 32, 40
     pred = _flow_case(b, t, fs, seed=res)
     src = torch.rand(b, c, res, res, generator=torch.Generator().manual_seed(5))
@@ -397,6 +398,8 @@ def test_warp_planar(backend, res, fs):
     out = ops.warp_planar(src.to(dev), t, pd[:, 0], pd[:, 1], None, fs, fs, fsb, fst)
     ref = torch.stack([O.deform_input(src, pred[:, :2, ti].permute(0, 2, 3, 1)) for ti in range(t)], dim=2)
     assert_close(out.cpu(), ref, TOL, "warp_planar deform")
+    if c != 3:
+        return
     # final blend with a CL 'prev' (sigmoid output of the last conv, ld = 4)
     prev = torch.rand(b * t * res * res, 4, generator=torch.Generator().manual_seed(6))
     prev_nchw = from_cl(prev[:, :3].contiguous(), b * t, res, res).reshape(b, t, 3, res, res)
