@@ -56,6 +56,16 @@ class WarpParams(C.Structure):
     ]
 
 
+class WgradParams(C.Structure):
+    _fields_ = [
+        ("x", f32p), ("cin", i32), ("ldx", i32),
+        ("n_img", i32), ("hi", i32), ("wi", i32), ("hq", i32), ("wq", i32),
+        ("stride", i32), ("kh", i32), ("kw", i32), ("pad_y", i32), ("pad_x", i32),
+        ("dy", f32p), ("cout", i32), ("lddy", i32),
+        ("dw", f32p),
+    ]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "lfdm_last_error": (C.c_char_p, []),
@@ -90,6 +100,17 @@ _SIGNATURES = {
     "lfdm_avgpool2_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
     "lfdm_planar_to_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
     "lfdm_cl_to_planar_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
+    # ---- training (backward) kernels
+    "lfdm_conv2d_wgrad_ws_bytes": (sz, [C.POINTER(WgradParams)]),
+    "lfdm_conv2d_wgrad_cl_f32": (i32, [C.POINTER(WgradParams), C.c_void_p, sz, stream_t]),
+    "lfdm_sum_leading_f32": (i32, [f32p, f32p, i64, i32, stream_t]),
+    "lfdm_colsum_ws_bytes": (sz, [i64, i32]),
+    "lfdm_colsum_f32": (i32, [f32p, i64, i32, i32, f32p, C.c_void_p, sz, stream_t]),
+    "lfdm_groupnorm_bwd_ws_bytes": (sz, [i32, i32, i32]),
+    "lfdm_groupnorm_silu_bwd_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32, i32,
+                                            f32p, i32, f32p, f32p, i32, C.c_void_p, sz, stream_t]),
+    "lfdm_layernorm_bwd_ws_bytes": (sz, [i64, i32]),
+    "lfdm_layernorm_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, f32p, f32, f32p, C.c_void_p, sz, stream_t]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

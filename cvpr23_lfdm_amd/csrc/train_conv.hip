@@ -1,0 +1,256 @@
+// Backward kernels of the convolution family for the DM training step
+// (include/lfdm_hip.h: lfdm_conv2d_wgrad_cl_f32, lfdm_colsum_f32, lfdm_sum_leading_f32).
+//
+// What autograd does for `loss.backward()` through every Conv3d/Linear of Unet3D
+// (DM/modules/video_flow_diffusion.py:199,224,246-247,300-301,158,167,410 via
+// DM/modules/video_flow_diffusion_model.py:181-188) splits into
+//   data gradient   = a convolution with the transposed / flipped filter -> the forward kernels
+//                     (lfdm_conv2d_cl_f32) with re-packed weights, no new code;
+//   weight gradient = dW[tap][ci][co] = sum_r X[r shifted by tap][ci] * dY[r][co]  -> this file;
+//   bias gradient   = column sums of dY                                             -> this file.
+//
+// Weight gradient as an fp32-MFMA GEMM whose reduction axis is the PIXEL axis: with channels-last
+// rows both operands are read exactly as they lie in memory (row = pixel, contiguous channels), so a
+// chunk of 32 pixel rows is staged row-major in LDS (16-byte coalesced loads, no transpose) and
+// v_mfma_f32_32x32x2 consumes two pixel rows per instruction: lane l holds A[ci = l&31][r = l>>5]
+// and B[r = l>>5][co = l&31].  One workgroup owns one filter tap x (64*WM input channels) x
+// (64*WN output channels) and a slice of the rows (grid.z); slices land in `partial` and are summed in
+// a fixed order by lfdm_sum_leading_f32 (deterministic - no float atomics).
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, int splits, float* dst_base) {
+  constexpr int TCI = 64 * WM, TCO = 64 * WN, BR = 32;
+  constexpr int A_F4 = BR * TCI / 4 / 256, B_F4 = BR * TCO / 4 / 256;
+  constexpr int STAGE = BR * (TCI + TCO);
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kk = lane >> 5;
+  const int ci_tiles = (p.cin + TCI - 1) / TCI;
+  const int tap = blockIdx.x / ci_tiles;
+  const int ci0 = (blockIdx.x - tap * ci_tiles) * TCI;
+  const int co0 = blockIdx.y * TCO;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int hqwq = p.hq * p.wq;
+  const int M = p.n_img * hqwq;                     // < 2^31 (host check)
+  const int nchunks = (M + BR - 1) / BR;
+  const int c_begin = (int)((int64_t)nchunks * blockIdx.z / splits);
+  const int c_end = (int)((int64_t)nchunks * (blockIdx.z + 1) / splits);
+  const int nk = c_end - c_begin;
+
+  const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+  const lfdm_buf bufx = lfdm_make_buf(p.x, (uint32_t)(((in_rows - 1) * p.ldx + p.cin) * 4));
+  const lfdm_buf bufy = lfdm_make_buf(p.dy, (uint32_t)((((int64_t)M - 1) * p.lddy + p.cout) * 4));
+
+  float4 ra[A_F4], rb[B_F4];
+  auto fetch = [&](int chunk) {
+    const int r0 = chunk * BR;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (TCI / 4), c4 = f - row * (TCI / 4);
+      const int r = r0 + row;
+      uint32_t off = LFDM_BUF_OOB;
+      if (r < M && ci0 + 4 * c4 < p.cin) {
+        const int img = r / hqwq;
+        const int rem = r - img * hqwq;
+        const int qy = rem / p.wq, qx = rem - qy * p.wq;
+        const int iy = qy * p.stride + ky - p.pad_y, ix = qx * p.stride + kx - p.pad_x;
+        if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi)
+          off = (uint32_t)((((int64_t)(img * p.hi + iy) * p.wi + ix) * p.ldx + ci0 + 4 * c4) * 4);
+      }
+      ra[i] = lfdm_buf_load_f4(bufx, off);
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (TCO / 4), c4 = f - row * (TCO / 4);
+      const int r = r0 + row;
+      const uint32_t off = (r < M && co0 + 4 * c4 < p.cout) ? (uint32_t)(((int64_t)r * p.lddy + co0 + 4 * c4) * 4)
+                                                           : LFDM_BUF_OOB;
+      rb[i] = lfdm_buf_load_f4(bufy, off);
+    }
+  };
+  auto stage = [&](int buf) {
+    float* const As = smem + buf * STAGE;
+    float* const Bs = As + BR * TCI;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(As + 4 * (tid + 256 * i)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(Bs + 4 * (tid + 256 * i)) = rb[i];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    fetch(c_begin);
+    stage(0);
+    __syncthreads();
+    fetch(c_begin + (nk > 1 ? 1 : 0));
+    for (int c = 0; c < nk; ++c) {
+      const int cur = c & 1;
+      stage(cur ^ 1);
+      {
+        const int nxt = c + 2 < nk ? c + 2 : nk - 1;
+        fetch(c_begin + nxt);
+      }
+      const float* const As = smem + cur * STAGE + wm * (32 * WM) + l31;
+      const float* const Bs = smem + cur * STAGE + BR * TCI + wn * (32 * WN) + l31;
+#pragma unroll
+      for (int s = 0; s < BR / 2; ++s) {
+        const int r = 2 * s + kk;
+        float a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = As[r * TCI + 32 * i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = Bs[r * TCO + 32 * j];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = mfma_32x32x2(a[i], b[j], acc[i][j]);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* const dst = dst_base + (int64_t)blockIdx.z * ((int64_t)p.kh * p.kw * p.cin * p.cout);
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int co = co0 + wn * (32 * WN) + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * (32 * WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (ci < p.cin && co < p.cout) dst[((int64_t)tap * p.cin + ci) * p.cout + co] = acc[i][j][r];
+      }
+    }
+}
+
+// out[i] = sum_s in[s*n + i]  (fixed order)
+__global__ __launch_bounds__(256) void sum_leading_kernel(const float* in, float* out, int64_t n, int s) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int k = 0; k < s; ++k) acc += in[(int64_t)k * n + i];
+    out[i] = acc;
+  }
+}
+
+// partial[blk][c] = sum over the block's rows of x[r][c]; 64 columns per workgroup column strip
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial,
+                                                     int rows_per_blk) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk;
+  if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  if (col < c)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += x[r * ld + col];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < c)
+    partial[(int64_t)blockIdx.y * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+struct WgradPlan {
+  int wm, wn, splits;
+};
+
+WgradPlan wgrad_plan(const lfdm_wgrad_params& p) {
+  WgradPlan pl;
+  pl.wm = p.cin >= 96 ? 2 : 1;
+  pl.wn = p.cout >= 96 ? 2 : 1;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  const int64_t nchunks = (M + 31) / 32;
+  const int64_t tiles = (int64_t)p.kh * p.kw * ((p.cin + 64 * pl.wm - 1) / (64 * pl.wm)) * ((p.cout + 64 * pl.wn - 1) / (64 * pl.wn));
+  int64_t s = (1024 + tiles - 1) / tiles;
+  if (s > nchunks / 8) s = nchunks / 8;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  pl.splits = (int)s;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t lfdm_conv2d_wgrad_ws_bytes(const lfdm_wgrad_params* p) {
+  if (!p) return 0;
+  const WgradPlan pl = wgrad_plan(*p);
+  return pl.splits > 1 ? (size_t)pl.splits * p->kh * p->kw * p->cin * p->cout * sizeof(float) : 0;
+}
+
+extern "C" int lfdm_sum_leading_f32(const float* in, float* out, int64_t n, int s, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !out || n <= 0 || s <= 0) { lfdm_set_error("sum_leading: bad arguments"); return LFDM_EINVAL; }
+  int64_t nb = (n + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  LFDM_LAUNCH(sum_leading_kernel, dim3((unsigned)nb), dim3(256), 0, stream, in, out, n, s);
+  return lfdm_check_launch("sum_leading");
+}
+
+extern "C" int lfdm_conv2d_wgrad_cl_f32(const lfdm_wgrad_params* pp, void* ws, size_t ws_bytes, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!pp) { lfdm_set_error("wgrad: null params"); return LFDM_EINVAL; }
+  const lfdm_wgrad_params p = *pp;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+  if (!p.x || !p.dy || !p.dw || p.cin <= 0 || p.cout <= 0 || p.n_img <= 0 || p.hi <= 0 || p.wi <= 0 || p.hq <= 0 ||
+      p.wq <= 0 || p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.ldx < p.cin || p.lddy < p.cout || M >= (1ll << 31) ||
+      in_rows >= (1ll << 31)) {
+    lfdm_set_error("wgrad: invalid geometry");
+    return LFDM_EINVAL;
+  }
+  if (p.cin % 4 || p.cout % 4 || p.ldx % 4 || p.lddy % 4 || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.dy) & 15) ||
+      in_rows * p.ldx * 4 >= (1ll << 32) - 64 || M * p.lddy * 4 >= (1ll << 32) - 64) {
+    lfdm_set_error("wgrad: channels and row strides must be multiples of 4, buffers 16-byte aligned and < 4 GiB");
+    return LFDM_EINVAL;
+  }
+  const WgradPlan pl = wgrad_plan(p);
+  const size_t need = lfdm_conv2d_wgrad_ws_bytes(&p);
+  if (need > 0 && (!ws || ws_bytes < need)) { lfdm_set_error("wgrad: workspace too small (lfdm_conv2d_wgrad_ws_bytes)"); return LFDM_EWORKSPACE; }
+  float* dst = pl.splits > 1 ? (float*)ws : p.dw;
+  const dim3 grid((unsigned)(p.kh * p.kw * ((p.cin + 64 * pl.wm - 1) / (64 * pl.wm))), (unsigned)((p.cout + 64 * pl.wn - 1) / (64 * pl.wn)),
+                  (unsigned)pl.splits);
+  if (pl.wm == 2 && pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst);
+  else if (pl.wm == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst);
+  else if (pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst);
+  else LFDM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst);
+  int rc = lfdm_check_launch("conv_wgrad");
+  if (rc) return rc;
+  if (pl.splits > 1) return lfdm_sum_leading_f32((const float*)ws, p.dw, (int64_t)p.kh * p.kw * p.cin * p.cout, pl.splits, stream_);
+  return LFDM_OK;
+}
+
+extern "C" size_t lfdm_colsum_ws_bytes(int64_t rows, int c) {
+  int64_t nblk = (rows + 1023) / 1024;
+  if (nblk > 512) nblk = 512;
+  return (size_t)nblk * c * sizeof(float);
+}
+
+extern "C" int lfdm_colsum_f32(const float* x, int64_t rows, int c, int ld, float* out, void* ws, size_t ws_bytes,
+                               lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || rows <= 0 || c <= 0 || ld < c) { lfdm_set_error("colsum: bad arguments"); return LFDM_EINVAL; }
+  int64_t nblk = (rows + 1023) / 1024;
+  if (nblk > 512) nblk = 512;
+  if (!ws || ws_bytes < (size_t)nblk * c * sizeof(float)) { lfdm_set_error("colsum: workspace too small"); return LFDM_EWORKSPACE; }
+  const int rows_per_blk = (int)((rows + nblk - 1) / nblk);
+  LFDM_LAUNCH(colsum_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)nblk), dim3(256), 0, stream, x, rows, c, ld, (float*)ws,
+              rows_per_blk);
+  int rc = lfdm_check_launch("colsum");
+  if (rc) return rc;
+  return lfdm_sum_leading_f32((const float*)ws, out, c, (int)nblk, stream_);
+}

@@ -257,6 +257,59 @@ int lfdm_planar_to_cl_f32(const float* x, float* out, int n_img, int channels, i
 int lfdm_cl_to_planar_f32(const float* x, float* out, int n_img, int channels, int hw, int ldx,
                           lfdm_stream_t stream);
 
+/* ==========================================================================================
+ * TRAINING (backward) kernels - the DM gradient step of
+ * DM/modules/video_flow_diffusion_model.py:181-188 (loss.backward(); optimizer_diff.step()).
+ * Data gradients of convolutions are convolutions with re-packed weights (lfdm_conv2d_cl_f32).
+ * ========================================================================================== */
+
+/* Weight gradient of every Conv3d k=(1,kh,kw) / Linear of Unet3D
+ * (video_flow_diffusion.py:199,224,246-247,300-301,158,167,410):
+ *   dw[(ky*kw + kx)][ci][co] = sum over output pixels r = (n, qy, qx) of
+ *        x[n, qy*stride + ky - pad_y, qx*stride + kx - pad_x][ci] * dy[r][co]      (zeros outside)
+ * x: CL rows (n_img*hi*wi, cin) stride ldx; dy: CL rows (n_img*hq*wq, cout) stride lddy.
+ * The tap-major result is a plain permutation of the reference (cout, cin, 1, kh, kw) layout.
+ * A ConvTranspose weight gradient is the same call with the roles of x and dy exchanged (stride 2). */
+typedef struct lfdm_wgrad_params {
+  const float* x;
+  int cin, ldx;
+  int n_img, hi, wi;
+  int hq, wq;
+  int stride, kh, kw, pad_y, pad_x;
+  const float* dy;
+  int cout, lddy;
+  float* dw;              /* [kh*kw][cin][cout] */
+} lfdm_wgrad_params;
+size_t lfdm_conv2d_wgrad_ws_bytes(const lfdm_wgrad_params* p);
+int lfdm_conv2d_wgrad_cl_f32(const lfdm_wgrad_params* p, void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* out[i] = sum_s in[s*n + i], s in fixed order (second stage of every deterministic split reduction) */
+int lfdm_sum_leading_f32(const float* in, float* out, int64_t n, int s, lfdm_stream_t stream);
+
+/* Bias gradient: out[c] = sum_r x[r][c] over CL rows (stride ld). */
+size_t lfdm_colsum_ws_bytes(int64_t rows, int c);
+int lfdm_colsum_f32(const float* x, int64_t rows, int c, int ld, float* out, void* ws, size_t ws_bytes,
+                    lfdm_stream_t stream);
+
+/* Backward of lfdm_groupnorm_silu_cl_f32 (Block.forward norm/scale-shift/act, video_flow_diffusion.py:200-211).
+ * x: the forward INPUT rows, dy: gradient of the output (before any residual add), partial/nchunk: the
+ * (sum, sumsq) partials the forward pass used (first batch*nchunk*groups*2 floats of its workspace, or the
+ * convolution's gn_partial).  Outputs: dx rows; dgamma_dbeta = [dgamma(C) | dbeta(C)];
+ * dscale_shift (when scale_shift != NULL) = B rows [dscale(C) | dshift(C)] with stride dss_ld. */
+size_t lfdm_groupnorm_bwd_ws_bytes(int batch, int pixels, int channels);
+int lfdm_groupnorm_silu_bwd_cl_f32(const float* x, const float* dy, float* dx, int batch, int pixels,
+                                   int channels, int groups, const float* gamma, const float* beta,
+                                   const float* scale_shift, int ss_ld, float eps, int apply_silu,
+                                   const float* partial, int nchunk, float* dgamma_dbeta,
+                                   float* dscale_shift, int dss_ld, void* ws, size_t ws_bytes,
+                                   lfdm_stream_t stream);
+
+/* Backward of lfdm_layernorm_cl_f32 (LayerNorm, video_flow_diffusion.py:170-179): dx rows and dgamma (C). */
+size_t lfdm_layernorm_bwd_ws_bytes(int64_t rows, int channels);
+int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels,
+                              const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes,
+                              lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,93 @@
+"""Backward kernels (include/lfdm_hip.h, training section) against torch autograd of the ATen op the
+reference calls.  Same dual-backend scheme as test_ops_parity.py: "emu" (x86 emulation of the same kernel
+sources, CPU) and "hip" (MI355X, marked gpu)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cvpr23_lfdm_amd import ops, train_ops
+from util import assert_close, from_cl, rnd, to_cl
+
+TOL = 2e-4
+
+
+def big(dev):
+    return dev == "cuda"
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,res", [(8, 12, 3, 1, 6), (68, 72, 3, 1, 5), (132, 8, 1, 1, 4),
+                                                   (8, 8, 4, 2, 8), (4, 64, 7, 1, 8)])
+def test_conv_wgrad(backend, cin, cout, k, stride, res):
+    dev = backend
+    n = 3
+    if big(dev):
+        cin, cout, res, n = {8: (64, 64), 68: (256, 128), 132: (512, 768), 4: (4, 64)}[cin] + (16, 10)
+        if k == 4:
+            cin, cout = 128, 128
+    pad = {3: 1, 1: 0, 4: 1, 7: 3}[k]
+    x = rnd(n, cin, res, res, seed=1).requires_grad_(False)
+    w = (rnd(cout, cin, k, k, seed=2) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    dy = rnd(*y.shape, seed=3)
+    y.backward(dy)
+    hq = y.shape[2]
+    dw = train_ops.conv_wgrad(to_cl(x).to(dev), to_cl(dy).to(dev), n, res, res, hq, hq, k, k, stride=stride, pad=(pad, pad))
+    got = dw.cpu().view(k, k, cin, cout).permute(3, 2, 0, 1)
+    scale = float(w.grad.abs().max())
+    assert_close(got / scale, w.grad / scale, TOL, "conv wgrad")
+    db = train_ops.colsum(to_cl(dy).to(dev))
+    ref_db = dy.sum(dim=(0, 2, 3))
+    assert_close(db.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias grad")
+
+
+@pytest.mark.parametrize("c,with_ss,silu", [(32, True, True), (64, False, True), (32, False, False)])
+def test_groupnorm_bwd(backend, c, with_ss, silu):
+    dev = backend
+    b, t, s = 2, 3, 4
+    if big(dev):
+        b, t, s, c = 2, 40, 16, {32: 128, 64: 512}[c]
+    x = rnd(b, c, t, s, s, seed=1).requires_grad_(True)
+    gamma = (1 + 0.2 * rnd(c, seed=2)).requires_grad_(True)
+    beta = (0.1 * rnd(c, seed=3)).requires_grad_(True)
+    ss = (0.3 * rnd(b, 2 * c, seed=4)).requires_grad_(True) if with_ss else None
+    y = F.group_norm(x, 8, gamma, beta, eps=1e-5)
+    if with_ss:
+        y = y * (ss[:, :c].view(b, c, 1, 1, 1) + 1) + ss[:, c:].view(b, c, 1, 1, 1)
+    if silu:
+        y = F.silu(y)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy)
+    to_rows = lambda v: v.detach().permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous().to(dev)
+    xd = to_rows(x)
+    yk, partial, nchunk = train_ops.groupnorm_silu_train(xd, b, gamma.detach().to(dev), beta.detach().to(dev),
+                                                         scale_shift=ss.detach().to(dev) if with_ss else None, silu=silu)
+    assert_close(yk.cpu(), to_rows(y).cpu(), TOL, "gn fwd")
+    dx, dg, db, dss = train_ops.groupnorm_silu_bwd(xd, to_rows(dy), b, gamma.detach().to(dev), beta.detach().to(dev), partial,
+                                                   nchunk, scale_shift=ss.detach().to(dev) if with_ss else None, silu=silu)
+    assert_close(dx.cpu(), to_rows(x.grad).cpu(), TOL, "gn dx")
+    sc = float(gamma.grad.abs().max())
+    assert_close(dg.cpu() / sc, gamma.grad / sc, TOL, "gn dgamma")
+    sc = float(beta.grad.abs().max())
+    assert_close(db.cpu() / sc, beta.grad / sc, TOL, "gn dbeta")
+    if with_ss:
+        sc = float(ss.grad.abs().max())
+        assert_close(dss.cpu() / sc, ss.grad / sc, TOL, "gn dscale_shift")
+
+
+@pytest.mark.parametrize("c", [32, 72])
+def test_layernorm_bwd(backend, c):
+    dev = backend
+    rows = 37
+    if big(dev):
+        rows, c = 40 * 1024 + 3, {32: 64, 72: 512}[c]
+    x = rnd(rows, c, seed=1).requires_grad_(True)
+    gamma = (1 + 0.2 * rnd(c, seed=2)).requires_grad_(True)
+    mean = x.mean(dim=1, keepdim=True)
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    y = (x - mean) / (var + 1e-5).sqrt() * gamma          # reference LayerNorm :176-179
+    dy = rnd(rows, c, seed=3)
+    y.backward(dy)
+    dx, dg = train_ops.layernorm_bwd(x.detach().to(dev), dy.to(dev), gamma.detach().to(dev))
+    assert_close(dx.cpu(), x.grad, TOL, "ln dx")
+    sc = float(gamma.grad.abs().max())
+    assert_close(dg.cpu() / sc, gamma.grad / sc, TOL, "ln dgamma")

@@ -34,3 +34,8 @@ def assert_close(a, b, tol, what=""):
     err = float((a - b).abs().max())
     scale = float(b.abs().max()) + 1e-12
     assert err <= tol * max(1.0, scale), "%s: max abs err %.3e (ref scale %.3e, tol %.1e)" % (what, err, scale, tol)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
