@@ -109,6 +109,11 @@ _SIGNATURES = {
     "lfdm_groupnorm_bwd_ws_bytes": (sz, [i32, i32, i32]),
     "lfdm_groupnorm_silu_bwd_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32, i32,
                                             f32p, i32, f32p, f32p, i32, C.c_void_p, sz, stream_t]),
+    "lfdm_attention_bwd_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "lfdm_attention_bwd_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32p, C.c_void_p, sz,
+                                       stream_t]),
+    "lfdm_linear_attention_bwd_ws_bytes": (sz, [i32]),
+    "lfdm_linear_attention_bwd_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, C.c_void_p, sz, stream_t]),
     "lfdm_layernorm_bwd_ws_bytes": (sz, [i64, i32]),
     "lfdm_layernorm_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, f32p, f32, f32p, C.c_void_p, sz, stream_t]),
 }

@@ -1,0 +1,525 @@
+// Backward of the attention kernels (include/lfdm_hip.h, training section).
+//
+// 1. lfdm_attention_bwd_cl_f32 - gradient of Attention.forward (video_flow_diffusion.py:303-363) w.r.t. the
+//    qkv rows and the relative-position bias.  One wavefront owns one (sequence, head) exactly like the
+//    forward kernel: Q (scaled, rotated), K (rotated), V and dO are staged in LDS, S = QK^T + bias and the
+//    softmax are RECOMPUTED (nothing but qkv was saved), then on v_mfma_f32_16x16x4_f32:
+//        dP = dO V^T,  dS = P o (dP - rowsum(P o dP)),  dV = P^T dO,  dQr = dS K,  dKr = dS^T Q,
+//    the rotary rotation is undone (R^T) and 32^-0.5 re-applied for dq.  The L x L scores never leave
+//    LDS/registers.  The bias gradient is accumulated per wavefront over a grid-stride loop (the stride is
+//    a multiple of 8, so a wavefront always serves the same head) and written as per-wave partials that
+//    lfdm_sum_leading_f32 adds in a fixed order.
+// 2. lfdm_linear_attention_bwd_cl_f32 - gradient of SpatialLinearAttention's core (:254-263):
+//        ks = softmax_n(k), qs = softmax_d(q)*scale, ctx = ks v^T, out = ctx^T qs
+//        dctx[d][e] = sum_n qs[d,n] dout[e,n];  dqs = ctx dout;  dks = dctx v;  dv = dctx^T ks
+//        dk = ks o (dks - sum_e dctx[d,e] ctx[d,e]);  dq = scale * qs/scale o (dqs - sum_d (qs/scale) dqs)
+//    A per-(frame, head) reduction kernel (k-softmax statistics, ctx, dctx) and a per-token apply kernel.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int QKV_LD = 3 * HEADS * DH;  // 768
+constexpr int OUT_LD = HEADS * DH;      // 256
+constexpr int SQ = 34;                  // LDS row stride of Q, K
+constexpr int SV = 36;                  // LDS row stride of V, dO
+constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
+
+template <int LP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv, int batch, int frames,
+    int hw, int mode, const float* __restrict__ bias, const float* __restrict__ rot_cos,
+    const float* __restrict__ rot_sin, float* __restrict__ dbias_part) {
+  constexpr int NT = LP / 16;
+  constexpr int SP = LP + 2;
+  constexpr int PER_WAVE = LP * (2 * SQ + 2 * SV) + LP * SP;
+  __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Qs = smem + wave * PER_WAVE;
+  float* Ks = Qs + LP * SQ;
+  float* Vs = Ks + LP * SQ;
+  float* Gs = Vs + LP * SV;     // dO
+  float* Ps = Gs + LP * SV;     // P, later dS
+
+  const int L = mode == 0 ? frames : hw;
+  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
+  const int64_t units = nseq * HEADS;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  f32x4 db[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) db[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t base = (int64_t)blockIdx.x * WPB; base < units; base += (int64_t)gridDim.x * WPB) {
+    const int64_t unit = base + wave;
+    const bool valid = unit < units;
+    const int64_t seq = valid ? unit / HEADS : 0;
+    const int head = valid ? (int)(unit - seq * HEADS) : 0;
+    int64_t row0, tstride;
+    if (mode == 0) {
+      const int64_t b = seq / hw, pix = seq - b * hw;
+      row0 = b * frames * hw + pix;
+      tstride = hw;
+    } else {
+      row0 = seq * hw;
+      tstride = 1;
+    }
+
+    // ---- stage Q (scaled + rotary), K (rotary), V, dO ----
+    {
+      constexpr int NR = LP / 8;
+      const int rr = lane >> 3, c4 = lane & 7;
+      float4 qv[NR], kv[NR], vv[NR], gv[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int t = rr + 8 * i;
+        qv[i] = kv[i] = vv[i] = gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && t < L) {
+          const int64_t row = row0 + (int64_t)t * tstride;
+          const float* src = qkv + row * QKV_LD + head * DH + 4 * c4;
+          qv[i] = *reinterpret_cast<const float4*>(src);
+          kv[i] = *reinterpret_cast<const float4*>(src + OUT_LD);
+          vv[i] = *reinterpret_cast<const float4*>(src + 2 * OUT_LD);
+          gv[i] = *reinterpret_cast<const float4*>(dout + row * OUT_LD + head * DH + 4 * c4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int t = rr + 8 * i;
+        float4 q = qv[i], k = kv[i];
+        q.x *= ATT_SCALE; q.y *= ATT_SCALE; q.z *= ATT_SCALE; q.w *= ATT_SCALE;
+        if (rot_cos && t < L) {
+          const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
+          const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
+          float4 qr, kr;
+          qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
+          qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
+          kr.x = k.x * c0 - k.y * s0; kr.y = k.y * c0 + k.x * s0;
+          kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
+          q = qr; k = kr;
+        }
+        float* dq = Qs + t * SQ + 4 * c4;
+        dq[0] = q.x; dq[1] = q.y; dq[2] = q.z; dq[3] = q.w;
+        float* dk = Ks + t * SQ + 4 * c4;
+        dk[0] = k.x; dk[1] = k.y; dk[2] = k.z; dk[3] = k.w;
+        *reinterpret_cast<float4*>(Vs + t * SV + 4 * c4) = vv[i];
+        *reinterpret_cast<float4*>(Gs + t * SV + 4 * c4) = gv[i];
+      }
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T, dP = dO V^T ----
+    f32x4 p[NT][NT], dp[NT][NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < DH / 4; ++s) {
+          const float a = Qs[(ti * 16 + l15) * SQ + 4 * s + lq];
+          const float b = Ks[(tj * 16 + l15) * SQ + 4 * s + lq];
+          acc = mfma_16x16x4(a, b, acc);
+          const float a2 = Gs[(ti * 16 + l15) * SV + 4 * s + lq];
+          const float b2 = Vs[(tj * 16 + l15) * SV + 4 * s + lq];
+          acc2 = mfma_16x16x4(a2, b2, acc2);
+        }
+        p[ti][tj] = acc;
+        dp[ti][tj] = acc2;
+      }
+
+    // ---- softmax (same arithmetic as the forward kernel), dS, bias gradient ----
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + lq * 4 + r;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int col = tj * 16 + l15;
+          float v = p[ti][tj][r];
+          if (col >= L) v = -3.0e38f;
+          else if (bias && row < L) v += bias[((int64_t)head * L + row) * L + col];
+          p[ti][tj][r] = v;
+          m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
+        float sum = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int col = tj * 16 + l15;
+          const float e = col < L ? expf(p[ti][tj][r] - m) : 0.f;
+          p[ti][tj][r] = e;
+          sum += e;
+        }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) sum += __shfl_xor(sum, x);
+        float dot = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const float pv = p[ti][tj][r] / sum;
+          p[ti][tj][r] = pv;
+          Ps[row * SP + tj * 16 + l15] = pv;
+          dot += pv * dp[ti][tj][r];
+        }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) dot += __shfl_xor(dot, x);
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const float ds = (valid && row < L) ? p[ti][tj][r] * (dp[ti][tj][r] - dot) : 0.f;
+          dp[ti][tj][r] = ds;                     // dp now holds dS
+          db[ti][tj][r] += ds;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- dV = P^T dO ----
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      f32x4 o[2];
+      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      o[1] = o[0];
+#pragma unroll
+      for (int s = 0; s < LP / 4; ++s) {
+        const float a = Ps[(4 * s + lq) * SP + tj * 16 + l15];      // A[m = token j][k = token i] = P[i][j]
+        const float b0 = Gs[(4 * s + lq) * SV + l15];
+        const float b1 = Gs[(4 * s + lq) * SV + 16 + l15];
+        o[0] = mfma_16x16x4(a, b0, o[0]);
+        o[1] = mfma_16x16x4(a, b1, o[1]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = tj * 16 + lq * 4 + r;
+        if (valid && t < L) {
+          float* dst = dqkv + (row0 + (int64_t)t * tstride) * QKV_LD + 2 * OUT_LD + head * DH;
+          dst[l15] = o[0][r];
+          dst[16 + l15] = o[1][r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dS -> LDS (over P) ----
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) Ps[(ti * 16 + lq * 4 + r) * SP + tj * 16 + l15] = dp[ti][tj][r];
+    __syncthreads();
+
+    // ---- dQr = dS K ; dKr = dS^T Q ; undo rotary ; store ----
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      f32x4 oq[2], ok[2];
+      oq[0] = oq[1] = ok[0] = ok[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < LP / 4; ++s) {
+        const float aq = Ps[(ti * 16 + l15) * SP + 4 * s + lq];      // dS[i][j = 4s+lq]
+        const float ak = Ps[(4 * s + lq) * SP + ti * 16 + l15];      // dS[i = 4s+lq][j]
+        const float bk0 = Ks[(4 * s + lq) * SQ + l15], bk1 = Ks[(4 * s + lq) * SQ + 16 + l15];
+        const float bq0 = Qs[(4 * s + lq) * SQ + l15], bq1 = Qs[(4 * s + lq) * SQ + 16 + l15];
+        oq[0] = mfma_16x16x4(aq, bk0, oq[0]);
+        oq[1] = mfma_16x16x4(aq, bk1, oq[1]);
+        ok[0] = mfma_16x16x4(ak, bq0, ok[0]);
+        ok[1] = mfma_16x16x4(ak, bq1, ok[1]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = ti * 16 + lq * 4 + r;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float gq = oq[hh][r], gk = ok[hh][r];
+          if (rot_cos) {
+            // feature d = 16*hh + l15; pair index d>>1; even lane holds x, odd lane holds y of the pair
+            const float gq_o = __shfl_xor(gq, 1), gk_o = __shfl_xor(gk, 1);
+            const int tt = t < L ? t : 0;
+            const float c = rot_cos[tt * 16 + ((16 * hh + l15) >> 1)], sn = rot_sin[tt * 16 + ((16 * hh + l15) >> 1)];
+            if ((l15 & 1) == 0) {          // dx = gx*c + gy*s
+              gq = gq * c + gq_o * sn;
+              gk = gk * c + gk_o * sn;
+            } else {                        // dy = gy*c - gx*s
+              gq = gq * c - gq_o * sn;
+              gk = gk * c - gk_o * sn;
+            }
+          }
+          if (valid && t < L) {
+            float* dst = dqkv + (row0 + (int64_t)t * tstride) * QKV_LD + head * DH + 16 * hh + l15;
+            dst[0] = gq * ATT_SCALE;
+            dst[OUT_LD] = gk;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (dbias_part) {
+    // per-wave partial [LP][LP] rows; global wave id w = blockIdx.x*WPB + wave serves head w % 8
+    float* dst = dbias_part + ((int64_t)blockIdx.x * WPB + wave) * (L * L);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int row = ti * 16 + lq * 4 + r, col = tj * 16 + l15;
+          if (row < L && col < L) dst[row * L + col] = db[ti][tj][r];
+        }
+  }
+}
+
+int attn_bwd_blocks(int64_t units, int wpb) {
+  int64_t nb = (units + wpb - 1) / wpb;
+  const int cap = 2048 / wpb;            // 2048 wavefronts in flight; a multiple of 8 per grid stride
+  if (nb > cap) nb = cap;
+  // grid*wpb must be a multiple of 8 so that a wavefront keeps its head
+  while ((nb * wpb) % 8 != 0) ++nb;
+  return (int)nb;
+}
+
+// ---------------- linear attention ----------------
+constexpr int LA_WS = 2 * DH * DH + 4 * DH;   // per (frame, head): ctx | dctx | kmax | ksum | rowdot | pad
+
+// grid (n_frames*8), 256 threads.  thread (d = tid>>3, e0 = 4*(tid&7)) owns ctx[d][e0..e0+3] and dctx likewise.
+__global__ __launch_bounds__(256) void linattn_bwd_context_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ dout, int hw,
+                                                                  float* __restrict__ ws) {
+  __shared__ float red[4][32];
+  __shared__ float kmax[32];
+  __shared__ float ek[64][33], qs[64][33];
+  __shared__ __attribute__((aligned(16))) float vv[64][36], go[64][36];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x >> 3, h = blockIdx.x & 7;
+  const float* qbase = qkv + (int64_t)f * hw * QKV_LD + h * DH;
+  const float* kbase = qbase + OUT_LD;
+  const float* vbase = kbase + OUT_LD;
+  const float* gbase = dout + (int64_t)f * hw * OUT_LD + h * DH;
+
+  {  // pass 1: per-feature max of k over tokens
+    const int c4 = tid & 7, part = tid >> 3;
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    for (int n = part; n < hw; n += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(kbase + (int64_t)n * QKV_LD + 4 * c4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+#pragma unroll
+    for (int x = 8; x <= 32; x <<= 1) {
+      m.x = fmaxf(m.x, __shfl_xor(m.x, x)); m.y = fmaxf(m.y, __shfl_xor(m.y, x));
+      m.z = fmaxf(m.z, __shfl_xor(m.z, x)); m.w = fmaxf(m.w, __shfl_xor(m.w, x));
+    }
+    if ((tid & 63) < 8) {
+      const int w = tid >> 6;
+      red[w][4 * c4 + 0] = m.x; red[w][4 * c4 + 1] = m.y; red[w][4 * c4 + 2] = m.z; red[w][4 * c4 + 3] = m.w;
+    }
+    __syncthreads();
+    if (tid < 32) kmax[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+    __syncthreads();
+  }
+
+  const int d = tid >> 3, e0 = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, dacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;
+  const int ln = tid >> 3, lc4 = tid & 7;
+  for (int n0 = 0; n0 < hw; n0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int nl = ln + 32 * u;
+      const int n = n0 + nl;
+      const bool ok = n < hw;
+      float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), rv = rk, rq = rk, rg = rk;
+      if (ok) {
+        rq = *reinterpret_cast<const float4*>(qbase + (int64_t)n * QKV_LD + 4 * lc4);
+        rk = *reinterpret_cast<const float4*>(kbase + (int64_t)n * QKV_LD + 4 * lc4);
+        rv = *reinterpret_cast<const float4*>(vbase + (int64_t)n * QKV_LD + 4 * lc4);
+        rg = *reinterpret_cast<const float4*>(gbase + (int64_t)n * OUT_LD + 4 * lc4);
+      }
+      ek[nl][4 * lc4 + 0] = ok ? expf(rk.x - kmax[4 * lc4 + 0]) : 0.f;
+      ek[nl][4 * lc4 + 1] = ok ? expf(rk.y - kmax[4 * lc4 + 1]) : 0.f;
+      ek[nl][4 * lc4 + 2] = ok ? expf(rk.z - kmax[4 * lc4 + 2]) : 0.f;
+      ek[nl][4 * lc4 + 3] = ok ? expf(rk.w - kmax[4 * lc4 + 3]) : 0.f;
+      // q softmax over the 32 features of this token: the 8 lanes (lc4) that share the token
+      float m = fmaxf(fmaxf(rq.x, rq.y), fmaxf(rq.z, rq.w));
+#pragma unroll
+      for (int x = 1; x < 8; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
+      float4 eq;
+      eq.x = expf(rq.x - m); eq.y = expf(rq.y - m); eq.z = expf(rq.z - m); eq.w = expf(rq.w - m);
+      float sm = (eq.x + eq.y) + (eq.z + eq.w);
+#pragma unroll
+      for (int x = 1; x < 8; x <<= 1) sm += __shfl_xor(sm, x);
+      qs[nl][4 * lc4 + 0] = ok ? eq.x / sm * ATT_SCALE : 0.f;
+      qs[nl][4 * lc4 + 1] = ok ? eq.y / sm * ATT_SCALE : 0.f;
+      qs[nl][4 * lc4 + 2] = ok ? eq.z / sm * ATT_SCALE : 0.f;
+      qs[nl][4 * lc4 + 3] = ok ? eq.w / sm * ATT_SCALE : 0.f;
+      *reinterpret_cast<float4*>(&vv[nl][4 * lc4]) = rv;
+      *reinterpret_cast<float4*>(&go[nl][4 * lc4]) = rg;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < 64; ++n) {
+      const float e = ek[n][d];
+      const float qd = qs[n][d];
+      const float4 v4 = *reinterpret_cast<const float4*>(&vv[n][e0]);
+      const float4 g4 = *reinterpret_cast<const float4*>(&go[n][e0]);
+      acc[0] = fmaf(e, v4.x, acc[0]); acc[1] = fmaf(e, v4.y, acc[1]);
+      acc[2] = fmaf(e, v4.z, acc[2]); acc[3] = fmaf(e, v4.w, acc[3]);
+      dacc[0] = fmaf(qd, g4.x, dacc[0]); dacc[1] = fmaf(qd, g4.y, dacc[1]);
+      dacc[2] = fmaf(qd, g4.z, dacc[2]); dacc[3] = fmaf(qd, g4.w, dacc[3]);
+      ssum += e;
+    }
+    __syncthreads();
+  }
+  float* w = ws + (int64_t)blockIdx.x * LA_WS;
+  float rd = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float c = acc[i] / ssum;
+    w[d * DH + e0 + i] = c;
+    w[DH * DH + d * DH + e0 + i] = dacc[i];
+    rd += c * dacc[i];
+  }
+#pragma unroll
+  for (int x = 1; x < 8; x <<= 1) rd += __shfl_xor(rd, x);
+  if ((tid & 7) == 0) {
+    w[2 * DH * DH + d] = kmax[d];
+    w[2 * DH * DH + DH + d] = ssum;
+    w[2 * DH * DH + 2 * DH + d] = rd;
+  }
+}
+
+// grid (ceil(hw/32), n_frames*8); 256 threads = 8 tokens x 32 features per iteration, 4 iterations
+__global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ dout,
+                                                                const float* __restrict__ ws, int hw,
+                                                                float* __restrict__ dqkv) {
+  __shared__ float ctx[DH][DH + 1], dctx[DH][DH + 1];
+  __shared__ float kmax[DH], ksum[DH], rowdot[DH];
+  __shared__ float t_go[8][DH], t_v[8][DH], t_ks[8][DH];
+  const int tid = threadIdx.x;
+  const int fh = blockIdx.y, f = fh >> 3, h = fh & 7;
+  const float* w = ws + (int64_t)fh * LA_WS;
+  for (int i = tid; i < DH * DH; i += 256) {
+    ctx[i >> 5][i & 31] = w[i];
+    dctx[i >> 5][i & 31] = w[DH * DH + i];
+  }
+  if (tid < DH) {
+    kmax[tid] = w[2 * DH * DH + tid];
+    ksum[tid] = w[2 * DH * DH + DH + tid];
+    rowdot[tid] = w[2 * DH * DH + 2 * DH + tid];
+  }
+  __syncthreads();
+  const int tl = tid >> 5, j = tid & 31;
+  for (int it = 0; it < 4; ++it) {
+    const int n = blockIdx.x * 32 + it * 8 + tl;
+    const bool ok = n < hw;
+    const int64_t row = (int64_t)f * hw + (ok ? n : 0);
+    const float* src = qkv + row * QKV_LD + h * DH + j;
+    const float q = ok ? src[0] : 0.f, k = ok ? src[OUT_LD] : 0.f, v = ok ? src[2 * OUT_LD] : 0.f;
+    const float g = ok ? dout[row * OUT_LD + h * DH + j] : 0.f;
+    float m = q;
+#pragma unroll
+    for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
+    const float eq = expf(q - m);
+    float sm = eq;
+#pragma unroll
+    for (int x = 1; x < 32; x <<= 1) sm += __shfl_xor(sm, x);
+    const float s = eq / sm;                                  // softmax_d(q)
+    const float ks = expf(k - kmax[j]) / ksum[j];             // softmax_n(k)
+    t_go[tl][j] = g;
+    t_v[tl][j] = v;
+    t_ks[tl][j] = ks;
+    __syncthreads();
+    float dqs = 0.f, dks = 0.f, dv = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < DH; ++e) {
+      dqs = fmaf(ctx[j][e], t_go[tl][e], dqs);
+      dks = fmaf(dctx[j][e], t_v[tl][e], dks);
+      dv = fmaf(dctx[e][j], t_ks[tl][e], dv);
+    }
+    const float dl = dqs * ATT_SCALE;
+    float dot = s * dl;
+#pragma unroll
+    for (int x = 1; x < 32; x <<= 1) dot += __shfl_xor(dot, x);
+    if (ok) {
+      float* dst = dqkv + row * QKV_LD + h * DH + j;
+      dst[0] = s * (dl - dot);
+      dst[OUT_LD] = ks * (dks - rowdot[j]);
+      dst[2 * OUT_LD] = dv;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" size_t lfdm_attention_bwd_ws_bytes(int batch, int frames, int hw, int mode) {
+  const int L = mode == 0 ? frames : hw;
+  const int wpb = L > 48 ? 2 : 4;
+  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
+  const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
+  return (size_t)nb * wpb * L * L * sizeof(float);
+}
+
+extern "C" int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int batch, int frames,
+                                         int hw, int mode, const float* bias, const float* rot_cos,
+                                         const float* rot_sin, float* dbias, void* ws, size_t ws_bytes,
+                                         lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int L = mode == 0 ? frames : hw;
+  if (!qkv || !dout || !dqkv || batch <= 0 || frames <= 0 || hw <= 0 || (mode != 0 && mode != 1) || L > 64 ||
+      ((rot_cos == nullptr) != (rot_sin == nullptr)) || ((bias == nullptr) != (dbias == nullptr))) {
+    lfdm_set_error("attention_bwd: unsupported arguments (sequence length must be <= 64; dbias iff bias)");
+    return LFDM_EINVAL;
+  }
+  const int wpb = L > 48 ? 2 : 4;
+  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
+  const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
+  float* part = nullptr;
+  if (dbias) {
+    if (!ws || ws_bytes < lfdm_attention_bwd_ws_bytes(batch, frames, hw, mode)) {
+      lfdm_set_error("attention_bwd: workspace too small");
+      return LFDM_EWORKSPACE;
+    }
+    part = (float*)ws;
+  }
+  const dim3 grid(nb), block(64 * wpb);
+  if (L <= 16) LFDM_LAUNCH((attention_bwd_kernel<16, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  else if (L <= 32) LFDM_LAUNCH((attention_bwd_kernel<32, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  else if (L <= 48) LFDM_LAUNCH((attention_bwd_kernel<48, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  else LFDM_LAUNCH((attention_bwd_kernel<64, 2>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  int rc = lfdm_check_launch("attention_bwd");
+  if (rc) return rc;
+  if (dbias) {
+    // partial index w = q*8 + head  ->  [q][head][L][L]; sum over q
+    return lfdm_sum_leading_f32(part, dbias, (int64_t)HEADS * L * L, nb * wpb / HEADS, stream_);
+  }
+  return LFDM_OK;
+}
+
+extern "C" size_t lfdm_linear_attention_bwd_ws_bytes(int n_frames) {
+  return (size_t)n_frames * HEADS * LA_WS * sizeof(float);
+}
+
+extern "C" int lfdm_linear_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int n_frames,
+                                                int hw, void* ws, size_t ws_bytes, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!qkv || !dout || !dqkv || n_frames <= 0 || hw <= 0) {
+    lfdm_set_error("linear_attention_bwd: bad arguments");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_linear_attention_bwd_ws_bytes(n_frames)) {
+    lfdm_set_error("linear_attention_bwd: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  LFDM_LAUNCH(linattn_bwd_context_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, qkv, dout, hw, (float*)ws);
+  LFDM_LAUNCH(linattn_bwd_apply_kernel, dim3((hw + 31) / 32, n_frames * HEADS), dim3(256), 0, stream, qkv, dout,
+              (const float*)ws, hw, dqkv);
+  return lfdm_check_launch("linear_attention_bwd");
+}

@@ -113,3 +113,33 @@ def layernorm_bwd(x, dy, gamma, eps=1e-5):
     lib.check(lib.lfdm_layernorm_bwd_cl_f32(_p(x), _p(dy), _p(dx), rows, c, _p(gamma), eps, _p(dgamma), _p(ws), nbytes,
                                             _stream(lib)), "lfdm_layernorm_bwd_cl_f32")
     return dx, dgamma
+
+
+def attention_bwd(qkv, dout, batch, frames, hw, mode, bias=None, rot_cos=None, rot_sin=None):
+    """-> (dqkv rows of 768, dbias (8, L, L) or None)."""
+    lib = _lib()
+    _chk(lib, qkv, dout, bias, rot_cos, rot_sin)
+    assert qkv.is_contiguous() and dout.is_contiguous() and qkv.shape[1] == 768 and dout.shape[1] == 256
+    dqkv = torch.empty_like(qkv)
+    dbias, ws, nbytes = None, None, 0
+    if bias is not None:
+        seq = frames if mode == 0 else hw
+        dbias = torch.empty(8, seq, seq, dtype=torch.float32, device=qkv.device)
+        nbytes = lib.lfdm_attention_bwd_ws_bytes(batch, frames, hw, mode)
+        ws = _ws(nbytes, qkv)
+    lib.check(lib.lfdm_attention_bwd_cl_f32(_p(qkv), _p(dout), _p(dqkv), batch, frames, hw, mode, _p(bias), _p(rot_cos),
+                                            _p(rot_sin), _p(dbias), _p(ws), nbytes, _stream(lib)),
+              "lfdm_attention_bwd_cl_f32")
+    return dqkv, dbias
+
+
+def linear_attention_bwd(qkv, dout, n_frames, hw):
+    lib = _lib()
+    _chk(lib, qkv, dout)
+    assert qkv.is_contiguous() and dout.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    nbytes = lib.lfdm_linear_attention_bwd_ws_bytes(n_frames)
+    ws = _ws(nbytes, qkv)
+    lib.check(lib.lfdm_linear_attention_bwd_cl_f32(_p(qkv), _p(dout), _p(dqkv), n_frames, hw, _p(ws), nbytes, _stream(lib)),
+              "lfdm_linear_attention_bwd_cl_f32")
+    return dqkv

@@ -310,6 +310,22 @@ int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_
                               const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes,
                               lfdm_stream_t stream);
 
+/* Backward of lfdm_attention_cl_f32 (Attention.forward, video_flow_diffusion.py:303-363): dqkv rows
+ * (768 = [dq | dk | dv], same order as qkv) from the saved qkv rows and dout (rows of 256).  Scores and
+ * softmax are recomputed.  dbias (8, L, L) = gradient of the relative-position bias table (must be given
+ * iff bias is; the embedding gradient is its scatter by bucket, done by the caller).
+ * ws: lfdm_attention_bwd_ws_bytes (per-wavefront bias partials, summed in a fixed order). */
+size_t lfdm_attention_bwd_ws_bytes(int batch, int frames, int hw, int mode);
+int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int batch, int frames,
+                              int hw, int mode, const float* bias, const float* rot_cos,
+                              const float* rot_sin, float* dbias, void* ws, size_t ws_bytes,
+                              lfdm_stream_t stream);
+
+/* Backward of lfdm_linear_attention_cl_f32 (SpatialLinearAttention core, :254-263): dqkv rows from qkv, dout. */
+size_t lfdm_linear_attention_bwd_ws_bytes(int n_frames);
+int lfdm_linear_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int n_frames,
+                                     int hw, void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

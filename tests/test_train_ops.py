@@ -91,3 +91,75 @@ def test_layernorm_bwd(backend, c):
     assert_close(dx.cpu(), x.grad, TOL, "ln dx")
     sc = float(gamma.grad.abs().max())
     assert_close(dg.cpu() / sc, gamma.grad / sc, TOL, "ln dgamma")
+
+
+def _attention_ref(qkv_tokens, bias, rotary):
+    """Attention.forward semantics (video_flow_diffusion.py:303-363) on (..., n, 768) tokens."""
+    import lfdm_oracle as O
+    q, k, v = qkv_tokens.chunk(3, dim=-1)
+    heads = lambda z: z.reshape(*z.shape[:-1], 8, 32).transpose(-2, -3)
+    q, k, v = heads(q), heads(k), heads(v)
+    q = q * (32 ** -0.5)
+    if rotary is not None:
+        q, k = O.apply_rotary(q, *rotary), O.apply_rotary(k, *rotary)
+    sim = q @ k.transpose(-1, -2)
+    if bias is not None:
+        sim = sim + bias
+    sim = sim - sim.amax(dim=-1, keepdim=True).detach()
+    out = sim.softmax(dim=-1) @ v
+    return out.transpose(-2, -3).reshape(*qkv_tokens.shape[:-1], 256)
+
+
+@pytest.mark.parametrize("frames", [4, 40])
+def test_attention_temporal_bwd(backend, frames):
+    import lfdm_oracle as O
+    dev = backend
+    b, s = (1, 16) if (big(dev) and frames == 40) else (2, 2)
+    if not big(dev) and frames == 40:
+        b, s = 1, 3                      # 9 sequences x 8 heads: more units than one grid stride is not needed
+    hw = s * s
+    qkv = rnd(b, frames, hw, 768, seed=1).requires_grad_(True)
+    emb = rnd(32, 8, seed=2)
+    bias = O.rel_pos_bias(emb, frames).clone().requires_grad_(True)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    cos, sin = O.rotary_tables(freqs, frames)
+    out = _attention_ref(qkv.permute(0, 2, 1, 3), bias, (cos, sin)).permute(0, 2, 1, 3).reshape(-1, 256)
+    dout = rnd(*out.shape, seed=3)
+    out.backward(dout)
+    dqkv, dbias = train_ops.attention_bwd(qkv.detach().reshape(-1, 768).to(dev), dout.to(dev), b, frames, hw, 0,
+                                          bias=bias.detach().contiguous().to(dev),
+                                          rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
+    assert_close(dqkv.cpu(), qkv.grad.reshape(-1, 768), TOL, "temporal attention dqkv")
+    sc = float(bias.grad.abs().max())
+    assert_close(dbias.cpu() / sc, bias.grad / sc, TOL, "temporal attention dbias")
+
+
+@pytest.mark.parametrize("hw", [16, 64])
+def test_attention_spatial_bwd(backend, hw):
+    dev = backend
+    b, frames = 1, 3
+    qkv = rnd(b, frames, hw, 768, seed=3).requires_grad_(True)
+    out = _attention_ref(qkv, None, None).reshape(-1, 256)
+    dout = rnd(*out.shape, seed=4)
+    out.backward(dout)
+    dqkv, _ = train_ops.attention_bwd(qkv.detach().reshape(-1, 768).to(dev), dout.to(dev), b, frames, hw, 1)
+    assert_close(dqkv.cpu(), qkv.grad.reshape(-1, 768), TOL, "spatial attention dqkv")
+
+
+@pytest.mark.parametrize("hw", [16, 80])
+def test_linear_attention_bwd(backend, hw):
+    dev = backend
+    nf = 3
+    if big(dev) and hw == 80:
+        nf, hw = 40, 1024
+    qkv = rnd(nf, hw, 768, seed=4).requires_grad_(True)
+    q, k, v = [z.reshape(nf, hw, 8, 32).permute(0, 2, 3, 1) for z in qkv.chunk(3, dim=-1)]  # b h d n
+    q = q.softmax(dim=-2) * (32 ** -0.5)
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(nf * hw, 256)
+    dout = rnd(*out.shape, seed=5)
+    out.backward(dout)
+    dqkv = train_ops.linear_attention_bwd(qkv.detach().reshape(-1, 768).to(dev), dout.to(dev), nf, hw)
+    sc = float(qkv.grad.abs().max())
+    assert_close(dqkv.cpu() / sc, qkv.grad.reshape(-1, 768) / sc, TOL, "linear attention dqkv")
