@@ -1,0 +1,207 @@
+"""torch.autograd.Function wrappers around the native forward + backward kernels (include/lfdm_hip.h), so that the
+reference training scripts' `loss.backward()` (DM/modules/video_flow_diffusion_model.py:181-188) runs through
+liblfdm_hip.so.  torch.autograd is used as the tape (saved tensors, gradient accumulation of shared tensors); every
+activation-sized computation - forward and backward - is a HIP kernel.  Activations are channels-last rows
+(N*H*W, C), frames n = b*T + t, exactly as on the sampling path.
+
+Data gradients of convolutions reuse the forward implicit-GEMM kernels with re-packed weights:
+  Conv (stride 1)        -> same-geometry conv with W^T flipped, pad k-1-p
+  Conv k4 s2 p1          -> the four-parity transposed convolution (Downsample, :166-167)
+  ConvTranspose k4 s2 p1 -> stride-2 conv (Upsample, :156-158)
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops, train_ops
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ConvCL(Function):
+    """y = conv(cat(x0, x1), weight) + bias (+ residual).  weight in the reference layout (Cout, Cin, [1,] kh, kw)
+    (or ConvTranspose (Cin, Cout, [1,] 4, 4) when geom['kind'] == 'deconv').  geom: n_img, hi, wi, stride, pad."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, residual, geom):
+        kind = geom.get("kind", "conv")
+        n_img, hi, wi = geom["n_img"], geom["hi"], geom["wi"]
+        w4 = weight.detach().reshape(weight.shape[0], weight.shape[1], weight.shape[-2], weight.shape[-1]) \
+            if weight.dim() > 2 else weight.detach()[:, :, None, None]
+        kh, kw = w4.shape[2], w4.shape[3]
+        b = None if bias is None else _c(bias.detach())
+        res = None if residual is None else _c(residual.detach())
+        if kind == "conv":
+            stride = geom.get("stride", 1)
+            pad = geom.get("pad", (kh // 2, kw // 2))
+            y = ops.conv2d_cl(_c(x0.detach()), ops.pack_conv_weight(w4), w4.shape[0], kh, kw, n_img, hi, wi,
+                              src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad)
+            hq = (hi + 2 * pad[0] - kh) // stride + 1
+            wq = (wi + 2 * pad[1] - kw) // stride + 1
+        else:
+            assert x1 is None and residual is None and kh == 4 and kw == 4
+            y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_deconv_weight(w4), w4.shape[1], n_img, hi, wi, bias=b)
+            stride, pad, hq, wq = 2, (1, 1), 2 * hi, 2 * wi
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight = ctx.saved_tensors
+        kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, has_bias, has_res = ctx.meta
+        dy = _c(dy)
+        w4 = weight.detach().reshape(weight.shape[0], weight.shape[1], kh, kw)
+        need = ctx.needs_input_grad
+        dx0 = dx1 = dw = db = None
+        if has_bias and need[3]:
+            db = train_ops.colsum(dy)
+        if kind == "conv":
+            cout = w4.shape[0]
+            c0 = x0.shape[1]
+            if need[2]:
+                parts = [train_ops.conv_wgrad(_c(x0), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad)]
+                if x1 is not None:
+                    parts.append(train_ops.conv_wgrad(_c(x1), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad))
+                dwt = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)            # (taps, cin, cout)
+                dw = dwt.view(kh, kw, -1, cout).permute(3, 2, 0, 1).reshape(weight.shape)
+            srcs = [(x0, 0, c0, need[0])] + ([(x1, c0, c0 + x1.shape[1], need[1])] if x1 is not None else [])
+            grads = []
+            for xs, lo, hi_c, wanted in srcs:
+                if not wanted:
+                    grads.append(None)
+                    continue
+                ws = w4[:, lo:hi_c]
+                if stride == 1:
+                    wd = ws.transpose(0, 1).flip(-2, -1).contiguous()                         # (cin, cout, kh, kw)
+                    g = ops.conv2d_cl(dy, ops.pack_conv_weight(wd), hi_c - lo, kh, kw, n_img, hq, wq,
+                                      pad=(kh - 1 - pad[0], kw - 1 - pad[1]))
+                else:
+                    assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
+                    g = ops.deconv4x4s2_cl(dy, ops.pack_deconv_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)
+                grads.append(g)
+            dx0 = grads[0]
+            dx1 = grads[1] if x1 is not None else None
+        else:
+            cin, cout = w4.shape[0], w4.shape[1]
+            if need[2]:
+                # roles exchanged: "input" = dy at (2h, 2w), "grad" = x at (h, w), stride 2, pad 1
+                dwt = train_ops.conv_wgrad(dy, _c(x0), n_img, hq, wq, hi, wi, 4, 4, stride=2, pad=(1, 1))   # (16, cout, cin)
+                dw = dwt.view(4, 4, cout, cin).permute(3, 2, 0, 1).reshape(weight.shape)
+            if need[0]:
+                dx0 = ops.conv2d_cl(dy, ops.pack_conv_weight(w4), cin, 4, 4, n_img, hq, wq, stride=2, pad=(1, 1))
+        dres = dy if (has_res and need[4]) else None
+        return dx0, dx1, dw, db, dres, None
+
+
+class GroupNormSiLU(Function):
+    """Block.forward norm -> (scale+1, shift) -> SiLU (+ residual after the activation), :200-211 / :237."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale_shift, residual, batch, silu):
+        xs = _c(x.detach())
+        ss = None if scale_shift is None else _c(scale_shift.detach())
+        y, partial, nchunk = train_ops.groupnorm_silu_train(
+            xs, batch, _c(gamma.detach()), _c(beta.detach()), scale_shift=ss,
+            residual=None if residual is None else _c(residual.detach()), silu=silu)
+        ctx.save_for_backward(xs, gamma, beta, ss, partial)
+        ctx.meta = (batch, nchunk, silu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, ss, partial = ctx.saved_tensors
+        batch, nchunk, silu, has_res = ctx.meta
+        dy = _c(dy)
+        dx, dg, db, dss = train_ops.groupnorm_silu_bwd(x, dy, batch, _c(gamma.detach()), _c(beta.detach()), partial, nchunk,
+                                                       scale_shift=ss, silu=silu)
+        return dx, dg, db, dss, (dy if has_res else None), None, None
+
+
+class LayerNormCL(Function):
+    """Channel LayerNorm (gamma only), :170-179."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        xs = _c(x.detach())
+        g = _c(gamma.detach().reshape(-1))
+        ctx.save_for_backward(xs, g)
+        ctx.gshape = gamma.shape
+        return ops.layernorm_cl(xs, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg = train_ops.layernorm_bwd(x, _c(dy), g)
+        return dx, dg.reshape(ctx.gshape)
+
+
+class AttentionCL(Function):
+    """Attention.forward core (:303-363) on qkv rows; bias = (8, L, L) relative-position table or None."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, rot_cos, rot_sin, batch, frames, hw, mode):
+        q = _c(qkv.detach())
+        b = None if bias is None else _c(bias.detach())
+        ctx.save_for_backward(q, b, rot_cos, rot_sin)
+        ctx.meta = (batch, frames, hw, mode)
+        return ops.attention_cl(q, batch, frames, hw, mode, bias=b, rot_cos=rot_cos, rot_sin=rot_sin)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, b, rot_cos, rot_sin = ctx.saved_tensors
+        batch, frames, hw, mode = ctx.meta
+        dqkv, dbias = train_ops.attention_bwd(q, _c(dout), batch, frames, hw, mode, bias=b, rot_cos=rot_cos, rot_sin=rot_sin)
+        return dqkv, dbias, None, None, None, None, None, None
+
+
+class LinearAttentionCL(Function):
+    """SpatialLinearAttention core (:254-263) on qkv rows."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_frames, hw):
+        q = _c(qkv.detach())
+        ctx.save_for_backward(q)
+        ctx.meta = (n_frames, hw)
+        return ops.linear_attention_cl(q, n_frames, hw)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q,) = ctx.saved_tensors
+        n_frames, hw = ctx.meta
+        return train_ops.linear_attention_bwd(q, _c(dout), n_frames, hw), None, None
+
+
+class PlanarToCL(Function):
+    """(N, C, HW) planar -> (N*HW, C) rows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, c, hw = x.shape
+        ctx.meta = (n, c, hw)
+        return ops.planar_to_cl(_c(x.detach()), n, c, hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, hw = ctx.meta
+        return ops.cl_to_planar(_c(dy), n, c, hw).view(n, c, hw)
+
+
+class CLToPlanar(Function):
+    """(N*HW, C) rows -> (N, C, HW) planar."""
+
+    @staticmethod
+    def forward(ctx, x, n, hw):
+        c = x.shape[1]
+        ctx.meta = (n, c, hw)
+        return ops.cl_to_planar(_c(x.detach()), n, c, hw).view(n, c, hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, hw = ctx.meta
+        return ops.planar_to_cl(_c(dy), n, c, hw), None, None
+
+
+def conv_cl(x0, weight, bias, *, x1=None, residual=None, **geom):
+    return ConvCL.apply(x0, x1, weight, bias, residual, geom)

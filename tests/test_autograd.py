@@ -1,0 +1,77 @@
+"""torch.autograd.Function wrappers (cvpr23_lfdm_amd/autograd.py) against torch autograd of the ATen graph the
+reference builds.  backend = emu (CPU) / hip (gpu)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cvpr23_lfdm_amd import autograd as A
+from util import assert_close, from_cl, rnd, to_cl
+
+TOL = 3e-4
+
+
+def _cmp(got, ref, what):
+    sc = float(ref.abs().max()) + 1e-12
+    assert_close(got.detach().cpu() / sc, ref.detach() / sc, TOL, what)
+
+
+@pytest.mark.parametrize("case", ["conv3_cat_res", "linear", "down", "deconv", "stem4"])
+def test_conv_function(backend, case):
+    dev = backend
+    n, h = 2, 6
+    if case == "conv3_cat_res":
+        c0, c1, co, k = 8, 8, 12, 3
+        x0, x1 = rnd(n, c0, h, h, seed=1).requires_grad_(True), rnd(n, c1, h, h, seed=2).requires_grad_(True)
+        w = (rnd(co, c0 + c1, 1, k, k, seed=3) * 0.1).requires_grad_(True)
+        b = rnd(co, seed=4).requires_grad_(True)
+        res = rnd(n, co, h, h, seed=5).requires_grad_(True)
+        ref = F.conv2d(torch.cat((x0, x1), 1), w[:, :, 0], b, padding=1) + res
+        args = dict(x1=x1, residual=res)
+    elif case == "linear":
+        c0, co, k = 16, 24, 1
+        x0, x1, res = rnd(n, c0, h, h, seed=1).requires_grad_(True), None, None
+        w = (rnd(co, c0, seed=3) * 0.1).requires_grad_(True)
+        b = None
+        ref = F.conv2d(x0, w[:, :, None, None])
+        args = {}
+    elif case == "down":
+        c0, co, k = 8, 8, 4
+        x0, x1, res = rnd(n, c0, h, h, seed=1).requires_grad_(True), None, None
+        w = (rnd(co, c0, 1, 4, 4, seed=3) * 0.1).requires_grad_(True)
+        b = rnd(co, seed=4).requires_grad_(True)
+        ref = F.conv2d(x0, w[:, :, 0], b, stride=2, padding=1)
+        args = dict(stride=2, pad=(1, 1))
+    elif case == "deconv":
+        c0, co, k = 8, 12, 4
+        x0, x1, res = rnd(n, c0, h, h, seed=1).requires_grad_(True), None, None
+        w = (rnd(c0, co, 1, 4, 4, seed=3) * 0.1).requires_grad_(True)
+        b = rnd(co, seed=4).requires_grad_(True)
+        ref = F.conv_transpose2d(x0, w[:, :, 0], b, stride=2, padding=1)
+        args = dict(kind="deconv")
+    else:
+        c0, co, k = 4, 16, 7
+        x0, x1, res = rnd(n, c0, h, h, seed=1), None, None
+        w = (rnd(co, c0, 1, 7, 7, seed=3) * 0.1).requires_grad_(True)
+        b = rnd(co, seed=4).requires_grad_(True)
+        ref = F.conv2d(x0, w[:, :, 0], b, padding=3)
+        args = dict(pad=(3, 3))
+    dy = rnd(*ref.shape, seed=9)
+    ref.backward(dy)
+    leaf = lambda t: None if t is None else t.detach().clone().to(dev).requires_grad_(t.requires_grad)
+    cl = lambda t: None if t is None else to_cl(t.detach()).to(dev).requires_grad_(t.requires_grad)
+    kx0, kx1, kres, kw, kb = cl(x0), cl(x1), cl(res), leaf(w), leaf(b)
+    kargs = dict(args)
+    if "x1" in kargs:
+        kargs["x1"], kargs["residual"] = kx1, kres
+    y = A.conv_cl(kx0, kw, kb, n_img=n, hi=h, wi=h, **kargs)
+    ho = ref.shape[2]
+    _cmp(from_cl(y, n, ho, ho), ref, case + " fwd")
+    y.backward(to_cl(dy).to(dev))
+    _cmp(kw.grad, w.grad, case + " dW")
+    if b is not None:
+        _cmp(kb.grad, b.grad, case + " db")
+    if x0.requires_grad:
+        _cmp(from_cl(kx0.grad, n, h, h), x0.grad, case + " dx0")
+    if x1 is not None:
+        _cmp(from_cl(kx1.grad, n, h, h), x1.grad, case + " dx1")
+        _cmp(from_cl(kres.grad, n, h, h), res.grad, case + " dres")
