@@ -1,0 +1,175 @@
+"""Optimizer + data-parallel gradient exchange of the DM training step.
+
+`FlatAdam` is a real `torch.optim.Optimizer` (the training scripts call `.state_dict()`, `.load_state_dict()`,
+`.param_groups[0]['lr']` and wrap it in `MultiStepLR`: DM/train_video_flow_diffusion_mug.py:181,210-211,367) whose
+step is ONE fused HIP launch (lfdm_adam_step_f32) over flat fp32 buffers: parameters, gradients and both moments
+live contiguously, each tensor being a view.  The same flat gradient buffer is what `GradAllReduce` hands to RCCL -
+bucketed sum all-reduce over xGMI launched from autograd hooks while backward is still running; the 1/world of the
+mean is folded into the Adam kernel.  (Reference multi-GPU: nn.DataParallel threads + NCCL reduce to GPU 0,
+SURVEY.md 3.4; here: one process per GPU, every rank applies the identical update, no parameter broadcast.)
+"""
+import torch
+
+from . import _native
+from .ops import _chk, _lib, _p, _stream
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._flat = None            # per group: dict(param, grad, m, v, views)
+        self.grad_scale = 1.0        # GradAllReduce sets 1/world
+
+    # ------------------------------------------------------------------ flat storage
+    def _build(self):
+        flats = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            dev, n = ps[0].device, 0
+            offs = []
+            for p in ps:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+            fp = torch.zeros(n, dtype=torch.float32, device=dev)
+            fg = torch.zeros_like(fp)
+            fm = torch.zeros_like(fp)
+            fv = torch.zeros_like(fp)
+            for p, o in zip(ps, offs):
+                k = p.numel()
+                fp[o:o + k].copy_(p.data.reshape(-1))
+                p.data = fp[o:o + k].view(p.shape)
+                g = fg[o:o + k].view(p.shape)
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                p.grad = g
+                st = self.state[p]
+                if "exp_avg" in st:                    # state loaded before the first step
+                    fm[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                    fv[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                st.setdefault("step", torch.tensor(0.0))
+                st["exp_avg"] = fm[o:o + k].view(p.shape)
+                st["exp_avg_sq"] = fv[o:o + k].view(p.shape)
+            flats.append(dict(params=ps, offs=offs, p=fp, g=fg, m=fm, v=fv))
+        self._flat = flats
+
+    def _valid(self):
+        if self._flat is None:
+            return False
+        for fl in self._flat:
+            base = fl["p"].data_ptr()
+            for p, o in zip(fl["params"], fl["offs"]):
+                if p.data_ptr() != base + 4 * o or p.grad is None or p.grad.data_ptr() != fl["g"].data_ptr() + 4 * o:
+                    return False
+        return True
+
+    def ensure_flat(self):
+        """(Re)build the flat buffers if parameters were moved / replaced (e.g. `.cuda()` after construction)."""
+        if not self._valid():
+            self._build()
+        return self._flat
+
+    def flat_grads(self):
+        return [fl["g"] for fl in self.ensure_flat()]
+
+    def zero_grad(self, set_to_none=True):
+        """Keeps the gradient views alive: zeroes the flat buffer in place (set_to_none is ignored on purpose)."""
+        for fl in self.ensure_flat():
+            fl["g"].zero_()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = None             # loaded moments are folded into fresh flat buffers at the next step
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib()
+        for group, fl in zip(self.param_groups, self.ensure_flat()):
+            st0 = self.state[fl["params"][0]]
+            step = int(st0["step"]) + 1
+            for p in fl["params"]:
+                self.state[p]["step"] = torch.tensor(float(step))
+            _chk(lib, fl["p"], fl["g"], fl["m"], fl["v"])
+            b1, b2 = group["betas"]
+            lib.check(lib.lfdm_adam_step_f32(_p(fl["p"]), _p(fl["g"]), _p(fl["m"]), _p(fl["v"]), fl["p"].numel(),
+                                             float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                             float(group["weight_decay"]), step, float(self.grad_scale), _stream(lib)),
+                      "lfdm_adam_step_f32")
+        return loss
+
+
+class GradAllReduce:
+    """Sum all-reduce of FlatAdam's gradient buffer across ranks (torch.distributed; backend "nccl" = RCCL over xGMI
+    on the GPU box, "gloo" in CPU tests).  Buckets are contiguous slices of the flat buffer, walked from the END
+    (the last layers finish their gradients first); a bucket is launched asynchronously by the autograd hook of the
+    last of its parameters to become ready, so the exchange overlaps the remaining backward.  `finish()` waits for
+    all buckets (and launches any that never fired, e.g. parameters without gradient this step)."""
+
+    def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.opt = optimizer
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        optimizer.grad_scale = 1.0 / self.world
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        self._hooks = []
+        self._buckets = None
+        self._flat_id = None
+
+    def _setup(self):
+        flats = self.opt.ensure_flat()
+        if self._flat_id == id(flats):
+            return
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._buckets = [], []
+        for fl in flats:
+            n = fl["p"].numel()
+            ends = list(fl["offs"][1:]) + [n]
+            # buckets from the end of the buffer
+            cur_hi, members = n, []
+            items = list(zip(fl["params"], fl["offs"], ends))
+            for p, lo, hi in reversed(items):
+                members.append(p)
+                if cur_hi - lo >= self.bucket_elems or lo == 0:
+                    self._buckets.append(dict(view=fl["g"][lo:cur_hi], params=members, pending=0, handle=None))
+                    cur_hi, members = lo, []
+        for bi, b in enumerate(self._buckets):
+            for p in b["params"]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self._flat_id = id(flats)
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            b = self._buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.world > 1 and b["handle"] is None:
+            b["handle"] = self.dist.all_reduce(b["view"], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def prepare(self):
+        """Call before backward (after zero_grad)."""
+        self._setup()
+        for b in self._buckets:
+            b["pending"] = len(b["params"])
+            b["handle"] = None
+
+    def finish(self):
+        """Call after backward, before optimizer.step()."""
+        for b in self._buckets:
+            if b["handle"] is None:
+                self._launch(b)
+        for b in self._buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                b["handle"] = None

@@ -326,6 +326,13 @@ size_t lfdm_linear_attention_bwd_ws_bytes(int n_frames);
 int lfdm_linear_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int n_frames,
                                      int hw, void* ws, size_t ws_bytes, lfdm_stream_t stream);
 
+/* Fused Adam over one flat parameter buffer: torch.optim.Adam(betas, eps, weight_decay) semantics (no amsgrad),
+ * video_flow_diffusion_model.py:113-114,188.  grad is multiplied by grad_scale first (1/world for the
+ * data-parallel mean).  step = 1-based step count (bias correction). */
+int lfdm_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float grad_scale, lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""FlatAdam (one fused lfdm_adam_step_f32 launch over flat buffers) against torch.optim.Adam, its Optimizer-API
+compatibility (state_dict round trip, MultiStepLR), and the data-parallel gradient exchange (GradAllReduce) with
+two gloo ranks on CPU (emulation build of the kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from cvpr23_lfdm_amd.optim import FlatAdam
+from util import assert_close, rnd
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params(dev, seed=0):
+    shapes = [(7, 5), (13,), (4, 3, 3, 3), (1,), (64, 9)]
+    return [torch.nn.Parameter(rnd(*s, seed=seed + i).to(dev)) for i, s in enumerate(shapes)]
+
+
+def test_flat_adam_matches_torch(backend):
+    dev = backend
+    pa, pb = _params(dev), _params(dev)
+    a = FlatAdam(pa, lr=2e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    b = torch.optim.Adam(pb, lr=2e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.MultiStepLR(a, milestones=[2], gamma=0.1)
+    sched_b = torch.optim.lr_scheduler.MultiStepLR(b, milestones=[2], gamma=0.1)
+    for it in range(4):
+        a.zero_grad()
+        b.zero_grad()
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            g = rnd(*x.shape, seed=100 * it + i).to(dev)
+            (x * g).sum().backward()
+            (y * g).sum().backward()
+        a.step()
+        b.step()
+        sched.step()
+        sched_b.step()
+        if it == 1:                              # state_dict round trip in the middle of training
+            sd = a.state_dict()
+            a2 = FlatAdam(pa, lr=2e-3, betas=(0.9, 0.99), weight_decay=0.01)
+            a2.load_state_dict(sd)
+            sched2 = torch.optim.lr_scheduler.MultiStepLR(a2, milestones=[2], gamma=0.1)
+            sched2.load_state_dict(sched.state_dict())
+            a, sched = a2, sched2
+    for x, y in zip(pa, pb):
+        assert_close(x, y, 1e-6, "adam params")
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["param_groups"][0]["lr"] == pytest.approx(sb["param_groups"][0]["lr"])
+    for k in sb["state"]:
+        assert_close(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], 1e-6, "exp_avg")
+        assert_close(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], 1e-6, "exp_avg_sq")
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests"))
+import torch, torch.distributed as dist
+from cvpr23_lfdm_amd import _build, _native
+_native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))   # CPU test: emulation build
+from cvpr23_lfdm_amd.optim import FlatAdam, GradAllReduce
+from util import rnd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+shapes = [(7, 5), (13,), (4, 3, 3, 3), (1,), (64, 9)]
+ps = [torch.nn.Parameter(rnd(*s, seed=i)) for i, s in enumerate(shapes)]
+opt = FlatAdam(ps, lr=1e-2, betas=(0.9, 0.99))
+dp = GradAllReduce(opt, bucket_bytes=256)          # tiny buckets -> several all-reduces
+for it in range(3):
+    opt.zero_grad()
+    dp.prepare()
+    loss = sum((p * rnd(*p.shape, seed=1000 * it + 10 * rank + i)).sum() for i, p in enumerate(ps))   # rank-specific data
+    loss.backward()
+    dp.finish()
+    opt.step()
+out = [p.detach().reshape(-1).tolist() for p in ps]
+gathered = [None] * world
+dist.all_gather_object(gathered, out)
+if rank == 0:
+    print(json.dumps({"ranks": gathered, "nbuckets": len(dp._buckets)}))
+dist.destroy_process_group()
+'''
+
+
+def test_grad_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(WORKER % {"repo": REPO})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29573", str(script)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["nbuckets"] >= 3
+    r0, r1 = out["ranks"]
+    assert r0 == r1                                             # identical update on every rank
+    # single-process reference: mean of the two ranks' gradients, torch Adam
+    shapes = [(7, 5), (13,), (4, 3, 3, 3), (1,), (64, 9)]
+    ps = [torch.nn.Parameter(rnd(*s, seed=i)) for i, s in enumerate(shapes)]
+    opt = torch.optim.Adam(ps, lr=1e-2, betas=(0.9, 0.99))
+    for it in range(3):
+        opt.zero_grad()
+        loss = sum(0.5 * (p * rnd(*p.shape, seed=1000 * it + 10 * rk + i)).sum() for rk in range(2) for i, p in enumerate(ps))
+        loss.backward()
+        opt.step()
+    for got, p in zip(r0, ps):
+        assert_close(torch.tensor(got), p.detach().reshape(-1), 1e-6, "dp params")
