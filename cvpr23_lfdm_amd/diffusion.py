@@ -263,8 +263,10 @@ class GaussianDiffusion(nn.Module):
                 + self.sqrt_one_minus_alphas_cumprod[t].reshape(shp) * noise)
 
     def p_losses(self, x_start, t, fea, cond=None, noise=None, clip_denoised=True, **kwargs):
-        """:856-895 forward semantics (loss value + thresholded pred_x0).  The backward kernels are
-        not built yet, so the returned loss carries no autograd graph."""
+        """:856-895.  x_start (B,3,T,S,S), fea (B,256,T,S,S) (frame-constant when it comes from `forward`).
+        In training mode with autograd enabled the denoiser runs through unet_train_forward (native forward and
+        backward kernels) and the returned loss carries the graph; otherwise the forward-only sampling executor
+        evaluates the same function."""
         if noise is None:
             noise = torch.randn_like(x_start)
         x_noisy = self.q_sample(x_start, t, noise)
@@ -272,33 +274,49 @@ class GaussianDiffusion(nn.Module):
         if is_list_str(cond):
             none_cond_mask = [c == "None" for c in cond]
             cond = self._embed(cond, x_start.device)
-        was_training = self.denoise_fn.training
-        self.denoise_fn.eval()
-        try:
-            with torch.no_grad():
-                pred_noise = self.denoise_fn.forward(torch.cat([x_noisy, fea], dim=1), t, cond=cond,
-                                                     null_cond_prob=self.null_cond_prob,
-                                                     none_cond_mask=none_cond_mask, **kwargs)
-        finally:
-            self.denoise_fn.train(was_training)
+        elif cond is not None:
+            cond = cond.to(device=x_start.device, dtype=torch.float32)
+        unet = self.denoise_fn
+        if torch.is_grad_enabled() and unet.training and any(p.requires_grad for p in unet.parameters()):
+            from .unet_train import unet_train_forward
+            if kwargs:
+                raise NotImplementedError("p_losses(**%s): focus_present_mask is never enabled by the LFDM scripts" % list(kwargs))
+            if fea.dim() == 5 and fea.stride(2) != 0 and fea.shape[2] > 1:
+                raise NotImplementedError("training with per-frame `fea`: the LFDM pipeline conditions on ONE reference "
+                                          "frame (video_flow_diffusion.py:901); pass the (B,256,S,S) feature map")
+            fea2d = fea[:, :, 0] if fea.dim() == 5 else fea
+            pred_noise = unet_train_forward(unet, x_noisy, fea2d, t, cond, null_cond_prob=self.null_cond_prob,
+                                            none_cond_mask=none_cond_mask)
+        else:
+            was_training = unet.training
+            unet.eval()
+            try:
+                with torch.no_grad():
+                    fea5 = fea if fea.dim() == 5 else fea.unsqueeze(2).expand(-1, -1, x_start.shape[2], -1, -1)
+                    pred_noise = unet.forward(torch.cat([x_noisy, fea5], dim=1), t, cond=cond,
+                                              null_cond_prob=self.null_cond_prob, none_cond_mask=none_cond_mask,
+                                              **kwargs)
+            finally:
+                unet.train(was_training)
         if self.loss_type == 'l1':
             loss = F.l1_loss(noise, pred_noise)
         elif self.loss_type == 'l2':
             loss = F.mse_loss(noise, pred_noise)
         else:
             raise NotImplementedError()
-        pred_x0 = self.predict_start_from_noise(x_noisy, t, pred_noise)
-        if clip_denoised:
-            b = pred_x0.shape[0]
-            sthr = ops.abs_quantile(pred_x0.reshape(b, -1).contiguous(), self.dynamic_thres_percentile) \
-                if self.use_dynamic_thres else torch.ones(b, device=pred_x0.device)
-            sthr = sthr.clamp(min=1.).view(-1, *((1,) * (pred_x0.dim() - 1)))
-            self.pred_x0 = pred_x0.clamp(-sthr, sthr) / sthr
+        with torch.no_grad():
+            pred_x0 = self.predict_start_from_noise(x_noisy, t, pred_noise.detach())
+            if clip_denoised:
+                b = pred_x0.shape[0]
+                sthr = ops.abs_quantile(pred_x0.reshape(b, -1).contiguous(), self.dynamic_thres_percentile) \
+                    if self.use_dynamic_thres else torch.ones(b, device=pred_x0.device)
+                sthr = sthr.clamp(min=1.).view(-1, *((1,) * (pred_x0.dim() - 1)))
+                self.pred_x0 = pred_x0.clamp(-sthr, sthr) / sthr
         return loss
 
     def forward(self, x, fea, text, *args, **kwargs):
         """:897-903."""
         b, device = x.shape[0], x.device
         t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
-        fea = fea.unsqueeze(dim=2).repeat(1, 1, x.size(2), 1, 1)
+        fea = fea.unsqueeze(dim=2).expand(-1, -1, x.size(2), -1, -1)      # reference: .repeat (:901); a view is enough
         return self.p_losses(x, t, fea, cond=text, *args, **kwargs)

@@ -3,9 +3,9 @@
 setters and `sample_one_video`, so demo_*.py / test_*.py style callers can switch over.
 The sampling path (a28) is fully native: LFAE encoder once per video -> hipGraph-replayed
 DDIM/DDPM loop -> batched LFAE decode of all T frames.
-The DM *training* step (a29: pseudo-GT LFAE forward + UNet backward + Adam) is the next row to
-be built; `forward()` / `optimize_parameters()` say so loudly instead of
-silently running something else.
+The DM training step (a29) = frozen-LFAE pseudo ground truth batched over all frames (lfae_predictors.py) ->
+diffusion loss through the native UNet forward/backward (unet_train.py, autograd.py) -> fused Adam (optim.py), with
+an optional one-process-per-GPU gradient all-reduce (`enable_data_parallel`).
 """
 import torch
 import yaml
@@ -14,19 +14,25 @@ from torch import nn
 from .diffusion import GaussianDiffusion
 from .generator import Generator
 from .params import ParamTree, bg_predictor_spec, build_tree, region_predictor_spec
+from .optim import FlatAdam, GradAllReduce
 from .unet import Unet3D
 
 
 class RegionPredictor(ParamTree):
-    """Parameter holder (checkpoint compatibility) for LFAE/modules/region_predictor.py; only the
-    training pseudo-GT path evaluates it (not built yet)."""
+    """LFAE/modules/region_predictor.py: same state-dict keys; forward = lfae_predictors.RegionPredictorExec
+    (any number of frames per call)."""
 
     def __init__(self, num_regions, num_channels, estimate_affine=True, **params):
         super().__init__()
         build_tree(self, region_predictor_spec(num_regions=num_regions, num_channels=num_channels, **params))
+        from .lfae_predictors import RegionPredictorExec
+        self._exec = RegionPredictorExec(self, num_blocks=params.get("num_blocks", 5),
+                                         temperature=params.get("temperature", 0.1),
+                                         scale_factor=params.get("scale_factor", 0.25),
+                                         pca_based=params.get("pca_based", True), pad=params.get("pad", 3))
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("RegionPredictor.forward: training pseudo-GT path, SURVEY.md 8(f).1")
+    def forward(self, x):
+        return self._exec(x)
 
 
 class BGMotionPredictor(ParamTree):
@@ -38,8 +44,12 @@ class BGMotionPredictor(ParamTree):
         with torch.no_grad():   # reference initialises fc to the identity affine (bg_motion_predictor.py:33-39)
             self.get("fc.bias").copy_(torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float))
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("BGMotionPredictor.forward: training pseudo-GT path, SURVEY.md 8(f).1")
+        from .lfae_predictors import BGMotionPredictorExec
+        self._exec = BGMotionPredictorExec(self, num_blocks=params.get("num_blocks", 5),
+                                           bg_type=params.get("bg_type", "affine"))
+
+    def forward(self, source_image, driving_image):
+        return self._exec(source_image, driving_image)
 
 
 class FlowDiffusion(nn.Module):
@@ -85,7 +95,9 @@ class FlowDiffusion(nn.Module):
             self.loss = torch.tensor(0.0)
             self.rec_loss = torch.tensor(0.0)
             self.rec_warp_loss = torch.tensor(0.0)
-            self.optimizer_diff = torch.optim.Adam(self.diffusion.parameters(), lr=lr, betas=adam_betas)
+            # a torch.optim.Optimizer (state_dict / param_groups / lr schedulers work) whose step is one fused HIP launch
+            self.optimizer_diff = FlatAdam(self.diffusion.parameters(), lr=lr, betas=adam_betas)
+        self._dp = None
 
     # ------------------------------------------------------------------ sampling (a28)
     def sample_one_video(self, cond_scale):
@@ -127,12 +139,64 @@ class FlowDiffusion(nn.Module):
         self.ref_text = ref_text
 
     def forward(self):
-        raise NotImplementedError(
-            "FlowDiffusion.forward (DM training step: pseudo-GT LFAE forward + UNet loss) is not built yet; "
-            "SURVEY.md 8(f).1 / DESIGN.md 'what comes next'")
+        """Reference :116-179.  Pseudo ground-truth flow / occlusion of every frame from the frozen LFAE (all B*T
+        frames in one batched pass), the diffusion loss on it (native UNet forward under autograd), and - for the
+        logged reconstructions - the decode of the denoised prediction."""
+        b, _, nf, H, W = self.real_vid.shape
+        gen = self.generator
+        with torch.no_grad():
+            ref = self.ref_img.float().contiguous()
+            frames = self.real_vid.float().permute(0, 2, 1, 3, 4).reshape(b * nf, -1, H, W).contiguous()
+            source_region_params = self.region_predictor(ref)
+            driving_region_params = self.region_predictor(frames)
+            ref_rep = ref.unsqueeze(1).expand(b, nf, *ref.shape[1:]).reshape(b * nf, *ref.shape[1:])
+            bg_params = self.bg_predictor(ref_rep, frames)
+            generated = gen.forward_frames(ref, nf, driving_region_params, source_region_params, bg_params)
+        self.real_vid_grid = generated["optical_flow"]
+        self.real_vid_conf = generated["occlusion_map"]
+        self.real_out_vid = generated["prediction"]
+        self.real_warped_vid = generated["deformed"]
+        self.ref_img_fea = generated["bottle_neck_feat"].clone().detach()
+
+        if self.is_train:
+            h, w = self.real_vid_grid.shape[-2:]
+            identity_grid = self.get_grid(b, nf, h, w, normalize=True).to(ref.device) if self.use_residual_flow else None
+            grid = self.real_vid_grid - identity_grid if self.use_residual_flow else self.real_vid_grid
+            self.loss = self.diffusion(torch.cat((grid, self.real_vid_conf * 2 - 1), dim=1), self.ref_img_fea,
+                                       self.ref_text)
+            with torch.no_grad():
+                pred = self.diffusion.pred_x0
+                self.fake_vid_grid = pred[:, :2] + identity_grid if self.use_residual_flow else pred[:, :2]
+                self.fake_vid_conf = (pred[:, 2].unsqueeze(dim=1) + 1) * 0.5
+                maps = torch.cat((self.fake_vid_grid, pred[:, 2:3]), dim=1).contiguous()
+                skips = gen.encode(ref)
+                out, warped = gen.decode_video(ref, skips, maps[:, 0], maps[:, 1], maps[:, 2], nf, h, w,
+                                               3 * nf * h * w, h * w, occ_scale=0.5, occ_bias=0.5)
+                self.fake_out_vid, self.fake_warped_vid = out, warped
+                self.rec_loss = (self.real_vid - out).abs().mean()
+                self.rec_warp_loss = (self.real_vid - warped).abs().mean()
+
+    def enable_data_parallel(self, bucket_bytes=64 << 20):
+        """One process per GPU (torch.distributed initialised by the launcher): average the DM gradients over the
+        ranks with a bucketed RCCL all-reduce that overlaps backward.  No-op for world size 1."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self._dp = GradAllReduce(self.optimizer_diff, bucket_bytes=bucket_bytes)
+        return self
 
     def optimize_parameters(self):
+        """:181-188."""
         self.forward()
+        self.optimizer_diff.zero_grad()
+        if self._dp is not None:
+            self._dp.prepare()
+        if self.only_use_flow:
+            self.loss.backward()
+        else:
+            (self.loss + self.rec_loss + self.rec_warp_loss).backward()
+        if self._dp is not None:
+            self._dp.finish()
+        self.optimizer_diff.step()
 
     # ------------------------------------------------------------------ misc (reference :227-253)
     def print_learning_rate(self):

@@ -37,6 +37,12 @@ class Generator(ParamTree):
         self.block_expansion = block_expansion
         self.max_features = max_features
         self.skips = skips
+        self.num_regions = num_regions
+        self.flow_predictor_cfg = dict(
+            num_blocks=fp.get("num_blocks", 5), scale_factor=fp.get("scale_factor", 1),
+            use_covar_heatmap=fp.get("use_covar_heatmap", False), use_deformed_source=fp.get("use_deformed_source", True),
+            revert_axis_swap=revert_axis_swap)
+        self._fp = None
         self.frames_per_chunk = 160      # decode working set bound (images per launch)
         self._pk = None
         self._pk_sig = None
@@ -193,7 +199,46 @@ class Generator(ParamTree):
                                                3 * fh * fw, 0)
             return {"prediction": pred[:, :, 0], "deformed": deformed[:, :, 0]}
 
+    # ------------------------------------------------------------------ training pseudo ground truth (a35)
+    def flow_predictor(self):
+        if getattr(self, "_fp", None) is None:
+            from .lfae_predictors import PixelwiseFlowPredictorExec
+            if not self.has("pixelwise_flow_predictor.mask.weight"):
+                raise RuntimeError("Generator was built without pixelwise_flow_predictor_params")
+            self._fp = PixelwiseFlowPredictorExec(self, self.num_regions, **self.flow_predictor_cfg)
+        return self._fp
+
+    def forward_frames(self, source_image, frames, driving_region_params, source_region_params, bg_params=None):
+        """Batched Generator.forward for `frames` driving frames per source image (the training loop of
+        video_flow_diffusion_model.py:124-137 in one pass).  source_image (B,C,H,W); driving params / bg_params have
+        leading dimension B*frames (n = b*frames + t); source params leading dimension B.
+        -> dict: optical_flow (B,2,T,h,w), occlusion_map (B,1,T,h,w), prediction / deformed (B,C,T,H,W),
+                 bottle_neck_feat (B,256,h,w)."""
+        with torch.no_grad():
+            img = source_image.float().contiguous()
+            b, c, h, w = img.shape
+            n = b * frames
+            rep = lambda v: v.unsqueeze(1).expand(b, frames, *v.shape[1:]).reshape(n, *v.shape[1:])
+            src = {k: rep(v) for k, v in source_region_params.items() if k in ("shift", "covar", "affine")}
+            motion = self.flow_predictor()(rep(img), driving_region_params, src, bg_params=bg_params)
+            flow, occ = motion["optical_flow"], motion["occlusion_map"]          # (N,h,w,2), (N,1,h,w)
+            fh, fw = flow.shape[1], flow.shape[2]
+            maps = torch.empty(b, 3, frames, fh, fw, dtype=torch.float32, device=img.device)
+            maps[:, 0] = flow[..., 0].reshape(b, frames, fh, fw)
+            maps[:, 1] = flow[..., 1].reshape(b, frames, fh, fw)
+            maps[:, 2] = occ[:, 0].reshape(b, frames, fh, fw)
+            skips = self.encode(img)
+            d = 2 ** self.num_down_blocks
+            fea = self.compute_fea_from_skips(skips, b, h // d, w // d).clone()
+            pred, deformed = self.decode_video(img, skips, maps[:, 0], maps[:, 1], maps[:, 2], frames, fh, fw,
+                                               3 * frames * fh * fw, fh * fw)
+            return {"optical_flow": maps[:, :2], "occlusion_map": maps[:, 2:3], "prediction": pred,
+                    "deformed": deformed, "bottle_neck_feat": fea}
+
     def forward(self, source_image, driving_region_params, source_region_params, bg_params=None):
-        raise NotImplementedError(
-            "Generator.forward (pseudo ground-truth flow for DM training, needs PixelwiseFlowPredictor) is "
-            "the next widening step (SURVEY.md 8(f).1); sampling uses forward_with_flow / decode_video")
+        """Reference :90-128 (one driving frame per source image): dict with `prediction`, `deformed` (B,C,H,W),
+        `optical_flow` (B,h,w,2), `occlusion_map` (B,1,h,w), `bottle_neck_feat` (B,256,h,w)."""
+        out = self.forward_frames(source_image, 1, driving_region_params, source_region_params, bg_params)
+        return {"prediction": out["prediction"][:, :, 0], "deformed": out["deformed"][:, :, 0],
+                "optical_flow": out["optical_flow"][:, :, 0].permute(0, 2, 3, 1).contiguous(),
+                "occlusion_map": out["occlusion_map"][:, :, 0], "bottle_neck_feat": out["bottle_neck_feat"]}

@@ -97,6 +97,52 @@ def generator_case(name, b, hw):
     save(name, b=b, hw=hw, fea=fea, prediction=out["prediction"], deformed=out["deformed"])
 
 
+def train_case(name, b, t, hw, labels):
+    """One full DM training step of the reference (FlowDiffusion.optimize_parameters, single-GPU class) on synthetic
+    frozen-LFAE + UNet checkpoints: pseudo ground truth, losses, per-parameter gradient / updated-weight statistics.
+    Randomness (t, noise) is replaced by recorded tensors; null_cond_prob = 0 (labels 'None' exercise none_cond_mask);
+    text -> embedding is a fixed tensor (the reference's BERT download is unavailable)."""
+    m = ref.vfdm.FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=0.0,
+                               is_train=True, lr=1e-3, config_pth=synth.CONFIG, pretrained_pth="")
+    m.unet.load_state_dict(synth.unet_state())
+    m.generator.load_state_dict(synth.generator_state())
+    m.region_predictor.load_state_dict(synth.region_state())
+    m.bg_predictor.load_state_dict(synth.bg_state())
+    for net in (m.generator, m.region_predictor, m.bg_predictor):     # what pretrained_pth != "" does (:42-61)
+        net.eval()
+        m.set_requires_grad(net, False)
+    ref_img, real_vid, cond, tt, noise = synth.train_inputs(b, t, hw)
+    ref.vfd.tokenize = lambda texts: texts
+    ref.vfd.bert_embed = lambda tokens, return_cls_repr=False: cond
+    randint, randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: tt.clone()
+    torch.randn_like = lambda x, **k: noise.clone()
+    try:
+        m.set_train_input(ref_img=ref_img, real_vid=real_vid, ref_text=labels)
+        m.optimize_parameters()
+    finally:
+        torch.randint, torch.randn_like = randint, randn_like
+    rng = np.random.Generator(np.random.PCG64(77))
+    names, gnorm, pnorm, gprobe = [], [], [], []
+    small = {}
+    for k, p in m.diffusion.named_parameters():
+        names.append(k)
+        g = p.grad.detach().double()
+        probe = torch.from_numpy(rng.standard_normal(p.numel())).view_as(g)
+        gnorm.append(float(g.norm()))
+        gprobe.append(float((g * probe).sum()))
+        pnorm.append(float(p.detach().double().norm()))
+        if p.numel() <= 128:
+            small["grad/" + k] = p.grad.detach()
+    save(name, b=b, t=t, hw=hw, labels=np.array(labels), names=np.array(names), grad_norm=np.array(gnorm),
+         grad_probe=np.array(gprobe), param_norm_after=np.array(pnorm),
+         real_vid_grid=m.real_vid_grid, real_vid_conf=m.real_vid_conf, real_out_vid=m.real_out_vid[:, :, -1],
+         real_warped_vid=m.real_warped_vid[:, :, -1], fake_out_vid=m.fake_out_vid[:, :, -1],
+         fake_warped_vid=m.fake_warped_vid[:, :, -1], ref_img_fea_sum=m.ref_img_fea.double().sum(),
+         ref_img_fea_slice=m.ref_img_fea[:, ::32, ::4, ::4], pred_x0=m.diffusion.pred_x0, loss=m.loss.detach(),
+         rec_loss=m.rec_loss, rec_warp_loss=m.rec_warp_loss, null_cond_mask=m.diffusion.denoise_fn.null_cond_mask, **small)
+
+
 def op_cases():
     g = torch.Generator().manual_seed(21)
     emb = torch.randn(32, 8, generator=g)
@@ -118,8 +164,12 @@ def op_cases():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true")
+    ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.train:
+        train_case("train_step_128", 2, 2, 128, ["label a", "None"])
+        return
     op_cases()
     unet_case("unet_tiny_deconv", 2, 4, 8)
     unet_case("unet_tiny_upconv_lnc", 2, 4, 8, learn_null_cond=True, use_deconv=False, padding_mode="reflect")

@@ -18,6 +18,36 @@ def generator_state(seed=4321):
     return P.synthetic_state_dict(P.generator_spec(), seed)
 
 
+def region_state(seed=5151):
+    return P.synthetic_state_dict(P.region_predictor_spec(), seed)
+
+
+def bg_state(seed=6161):
+    """fc near the reference's identity-affine initialisation (bg_motion_predictor.py:33-39) so the background
+    transform is a small perturbation of the identity rather than a degenerate random matrix."""
+    sd = P.synthetic_state_dict(P.bg_predictor_spec(), seed)
+    sd["fc.weight"] = sd["fc.weight"] * 0.02
+    sd["fc.bias"] = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32) + 0.2 * sd["fc.bias"]
+    return sd
+
+
+def train_inputs(batch, frames, img_hw, seed=9):
+    """(ref_img (B,3,H,W), real_vid (B,3,T,H,W) = smooth perturbations of ref_img, cond (B,768), t (B,), noise (B,3,T,h,w))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = rng.random((batch, 3, img_hw // 8, img_hw // 8), dtype=np.float32)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(base), size=(img_hw, img_hw), mode="bilinear", align_corners=False)
+    vid = []
+    for t in range(frames):
+        d = torch.from_numpy(rng.random((batch, 3, img_hw // 8, img_hw // 8), dtype=np.float32))
+        d = torch.nn.functional.interpolate(d, size=(img_hw, img_hw), mode="bilinear", align_corners=False)
+        vid.append((0.7 * torch.roll(ref, shifts=(2 * t + 1, -t), dims=(2, 3)) + 0.3 * d).clamp(0, 1))
+    real_vid = torch.stack(vid, dim=2).contiguous()
+    cond = torch.from_numpy(rng.standard_normal((batch, 768)).astype(np.float32))
+    tt = torch.tensor([417, 23, 801, 5][:batch])
+    noise = torch.from_numpy(rng.standard_normal((batch, 3, frames, img_hw // 4, img_hw // 4)).astype(np.float32))
+    return ref.contiguous(), real_vid, cond, tt, noise
+
+
 def inputs(batch, img_hw, seed=7):
     rng = np.random.Generator(np.random.PCG64(seed))
     img = torch.from_numpy(rng.random((batch, 3, img_hw, img_hw), dtype=np.float32))

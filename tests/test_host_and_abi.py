@@ -71,9 +71,8 @@ def test_state_dict_layout_and_roundtrip():
     assert len(m.region_predictor.state_dict()) == 73 and len(m.bg_predictor.state_dict()) == 37
     assert "denoise_fn.downs.2.3.fn.fn.fn.rotary_emb.freqs" in dsd and "betas" in dsd
     m.diffusion.load_state_dict(dsd)
-    assert isinstance(m.optimizer_diff, torch.optim.Adam) and m.optimizer_diff.param_groups[0]["betas"] == (0.9, 0.99)
-    with pytest.raises(NotImplementedError):
-        m.optimize_parameters()                             # the training row is not built yet: say so
+    assert isinstance(m.optimizer_diff, torch.optim.Optimizer) and m.optimizer_diff.param_groups[0]["betas"] == (0.9, 0.99)
+    torch.optim.lr_scheduler.MultiStepLR(m.optimizer_diff, milestones=[3], gamma=0.1)      # train script :210-211
 
 
 def test_bench_timing_protocol_gloo_world2(tmp_path):
