@@ -170,6 +170,43 @@ def warp_bench(model, img, iters=20):
                          "frac": round(gbs / 8000.0, 4), "traffic": None}}
 
 
+def train_bench(dev, rank, world, steps, warmup, batch):
+    """BASELINE.json configs[3] per GPU: one DM training step = frozen-LFAE pseudo ground truth of all B*T frames +
+    UNet forward/backward (native kernels under autograd) + [RCCL gradient all-reduce when world > 1] + fused Adam,
+    on `batch` 40-frame 128x128 videos per GPU (the reference script uses 64 videos over 8 GPUs)."""
+    import contextlib
+    import synth
+    from cvpr23_lfdm_amd import FlowDiffusion
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(sys.stderr):
+        m = FlowDiffusion(img_size=WORKLOAD["latent"], num_frames=WORKLOAD["frames"], sampling_timesteps=1000,
+                          null_cond_prob=0.1, is_train=True, lr=1e-4, config_pth=synth.CONFIG, pretrained_pth="")
+    m.unet.load_state_dict(synth.unet_state())
+    m.generator.load_state_dict(synth.generator_state())
+    m.region_predictor.load_state_dict(synth.region_state())
+    m.bg_predictor.load_state_dict(synth.bg_state())
+    for net in (m.generator, m.region_predictor, m.bg_predictor):
+        net.eval()
+        m.set_requires_grad(net, False)
+    m.to(dev)
+    m.enable_data_parallel()
+    ref_img, real_vid, cond, _, _ = synth.train_inputs(batch, WORKLOAD["frames"], WORKLOAD["image"], seed=100 + rank)
+    m.set_train_input(ref_img=ref_img.to(dev), real_vid=real_vid.to(dev), ref_text=cond.to(dev))
+    losses = []
+
+    def step():
+        m.optimize_parameters()
+        losses.append(m.loss.detach())
+
+    elapsed = timed_region(step, steps, warmup, world, torch.cuda.synchronize)
+    vals = [float(v) for v in losses]
+    return {"value": round(steps * batch * world / elapsed, 3), "unit": "training videos/s (40 frames, 128x128)",
+            "ms_per_step": round(1e3 * elapsed / steps, 1), "batch_per_gpu": batch, "global_batch": batch * world,
+            "steps": steps, "warmup": warmup, "grad_allreduce": "rccl bucketed, overlapped with backward" if world > 1 else "none (1 GPU)",
+            "loss_first": round(vals[0], 5), "loss_last": round(vals[-1], 5),
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
 def cpu_baseline():
     """The CPU oracle (oracle/lfdm_oracle.py, a port of the reference dataflow) on this host, bounded sample:
     2 UNet forwards at the C2 shape + compute_fea + 2 decoded frames, extrapolated linearly to one video
@@ -215,6 +252,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=2, help="timed DM training steps for the extra `train` object (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=8, help="training videos per GPU per step")
     ap.add_argument("--batch", type=int, default=1,
                     help="videos per GPU per step; 1 = BASELINE.json configs[1] (latency mode), >1 = throughput mode")
     args = ap.parse_args()
@@ -269,6 +308,17 @@ def main():
             line["warp"] = warp_bench(model, img)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+    train = None
+    if args.train_steps > 0:                 # every rank takes part (gradient all-reduce); after the headline measurement
+        del model
+        torch.cuda.empty_cache()
+        try:
+            train = train_bench(dev, rank, world, args.train_steps, 1, args.train_batch)
+        except Exception as e:               # never lose the headline line to the secondary measurement
+            train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if rank == 0:
+        if train is not None:
+            line["train"] = train
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
