@@ -103,8 +103,13 @@ class Generator(ParamTree):
             pk["r%d.w1" % i], pk["r%d.bb1" % i] = ops.pack_conv_weight(w), b
             pk["r%d.w2" % i] = ops.pack_conv_weight(g(p + "conv2.weight").contiguous())
             pk["r%d.b2" % i] = g(p + "conv2.bias").contiguous()
-        pk["final.w"] = ops.pack_conv_weight(g("final.weight").contiguous())
-        pk["final.b"] = g("final.bias").contiguous()
+        # output channels padded to a multiple of 4 (zero filters): float4 epilogue -> the 32-column KSW tile instead of
+        # a 64-column tile for 3 real channels
+        wf, bf = g("final.weight"), g("final.bias")
+        cpad = (4 - wf.shape[0] % 4) % 4
+        pk["final.w"] = ops.pack_conv_weight(torch.cat((wf, wf.new_zeros(cpad, *wf.shape[1:])), dim=0).contiguous())
+        pk["final.b"] = torch.cat((bf, bf.new_zeros(cpad))).contiguous()
+        pk["final.cout"] = wf.shape[0] + cpad
         return pk
 
     def _feat(self, i):
@@ -178,8 +183,8 @@ class Generator(ParamTree):
             res_h, res_w = res_h * 2, res_w * 2
         blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
                               out=self._buf("dec.wf", n * res_h * res_w, skips[0].shape[1]), **wk)
-        rgb = ops.conv2d_cl(blended, pk["final.w"], c, 7, 7, n, res_h, res_w, bias=pk["final.b"],
-                            act=ops.ACT_SIGMOID, out=self._buf("dec.rgb", n * res_h * res_w, 4)[:, :c])
+        rgb = ops.conv2d_cl(blended, pk["final.w"], pk["final.cout"], 7, 7, n, res_h, res_w, bias=pk["final.b"],
+                            act=ops.ACT_SIGMOID, out=self._buf("dec.rgb", n * res_h * res_w, pk["final.cout"]))[:, :c]
         prediction = ops.warp_planar(img, frames, flow_x, flow_y, occ, fh, fw, fsb, fst, prev=rgb, prev_is_cl=True,
                                      occ_scale=occ_scale, occ_bias=occ_bias)
         return prediction, deformed

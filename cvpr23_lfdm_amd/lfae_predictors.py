@@ -101,7 +101,7 @@ def antialias_down(x, weight, scale):
     ks = weight.shape[-1]
     ka = ks // 2
     kb = ka - 1 if ks % 2 == 0 else ka
-    return F.conv2d(F.pad(x, (ka, kb, ka, kb)), weight, groups=x.shape[1], stride=int(1 / scale))
+    return ops.depthwise_down_planar(x.float(), weight.detach().float(), int(1 / scale), ka, kb)
 
 
 def coordinate_grid(h, w, device):
@@ -111,15 +111,26 @@ def coordinate_grid(h, w, device):
     return torch.stack((x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)), dim=2)
 
 
+def inv2x2(m):
+    """Closed-form inverse of (..., 2, 2) matrices (the reference calls torch.inverse: batched LU on a solver library)."""
+    a, b, c, d = m[..., 0, 0], m[..., 0, 1], m[..., 1, 0], m[..., 1, 1]
+    det = a * d - b * c
+    return torch.stack((torch.stack((d, -b), dim=-1), torch.stack((-c, a), dim=-1)), dim=-2) / det.unsqueeze(-1).unsqueeze(-1)
+
+
 def region2gaussian(center, covar, h, w):
     """util.py:22-48 for a (N, K, 2) centre and a (N, K, 2, 2) covariance (or a float)."""
     grid = coordinate_grid(h, w, center.device).view(1, 1, h, w, 2)
     d = grid - center.view(*center.shape[:2], 1, 1, 2)
     if isinstance(covar, float):
         return torch.exp(-0.5 * (d ** 2).sum(-1) / covar)
-    inv = torch.inverse(covar).view(*covar.shape[:2], 1, 1, 2, 2)
-    under = torch.matmul(torch.matmul(d.unsqueeze(-2), inv), d.unsqueeze(-1))
-    return torch.exp(-0.5 * under.sum(dim=(-1, -2)))
+    # d^T C^-1 d written out for 2x2 (the reference's two broadcast matmuls became N*K*h*w tiny GEMMs: 50 ms each)
+    inv = inv2x2(covar)
+    i00, i01 = inv[..., 0, 0].unsqueeze(-1).unsqueeze(-1), inv[..., 0, 1].unsqueeze(-1).unsqueeze(-1)
+    i10, i11 = inv[..., 1, 0].unsqueeze(-1).unsqueeze(-1), inv[..., 1, 1].unsqueeze(-1).unsqueeze(-1)
+    dx, dy = d[..., 0], d[..., 1]
+    under = (dx * i00 + dy * i10) * dx + (dx * i01 + dy * i11) * dy
+    return torch.exp(-0.5 * under)
 
 
 class RegionPredictorExec:
@@ -143,8 +154,10 @@ class RegionPredictorExec:
         params = {"shift": mean, "heatmap": region}
         if not self.pca_based:
             raise NotImplementedError("regression-based affine (estimate_affine and not pca_based): no LFDM config uses it")
-        ms = grid - mean.unsqueeze(-2).unsqueeze(-2)
-        covar = (torch.matmul(ms.unsqueeze(-1), ms.unsqueeze(-2)) * r.unsqueeze(-1)).sum(dim=(2, 3))
+        ms = grid - mean.unsqueeze(-2).unsqueeze(-2)                       # (N, K, h, w, 2)
+        mx, my = ms[..., 0], ms[..., 1]
+        cxx, cxy, cyy = (mx * mx * region).sum(dim=(2, 3)), (mx * my * region).sum(dim=(2, 3)), (my * my * region).sum(dim=(2, 3))
+        covar = torch.stack((torch.stack((cxx, cxy), dim=-1), torch.stack((cxy, cyy), dim=-1)), dim=-2)
         params["covar"] = covar
         # one batched host SVD for all frames (the reference: one per frame, region_predictor.py:16-25)
         u, s, _ = torch.svd(covar.reshape(-1, 2, 2).cpu())
@@ -203,16 +216,21 @@ class PixelwiseFlowPredictorExec:
         ident = coordinate_grid(h, w, dev).view(1, 1, h, w, 2)
         cg = ident - driving["shift"].view(n, k, 1, 1, 2)
         if "affine" in driving:
-            aff = torch.matmul(source["affine"], torch.inverse(driving["affine"]))
+            aff = torch.matmul(source["affine"], inv2x2(driving["affine"]))                       # (N, K, 2, 2)
             if self.revert_axis_swap:
                 aff = aff * torch.sign(aff[:, :, 0:1, 0:1])
-            cg = torch.matmul(aff.view(n, k, 1, 1, 2, 2), cg.unsqueeze(-1)).squeeze(-1)
+            a = aff.view(n, k, 1, 1, 2, 2)
+            cx, cy = cg[..., 0], cg[..., 1]                                                        # per-pixel 2x2 @ 2x1, written out
+            cg = torch.stack((a[..., 0, 0] * cx + a[..., 0, 1] * cy, a[..., 1, 0] * cx + a[..., 1, 1] * cy), dim=-1)
         d2s = cg + source["shift"].view(n, k, 1, 1, 2)
         bg = ident.repeat(n, 1, 1, 1, 1)
         if bg_params is not None:
-            hom = torch.cat((bg, torch.ones_like(bg[..., :1])), dim=-1)
-            hom = torch.matmul(bg_params.view(n, 1, 1, 1, 3, 3), hom.unsqueeze(-1)).squeeze(-1)
-            bg = hom[..., :2] / hom[..., 2:3]
+            m3 = bg_params.view(n, 1, 1, 1, 3, 3)
+            gx, gy = bg[..., 0], bg[..., 1]
+            hx = m3[..., 0, 0] * gx + m3[..., 0, 1] * gy + m3[..., 0, 2]
+            hy = m3[..., 1, 0] * gx + m3[..., 1, 1] * gy + m3[..., 1, 2]
+            hz = m3[..., 2, 0] * gx + m3[..., 2, 1] * gy + m3[..., 2, 2]
+            bg = torch.stack((hx / hz, hy / hz), dim=-1)
         sparse = torch.cat((bg, d2s), dim=1)                                                       # (N, K+1, h, w, 2)
         # deformed source (:95-102)
         rep = source_image.unsqueeze(1).expand(n, k + 1, c, h, w).reshape(n * (k + 1), c, h, w)

@@ -453,3 +453,19 @@ def cl_to_planar(x, n_img, channels, hw, out=None):
     lib.check(lib.lfdm_cl_to_planar_f32(_p(x), _p(out), n_img, channels, hw, x.stride(0), _stream(lib)),
               "lfdm_cl_to_planar_f32")
     return out
+
+
+def depthwise_down_planar(x, weight, stride, pad_lo, pad_hi):
+    """AntiAliasInterpolation2d core: x (N,C,H,W) planar, weight (C,1,k,k) -> (N,C,Ho,Wo)."""
+    lib = _lib()
+    x = x.contiguous()
+    wt = weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).contiguous()
+    _chk(lib, x, wt)
+    n, c, h, w = x.shape
+    k = wt.shape[-1]
+    ho = (h + pad_lo + pad_hi - k + 1 + stride - 1) // stride
+    wo = (w + pad_lo + pad_hi - k + 1 + stride - 1) // stride
+    out = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_depthwise_down_planar_f32(_p(x), _p(wt), _p(out), n, c, h, w, k, pad_lo, pad_hi, stride, _stream(lib)),
+              "lfdm_depthwise_down_planar_f32")
+    return out

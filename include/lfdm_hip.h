@@ -333,6 +333,13 @@ int lfdm_adam_step_f32(float* param, const float* grad, float* exp_avg, float* e
                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                        float grad_scale, lfdm_stream_t stream);
 
+/* AntiAliasInterpolation2d (LFAE/modules/util.py:217-264; region / pixelwise-flow predictor inputs): planar
+ * (N, C, H, W) -> zero-pad (pad_lo before, pad_hi after) -> depthwise k x k filter wgt (C, k, k) -> every
+ * stride-th pixel: out (N, C, ceil((H+pad_lo+pad_hi-k+1)/stride), ...). */
+int lfdm_depthwise_down_planar_f32(const float* x, const float* wgt, float* out, int n_img, int channels,
+                                   int h, int w, int k, int pad_lo, int pad_hi, int stride,
+                                   lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

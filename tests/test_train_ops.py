@@ -163,3 +163,17 @@ def test_linear_attention_bwd(backend, hw):
     dqkv = train_ops.linear_attention_bwd(qkv.detach().reshape(-1, 768).to(dev), dout.to(dev), nf, hw)
     sc = float(qkv.grad.abs().max())
     assert_close(dqkv.cpu() / sc, qkv.grad.reshape(-1, 768) / sc, TOL, "linear attention dqkv")
+
+
+def test_depthwise_down(backend):
+    """AntiAliasInterpolation2d (util.py:217-264): pad (ka, kb) -> depthwise Gaussian -> [::4]."""
+    from cvpr23_lfdm_amd.params import antialias_kernel
+    dev = backend
+    n, c, h = (3, 3, 20) if not big(dev) else (40, 3, 128)
+    x = rnd(n, c, h, h, seed=1)
+    w = antialias_kernel(c, 0.25)
+    ks = w.shape[-1]
+    ka = ks // 2
+    ref = F.conv2d(F.pad(x, (ka, ka, ka, ka)), w, groups=c)[:, :, ::4, ::4]
+    out = ops.depthwise_down_planar(x.to(dev), w.to(dev), 4, ka, ka)
+    assert_close(out.cpu(), ref, 1e-5, "antialias down")
