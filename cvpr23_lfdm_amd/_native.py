@@ -116,6 +116,7 @@ _SIGNATURES = {
     "lfdm_linear_attention_bwd_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, C.c_void_p, sz, stream_t]),
     "lfdm_adam_step_f32": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, f32, i32, f32, stream_t]),
     "lfdm_depthwise_down_planar_f32": (i32, [f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, i32, stream_t]),
+    "lfdm_upsample2_pad_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, i32, i32, i32, stream_t]),
     "lfdm_layernorm_bwd_ws_bytes": (sz, [i64, i32]),
     "lfdm_layernorm_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, f32p, f32, f32p, C.c_void_p, sz, stream_t]),
 }

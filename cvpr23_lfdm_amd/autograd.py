@@ -203,5 +203,19 @@ class CLToPlanar(Function):
         return ops.planar_to_cl(_c(dy), n, c, hw), None, None
 
 
+class Upsample2Pad(Function):
+    """nearest x2 + pad (zeros / reflect) of CL rows: the input side of the use_deconv=False Upsample (:160-163)."""
+
+    @staticmethod
+    def forward(ctx, x, n_img, h, w, pad, reflect):
+        ctx.meta = (n_img, h, w, pad, reflect)
+        return train_ops.upsample2_pad(_c(x.detach()), n_img, h, w, pad, reflect)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n_img, h, w, pad, reflect = ctx.meta
+        return train_ops.upsample2_pad(_c(dy), n_img, h, w, pad, reflect, backward=True), None, None, None, None, None
+
+
 def conv_cl(x0, weight, bias, *, x1=None, residual=None, **geom):
     return ConvCL.apply(x0, x1, weight, bias, residual, geom)

@@ -165,6 +165,63 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t row
     partial[(int64_t)blockIdx.y * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Upsample (nearest x2) + pad by P (zeros or reflect) materialised for the training path of the
+// `use_deconv=False` Upsample (video_flow_diffusion.py:160-163): forward gathers, backward gathers the
+// adjoint (every input pixel sums the <= 3x3 output positions that read it).  P in {0, 1}.
+__device__ __forceinline__ int up_src(int p, int pad, int n2, int reflect) {   // padded coord -> upsampled coord or -1
+  int u = p - pad;
+  if (u < 0) u = reflect ? -u : -1;
+  else if (u >= n2) u = reflect ? 2 * n2 - 2 - u : -1;
+  return u;
+}
+
+__global__ __launch_bounds__(256) void upsample_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int n_img,
+                                                               int h, int w, int c, int pad, int reflect) {
+  const int c4n = c >> 2, ho = 2 * h + 2 * pad, wo = 2 * w + 2 * pad;
+  const int64_t total = (int64_t)n_img * ho * wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    int64_t r = i / c4n;
+    const int px = (int)(r % wo);
+    r /= wo;
+    const int py = (int)(r % ho);
+    const int n = (int)(r / ho);
+    const int uy = up_src(py, pad, 2 * h, reflect), ux = up_src(px, pad, 2 * w, reflect);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (uy >= 0 && ux >= 0) v = *reinterpret_cast<const float4*>(x + (((int64_t)n * h + (uy >> 1)) * w + (ux >> 1)) * c + 4 * c4);
+    *reinterpret_cast<float4*>(out + (((int64_t)n * ho + py) * wo + px) * c + 4 * c4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n_img,
+                                                               int h, int w, int c, int pad, int reflect) {
+  const int c4n = c >> 2, ho = 2 * h + 2 * pad, wo = 2 * w + 2 * pad;
+  const int64_t total = (int64_t)n_img * h * w * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    int64_t r = i / c4n;
+    const int j = (int)(r % w);
+    r /= w;
+    const int ii = (int)(r % h);
+    const int n = (int)(r / h);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // candidate padded rows / cols: the two direct ones and the reflected border ones
+    for (int py = 2 * ii + pad - 2; py <= 2 * ii + pad + 3; ++py) {
+      if (py < 0 || py >= ho) continue;
+      const int uy = up_src(py, pad, 2 * h, reflect);
+      if (uy < 0 || (uy >> 1) != ii) continue;
+      for (int px = 2 * j + pad - 2; px <= 2 * j + pad + 3; ++px) {
+        if (px < 0 || px >= wo) continue;
+        const int ux = up_src(px, pad, 2 * w, reflect);
+        if (ux < 0 || (ux >> 1) != j) continue;
+        const float4 v = *reinterpret_cast<const float4*>(dy + (((int64_t)n * ho + py) * wo + px) * c + 4 * c4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + (((int64_t)n * h + ii) * w + j) * c + 4 * c4) = acc;
+  }
+}
+
 struct WgradPlan {
   int wm, wn, splits;
 };
@@ -253,4 +310,20 @@ extern "C" int lfdm_colsum_f32(const float* x, int64_t rows, int c, int ld, floa
   int rc = lfdm_check_launch("colsum");
   if (rc) return rc;
   return lfdm_sum_leading_f32((const float*)ws, out, c, (int)nblk, stream_);
+}
+
+extern "C" int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int pad,
+                                         int reflect, int backward, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || n_img <= 0 || h <= 0 || w <= 0 || channels <= 0 || channels % 4 != 0 || pad < 0 || pad > 1 ||
+      (reflect && pad == 1 && (h < 1 || w < 1))) {
+    lfdm_set_error("upsample2_pad: bad arguments (C % 4 == 0, pad in {0,1})");
+    return LFDM_EINVAL;
+  }
+  const int64_t rows = backward ? (int64_t)n_img * h * w : (int64_t)n_img * (2 * h + 2 * pad) * (2 * w + 2 * pad);
+  int64_t nb = (rows * (channels / 4) + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  if (backward) LFDM_LAUNCH(upsample_pad_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, out, n_img, h, w, channels, pad, reflect);
+  else LFDM_LAUNCH(upsample_pad_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, out, n_img, h, w, channels, pad, reflect);
+  return lfdm_check_launch("upsample2_pad");
 }

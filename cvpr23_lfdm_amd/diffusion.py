@@ -31,8 +31,12 @@ def is_list_str(x):
 class GaussianDiffusion(nn.Module):
     def __init__(self, denoise_fn, *, image_size, num_frames, text_use_bert_cls=False, channels=3,
                  timesteps=1000, sampling_timesteps=250, ddim_sampling_eta=1., loss_type='l1',
-                 use_dynamic_thres=False, dynamic_thres_percentile=0.9, null_cond_prob=0.1):
+                 use_dynamic_thres=False, dynamic_thres_percentile=0.9, null_cond_prob=0.1,
+                 per_element_loss=False):
         super().__init__()
+        # True = the *_multiGPU.py flavour of the reference (video_flow_diffusion_multiGPU.py:857-880):
+        # un-reduced loss tensor and `(loss, null_cond_mask)` as the return value of p_losses / forward
+        self.per_element_loss = per_element_loss
         self.null_cond_prob = null_cond_prob
         self.channels = channels
         self.image_size = image_size
@@ -298,10 +302,11 @@ class GaussianDiffusion(nn.Module):
                                               **kwargs)
             finally:
                 unet.train(was_training)
+        red = "none" if self.per_element_loss else "mean"
         if self.loss_type == 'l1':
-            loss = F.l1_loss(noise, pred_noise)
+            loss = F.l1_loss(noise, pred_noise, reduction=red)
         elif self.loss_type == 'l2':
-            loss = F.mse_loss(noise, pred_noise)
+            loss = F.mse_loss(noise, pred_noise, reduction=red)
         else:
             raise NotImplementedError()
         with torch.no_grad():
@@ -312,6 +317,8 @@ class GaussianDiffusion(nn.Module):
                     if self.use_dynamic_thres else torch.ones(b, device=pred_x0.device)
                 sthr = sthr.clamp(min=1.).view(-1, *((1,) * (pred_x0.dim() - 1)))
                 self.pred_x0 = pred_x0.clamp(-sthr, sthr) / sthr
+        if self.per_element_loss:
+            return loss, unet.null_cond_mask
         return loss
 
     def forward(self, x, fea, text, *args, **kwargs):

@@ -138,43 +138,58 @@ class FlowDiffusion(nn.Module):
         self.real_vid = real_vid.to(dev)
         self.ref_text = ref_text
 
-    def forward(self):
-        """Reference :116-179.  Pseudo ground-truth flow / occlusion of every frame from the frozen LFAE (all B*T
-        frames in one batched pass), the diffusion loss on it (native UNet forward under autograd), and - for the
-        logged reconstructions - the decode of the denoised prediction."""
-        b, _, nf, H, W = self.real_vid.shape
+    def _train_forward(self, real_vid, ref_img, ref_text):
+        """Shared body of `forward` (reference :116-179) and of the functional *_multiGPU flavour
+        (video_flow_diffusion_model_multiGPU.py:89-157): pseudo ground-truth flow / occlusion of every frame from
+        the frozen LFAE (all B*T frames in one batched pass), the diffusion loss on it (native UNet forward under
+        autograd), and - for the logged reconstructions - the decode of the denoised prediction.  -> dict."""
+        b, _, nf, H, W = real_vid.shape
         gen = self.generator
+        out = {}
         with torch.no_grad():
-            ref = self.ref_img.float().contiguous()
-            frames = self.real_vid.float().permute(0, 2, 1, 3, 4).reshape(b * nf, -1, H, W).contiguous()
+            ref = ref_img.float().contiguous()
+            frames = real_vid.float().permute(0, 2, 1, 3, 4).reshape(b * nf, -1, H, W).contiguous()
             source_region_params = self.region_predictor(ref)
             driving_region_params = self.region_predictor(frames)
             ref_rep = ref.unsqueeze(1).expand(b, nf, *ref.shape[1:]).reshape(b * nf, *ref.shape[1:])
             bg_params = self.bg_predictor(ref_rep, frames)
             generated = gen.forward_frames(ref, nf, driving_region_params, source_region_params, bg_params)
-        self.real_vid_grid = generated["optical_flow"]
-        self.real_vid_conf = generated["occlusion_map"]
-        self.real_out_vid = generated["prediction"]
-        self.real_warped_vid = generated["deformed"]
-        self.ref_img_fea = generated["bottle_neck_feat"].clone().detach()
-
+        out["real_vid_grid"] = generated["optical_flow"]
+        out["real_vid_conf"] = generated["occlusion_map"]
+        out["real_out_vid"] = generated["prediction"]
+        out["real_warped_vid"] = generated["deformed"]
+        out["ref_img_fea"] = generated["bottle_neck_feat"].clone().detach()
         if self.is_train:
-            h, w = self.real_vid_grid.shape[-2:]
+            h, w = out["real_vid_grid"].shape[-2:]
             identity_grid = self.get_grid(b, nf, h, w, normalize=True).to(ref.device) if self.use_residual_flow else None
-            grid = self.real_vid_grid - identity_grid if self.use_residual_flow else self.real_vid_grid
-            self.loss = self.diffusion(torch.cat((grid, self.real_vid_conf * 2 - 1), dim=1), self.ref_img_fea,
-                                       self.ref_text)
+            grid = out["real_vid_grid"] - identity_grid if self.use_residual_flow else out["real_vid_grid"]
+            res = self.diffusion(torch.cat((grid, out["real_vid_conf"] * 2 - 1), dim=1), out["ref_img_fea"], ref_text)
+            if isinstance(res, tuple):
+                out["loss"], out["null_cond_mask"] = res
+            else:
+                out["loss"] = res
             with torch.no_grad():
                 pred = self.diffusion.pred_x0
-                self.fake_vid_grid = pred[:, :2] + identity_grid if self.use_residual_flow else pred[:, :2]
-                self.fake_vid_conf = (pred[:, 2].unsqueeze(dim=1) + 1) * 0.5
-                maps = torch.cat((self.fake_vid_grid, pred[:, 2:3]), dim=1).contiguous()
+                out["fake_vid_grid"] = pred[:, :2] + identity_grid if self.use_residual_flow else pred[:, :2]
+                out["fake_vid_conf"] = (pred[:, 2].unsqueeze(dim=1) + 1) * 0.5
+                maps = torch.cat((out["fake_vid_grid"], pred[:, 2:3]), dim=1).contiguous()
                 skips = gen.encode(ref)
-                out, warped = gen.decode_video(ref, skips, maps[:, 0], maps[:, 1], maps[:, 2], nf, h, w,
-                                               3 * nf * h * w, h * w, occ_scale=0.5, occ_bias=0.5)
-                self.fake_out_vid, self.fake_warped_vid = out, warped
-                self.rec_loss = (self.real_vid - out).abs().mean()
-                self.rec_warp_loss = (self.real_vid - warped).abs().mean()
+                fo, fw = gen.decode_video(ref, skips, maps[:, 0], maps[:, 1], maps[:, 2], nf, h, w,
+                                          3 * nf * h * w, h * w, occ_scale=0.5, occ_bias=0.5)
+                out["fake_out_vid"], out["fake_warped_vid"] = fo, fw
+        return out
+
+    def forward(self):
+        """Reference :116-179 (inputs from set_train_input, results as attributes)."""
+        out = self._train_forward(self.real_vid, self.ref_img, self.ref_text)
+        for k in ("real_vid_grid", "real_vid_conf", "real_out_vid", "real_warped_vid", "ref_img_fea"):
+            setattr(self, k, out[k])
+        if self.is_train:
+            for k in ("loss", "fake_vid_grid", "fake_vid_conf", "fake_out_vid", "fake_warped_vid"):
+                setattr(self, k, out[k])
+            with torch.no_grad():
+                self.rec_loss = (self.real_vid - self.fake_out_vid).abs().mean()
+                self.rec_warp_loss = (self.real_vid - self.fake_warped_vid).abs().mean()
 
     def enable_data_parallel(self, bucket_bytes=64 << 20):
         """One process per GPU (torch.distributed initialised by the launcher): average the DM gradients over the
@@ -219,3 +234,30 @@ class FlowDiffusion(nn.Module):
             if net is not None:
                 for p in net.parameters():
                     p.requires_grad = requires_grad
+
+
+class FlowDiffusionFunctional(FlowDiffusion):
+    """The *_multiGPU.py flavour of the wrapper (DM/modules/video_flow_diffusion_model_multiGPU.py): functional
+    `forward(real_vid, ref_img, ref_text) -> dict` with an un-reduced `loss` and `null_cond_mask`, functional
+    `sample_one_video(sample_img, sample_text, cond_scale) -> dict`, optimizer owned by the training script
+    (DM/train_video_flow_diffusion_mhad_multiGPU.py:182,249-299,357).  Data parallelism is one process per GPU here
+    (wrap the script's optimizer step with `GradAllReduce`, or use `FlowDiffusion.enable_data_parallel`)."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("lr", None)
+        super().__init__(*args, **kwargs)
+        self.diffusion.per_element_loss = True
+
+    def forward(self, real_vid, ref_img, ref_text):
+        out = self._train_forward(real_vid, ref_img, ref_text)
+        if self.is_train:
+            with torch.no_grad():
+                out["rec_loss"] = (real_vid - out["fake_out_vid"]).abs()
+                out["rec_warp_loss"] = (real_vid - out["fake_warped_vid"]).abs()
+        out.pop("ref_img_fea", None)
+        return out
+
+    def sample_one_video(self, sample_img, sample_text, cond_scale):
+        self.set_sample_input(sample_img=sample_img, sample_text=sample_text)
+        FlowDiffusion.sample_one_video(self, cond_scale)
+        return {k: getattr(self, k) for k in ("sample_vid_grid", "sample_vid_conf", "sample_out_vid", "sample_warped_vid")}

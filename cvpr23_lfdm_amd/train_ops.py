@@ -143,3 +143,17 @@ def linear_attention_bwd(qkv, dout, n_frames, hw):
     lib.check(lib.lfdm_linear_attention_bwd_cl_f32(_p(qkv), _p(dout), _p(dqkv), n_frames, hw, _p(ws), nbytes, _stream(lib)),
               "lfdm_linear_attention_bwd_cl_f32")
     return dqkv
+
+
+def upsample2_pad(x, n_img, h, w, pad, reflect, backward=False):
+    """forward: (n*h*w, C) -> (n*(2h+2pad)*(2w+2pad), C); backward: the adjoint."""
+    lib = _lib()
+    _chk(lib, x)
+    assert x.is_contiguous()
+    c = x.shape[1]
+    rows = n_img * h * w if backward else n_img * (2 * h + 2 * pad) * (2 * w + 2 * pad)
+    assert x.shape[0] == (n_img * (2 * h + 2 * pad) * (2 * w + 2 * pad) if backward else n_img * h * w)
+    out = torch.empty(rows, c, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_upsample2_pad_cl_f32(_p(x), _p(out), n_img, h, w, c, pad, int(reflect), int(backward), _stream(lib)),
+              "lfdm_upsample2_pad_cl_f32")
+    return out

@@ -81,8 +81,6 @@ def _linear_attn(unet, c, prefix, x, res):
 def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_cond_mask=None):
     """x_dyn (B, 3, T, S, S) noisy flow/occlusion, fea (B, 256, S, S) reference-image features (constant over T),
     time (B,) long, cond (B, 768)  ->  eps_hat (B, 3, T, S, S) with grad to every UNet parameter."""
-    if not unet.use_deconv:
-        raise NotImplementedError("training backward of the nearest-upsample + reflect-pad Upsample variant (use_deconv=False)")
     g = unet.get
     c = _Ctx()
     b, n_dyn, t, s, _ = x_dyn.shape
@@ -146,7 +144,11 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
         x = _linear_attn(unet, c, p + "2.", x, res)
         x = _temporal_attn(unet, c, p + "3.", x, res)
         if lvl < nl - 1:
-            x = A.conv_cl(x, g(p + "4.weight"), g(p + "4.bias"), n_img=n_img, hi=res, wi=res, kind="deconv")
+            if unet.use_deconv:
+                x = A.conv_cl(x, g(p + "4.weight"), g(p + "4.bias"), n_img=n_img, hi=res, wi=res, kind="deconv")
+            else:   # Upsample(nearest x2) -> Conv3d k=(1,3,3) with padding_mode (:160-163): padded input materialised
+                xp = A.Upsample2Pad.apply(x, n_img, res, res, 1, unet.padding_mode == "reflect")
+                x = A.conv_cl(xp, g(p + "4.1.weight"), g(p + "4.1.bias"), n_img=n_img, hi=2 * res + 2, wi=2 * res + 2, pad=(0, 0))
             res *= 2
 
     # --- output heads (:493-509, :587-588): two ResnetBlocks on cat(x, r), then the 1x1 convs as ONE 4-column

@@ -340,6 +340,13 @@ int lfdm_depthwise_down_planar_f32(const float* x, const float* wgt, float* out,
                                    int h, int w, int k, int pad_lo, int pad_hi, int stride,
                                    lfdm_stream_t stream);
 
+/* Nearest x2 upsample + pad (zeros or reflect, pad in {0,1}) of CL rows, materialised for the training path of the
+ * use_deconv=False Upsample (video_flow_diffusion.py:160-163: Upsample(scale 2, nearest) -> Conv3d(padding_mode)).
+ * backward = 0: x (n, h, w, C) -> out (n, 2h+2pad, 2w+2pad, C);  backward = 1: x is the gradient of that output and
+ * out (n, h, w, C) its adjoint (sum over the positions that read each input pixel). */
+int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int pad,
+                              int reflect, int backward, lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,19 @@ def test_conv_function(backend, case):
     if x1 is not None:
         _cmp(from_cl(kx1.grad, n, h, h), x1.grad, case + " dx1")
         _cmp(from_cl(kres.grad, n, h, h), res.grad, case + " dres")
+
+
+@pytest.mark.parametrize("reflect", [True, False])
+def test_upsample2_pad_function(backend, reflect):
+    dev = backend
+    n, c, h, w = 2, 8, 3, 5
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    up = F.interpolate(x, scale_factor=2, mode="nearest")
+    ref = F.pad(up, (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(dy)
+    kx = to_cl(x.detach()).to(dev).requires_grad_(True)
+    y = A.Upsample2Pad.apply(kx, n, h, w, 1, reflect)
+    _cmp(from_cl(y, n, 2 * h + 2, 2 * w + 2), ref, "upsample+pad fwd")
+    y.backward(to_cl(dy).to(dev))
+    _cmp(from_cl(kx.grad, n, h, w), x.grad, "upsample+pad bwd")

@@ -85,3 +85,33 @@ def test_training_step_matches_reference(monkeypatch):
     m.optimize_parameters()
     assert float(m.optimizer_diff.state_dict()["state"][0]["step"]) == 2.0
     assert torch.isfinite(m.loss)
+
+
+@pytest.mark.gpu
+def test_functional_multigpu_flavour(monkeypatch):
+    """DM/modules/video_flow_diffusion_model_multiGPU.py API: forward(real_vid, ref_img, ref_text) -> dict with an
+    un-reduced loss whose mean equals the single-GPU class's loss; functional sample_one_video -> dict."""
+    from DM.modules.video_flow_diffusion_model_multiGPU import FlowDiffusion as FD
+    g = np.load(GOLD)
+    b, t, hw = int(g["b"]), int(g["t"]), int(g["hw"])
+    dev = "cuda"
+    m = FD(img_size=hw // 4, num_frames=t, sampling_timesteps=3, timesteps=1000, null_cond_prob=0.0, is_train=True,
+           config_pth=synth.CONFIG, pretrained_pth="")
+    m.unet.load_state_dict(synth.unet_state())
+    m.generator.load_state_dict(synth.generator_state())
+    m.region_predictor.load_state_dict(synth.region_state())
+    m.bg_predictor.load_state_dict(synth.bg_state())
+    m.to(dev)
+    ref_img, real_vid, cond, tt, noise = synth.train_inputs(b, t, hw)
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: tt.clone().to(k.get("device", "cpu")))
+    monkeypatch.setattr(torch, "randn_like", lambda x, **k: noise.clone().to(x.device))
+    out = m.forward(real_vid=real_vid.to(dev), ref_img=ref_img.to(dev), ref_text=cond.to(dev))
+    monkeypatch.undo()
+    assert out["loss"].shape == (b, 3, t, hw // 4, hw // 4) and out["null_cond_mask"].shape == (b,)
+    assert out["rec_loss"].shape == real_vid.shape
+    # labels of the fixture: second sample is "None" -> null cond there; here nothing is nulled, so only sample 0 matches
+    assert_close(out["real_vid_grid"], torch.from_numpy(g["real_vid_grid"]), 1e-3, "pseudo-GT flow")
+    out["loss"].mean().backward()
+    assert all(p.grad is not None for p in m.diffusion.parameters())
+    s = m.sample_one_video(sample_img=ref_img[:1].to(dev), sample_text=cond[:1].to(dev), cond_scale=1.0)
+    assert s["sample_out_vid"].shape == (1, 3, t, hw, hw) and bool(torch.isfinite(s["sample_out_vid"]).all())

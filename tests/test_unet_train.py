@@ -13,9 +13,10 @@ from cvpr23_lfdm_amd.unet_train import unet_train_forward
 from util import assert_close
 
 
-def _run(dev, b, t, s, learn_null=False, null_mask=None):
-    usd = synth.unet_state(learn_null_cond=learn_null)
-    unet = Unet3D(dim=64, channels=259, out_grid_dim=2, out_conf_dim=1, use_bert_text_cond=True, learn_null_cond=learn_null)
+def _run(dev, b, t, s, learn_null=False, null_mask=None, use_deconv=True, padding_mode="zeros"):
+    usd = synth.unet_state(learn_null_cond=learn_null, use_deconv=use_deconv)
+    unet = Unet3D(dim=64, channels=259, out_grid_dim=2, out_conf_dim=1, use_bert_text_cond=True, learn_null_cond=learn_null,
+                  use_deconv=use_deconv, padding_mode=padding_mode)
     unet.load_state_dict(usd)
     unet.to(dev).train()
     x, time, cond = synth.unet_inputs(b, t, s)
@@ -44,7 +45,7 @@ def _run(dev, b, t, s, learn_null=False, null_mask=None):
     assert worst[1] < 2e-3, "largest relative gradient error %.3e at %s" % (worst[1], worst[0])
 
 
-@pytest.mark.parametrize("case", ["plain", "null_cond"])
+@pytest.mark.parametrize("case", ["plain", "null_cond", "upconv_reflect"])
 def test_unet_train_grads(backend, case):
     dev = backend
     if dev == "cpu":
@@ -55,5 +56,7 @@ def test_unet_train_grads(backend, case):
         _run(dev, 1, 2, 8)
     elif case == "plain":
         _run(dev, 2, 4, 8)
-    else:
+    elif case == "null_cond":
         _run(dev, 2, 3, 8, learn_null=True, null_mask=torch.tensor([True, False]))
+    else:   # the NATOPS configuration: learned null cond, nearest-upsample + reflect-pad Upsample
+        _run(dev, 1, 2, 8, learn_null=True, use_deconv=False, padding_mode="reflect")
