@@ -190,26 +190,36 @@ class GaussianDiffusion(nn.Module):
         if plan is None:
             plan = {
                 "x": torch.empty(shape, device=dev), "eps": torch.empty(shape, device=dev),
-                "eps2": torch.empty(shape, device=dev) if len(variants) > 1 else None,
+                # classifier-free guidance with cond_scale not in {0, 1}: cond and null passes run as ONE 2B batch
+                "x2": torch.empty((2 * batch,) + tuple(shape[1:]), device=dev) if len(variants) > 1 else None,
+                "eps2": torch.empty((2 * batch,) + tuple(shape[1:]), device=dev) if len(variants) > 1 else None,
+                "ss2": torch.empty(2 * batch, pk["cond.n"], device=dev) if len(variants) > 1 else None,
                 "noise": torch.empty(shape, device=dev), "step": torch.zeros(1, dtype=torch.int32, device=dev),
                 "ss": torch.empty(batch, pk["cond.n"], device=dev),
                 "ws": ops.sampler_ws(batch, n, dev), "graph": None, "pk": pk,
             }
             self._plans = {key: plan}      # keep one plan (static buffers are large)
         x, eps, noise, step_dev, ss = plan["x"], plan["eps"], plan["noise"], plan["step"], plan["ss"]
+        if len(variants) > 1:
+            fea_term = torch.cat((fea_term, fea_term), dim=0).contiguous()       # rows of samples [cond | null]
         bind = {"step_part": step_part, "variants": variants, "coef": coef_dev, "fea_term": fea_term,
                 "scale": float(cond_scale)}
         plan["bind"] = bind
 
         def one_step():
             b = plan["bind"]
-            outs = (eps, plan["eps2"])
-            for i, sample_part in enumerate(b["variants"]):
-                ops.step_cond(b["step_part"], sample_part, step_dev, ss)
+            if len(b["variants"]) == 1:
+                ops.step_cond(b["step_part"], b["variants"][0], step_dev, ss)
                 r = unet.stem(pk, x, b["fea_term"], batch, frames, s)
-                unet.run_trunk(pk, r, ss, batch, frames, s, outs[i])
-            if len(b["variants"]) > 1:      # null + (cond - null) * scale  (:525-526)
-                ops.cfg_combine(eps, plan["eps2"], b["scale"], eps)
+                unet.run_trunk(pk, r, ss, batch, frames, s, eps)
+            else:       # forward_with_cond_scale (:511-526): logits and null_logits in one batched pass
+                x2, eps2, ss2 = plan["x2"], plan["eps2"], plan["ss2"]
+                for i, sample_part in enumerate(b["variants"]):
+                    ops.step_cond(b["step_part"], sample_part, step_dev, ss2[i * batch:(i + 1) * batch])
+                    x2[i * batch:(i + 1) * batch].copy_(x)
+                r = unet.stem(pk, x2, b["fea_term"], 2 * batch, frames, s)
+                unet.run_trunk(pk, r, ss2, 2 * batch, frames, s, eps2)
+                ops.cfg_combine(eps2[:batch], eps2[batch:], b["scale"], eps)      # null + (cond - null) * scale
             ops.sampler_step(x, eps, noise, b["coef"], step_dev, quantile=self.dynamic_thres_percentile,
                              ws=plan["ws"])
 
