@@ -122,3 +122,24 @@ def test_second_call_reuses_graph(backend):
         m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
         m.sample_one_video(cond_scale=1.0)
         assert_close(m.sample_out_vid.cpu(), ref["sample_out_vid"], 1e-3, "call with seed %d" % seed)
+
+
+def test_c5_shape_natops_variant(backend):
+    """BASELINE.json configs[4] geometry (64x64 latent = 256x256 frames, nearest-upsample + reflect-pad Upsample,
+    learned null condition; 64-token mid spatial attention, 4x the spatial work per frame) at a reduced frame /
+    step count, against the oracle."""
+    dev = backend
+    if dev == "cpu":
+        pytest.skip("GPU-only size")
+    t, s, hw, steps = 6, 64, 256, 2
+    m, dsd, gsd = synth.build_flow_diffusion(dev, img_size=s, num_frames=t, sampling_timesteps=steps, learn_null_cond=True,
+                                             use_deconv=False, padding_mode="reflect")
+    img, cond = synth.inputs(1, hw, seed=21)
+    sd = dict(dsd)
+    sd.update(O.make_schedule(1000))
+    ref = O.sample_one_video(sd, gsd, img, cond, t, s, steps, noise_fn=synth.NoiseTape(21))
+    m.diffusion.noise_source = synth.NoiseTape(21)
+    m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
+    m.sample_one_video(cond_scale=1.0)
+    for k in ("sample_vid_grid", "sample_vid_conf", "sample_warped_vid", "sample_out_vid"):
+        assert_close(getattr(m, k).cpu(), ref[k], 1e-3, "%s (C5 shape)" % k)
