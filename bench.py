@@ -38,7 +38,9 @@ def dist_setup(n_gpus):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # "nccl" = RCCL over xGMI on the GPU box; LFDM_DIST_BACKEND=gloo lets the N>1 path be exercised with several
+        # ranks sharing ONE GPU (RCCL refuses duplicate devices) - a test hook, never used by the driver
+        backend = os.environ.get("LFDM_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend)
     return rank, world, local
 
@@ -254,6 +256,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=2, help="timed DM training steps for the extra `train` object (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=8, help="training videos per GPU per step")
+    ap.add_argument("--train-timeout", type=int, default=240, help="seconds before the training measurement is abandoned")
     ap.add_argument("--batch", type=int, default=1,
                     help="videos per GPU per step; 1 = BASELINE.json configs[1] (latency mode), >1 = throughput mode")
     args = ap.parse_args()
@@ -265,6 +268,7 @@ def main():
                                                     "batch=%d per GPU (throughput mode, NOT configs[1])" % args.batch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
@@ -290,6 +294,7 @@ def main():
     assert out.shape == (WORKLOAD["batch"], 3, WORKLOAD["frames"], WORKLOAD["image"], WORKLOAD["image"])
     assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0, "bad sample"
 
+    line = {}
     if rank == 0:
         line = {
             "metric": "40-frame 128x128 videos/sec (DDIM-100)",
@@ -312,10 +317,22 @@ def main():
     if args.train_steps > 0:                 # every rank takes part (gradient all-reduce); after the headline measurement
         del model
         torch.cuda.empty_cache()
+        import threading
+
+        def on_timeout():                    # a hung collective must not cost the headline line (watchdog thread:
+            if rank == 0:                    # works while the main thread is blocked inside a C call)
+                line["train"] = {"error": "timeout after %d s" % args.train_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.train_timeout, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             train = train_bench(dev, rank, world, args.train_steps, 1, args.train_batch)
         except Exception as e:               # never lose the headline line to the secondary measurement
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        watchdog.cancel()
     if rank == 0:
         if train is not None:
             line["train"] = train
