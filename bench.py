@@ -204,7 +204,7 @@ def train_bench(dev, rank, world, steps, warmup, batch):
     vals = [float(v) for v in losses]
     return {"value": round(steps * batch * world / elapsed, 3), "unit": "training videos/s (40 frames, 128x128)",
             "ms_per_step": round(1e3 * elapsed / steps, 1), "batch_per_gpu": batch, "global_batch": batch * world,
-            "steps": steps, "warmup": warmup, "grad_allreduce": "rccl bucketed, overlapped with backward" if world > 1 else "none (1 GPU)",
+            "steps": steps, "warmup": warmup, "grad_allreduce": ("%s, bucketed, overlapped with backward" % __import__("torch.distributed").distributed.get_backend()) if world > 1 else "none (1 GPU)",
             "loss_first": round(vals[0], 5), "loss_last": round(vals[-1], 5),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 

@@ -16,12 +16,14 @@ def big(dev):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,res", [(8, 12, 3, 1, 6), (68, 72, 3, 1, 5), (132, 8, 1, 1, 4),
-                                                   (8, 8, 4, 2, 8), (4, 64, 7, 1, 8)])
+                                                   (8, 8, 4, 2, 8), (4, 64, 7, 1, 8), (36, 20, 3, 1, 3)])
 def test_conv_wgrad(backend, cin, cout, k, stride, res):
     dev = backend
     n = 3
     if big(dev):
-        cin, cout, res, n = {8: (64, 64), 68: (256, 128), 132: (512, 768), 4: (4, 64)}[cin] + (16, 10)
+        cin, cout, res, n = {8: (64, 64), 68: (256, 128), 132: (512, 768), 4: (4, 64), 36: (36, 20)}[cin] + (16, 10)
+        if cin == 36:
+            res, n = 3, 1                     # M = 9 rows: less than one 32-row chunk
         if k == 4:
             cin, cout = 128, 128
     pad = {3: 1, 1: 0, 4: 1, 7: 3}[k]
@@ -40,12 +42,14 @@ def test_conv_wgrad(backend, cin, cout, k, stride, res):
     assert_close(db.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias grad")
 
 
-@pytest.mark.parametrize("c,with_ss,silu", [(32, True, True), (64, False, True), (32, False, False)])
+@pytest.mark.parametrize("c,with_ss,silu", [(32, True, True), (64, False, True), (32, False, False), (512, True, True)])
 def test_groupnorm_bwd(backend, c, with_ss, silu):
     dev = backend
     b, t, s = 2, 3, 4
     if big(dev):
-        b, t, s, c = 2, 40, 16, {32: 128, 64: 512}[c]
+        b, t, s, c = 2, 40, 16, {32: 128, 64: 512, 512: 1024}[c]
+    elif c == 512:
+        b, t, s = 1, 1, 3                     # 9 pixels: fewer than one statistics chunk, widest supported rows
     x = rnd(b, c, t, s, s, seed=1).requires_grad_(True)
     gamma = (1 + 0.2 * rnd(c, seed=2)).requires_grad_(True)
     beta = (0.1 * rnd(c, seed=3)).requires_grad_(True)
@@ -74,12 +78,12 @@ def test_groupnorm_bwd(backend, c, with_ss, silu):
         assert_close(dss.cpu() / sc, ss.grad / sc, TOL, "gn dscale_shift")
 
 
-@pytest.mark.parametrize("c", [32, 72])
+@pytest.mark.parametrize("c", [32, 72, 1024])
 def test_layernorm_bwd(backend, c):
     dev = backend
-    rows = 37
+    rows = 37 if c != 1024 else 5
     if big(dev):
-        rows, c = 40 * 1024 + 3, {32: 64, 72: 512}[c]
+        rows, c = 40 * 1024 + 3, {32: 64, 72: 512, 1024: 1024}[c]
     x = rnd(rows, c, seed=1).requires_grad_(True)
     gamma = (1 + 0.2 * rnd(c, seed=2)).requires_grad_(True)
     mean = x.mean(dim=1, keepdim=True)
@@ -110,13 +114,13 @@ def _attention_ref(qkv_tokens, bias, rotary):
     return out.transpose(-2, -3).reshape(*qkv_tokens.shape[:-1], 256)
 
 
-@pytest.mark.parametrize("frames", [4, 40])
+@pytest.mark.parametrize("frames", [4, 40, 64])
 def test_attention_temporal_bwd(backend, frames):
     import lfdm_oracle as O
     dev = backend
     b, s = (1, 16) if (big(dev) and frames == 40) else (2, 2)
-    if not big(dev) and frames == 40:
-        b, s = 1, 3                      # 9 sequences x 8 heads: more units than one grid stride is not needed
+    if not big(dev) and frames >= 40:
+        b, s = 1, (3 if frames == 40 else 1)     # few sequences under the emulator; 64 frames = the 2-wave LP=64 variant
     hw = s * s
     qkv = rnd(b, frames, hw, 768, seed=1).requires_grad_(True)
     emb = rnd(32, 8, seed=2)
