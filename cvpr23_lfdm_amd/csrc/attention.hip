@@ -10,6 +10,7 @@
 // 2. lfdm_linear_attention_cl_f32 - SpatialLinearAttention core (:256-263): k-softmax over
 //    tokens + context = k v^T (two-pass column reduction), then q-softmax over the 32-dim axis
 //    and out = context^T q.
+#include <stdlib.h>
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -20,33 +21,31 @@ constexpr int DH = 32;
 constexpr int QKV_LD = 3 * HEADS * DH;  // 768
 constexpr int OUT_LD = HEADS * DH;      // 256
 
-constexpr int SQ = 34;  // LDS row stride of Q and K
-constexpr int SV = 36;  // LDS row stride of V
-
+// One wavefront (= one 64-thread workgroup) per (sequence, head).  Nothing but P goes through LDS:
+//  * the sum over the 32 head features is order independent, so MFMA k-slot `lq` of step s is given feature
+//    k = 8*lq + s for BOTH operands: a lane's Q (and K) fragment for a 16-token tile is then 8 CONSECUTIVE floats of one
+//    row = two 16-byte global loads straight into the MFMA operand registers (16 rows x 128 B per tile, fully
+//    coalesced), with scale and rotary applied in registers (a rotation pair never leaves the lane);
+//  * V is consumed as the B operand of P*V in its natural row layout (lane = feature, k-slot = token (LP/4)*lq + s):
+//    24 scalar loads per lane, each element read exactly once;
+//  * only P changes layout (D fragment -> A fragment) and takes one trip through LDS, read back as float4.
+// The first version staged Q, K, V in LDS (20 KB per wave, 8 waves per CU, 60 % of the wave cycles in s_waitcnt).
 template <int LP>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
-                                                        float* __restrict__ out, int batch,
-                                                        int frames, int hw, int mode,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ rot_cos,
-                                                        const float* __restrict__ rot_sin) {
+__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int batch,
+                                                       int frames, int hw, int mode, const float* __restrict__ bias,
+                                                       const float* __restrict__ rot_cos,
+                                                       const float* __restrict__ rot_sin) {
   constexpr int NT = LP / 16;
-  constexpr int SP = LP + 2;                       // LDS row stride of P (aliases Q|K)
-  constexpr int PER_WAVE = LP * (SQ + SQ + SV);
-  __shared__ __attribute__((aligned(16))) float smem[4 * PER_WAVE];
+  constexpr int KS = LP / 4;                       // tokens per MFMA k-slot in P*V
+  constexpr int SP = LP + 4;                       // LDS row stride of P (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) float Ps[LP * SP];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* Qs = smem + wave * PER_WAVE;
-  float* Ks = Qs + LP * SQ;
-  float* Vs = Ks + LP * SQ;
-  float* Ps = Qs;
-
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lq = lane >> 4;
   const int L = mode == 0 ? frames : hw;
-  const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
-  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
-  const bool valid = unit < nseq * HEADS;
-  const int64_t seq = valid ? unit / HEADS : 0;
-  const int head = valid ? (int)(unit - seq * HEADS) : 0;
+  const int64_t unit = blockIdx.x;
+  const int64_t seq = unit / HEADS;
+  const int head = (int)(unit - seq * HEADS);
   int64_t row0, tstride;
   if (mode == 0) {
     const int64_t b = seq / hw, pix = seq - b * hw;
@@ -57,51 +56,58 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     tstride = 1;
   }
   const float scale = 0.17677669529663687f;  // 32^-0.5
+  const float* base = qkv + head * DH;
 
-  // ---- stage Q, K, V (8 lanes x float4 per 32-float row) ----
-  // All global loads of the wave are issued before the first use (LP/8 x 3 independent float4 per lane):
-  // with the loads inside the rotary / LDS-store loop the kernel was bound by 6 serial memory latencies.
-  {
-    constexpr int NR = LP / 8;
-    const int rr = lane >> 3, c4 = lane & 7;
-    float4 qv[NR], kv[NR], vv[NR];
+  // ---- Q / K fragments: token tile*16 + l15, features 8*lq .. 8*lq+7 ----
+  float qf[NT][8], kf[NT][8];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int t = rr + 8 * i;
-      qv[i] = kv[i] = vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (valid && t < L) {
-        const float* base = qkv + (row0 + (int64_t)t * tstride) * QKV_LD + head * DH + 4 * c4;
-        qv[i] = *reinterpret_cast<const float4*>(base);
-        kv[i] = *reinterpret_cast<const float4*>(base + OUT_LD);
-        vv[i] = *reinterpret_cast<const float4*>(base + 2 * OUT_LD);
-      }
+  for (int ti = 0; ti < NT; ++ti) {
+    const int t = ti * 16 + l15;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, k0 = q0, k1 = q0;
+    if (t < L) {
+      const float* src = base + (row0 + (int64_t)t * tstride) * QKV_LD + 8 * lq;
+      q0 = *reinterpret_cast<const float4*>(src);
+      q1 = *reinterpret_cast<const float4*>(src + 4);
+      k0 = *reinterpret_cast<const float4*>(src + OUT_LD);
+      k1 = *reinterpret_cast<const float4*>(src + OUT_LD + 4);
     }
+    qf[ti][0] = q0.x * scale; qf[ti][1] = q0.y * scale; qf[ti][2] = q0.z * scale; qf[ti][3] = q0.w * scale;
+    qf[ti][4] = q1.x * scale; qf[ti][5] = q1.y * scale; qf[ti][6] = q1.z * scale; qf[ti][7] = q1.w * scale;
+    kf[ti][0] = k0.x; kf[ti][1] = k0.y; kf[ti][2] = k0.z; kf[ti][3] = k0.w;
+    kf[ti][4] = k1.x; kf[ti][5] = k1.y; kf[ti][6] = k1.z; kf[ti][7] = k1.w;
+  }
+  // ---- V fragments (issued now, used after the softmax): token KS*lq + s, features l15 and 16 + l15 ----
+  float vf[2][KS];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int t = rr + 8 * i;
-      float4 q = qv[i], k = kv[i];
-      q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
-      if (rot_cos && t < L) {
-        const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
-        const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
-        float4 qr, kr;
-        qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
-        qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
-        kr.x = k.x * c0 - k.y * s0; kr.y = k.y * c0 + k.x * s0;
-        kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
-        q = qr; k = kr;
-      }
-      float* dq = Qs + t * SQ + 4 * c4;
-      dq[0] = q.x; dq[1] = q.y; dq[2] = q.z; dq[3] = q.w;
-      float* dk = Ks + t * SQ + 4 * c4;
-      dk[0] = k.x; dk[1] = k.y; dk[2] = k.z; dk[3] = k.w;
-      *reinterpret_cast<float4*>(Vs + t * SV + 4 * c4) = vv[i];
+  for (int s = 0; s < KS; ++s) {
+    const int t = KS * lq + s;
+    vf[0][s] = vf[1][s] = 0.f;
+    if (t < L) {
+      const float* src = base + (row0 + (int64_t)t * tstride) * QKV_LD + 2 * OUT_LD;
+      vf[0][s] = src[l15];
+      vf[1][s] = src[16 + l15];
     }
   }
-  __syncthreads();
+  if (rot_cos) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int t = ti * 16 + l15;
+      if (t < L) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const float c = rot_cos[t * 16 + 4 * lq + pr], sn = rot_sin[t * 16 + 4 * lq + pr];
+          const float qx = qf[ti][2 * pr], qy = qf[ti][2 * pr + 1];
+          const float kx = kf[ti][2 * pr], ky = kf[ti][2 * pr + 1];
+          qf[ti][2 * pr] = qx * c - qy * sn;
+          qf[ti][2 * pr + 1] = qy * c + qx * sn;
+          kf[ti][2 * pr] = kx * c - ky * sn;
+          kf[ti][2 * pr + 1] = ky * c + kx * sn;
+        }
+      }
+    }
+  }
 
-  // ---- S = Q K^T (16x16 tiles, K = 32 in 8 steps of 4) ----
-  const int l15 = lane & 15, lq = lane >> 4;
+  // ---- S = Q K^T ----
   f32x4 s_acc[NT][NT];
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti)
@@ -109,14 +115,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int tj = 0; tj < NT; ++tj) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < DH / 4; ++s) {
-        const float a = Qs[(ti * 16 + l15) * SQ + 4 * s + lq];
-        const float b = Ks[(tj * 16 + l15) * SQ + 4 * s + lq];
-        acc = mfma_16x16x4(a, b, acc);
-      }
+      for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(qf[ti][s], kf[tj][s], acc);
       s_acc[ti][tj] = acc;
     }
-  __syncthreads();  // all lanes done reading Q/K before P overwrites them
 
   // ---- bias, mask, softmax over columns; write P to LDS ----
 #pragma unroll
@@ -158,18 +159,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     f32x4 o[2];
     o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o[1] = o[0];
+    float pa[KS];
 #pragma unroll
-    for (int s = 0; s < LP / 4; ++s) {
-      const float a = Ps[(ti * 16 + l15) * SP + 4 * s + lq];
-      const float b0 = Vs[(4 * s + lq) * SV + l15];
-      const float b1 = Vs[(4 * s + lq) * SV + 16 + l15];
-      o[0] = mfma_16x16x4(a, b0, o[0]);
-      o[1] = mfma_16x16x4(a, b1, o[1]);
+    for (int q4 = 0; q4 < KS / 4; ++q4) {
+      const float4 pv = *reinterpret_cast<const float4*>(Ps + (ti * 16 + l15) * SP + KS * lq + 4 * q4);
+      pa[4 * q4] = pv.x; pa[4 * q4 + 1] = pv.y; pa[4 * q4 + 2] = pv.z; pa[4 * q4 + 3] = pv.w;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      o[0] = mfma_16x16x4(pa[s], vf[0][s], o[0]);
+      o[1] = mfma_16x16x4(pa[s], vf[1][s], o[1]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = ti * 16 + lq * 4 + r;
-      if (valid && t < L) {
+      if (t < L) {
         float* dst = out + (row0 + (int64_t)t * tstride) * OUT_LD + head * DH;
         dst[l15] = o[0][r];
         dst[16 + l15] = o[1][r];
@@ -337,7 +341,7 @@ extern "C" int lfdm_attention_cl_f32(const float* qkv, float* out, int batch, in
   }
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
   const int64_t units = nseq * HEADS;
-  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+  const dim3 grid((unsigned)units), block(64);
   if (L <= 16) LFDM_LAUNCH((attention_kernel<16>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
   else if (L <= 32) LFDM_LAUNCH((attention_kernel<32>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);
   else if (L <= 48) LFDM_LAUNCH((attention_kernel<48>), grid, block, 0, stream, qkv, out, batch, frames, hw, mode, bias, rot_cos, rot_sin);

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Temporal attention / linear attention kernels at the C2 shapes (B=1, T=40): us per call and effective GB/s."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvpr23_lfdm_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+t = 40
+ang = torch.arange(t, device="cuda").float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2, device="cuda").float() / 32)))[None]
+cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+bias = torch.randn(8, t, t, device="cuda")
+for s in (32, 16, 8, 4):
+    rows = t * s * s
+    qkv = torch.randn(rows, 768, device="cuda")
+    out = torch.empty(rows, 256, device="cuda")
+    us = timeit(lambda: ops.attention_cl(qkv, 1, t, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
+    ws = torch.empty(t * 8 * 32 * 32, device="cuda")
+    us2 = timeit(lambda: ops.linear_attention_cl(qkv, t, s * s, out=out, ws=ws))
+    mb = rows * 1024 * 4 / 1e6
+    print("res %2d: temporal attention %7.1f us (%5.0f GB/s)   linear attention %7.1f us" % (s, us, mb / us * 1e3 / 1e3 * 1e3 / 1e3, us2))
