@@ -156,11 +156,12 @@ def test_conv_fused_groupnorm_stats(backend, ksplit):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
 
 
-@pytest.mark.parametrize("c", [64, 512])
+@pytest.mark.parametrize("c", [64, 128, 512])
 def test_conv_fused_layernorm(backend, c):
-    """PreNorm (channel LayerNorm) folded into the 1x1 qkv projection."""
+    """PreNorm (channel LayerNorm) folded into the 1x1 qkv projection (c <= 128: row-panel schedule, ragged last
+    panel; c = 512: tiled schedule)."""
     dev = backend
-    b, t, s = (1, 40, 32) if (big(dev) and c == 64) else (2, 3, 4)
+    b, t, s = (1, 40, 32) if (big(dev) and c == 64) else ((1, 40, 16) if (big(dev) and c == 128) else (2, 6, 4))
     x = rnd(b, c, t, s, s, seed=1) * 2 + 0.7
     gamma = rnd(1, c, 1, 1, 1, seed=2) * 0.3 + 1
     w = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
