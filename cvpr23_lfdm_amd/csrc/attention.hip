@@ -26,19 +26,17 @@ constexpr int OUT_LD = HEADS * DH;      // 256
 //    k = 8*lq + s for BOTH operands: a lane's Q (and K) fragment for a 16-token tile is then 8 CONSECUTIVE floats of one
 //    row = two 16-byte global loads straight into the MFMA operand registers (16 rows x 128 B per tile, fully
 //    coalesced), with scale and rotary applied in registers (a rotation pair never leaves the lane);
-//  * V is consumed as the B operand of P*V in its natural row layout (lane = feature, k-slot = token (LP/4)*lq + s):
-//    24 scalar loads per lane, each element read exactly once;
-//  * only P changes layout (D fragment -> A fragment) and takes one trip through LDS, read back as float4.
-// The first version staged Q, K, V in LDS (20 KB per wave, 8 waves per CU, 60 % of the wave cycles in s_waitcnt).
+//  * V is consumed as the B operand of P*V in its natural row layout (lane = feature, k-slot = tokens 16*t + 4*lq + r):
+//    scalar loads, each element read exactly once;
+//  * the scores are computed transposed (S^T = K Q^T), which makes the softmax a register reduction + two shuffles and
+//    leaves P^T directly in the A-operand layout of P V: NO LDS and no barrier anywhere in the kernel.
+// The first version staged Q, K, V and P in LDS (20 KB per wave, 8 waves per CU, 60 % of the wave cycles in s_waitcnt).
 template <int LP>
 __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int batch,
                                                        int frames, int hw, int mode, const float* __restrict__ bias,
                                                        const float* __restrict__ rot_cos,
                                                        const float* __restrict__ rot_sin) {
   constexpr int NT = LP / 16;
-  constexpr int KS = LP / 4;                       // tokens per MFMA k-slot in P*V
-  constexpr int SP = LP + 4;                       // LDS row stride of P (16-byte aligned rows)
-  __shared__ __attribute__((aligned(16))) float Ps[LP * SP];
 
   const int lane = threadIdx.x & 63;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -76,18 +74,21 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
     kf[ti][0] = k0.x; kf[ti][1] = k0.y; kf[ti][2] = k0.z; kf[ti][3] = k0.w;
     kf[ti][4] = k1.x; kf[ti][5] = k1.y; kf[ti][6] = k1.z; kf[ti][7] = k1.w;
   }
-  // ---- V fragments (issued now, used after the softmax): token KS*lq + s, features l15 and 16 + l15 ----
-  float vf[2][KS];
+  // ---- V fragments (issued now, used after the softmax): vf[half][4*tj + r] = v[token 16*tj + 4*lq + r][16*half + l15]
+  // = the B operand of P V for the token order t(lq, s) = 16*(s>>2) + 4*lq + (s&3) ----
+  float vf[2][4 * NT];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int t = KS * lq + s;
-    vf[0][s] = vf[1][s] = 0.f;
-    if (t < L) {
-      const float* src = base + (row0 + (int64_t)t * tstride) * QKV_LD + 2 * OUT_LD;
-      vf[0][s] = src[l15];
-      vf[1][s] = src[16 + l15];
+  for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 16 * tj + 4 * lq + r;
+      vf[0][4 * tj + r] = vf[1][4 * tj + r] = 0.f;
+      if (t < L) {
+        const float* src = base + (row0 + (int64_t)t * tstride) * QKV_LD + 2 * OUT_LD;
+        vf[0][4 * tj + r] = src[l15];
+        vf[1][4 * tj + r] = src[16 + l15];
+      }
     }
-  }
   if (rot_cos) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
@@ -107,51 +108,65 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
     }
   }
 
-  // ---- S = Q K^T ----
-  f32x4 s_acc[NT][NT];
+  // ---- S^T = K Q^T: lane = query token 16*ti + l15, registers = key tokens 16*tj + 4*lq + r.  The softmax over the keys
+  // of a query is then a reduction over the lane's registers plus two shuffles (the four k-slots), and the result is
+  // already the A operand of P V in the token order above: the scores never touch LDS. ----
+  f32x4 st[NT][NT];
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(qf[ti][s], kf[tj][s], acc);
-      s_acc[ti][tj] = acc;
+      for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(kf[tj][s], qf[ti][s], acc);
+      st[ti][tj] = acc;
     }
-
-  // ---- bias, mask, softmax over columns; write P to LDS ----
+  const bool bias_vec = bias && (L % 4 == 0) && ((((uintptr_t)bias) & 15) == 0);
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
+    const int qt = ti * 16 + l15;
+    float m = -3.0e38f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ti * 16 + lq * 4 + r;
-      float m = -3.0e38f;
+    for (int tj = 0; tj < NT; ++tj) {
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      const int key0 = tj * 16 + lq * 4;
+      if (bias && qt < L && key0 < L) {
+        const float* bp = bias + ((int64_t)head * L + qt) * L + key0;
+        if (bias_vec) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bp);
+          bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+        } else {
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const int col = tj * 16 + l15;
-        float v = s_acc[ti][tj][r];
-        if (col >= L) v = -3.0e38f;
-        else if (bias && row < L) v += bias[((int64_t)head * L + row) * L + col];
-        s_acc[ti][tj][r] = v;
+          for (int r = 0; r < 4; ++r) bv[r] = (key0 + r < L) ? bp[r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = st[ti][tj][r];
+        if (key0 + r >= L) v = -3.0e38f;
+        else v += bv[r];
+        st[ti][tj][r] = v;
         m = fmaxf(m, v);
       }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
 #pragma unroll
-      for (int x = 1; x < 16; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
-      float sum = 0.f;
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const int col = tj * 16 + l15;
-        const float e = col < L ? expf(s_acc[ti][tj][r] - m) : 0.f;
-        s_acc[ti][tj][r] = e;
+      for (int r = 0; r < 4; ++r) {
+        const float e = (tj * 16 + lq * 4 + r) < L ? expf(st[ti][tj][r] - m) : 0.f;
+        st[ti][tj][r] = e;
         sum += e;
       }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
 #pragma unroll
-      for (int x = 1; x < 16; x <<= 1) sum += __shfl_xor(sum, x);
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) Ps[row * SP + tj * 16 + l15] = s_acc[ti][tj][r] / sum;
-    }
+      for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] / sum;
   }
-  __syncthreads();
 
   // ---- O = P V ----
 #pragma unroll
@@ -159,17 +174,13 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
     f32x4 o[2];
     o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o[1] = o[0];
-    float pa[KS];
 #pragma unroll
-    for (int q4 = 0; q4 < KS / 4; ++q4) {
-      const float4 pv = *reinterpret_cast<const float4*>(Ps + (ti * 16 + l15) * SP + KS * lq + 4 * q4);
-      pa[4 * q4] = pv.x; pa[4 * q4 + 1] = pv.y; pa[4 * q4 + 2] = pv.z; pa[4 * q4 + 3] = pv.w;
-    }
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      o[0] = mfma_16x16x4(pa[s], vf[0][s], o[0]);
-      o[1] = mfma_16x16x4(pa[s], vf[1][s], o[1]);
-    }
+      for (int r = 0; r < 4; ++r) {
+        o[0] = mfma_16x16x4(st[ti][tj][r], vf[0][4 * tj + r], o[0]);
+        o[1] = mfma_16x16x4(st[ti][tj][r], vf[1][4 * tj + r], o[1]);
+      }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = ti * 16 + lq * 4 + r;

@@ -1,0 +1,297 @@
+// PreNorm LayerNorm + to_qkv + temporal attention in ONE kernel (include/lfdm_hip.h:
+// lfdm_temporal_attention_fused_cl_f32) for the two finest UNet levels (C = 64, 128):
+// Residual(PreNorm(EinopsToAndFrom(Attention))) without its to_out projection,
+// DM/modules/video_flow_diffusion.py:170-189,270-283,303-363.
+//
+// Why: at C = 64 the separate kernels are bound by the 126 MB qkv tensor - the projection takes 66 us to WRITE
+// it (the GEMM itself is 26 us of MFMA) and the attention kernel 70 us to read it back.  Here qkv never exists.
+// One wavefront owns one pixel's sequence (T <= 64 tokens) and walks over the 8 heads:
+//  * the sequence's rows of x (T x C) are loaded ONCE, straight into MFMA operand registers: lane (token l&15,
+//    k-slot l>>4) holds the C/4 consecutive channels (C/4)*slot .. of its token = float4 loads; the channel
+//    LayerNorm statistics are two shuffles (the four slots of a token) and the rows are normalised in registers
+//    (gamma is folded into the weights by the host);
+//  * Q^T and K^T are computed TRANSPOSED (features x tokens = W_h . x^T): the accumulator layout of
+//    v_mfma_f32_16x16x4 then has lane = token, registers = features 16*f + 4*slot + r, which IS a legal
+//    operand layout for S = Q K^T (any feature order works if Q and K agree) - no layout change, scale and
+//    rotary are applied on the accumulators (a rotation pair stays inside a lane);
+//  * V = x W_v^T is computed untransposed: lane = feature, registers = tokens 16*t + 4*slot + r, exactly the
+//    B operand of P V with the token order t(slot, s) = 16*(s>>2) + 4*slot + (s&3);
+//  * the scores are computed TRANSPOSED too (S^T = K Q^T): lane = query token, registers = key tokens, so the softmax
+//    over the keys is a register reduction + two shuffles and P^T is already the A operand of P V: no LDS at all.
+// Weight fragments (rows of W, contiguous over channels) come from L2 as float4.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int OUT_LD = HEADS * DH;      // 256
+
+template <int LP, int C>
+__global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float* __restrict__ x, int ldx, int heads_per_block,
+                                                                 const float* __restrict__ wqkv,   // (768, C), gamma folded
+                                                                 float* __restrict__ out, int batch, int frames, int hw,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ rot_cos,
+                                                                 const float* __restrict__ rot_sin, float eps) {
+  constexpr int NT = LP / 16;
+  constexpr int CQ = C / 4;                        // channels per k-slot
+
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int L = frames;
+  const int64_t seq = blockIdx.x;
+  const int64_t b = seq / hw, pix = seq - b * hw;
+  const int64_t row0 = b * frames * hw + pix;
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+
+  // ---- the sequence's rows, normalised, as MFMA fragments: xf[ti][s] = xhat[token 16*ti + l15][CQ*lq + s] ----
+  float xf[NT][CQ];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int t = ti * 16 + l15;
+    float s1 = 0.f, s2 = 0.f;
+    if (t < L) {
+      const float* src = x + (row0 + (int64_t)t * hw) * ldx + CQ * lq;
+#pragma unroll
+      for (int q = 0; q < CQ / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+        xf[ti][4 * q] = v.x; xf[ti][4 * q + 1] = v.y; xf[ti][4 * q + 2] = v.z; xf[ti][4 * q + 3] = v.w;
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < CQ; ++s) xf[ti][s] = 0.f;
+    }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float mean = s1 * (1.0f / (float)C);
+    float var = s2 * (1.0f / (float)C) - mean * mean;
+    if (var < 0.f) var = 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (t < L) {
+#pragma unroll
+      for (int s = 0; s < CQ; ++s) xf[ti][s] = (xf[ti][s] - mean) * rstd;
+    }
+  }
+
+  // rotary factors of this lane's tokens / feature pairs (head independent)
+  float rc[NT][4], rs[NT][4];
+  if (rot_cos) {
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int t = ti * 16 + l15;
+      const int tt = t < L ? t : 0;
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          rc[ti][2 * fi + pr] = rot_cos[tt * 16 + 8 * fi + 2 * lq + pr];
+          rs[ti][2 * fi + pr] = rot_sin[tt * 16 + 8 * fi + 2 * lq + pr];
+        }
+    }
+  }
+  const bool bias_vec = bias && (L % 4 == 0) && ((((uintptr_t)bias) & 15) == 0);
+
+  // grid.y splits the 8 heads over workgroups when there are few sequences (x is re-read per workgroup: 10-20 KB)
+  const int head_begin = blockIdx.y * heads_per_block;
+#pragma unroll 1
+  for (int head = head_begin; head < head_begin + heads_per_block; ++head) {
+    // ---- Q^T, K^T: rows = features (2 tiles of 16), cols = tokens (NT tiles) ----
+    float qf[NT][8], kf[NT][8];
+    {
+      // four weight-row fragments (q/k x two feature tiles), all loads issued before the first MFMA; the NT token
+      // tiles of a fragment are independent accumulator chains and are interleaved step by step
+      float wa[4][CQ];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* wsrc = wqkv + ((int64_t)((g >> 1) * OUT_LD + head * DH + 16 * (g & 1) + l15)) * C + CQ * lq;
+#pragma unroll
+        for (int q = 0; q < CQ / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + 4 * q);
+          wa[g][4 * q] = v.x; wa[g][4 * q + 1] = v.y; wa[g][4 * q + 2] = v.z; wa[g][4 * q + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CQ; ++s)
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) acc[ti] = mfma_16x16x4(wa[g][s], xf[ti][s], acc[ti]);
+        // lane: token 16*ti + l15; acc[ti][r] = feature 16*fi + 4*lq + r
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if ((g >> 1) == 0) qf[ti][4 * (g & 1) + r] = acc[ti][r] * scale;
+            else kf[ti][4 * (g & 1) + r] = acc[ti][r];
+          }
+      }
+    }
+    if (rot_cos) {
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const float c = rc[ti][2 * fi + pr], sn = rs[ti][2 * fi + pr];   // pair of features 16*fi + 4*lq + 2*pr (+1)
+            const float qx = qf[ti][4 * fi + 2 * pr], qy = qf[ti][4 * fi + 2 * pr + 1];
+            const float kx = kf[ti][4 * fi + 2 * pr], ky = kf[ti][4 * fi + 2 * pr + 1];
+            qf[ti][4 * fi + 2 * pr] = qx * c - qy * sn;
+            qf[ti][4 * fi + 2 * pr + 1] = qy * c + qx * sn;
+            kf[ti][4 * fi + 2 * pr] = kx * c - ky * sn;
+            kf[ti][4 * fi + 2 * pr + 1] = ky * c + kx * sn;
+          }
+      }
+    }
+    // ---- S^T = K Q^T: lane = query token 16*ti + l15, registers = key tokens 16*tj + 4*lq + r.  In this orientation the
+    // softmax over the keys of a query is a reduction over the lane's registers plus two shuffles (the four k-slots),
+    // and the result is ALREADY the A operand of P V for the token order t(lq, s) = 16*(s>>2) + 4*lq + (s&3): no LDS. ----
+    f32x4 st[NT][NT];                                   // [ti (query tile)][tj (key tile)]
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(kf[tj][s], qf[ti][s], acc);
+        st[ti][tj] = acc;
+      }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int qt = ti * 16 + l15;                     // this lane's query token
+      float m = -3.0e38f;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        const int key0 = tj * 16 + lq * 4;
+        if (bias && qt < L && key0 < L) {
+          const float* bp = bias + ((int64_t)head * L + qt) * L + key0;
+          if (bias_vec) {                                 // four consecutive keys of one query row: one 16-byte load
+            const float4 b4 = *reinterpret_cast<const float4*>(bp);
+            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (key0 + r < L) ? bp[r] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = st[ti][tj][r];
+          if (key0 + r >= L) v = -3.0e38f;
+          else v += bv[r];
+          st[ti][tj][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = tj * 16 + lq * 4 + r;
+          const float e = key < L ? expf(st[ti][tj][r] - m) : 0.f;
+          st[ti][tj][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] / sum;
+    }
+
+    // ---- V: rows = tokens, cols = features; vf[half][4*ti + r] = v[token 16*ti + 4*lq + r][16*half + l15] ----
+    float vf[2][4 * NT];
+    {
+      float wb[2][CQ];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const float* wsrc = wqkv + ((int64_t)(2 * OUT_LD + head * DH + 16 * half + l15)) * C + CQ * lq;
+#pragma unroll
+        for (int q = 0; q < CQ / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + 4 * q);
+          wb[half][4 * q] = v.x; wb[half][4 * q + 1] = v.y; wb[half][4 * q + 2] = v.z; wb[half][4 * q + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CQ; ++s)
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti) acc[ti] = mfma_16x16x4(xf[ti][s], wb[half][s], acc[ti]);
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vf[half][4 * ti + r] = acc[ti][r];
+      }
+    }
+
+    // ---- O = P V ----
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      f32x4 o[2];
+      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      o[1] = o[0];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[0] = mfma_16x16x4(st[ti][tj][r], vf[0][4 * tj + r], o[0]);
+          o[1] = mfma_16x16x4(st[ti][tj][r], vf[1][4 * tj + r], o[1]);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = ti * 16 + lq * 4 + r;
+        if (t < L) {
+          float* dst = out + (row0 + (int64_t)t * hw) * OUT_LD + head * DH;
+          dst[l15] = o[0][r];
+          dst[16 + l15] = o[1][r];
+        }
+      }
+    }
+  }
+}
+
+template <int C>
+int launch_fused(const float* x, int ldx, const float* wqkv, float* out, int batch, int frames, int hw, const float* bias,
+                 const float* rot_cos, const float* rot_sin, float eps, hipStream_t stream) {
+  const int64_t nseq = (int64_t)batch * hw;
+  int hpb = 8;                                       // heads per workgroup: aim at >= 2048 workgroups
+  while (hpb > 1 && nseq * (HEADS / hpb) < 2048) hpb >>= 1;
+  const dim3 grid((unsigned)nseq, (unsigned)(HEADS / hpb)), block(64);
+  if (frames <= 16) LFDM_LAUNCH((temporal_attn_fused_kernel<16, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (frames <= 32) LFDM_LAUNCH((temporal_attn_fused_kernel<32, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (frames <= 48) LFDM_LAUNCH((temporal_attn_fused_kernel<48, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else LFDM_LAUNCH((temporal_attn_fused_kernel<64, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  return lfdm_check_launch("temporal_attention_fused");
+}
+
+}  // namespace
+
+extern "C" int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
+                                                    int batch, int frames, int hw, const float* bias,
+                                                    const float* rot_cos, const float* rot_sin, float ln_eps,
+                                                    lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wqkv || !out || batch <= 0 || frames <= 0 || frames > 64 || hw <= 0 || ldx < channels || ldx % 4 != 0 ||
+      (((uintptr_t)x | (uintptr_t)wqkv) & 15) || ((rot_cos == nullptr) != (rot_sin == nullptr)) ||
+      (channels != 64 && channels != 128)) {
+    lfdm_set_error("temporal_attention_fused: needs C in {64, 128}, frames <= 64, 16-byte aligned rows");
+    return LFDM_EINVAL;
+  }
+  if (channels == 64) return launch_fused<64>(x, ldx, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  return launch_fused<128>(x, ldx, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+}

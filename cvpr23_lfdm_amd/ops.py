@@ -252,6 +252,20 @@ def attention_cl(qkv, batch, frames, hw, mode, *, bias=None, rot_cos=None, rot_s
     return out
 
 
+def temporal_attention_fused_cl(x, wqkv, batch, frames, hw, *, bias=None, rot_cos=None, rot_sin=None, eps=1e-5, out=None):
+    """LayerNorm + to_qkv + temporal attention in one launch (C in {64, 128}); wqkv (768, C) with gamma folded."""
+    lib = _lib()
+    _chk(lib, x, wqkv, bias, rot_cos, rot_sin, out)
+    c = x.shape[1]
+    assert wqkv.shape == (768, c) and wqkv.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape[0], 256, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_temporal_attention_fused_cl_f32(_p(x), x.stride(0), c, _p(wqkv), _p(out), batch, frames, hw, _p(bias),
+                                                       _p(rot_cos), _p(rot_sin), eps, _stream(lib)),
+              "lfdm_temporal_attention_fused_cl_f32")
+    return out
+
+
 def linear_attention_cl(qkv, n_frames, hw, *, out=None, ws=None):
     lib = _lib()
     _chk(lib, qkv, out, ws)

@@ -143,8 +143,10 @@ class Unet3D(ParamTree):
                 off += w.shape[0]
 
         def temporal(prefix):
-            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(
-                g(prefix + "fn.fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma"))
+            wq, gam = g(prefix + "fn.fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma")
+            if wq.shape[1] == 64:      # finest level: LayerNorm + to_qkv + attention run as ONE kernel, qkv never materialised
+                pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
+            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
 
         def spatial_linear(prefix):
@@ -299,9 +301,14 @@ class Unet3D(ParamTree):
         return qkv, self._buf("at.o", rows, 256)
 
     def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables):
-        qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
         bias, cos, sin = tables
-        ops.attention_cl(qkv, batch, frames, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=att)
+        if (prefix + "qkv.wf") in pk and frames <= 64:
+            att = self._buf("at.o", x.shape[0], 256)
+            ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
+                                            rot_sin=sin, out=att)
+        else:
+            qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
+            ops.attention_cl(qkv, batch, frames, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=att)
         out = self._buf(outname, x.shape[0], c)
         return self._conv(att, pk[prefix + "out.w"], c, 1, batch * frames, s, residual=x, out=out)
 

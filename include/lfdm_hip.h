@@ -257,6 +257,16 @@ int lfdm_planar_to_cl_f32(const float* x, float* out, int n_img, int channels, i
 int lfdm_cl_to_planar_f32(const float* x, float* out, int n_img, int channels, int hw, int ldx,
                           lfdm_stream_t stream);
 
+/* PreNorm LayerNorm + to_qkv + temporal Attention (without to_out) in one launch, for C in {64, 128}:
+ * video_flow_diffusion.py:170-189 (LayerNorm, PreNorm), :270-283 (einops re-layout), :303-361 (Attention incl.
+ * rotary :329-331 and relative position bias :339-340).  x: CL rows (B*T*HW, C) stride ldx; wqkv: the to_qkv weight
+ * (768, C) row-major with the LayerNorm gamma folded in (w[n][c] * gamma[c]); out: rows of 256 (heads merged).
+ * The 768-wide qkv tensor is never materialised. */
+int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
+                                         int batch, int frames, int hw, const float* bias,
+                                         const float* rot_cos, const float* rot_sin, float ln_eps,
+                                         lfdm_stream_t stream);
+
 /* ==========================================================================================
  * TRAINING (backward) kernels - the DM gradient step of
  * DM/modules/video_flow_diffusion_model.py:181-188 (loss.backward(); optimizer_diff.step()).

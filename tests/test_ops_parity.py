@@ -426,3 +426,27 @@ def test_elementwise_and_layout(backend):
     assert torch.equal(cl.cpu(), y.permute(0, 2, 1).reshape(n * 35, 40))
     back = ops.cl_to_planar(cl, n, 40, 35)
     assert torch.equal(back.cpu(), y)
+
+
+@pytest.mark.parametrize("c,frames", [(64, 4), (128, 8), (64, 40)])
+def test_temporal_attention_fused(backend, c, frames):
+    """LayerNorm + to_qkv + temporal attention in one kernel vs the oracle's PreNorm/Attention pieces."""
+    dev = backend
+    b, s = (1, 16) if (big(dev) and frames == 40) else ((1, 2) if frames == 40 else (2, 2))
+    hw = s * s
+    x = rnd(b, c, frames, s, s, seed=1) * 2 + 0.5
+    gamma = rnd(1, c, 1, 1, 1, seed=2) * 0.3 + 1
+    wq = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
+    emb = rnd(32, 8, seed=4)
+    bias = O.rel_pos_bias(emb, frames)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    cos, sin = O.rotary_tables(freqs, frames)
+    normed = O.channel_layernorm(x, gamma)
+    tokens = normed.permute(0, 3, 4, 2, 1).reshape(b, hw, frames, c)
+    qkv = tokens @ wq.t()
+    ref = _attention_ref(qkv, bias, (cos, sin))                       # (b, hw, frames, 256)
+    ref = ref.permute(0, 2, 1, 3).reshape(-1, 256)                    # CL row order (b, t, pix)
+    wf = (wq * gamma.reshape(1, -1)).contiguous()
+    out = ops.temporal_attention_fused_cl(unet_to_cl(x).to(dev), wf.to(dev), b, frames, hw, bias=bias.contiguous().to(dev),
+                                          rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
+    assert_close(out.cpu(), ref, TOL, "fused LN + qkv + temporal attention")

@@ -35,3 +35,17 @@ for s in (32, 16, 8, 4):
     us2 = timeit(lambda: ops.linear_attention_cl(qkv, t, s * s, out=out, ws=ws))
     mb = rows * 1024 * 4 / 1e6
     print("res %2d: temporal attention %7.1f us (%5.0f GB/s)   linear attention %7.1f us" % (s, us, mb / us * 1e3 / 1e3 * 1e3 / 1e3, us2))
+
+print("fused LN + qkv + temporal attention (vs qkv conv + attention):")
+for s, c in ((32, 64), (16, 128)):
+    rows = t * s * s
+    x = torch.randn(rows, c, device="cuda")
+    wq = torch.randn(768, c, device="cuda") * 0.1
+    gamma = torch.ones(c, device="cuda")
+    out = torch.empty(rows, 256, device="cuda")
+    us = timeit(lambda: ops.temporal_attention_fused_cl(x, wq, 1, t, s * s, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
+    packed, wsum = ops.pack_ln_conv_weight(wq, gamma)
+    qkv = torch.empty(rows, 768, device="cuda")
+    us_a = timeit(lambda: ops.conv2d_cl(x, packed, 768, 1, 1, t, s, s, ln_wsum=wsum, out=qkv))
+    us_b = timeit(lambda: ops.attention_cl(qkv, 1, t, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
+    print("res %2d C=%3d: fused %7.1f us   separate %7.1f + %7.1f us" % (s, c, us, us_a, us_b))
