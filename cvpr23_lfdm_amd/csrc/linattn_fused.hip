@@ -1,0 +1,227 @@
+// PreNorm LayerNorm + to_qkv (1x1 conv) + SpatialLinearAttention core in three launches that never materialise qkv
+// (include/lfdm_hip.h: lfdm_linear_attention_fused_cl_f32), for C = 64 (the finest UNet level):
+// DM/modules/video_flow_diffusion.py:170-189 (LayerNorm / PreNorm) + :249-263 (to_qkv, softmaxes, context, out).
+//
+// Separate kernels spent 79 us writing the 126 MB qkv tensor and 81 us reading it twice.  Here every kernel starts from
+// the 10.5 MB input x and recomputes the projection it needs on the MFMA units, using accumulator layouts AS operand
+// layouts (v_mfma_f32_32x32x2: D has lane = column, registers = rows (r&3) + 8*(r>>2) + 4*half):
+//  A. context partials, one wavefront per (frame, head, 128-token split): K = xhat Wk^T and V = xhat Wv^T are normal
+//     GEMMs (rows = tokens, cols = features); their accumulators are exactly the A / B operands of
+//     ctx[d][e] += sum_n exp(K[n][d] - m[d]) V[n][e] for the token order t(half, s) - no layout change.  The k-softmax is
+//     over ALL tokens of a frame, so each split keeps its own max m_p and sum s_p (merged in B).
+//  B. merge of the splits (a few KB per frame/head): ctx = sum_p e^{m_p - M} ctx_p / sum_p e^{m_p - M} s_p.
+//  C. output, one wavefront per (frame, 32-token tile), all heads: Q^T = Wq xhat^T is computed TRANSPOSED so that its
+//     accumulator (lane = token, registers = 16 features) is the A operand of out = q~ ctx; softmax over the 32
+//     features = register reduction + one shuffle.
+// LayerNorm: a lane holds half of its token's channels; mean / variance = local sums + one shuffle; gamma is folded
+// into the weights by the host.
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int OUT_LD = HEADS * DH;      // 256
+constexpr int C = 64;                   // input channels (finest level)
+constexpr int CH = C / 2;               // channels per k-slot
+constexpr int SPLIT_TOK = 128;          // tokens per context partial
+constexpr int PART = DH * DH + 2 * DH;  // floats per partial: ctx[32][32] | m[32] | s[32]
+constexpr float LA_SCALE = 0.17677669529663687f;
+
+// xhat fragment of one token: lane (token l31 of the tile, half kh) holds channels CH*kh .. CH*kh + CH-1, normalised
+__device__ __forceinline__ void load_xhat(const float* __restrict__ xrow, bool ok, int kh, float eps, float (&xf)[CH]) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < CH / 4; ++q) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *reinterpret_cast<const float4*>(xrow + CH * kh + 4 * q);
+    xf[4 * q] = v.x; xf[4 * q + 1] = v.y; xf[4 * q + 2] = v.z; xf[4 * q + 3] = v.w;
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  const float mean = s1 * (1.0f / (float)C);
+  float var = s2 * (1.0f / (float)C) - mean * mean;
+  if (var < 0.f) var = 0.f;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int s = 0; s < CH; ++s) xf[s] = ok ? (xf[s] - mean) * rstd : 0.f;
+}
+
+__device__ __forceinline__ void load_wrow(const float* __restrict__ w, int row, int kh, float (&wf)[CH]) {
+  const float* src = w + (int64_t)row * C + CH * kh;
+#pragma unroll
+  for (int q = 0; q < CH / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+    wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
+  }
+}
+
+// ---- A: grid (n_frames*8, nsplit), 64 threads ----
+__global__ __launch_bounds__(64, 2) void linattn_fused_ctx_kernel(const float* __restrict__ x, int ldx,
+                                                                  const float* __restrict__ wqkv, int hw, float eps,
+                                                                  float* __restrict__ part) {
+  constexpr int NTILE = SPLIT_TOK / 32;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+  const int f = blockIdx.x >> 3, h = blockIdx.x & 7;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int n0 = split * SPLIT_TOK;
+
+  float wk[CH], wv[CH];
+  load_wrow(wqkv, OUT_LD + h * DH + l31, kh, wk);          // B operands: lane = feature l31, k-slot = channel half
+  load_wrow(wqkv, 2 * OUT_LD + h * DH + l31, kh, wv);
+
+  f32x16 kacc[NTILE], vacc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int n = n0 + 32 * t + l31;
+    float xf[CH];
+    load_xhat(x + ((int64_t)f * hw + (n < hw ? n : 0)) * ldx, n < hw, kh, eps, xf);
+    f32x16 ka, va;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ka[r] = va[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      ka = mfma_32x32x2(xf[s], wk[s], ka);                 // rows = tokens, cols = features d
+      va = mfma_32x32x2(xf[s], wv[s], va);                 // rows = tokens, cols = features e
+    }
+    kacc[t] = ka;
+    vacc[t] = va;
+  }
+  // lane: feature l31; register r of tile t = token n0 + 32*t + (r&3) + 8*(r>>2) + 4*kh
+  float m = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (n < hw) m = fmaxf(m, kacc[t][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float ssum = 0.f;
+  f32x16 ctx;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const float e = n < hw ? expf(kacc[t][r] - m) : 0.f;
+      ssum += e;
+      ctx = mfma_32x32x2(e, vacc[t][r], ctx);              // A: lane = d, k-slot half = token; B: lane = e, same token
+    }
+  ssum += __shfl_xor(ssum, 32);
+  float* dst = part + ((int64_t)blockIdx.x * nsplit + split) * PART;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * kh) * DH + l31] = ctx[r];   // ctx[d][e], lane = e
+  if (kh == 0) {
+    dst[DH * DH + l31] = m;
+    dst[DH * DH + DH + l31] = ssum;
+  }
+}
+
+// ---- B: grid (n_frames*8), 256 threads: ctx[d][e] merged over the splits ----
+__global__ __launch_bounds__(256) void linattn_fused_merge_kernel(const float* __restrict__ part, int nsplit,
+                                                                  float* __restrict__ ctx_out) {
+  __shared__ float s_m[DH], s_den[DH];
+  const int tid = threadIdx.x;
+  const float* base = part + (int64_t)blockIdx.x * nsplit * PART;
+  if (tid < DH) {
+    float mm = -3.0e38f;
+    for (int p = 0; p < nsplit; ++p) mm = fmaxf(mm, base[(int64_t)p * PART + DH * DH + tid]);
+    float den = 0.f;
+    for (int p = 0; p < nsplit; ++p)
+      den += expf(base[(int64_t)p * PART + DH * DH + tid] - mm) * base[(int64_t)p * PART + DH * DH + DH + tid];
+    s_m[tid] = mm;
+    s_den[tid] = den;
+  }
+  __syncthreads();
+  for (int i = tid; i < DH * DH; i += 256) {
+    const int d = i >> 5;
+    float acc = 0.f;
+    for (int p = 0; p < nsplit; ++p)
+      acc += expf(base[(int64_t)p * PART + DH * DH + d] - s_m[d]) * base[(int64_t)p * PART + i];
+    ctx_out[(int64_t)blockIdx.x * DH * DH + i] = acc / s_den[d];
+  }
+}
+
+// ---- C: grid (ceil(hw/32), n_frames), 64 threads; all 8 heads ----
+__global__ __launch_bounds__(64, 2) void linattn_fused_out_kernel(const float* __restrict__ x, int ldx,
+                                                                  const float* __restrict__ wqkv,
+                                                                  const float* __restrict__ ctx, int hw, float eps,
+                                                                  float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+  const int f = blockIdx.y;
+  const int n = blockIdx.x * 32 + l31;
+  float xf[CH];                                            // B operand of Q^T = Wq xhat^T: lane = token
+  load_xhat(x + ((int64_t)f * hw + (n < hw ? n : 0)) * ldx, n < hw, kh, eps, xf);
+#pragma unroll 1
+  for (int h = 0; h < HEADS; ++h) {
+    float wq[CH];
+    load_wrow(wqkv, h * DH + l31, kh, wq);                 // A operand: lane = feature d
+    f32x16 q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) q = mfma_32x32x2(wq[s], xf[s], q);
+    // lane = token; q[r] = feature d(kh, r) = (r&3) + 8*(r>>2) + 4*kh : softmax over the 32 features
+    float m = q[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      q[r] = expf(q[r] - m);
+      sum += q[r];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = LA_SCALE / sum;
+    // out[token][e] = sum_d q~[token][d] ctx[d][e]: A = q (lane = token, slot = d half), B = ctx[d(kh, r)][e = l31]
+    const float* cb = ctx + ((int64_t)f * HEADS + h) * DH * DH + l31;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o = mfma_32x32x2(q[r] * inv, cb[((r & 3) + 8 * (r >> 2) + 4 * kh) * DH], o);
+    // lane = feature e; o[r] = token (r&3) + 8*(r>>2) + 4*kh of the tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tok = blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (tok < hw) out[((int64_t)f * hw + tok) * OUT_LD + h * DH + l31] = o[r];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw) {
+  const int nsplit = (hw + SPLIT_TOK - 1) / SPLIT_TOK;
+  return ((size_t)n_frames * HEADS * nsplit * PART + (size_t)n_frames * HEADS * DH * DH) * sizeof(float);
+}
+
+extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
+                                                  int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
+                                                  lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || channels != C || ldx < C || ldx % 4 != 0 ||
+      (((uintptr_t)x | (uintptr_t)wqkv) & 15) || (int64_t)n_frames * HEADS > 0x7fffffff) {
+    lfdm_set_error("linear_attention_fused: needs C == 64 and 16-byte aligned rows");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) {
+    lfdm_set_error("linear_attention_fused: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  const int nsplit = (hw + SPLIT_TOK - 1) / SPLIT_TOK;
+  float* part = (float*)ws;
+  float* ctx = part + (size_t)n_frames * HEADS * nsplit * PART;
+  LFDM_LAUNCH(linattn_fused_ctx_kernel, dim3(n_frames * HEADS, nsplit), dim3(64), 0, stream, x, ldx, wqkv, hw, ln_eps, part);
+  LFDM_LAUNCH(linattn_fused_merge_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, (const float*)part, nsplit, ctx);
+  LFDM_LAUNCH(linattn_fused_out_kernel, dim3((hw + 31) / 32, n_frames), dim3(64), 0, stream, x, ldx, wqkv, (const float*)ctx,
+              hw, ln_eps, out);
+  return lfdm_check_launch("linear_attention_fused");
+}

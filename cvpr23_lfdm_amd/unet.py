@@ -150,8 +150,10 @@ class Unet3D(ParamTree):
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
 
         def spatial_linear(prefix):
-            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(
-                g(prefix + "fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma"))
+            wq, gam = g(prefix + "fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma")
+            if wq.shape[1] == 64:      # finest level: LayerNorm + to_qkv + linear attention without a qkv tensor
+                pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
+            pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
             pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
 
@@ -320,9 +322,15 @@ class Unet3D(ParamTree):
 
     def _linear_attn(self, pk, prefix, x, batch, frames, s, c, outname):
         n_img = batch * frames
-        qkv, att = self._attn_common(pk, prefix, x, n_img, s, c)
-        ws = self._buf("la.ws", n_img, 8 * 32 * 32)
-        ops.linear_attention_cl(qkv, n_img, s * s, out=att, ws=ws)
+        if (prefix + "qkv.wf") in pk:
+            att = self._buf("at.o", x.shape[0], 256)
+            nsplit = (s * s + 127) // 128
+            ws = self._buf("la.wsf", n_img * 8, nsplit * (32 * 32 + 64) + 32 * 32)
+            ops.linear_attention_fused_cl(x, pk[prefix + "qkv.wf"], n_img, s * s, out=att, ws=ws)
+        else:
+            qkv, att = self._attn_common(pk, prefix, x, n_img, s, c)
+            ws = self._buf("la.ws", n_img, 8 * 32 * 32)
+            ops.linear_attention_cl(qkv, n_img, s * s, out=att, ws=ws)
         out = self._buf(outname, x.shape[0], c)
         return self._conv(att, pk[prefix + "out.w"], c, 1, n_img, s, bias=pk[prefix + "out.b"], residual=x, out=out)
 

@@ -267,6 +267,14 @@ int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int channels, 
                                          const float* rot_cos, const float* rot_sin, float ln_eps,
                                          lfdm_stream_t stream);
 
+/* PreNorm LayerNorm + to_qkv (1x1 conv, no bias) + SpatialLinearAttention core (without to_out) for C == 64:
+ * video_flow_diffusion.py:170-189, :249-263.  x: CL rows (n_frames*hw, C) stride ldx; wqkv (768, C) row-major with the
+ * LayerNorm gamma folded in; out rows of 256.  qkv is never materialised (every pass recomputes its projection). */
+size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw);
+int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
+                                       int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
+                                       lfdm_stream_t stream);
+
 /* ==========================================================================================
  * TRAINING (backward) kernels - the DM gradient step of
  * DM/modules/video_flow_diffusion_model.py:181-188 (loss.backward(); optimizer_diff.step()).

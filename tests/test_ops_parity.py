@@ -450,3 +450,29 @@ def test_temporal_attention_fused(backend, c, frames):
     out = ops.temporal_attention_fused_cl(unet_to_cl(x).to(dev), wf.to(dev), b, frames, hw, bias=bias.contiguous().to(dev),
                                           rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + temporal attention")
+
+
+@pytest.mark.parametrize("hw", [16, 144, 1024])
+def test_linear_attention_fused(backend, hw):
+    """LayerNorm + to_qkv + SpatialLinearAttention core (3 launches, no qkv tensor) vs the reference formulas."""
+    dev = backend
+    nf, c = 2, 64
+    if hw == 1024:
+        if not big(dev):
+            pytest.skip("full-resolution frame: GPU only")
+        nf = 40
+    x = rnd(nf, hw, c, seed=1) * 2 + 0.3                              # CL rows per frame
+    gamma = rnd(c, seed=2) * 0.3 + 1
+    wq = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
+    mean = x.mean(dim=-1, keepdim=True)
+    var = x.var(dim=-1, unbiased=False, keepdim=True)
+    normed = (x - mean) / (var + 1e-5).sqrt() * gamma
+    qkv = normed @ wq.t()                                             # (nf, hw, 768)
+    q, k, v = [z.reshape(nf, hw, 8, 32).permute(0, 2, 3, 1) for z in qkv.chunk(3, dim=-1)]  # b h d n
+    q = q.softmax(dim=-2) * (32 ** -0.5)
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(nf * hw, 256)
+    wf = (wq * gamma.reshape(1, -1)).contiguous()
+    out = ops.linear_attention_fused_cl(x.reshape(-1, c).to(dev), wf.to(dev), nf, hw)
+    assert_close(out.cpu(), ref, TOL, "fused LN + qkv + linear attention")

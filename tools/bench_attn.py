@@ -49,3 +49,13 @@ for s, c in ((32, 64), (16, 128)):
     us_a = timeit(lambda: ops.conv2d_cl(x, packed, 768, 1, 1, t, s, s, ln_wsum=wsum, out=qkv))
     us_b = timeit(lambda: ops.attention_cl(qkv, 1, t, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
     print("res %2d C=%3d: fused %7.1f us   separate %7.1f + %7.1f us" % (s, c, us, us_a, us_b))
+
+print("fused LN + qkv + linear attention (vs qkv conv + linear attention):")
+s, c = 32, 64
+rows = t * s * s
+x = torch.randn(rows, c, device="cuda")
+wq = torch.randn(768, c, device="cuda") * 0.1
+out = torch.empty(rows, 256, device="cuda")
+ws = torch.empty(16 << 20, device="cuda")
+us = timeit(lambda: ops.linear_attention_fused_cl(x, wq, t, s * s, out=out, ws=ws))
+print("res %2d C=%3d: fused %7.1f us" % (s, c, us))
