@@ -25,7 +25,7 @@ constexpr int DH = 32;
 constexpr int OUT_LD = HEADS * DH;      // 256
 constexpr int C = 64;                   // input channels (finest level)
 constexpr int CH = C / 2;               // channels per k-slot
-constexpr int SPLIT_TOK = 128;          // tokens per context partial
+constexpr int SPLIT_TOK = 64;           // tokens per context partial
 constexpr int PART = DH * DH + 2 * DH;  // floats per partial: ctx[32][32] | m[32] | s[32]
 constexpr float LA_SCALE = 0.17677669529663687f;
 
@@ -60,7 +60,7 @@ __device__ __forceinline__ void load_wrow(const float* __restrict__ w, int row, 
 }
 
 // ---- A: grid (n_frames*8, nsplit), 64 threads ----
-__global__ __launch_bounds__(64, 2) void linattn_fused_ctx_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* __restrict__ x, int ldx,
                                                                   const float* __restrict__ wqkv, int hw, float eps,
                                                                   float* __restrict__ part) {
   constexpr int NTILE = SPLIT_TOK / 32;
@@ -126,29 +126,32 @@ __global__ __launch_bounds__(64, 2) void linattn_fused_ctx_kernel(const float* _
 // ---- B: grid (n_frames*8), 256 threads: ctx[d][e] merged over the splits ----
 __global__ __launch_bounds__(256) void linattn_fused_merge_kernel(const float* __restrict__ part, int nsplit,
                                                                   float* __restrict__ ctx_out) {
-  __shared__ float s_m[DH], s_den[DH];
+  constexpr int MAXS = 64;
+  __shared__ float s_w[MAXS][DH];                  // weight of split p for feature d: e^{m_p - M} / denominator
   const int tid = threadIdx.x;
   const float* base = part + (int64_t)blockIdx.x * nsplit * PART;
   if (tid < DH) {
     float mm = -3.0e38f;
     for (int p = 0; p < nsplit; ++p) mm = fmaxf(mm, base[(int64_t)p * PART + DH * DH + tid]);
     float den = 0.f;
-    for (int p = 0; p < nsplit; ++p)
-      den += expf(base[(int64_t)p * PART + DH * DH + tid] - mm) * base[(int64_t)p * PART + DH * DH + DH + tid];
-    s_m[tid] = mm;
-    s_den[tid] = den;
+    for (int p = 0; p < nsplit; ++p) {
+      const float w = expf(base[(int64_t)p * PART + DH * DH + tid] - mm);
+      s_w[p][tid] = w;
+      den += w * base[(int64_t)p * PART + DH * DH + DH + tid];
+    }
+    const float inv = 1.0f / den;
+    for (int p = 0; p < nsplit; ++p) s_w[p][tid] *= inv;
   }
   __syncthreads();
   for (int i = tid; i < DH * DH; i += 256) {
     const int d = i >> 5;
     float acc = 0.f;
-    for (int p = 0; p < nsplit; ++p)
-      acc += expf(base[(int64_t)p * PART + DH * DH + d] - s_m[d]) * base[(int64_t)p * PART + i];
-    ctx_out[(int64_t)blockIdx.x * DH * DH + i] = acc / s_den[d];
+    for (int p = 0; p < nsplit; ++p) acc += s_w[p][d] * base[(int64_t)p * PART + i];
+    ctx_out[(int64_t)blockIdx.x * DH * DH + i] = acc;
   }
 }
 
-// ---- C: grid (ceil(hw/32), n_frames), 64 threads; all 8 heads ----
+// ---- C: grid (ceil(hw/32), n_frames, head groups), 64 threads ----
 __global__ __launch_bounds__(64, 2) void linattn_fused_out_kernel(const float* __restrict__ x, int ldx,
                                                                   const float* __restrict__ wqkv,
                                                                   const float* __restrict__ ctx, int hw, float eps,
@@ -158,8 +161,11 @@ __global__ __launch_bounds__(64, 2) void linattn_fused_out_kernel(const float* _
   const int n = blockIdx.x * 32 + l31;
   float xf[CH];                                            // B operand of Q^T = Wq xhat^T: lane = token
   load_xhat(x + ((int64_t)f * hw + (n < hw ? n : 0)) * ldx, n < hw, kh, eps, xf);
+  // grid.z splits the heads (the token tile's 8 KB of x are simply read again): more wavefronts per SIMD to hide the
+  // weight / context fragment latency of the serial per-head chain
+  const int hpb = HEADS / gridDim.z;
 #pragma unroll 1
-  for (int h = 0; h < HEADS; ++h) {
+  for (int h = blockIdx.z * hpb; h < (blockIdx.z + 1) * hpb; ++h) {
     float wq[CH];
     load_wrow(wqkv, h * DH + l31, kh, wq);                 // A operand: lane = feature d
     f32x16 q;
@@ -207,7 +213,7 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
                                                   int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                                   lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || channels != C || ldx < C || ldx % 4 != 0 ||
+  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || hw > 64 * SPLIT_TOK || channels != C || ldx < C || ldx % 4 != 0 ||
       (((uintptr_t)x | (uintptr_t)wqkv) & 15) || (int64_t)n_frames * HEADS > 0x7fffffff) {
     lfdm_set_error("linear_attention_fused: needs C == 64 and 16-byte aligned rows");
     return LFDM_EINVAL;
@@ -221,7 +227,9 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
   float* ctx = part + (size_t)n_frames * HEADS * nsplit * PART;
   LFDM_LAUNCH(linattn_fused_ctx_kernel, dim3(n_frames * HEADS, nsplit), dim3(64), 0, stream, x, ldx, wqkv, hw, ln_eps, part);
   LFDM_LAUNCH(linattn_fused_merge_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, (const float*)part, nsplit, ctx);
-  LFDM_LAUNCH(linattn_fused_out_kernel, dim3((hw + 31) / 32, n_frames), dim3(64), 0, stream, x, ldx, wqkv, (const float*)ctx,
-              hw, ln_eps, out);
+  const int64_t tiles = (int64_t)((hw + 31) / 32) * n_frames;
+  const int hgroups = tiles >= 4096 ? 1 : (tiles >= 2048 ? 2 : 4);
+  LFDM_LAUNCH(linattn_fused_out_kernel, dim3((hw + 31) / 32, n_frames, hgroups), dim3(64), 0, stream, x, ldx, wqkv,
+              (const float*)ctx, hw, ln_eps, out);
   return lfdm_check_launch("linear_attention_fused");
 }

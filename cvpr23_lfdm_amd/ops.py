@@ -266,6 +266,10 @@ def temporal_attention_fused_cl(x, wqkv, batch, frames, hw, *, bias=None, rot_co
     return out
 
 
+def linear_attention_fused_ws_floats(n_frames, hw):
+    return (int(_lib().lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) + 3) // 4
+
+
 def linear_attention_fused_cl(x, wqkv, n_frames, hw, *, eps=1e-5, out=None, ws=None):
     """LayerNorm + to_qkv + linear attention core without materialising qkv (C == 64); wqkv (768, 64) with gamma folded."""
     lib = _lib()
@@ -274,6 +278,8 @@ def linear_attention_fused_cl(x, wqkv, n_frames, hw, *, eps=1e-5, out=None, ws=N
     if out is None:
         out = torch.empty(x.shape[0], 256, dtype=torch.float32, device=x.device)
     need = lib.lfdm_linear_attention_fused_ws_bytes(n_frames, hw)
+    if ws is not None:
+        ws = ws.reshape(-1)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     lib.check(lib.lfdm_linear_attention_fused_cl_f32(_p(x), x.stride(0), x.shape[1], _p(wqkv), _p(out), n_frames, hw, eps,

@@ -324,8 +324,7 @@ class Unet3D(ParamTree):
         n_img = batch * frames
         if (prefix + "qkv.wf") in pk:
             att = self._buf("at.o", x.shape[0], 256)
-            nsplit = (s * s + 127) // 128
-            ws = self._buf("la.wsf", n_img * 8, nsplit * (32 * 32 + 64) + 32 * 32)
+            ws = self._buf("la.wsf", 1, ops.linear_attention_fused_ws_floats(n_img, s * s))
             ops.linear_attention_fused_cl(x, pk[prefix + "qkv.wf"], n_img, s * s, out=att, ws=ws)
         else:
             qkv, att = self._attn_common(pk, prefix, x, n_img, s, c)
