@@ -33,6 +33,11 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef LFDM_KSW_TIMING
+  // probe build only (tools/probe_ksw_phases.py): phase time stamps of every workgroup go to p.partial
+  unsigned long long tstamp[5];
+  tstamp[0] = __builtin_readcyclecounter();
+#endif
   const int hqwq = p.hq * p.wq;
   const int64_t M = (int64_t)p.n_img * hqwq;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -140,10 +145,16 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     }
   };
 
+#ifdef LFDM_KSW_TIMING
+  tstamp[1] = __builtin_readcyclecounter();
+#endif
   fetch(kc_begin);                                  // nk >= 1 (host clamps ksplit to the chunk count)
   stage(0);
   __syncthreads();
   fetch(kc_begin + (nk > 1 ? 1 : 0));
+#ifdef LFDM_KSW_TIMING
+  tstamp[2] = __builtin_readcyclecounter();
+#endif
 
   const int koff = 8 * wave + 4 * (lane >> 5);   // this wave's k slice of a chunk, this lane half's quad
   const int l31 = lane & 31;
@@ -179,6 +190,9 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     __syncthreads();
   }
 
+#ifdef LFDM_KSW_TIMING
+  tstamp[3] = __builtin_readcyclecounter();
+#endif
   // ---- cross-wave reduction + epilogue, one 32x32 tile at a time ----
   float* const scratch = smem;                     // [4 waves][32][LD]
   const int trow = tid >> 3, c4 = tid & 7;
@@ -235,6 +249,13 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     }
   }
 
+#ifdef LFDM_KSW_TIMING
+  tstamp[4] = __builtin_readcyclecounter();
+  if (tid == 0 && p.partial && ksplit == 1) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partial) + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 5;
+    for (int i = 0; i < 5; ++i) dst[i] = tstamp[i];
+  }
+#endif
   if (p.gn_partial && ksplit == 1) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
