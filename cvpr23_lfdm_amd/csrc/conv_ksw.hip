@@ -203,6 +203,28 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) gs[j][e] = gq[j][e] = 0.f;
 
+  // bias depends only on the column: ONE load per column tile before the rounds; the residual float4 of round t+1 is
+  // requested while round t is reduced.  (Per-round bias -> wait -> residual -> wait chains cost 0.6 us x 10 rounds.)
+  float4 bias4[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int colbase = n0 + 32 * j + 4 * c4;
+    bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && ksplit == 1 && colbase < p.cout) bias4[j] = *reinterpret_cast<const float4*>(p.bias + colbase);
+  }
+  auto out_row = [&](int i) -> int64_t {
+    const int row = 32 * i + trow;
+    const int oy = s_qy[row] * p.out_scale + p.out_off_y;
+    const int ox = s_qx[row] * p.out_scale + p.out_off_x;
+    return ((int64_t)s_img[row] * p.ho + oy) * p.wo + ox;
+  };
+  auto load_res = [&](int i, int j) -> float4 {
+    const int colbase = n0 + 32 * j + 4 * c4;
+    if (p.residual && ksplit == 1 && s_img[32 * i + trow] >= 0 && colbase < p.cout)
+      return *reinterpret_cast<const float4*>(p.residual + out_row(i) * p.ldr + colbase);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4 res_next = load_res(0, 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -210,6 +232,11 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         scratch[wave * (32 * LD) + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LD + l31] = acc[i][j][r];
+      const float4 rr = res_next;
+      {
+        const int t = i * TN + j + 1;
+        if (t < TM * TN) res_next = load_res(t / TN, t % TN);
+      }
       __syncthreads();
       float4 v = *reinterpret_cast<const float4*>(scratch + trow * LD + 4 * c4);
 #pragma unroll
@@ -225,23 +252,20 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
           if (colbase < p.coutp)
             *reinterpret_cast<float4*>(p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp + colbase) = v;
         } else if (colbase < p.cout) {
-          const int oy = s_qy[row] * p.out_scale + p.out_off_y;
-          const int ox = s_qx[row] * p.out_scale + p.out_off_x;
-          const int64_t orow = ((int64_t)img * p.ho + oy) * p.wo + ox;
-          if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-          }
+          const int64_t orow = out_row(i);
+          v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
           if (p.gn_partial) {
             gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
             gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
           }
-          if (p.residual) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          if (p.act != LFDM_ACT_NONE) {
+            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
           }
-          v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-          v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+#ifdef LFDM_PROBE_NOSTORE
+          if (v.x == 123456.789f)
+#endif
           *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
         }
       }

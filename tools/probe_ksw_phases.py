@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "cvpr23_lfdm_amd", "csrc")
 out = os.path.join(tempfile.gettempdir(), "liblfdm_probe_timing.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-                       "-amdgpu-mfma-vgpr-form", "-DLFDM_KSW_TIMING", "-o", out] + sorted(glob.glob(os.path.join(csrc, "*.hip"))))
+                       "-amdgpu-mfma-vgpr-form", "-DLFDM_KSW_TIMING"] + sys.argv[1:] + ["-o", out] + sorted(glob.glob(os.path.join(csrc, "*.hip"))))
 os.environ["LFDM_HIP_LIB"] = out
 import torch  # noqa: E402
 from cvpr23_lfdm_amd import ops  # noqa: E402
