@@ -17,7 +17,9 @@
 
 namespace {
 
-template <int TM, int TN>
+// ACT = false: no activation code in the (fully unrolled, executed-once) epilogue - the UNet's convolutions have
+// none, and the unrolled expf / division sequences of the generic epilogue tripled its instruction footprint.
+template <int TM, int TN, bool ACT>
 __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = BK + 4;
   constexpr int STAGE = (BM + BN) * LD;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
             gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
           }
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          if (p.act != LFDM_ACT_NONE) {
+          if (ACT) {
             v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
             v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
           }
@@ -320,7 +322,13 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   const dim3 grid((unsigned)((M + 159) / 160), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
-  if (bn == 64) LFDM_LAUNCH((conv_ksw_kernel<5, 2>), grid, dim3(256), 0, stream, p);
-  else LFDM_LAUNCH((conv_ksw_kernel<5, 1>), grid, dim3(256), 0, stream, p);
+  const bool act = p.act != LFDM_ACT_NONE;
+  if (bn == 64) {
+    if (act) LFDM_LAUNCH((conv_ksw_kernel<5, 2, true>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_ksw_kernel<5, 2, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (act) LFDM_LAUNCH((conv_ksw_kernel<5, 1, true>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_ksw_kernel<5, 1, false>), grid, dim3(256), 0, stream, p);
+  }
   return lfdm_check_launch("conv_ksw");
 }
