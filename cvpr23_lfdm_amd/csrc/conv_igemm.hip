@@ -580,6 +580,9 @@ int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);
 
 namespace {
 
+struct ConvPlan;
+bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p);
+
 struct ConvPlan {
   int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip)
   int bm, bn, ksplit;
@@ -656,12 +659,20 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   return pl;
 }
 
+// in-launch slab reduction: KSW schedule with enough zeroed tile counters
+bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
+  if (pl.kind != 1 || pl.ksplit <= 1 || !p.tile_counters) return false;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  const int64_t tiles = ((M + 159) / 160) * ((p.coutp + pl.bn - 1) / pl.bn);
+  return (int64_t)p.tile_counters_len >= tiles;
+}
+
 }  // namespace
 
 extern "C" int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit) {
   if (!p) return LFDM_EINVAL;
   const ConvPlan pl = make_plan(*p);
-  if (tile_rows) *tile_rows = pl.ksplit > 1 ? SPLITK_ROWS : pl.bm;   // granularity of gn_partial
+  if (tile_rows) *tile_rows = (pl.ksplit > 1 && !splitk_fused(pl, *p)) ? SPLITK_ROWS : pl.bm;   // granularity of gn_partial
   if (ksplit) *ksplit = pl.ksplit;
   return LFDM_OK;
 }
@@ -697,11 +708,12 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (p.gn_partial) {
     const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;
-    const int rows = p.ksplit > 1 ? SPLITK_ROWS : pl.bm;
+    const bool fused = splitk_fused(pl, p);
+    const int rows = (p.ksplit > 1 && !fused) ? SPLITK_ROWS : pl.bm;
     const bool ok = p.gn_groups > 0 && p.cout % p.gn_groups == 0 && cg % 4 == 0 && p.gn_pixels > 0 &&
                     p.gn_pixels % rows == 0 && p.cout % 4 == 0 && p.ldo % 4 == 0 &&
                     (((uintptr_t)p.out) & 15) == 0 &&
-                    (p.ksplit > 1 ? (256 % (p.coutp / 4) == 0 && p.cout == p.coutp) : (pl.bn % cg == 0));
+                    ((p.ksplit > 1 && !fused) ? (256 % (p.coutp / 4) == 0 && p.cout == p.coutp) : (pl.bn % cg == 0));
     if (!ok) {
       lfdm_set_error("conv2d: fused GroupNorm statistics need pixels % tile_rows == 0 and a group size dividing "
                      "the column tile (see lfdm_conv2d_plan)");
@@ -726,7 +738,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     rc = lfdm_check_launch("conv_igemm");
   }
   if (rc) return rc;
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && !splitk_fused(pl, p)) {
     LFDM_LAUNCH(conv_splitk_reduce_kernel,
                 dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M)), dim3(256), 0,
                 stream, p);

@@ -198,6 +198,8 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   // ---- cross-wave reduction + epilogue, one 32x32 tile at a time ----
   float* const scratch = smem;                     // [4 waves][32][LD]
   const int trow = tid >> 3, c4 = tid & 7;
+  const int ntiles = (int)(gridDim.x * gridDim.y);
+  const bool fuse = ksplit > 1 && p.tile_counters != nullptr && p.tile_counters_len >= ntiles;   // in-launch slab reduction
   // (the host only selects this kernel when float4 epilogue accesses are legal)
   float gs[TN][4], gq[TN][4];
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   for (int j = 0; j < TN; ++j) {
     const int colbase = n0 + 32 * j + 4 * c4;
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && ksplit == 1 && colbase < p.cout) bias4[j] = *reinterpret_cast<const float4*>(p.bias + colbase);
+    if (p.bias && (ksplit == 1 || fuse) && colbase < p.cout) bias4[j] = *reinterpret_cast<const float4*>(p.bias + colbase);
   }
   auto out_row = [&](int i) -> int64_t {
     const int row = 32 * i + trow;
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   };
   auto load_res = [&](int i, int j) -> float4 {
     const int colbase = n0 + 32 * j + 4 * c4;
-    if (p.residual && ksplit == 1 && s_img[32 * i + trow] >= 0 && colbase < p.cout)
+    if (p.residual && (ksplit == 1 || fuse) && s_img[32 * i + trow] >= 0 && colbase < p.cout)
       return *reinterpret_cast<const float4*>(p.residual + out_row(i) * p.ldr + colbase);
     return make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  float4 res_next = load_res(0, 0);
+  float4 res_next = ksplit == 1 ? load_res(0, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
       const float4 rr = res_next;
       {
         const int t = i * TN + j + 1;
-        if (t < TM * TN) res_next = load_res(t / TN, t % TN);
+        if (t < TM * TN && ksplit == 1) res_next = load_res(t / TN, t % TN);
       }
       __syncthreads();
       float4 v = *reinterpret_cast<const float4*>(scratch + trow * LD + 4 * c4);
@@ -275,6 +277,62 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     }
   }
 
+
+  if (fuse) {
+    // ---- split-K: the workgroup that completes a tile's last slice reduces the slabs itself (no reduce launch) ----
+    LFDM_DRAIN_STORES();                              // every storing wave
+    __syncthreads();
+    int* const s_last = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      LFDM_FENCE_RELEASE_AGENT();
+      LFDM_DRAIN_STORES();
+      unsigned* cnt = p.tile_counters + (blockIdx.y * gridDim.x + blockIdx.x);
+      const bool last = lfdm_ticket_take(cnt) == (unsigned)(ksplit - 1);
+      if (last) {
+        lfdm_ticket_reset(cnt);                       // ready for the next launch
+        LFDM_FENCE_ACQUIRE_AGENT();
+      }
+      s_last[0] = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last[0]) return;
+    float4 rnext = load_res(0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float4 rr = rnext;
+        {
+          const int t = i * TN + j + 1;
+          if (t < TM * TN) rnext = load_res(t / TN, t % TN);
+        }
+        const int row = 32 * i + trow;
+        const int colbase = n0 + 32 * j + 4 * c4;
+        if (s_img[row] >= 0 && colbase < p.cout) {
+          const float* src = p.partial + ((int64_t)(m0 + row)) * p.coutp + colbase;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+          for (int z = 0; z < ksplit; ++z) {          // fixed order: bit-reproducible
+            const float4 u = *reinterpret_cast<const float4*>(src + (int64_t)z * M * p.coutp);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          }
+          const int64_t orow = out_row(i);
+          v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
+          if (p.gn_partial) {
+            gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
+            gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
+          }
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          if (ACT) {
+            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+          }
+          *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
+        }
+      }
+    }
+  }
+
 #ifdef LFDM_KSW_TIMING
   tstamp[4] = __builtin_readcyclecounter();
   if (tid == 0 && p.partial && ksplit == 1) {
@@ -282,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     for (int i = 0; i < 5; ++i) dst[i] = tstamp[i];
   }
 #endif
-  if (p.gn_partial && ksplit == 1) {
+  if (p.gn_partial && (ksplit == 1 || fuse)) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll

@@ -67,6 +67,28 @@ __device__ __forceinline__ float4 lfdm_buf_load_f4(lfdm_buf b, uint32_t off) {
 #endif
 #define LFDM_BUF_OOB 0xFFFFFFF0u
 
+// In-launch hand-off between workgroups (split-K: the last workgroup of a tile reduces the slabs).  Protocol of
+// cdna_hip_programming.md section 6 Guideline 16 (counter form): every storing wave drains its stores, one lane issues an
+// agent-scope release and takes a relaxed agent-scope ticket; the workgroup that draws the last ticket issues ONE
+// agent-scope acquire before any of its waves reads the slabs.  Placement independent (8 XCDs, non-coherent L2s).
+#if defined(LFDM_EMU_BUILD)
+#define LFDM_DRAIN_STORES() ((void)0)
+#define LFDM_FENCE_RELEASE_AGENT() ((void)0)
+#define LFDM_FENCE_ACQUIRE_AGENT() ((void)0)
+static inline unsigned lfdm_ticket_take(unsigned* c) { const unsigned v = *c; *c = v + 1u; return v; }   // workgroups run one by one
+static inline void lfdm_ticket_reset(unsigned* c) { *c = 0u; }
+#else
+#define LFDM_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define LFDM_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define LFDM_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+__device__ __forceinline__ unsigned lfdm_ticket_take(unsigned* c) {
+  return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lfdm_ticket_reset(unsigned* c) {
+  __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

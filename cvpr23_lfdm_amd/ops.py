@@ -115,7 +115,8 @@ def pack_planar_in_weight(w):
 
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
-                ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5):
+                ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
+                tile_counters=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -147,9 +148,14 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     p.act, p.ksplit, p.partial = act, ksplit, None
     p.gn_partial, p.gn_groups, p.gn_pixels = None, 0, 0
     p.ln_wsum, p.ln_eps = _p(ln_wsum), ln_eps
+    p.tile_counters, p.tile_counters_len = None, 0
+    if tile_counters is not None:       # zero-initialised int32 words: split-K slabs are reduced inside the launch
+        assert tile_counters.dtype == torch.int32 and tile_counters.is_contiguous()
+        _chk(lib, tile_counters)
+        p.tile_counters, p.tile_counters_len = tile_counters.data_ptr(), tile_counters.numel()
     if ln_wsum is not None:
         p.ksplit = 1
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum)      # keep the tensors alive with the struct
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters)      # keep the tensors alive with the struct
     return p, out
 
 

@@ -75,6 +75,7 @@ class Unet3D(ParamTree):
         self._pk = None
         self._pk_sig = None
         self._bufs = {}
+        self.fuse_splitk = False
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
@@ -91,6 +92,15 @@ class Unet3D(ParamTree):
         for p in self.parameters():
             sig += p._version
         return (sig, next(self.parameters()).device)
+
+    def _tile_counters(self):
+        """Zero-initialised arrival counters of the in-launch split-K reduction (every launch leaves them at zero)."""
+        dev = next(self.parameters()).device
+        cur = self._bufs.get("splitk.counters")
+        if cur is None or cur.device != dev:
+            cur = torch.zeros(4096, dtype=torch.int32, device=dev)
+            self._bufs["splitk.counters"] = cur
+        return cur
 
     def _buf(self, name, rows, ch, dtype=torch.float32):
         need = rows * ch
@@ -249,6 +259,9 @@ class Unet3D(ParamTree):
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, **kw)
+        if self.fuse_splitk:     # split-K slabs reduced inside the launch (measured neutral-to-slower on MI355X: off)
+            cnt = self._tile_counters()
+            p.tile_counters, p.tile_counters_len = cnt.data_ptr(), cnt.numel()
         tile_rows, ksplit = ops.conv_plan(p)
         m = n_img * p.hq * p.wq
         if ksplit > 1:
@@ -259,8 +272,9 @@ class Unet3D(ParamTree):
             batch = gn[0]
             pixels = m // batch
             cg = cout // 8
+            fused = ksplit > 1 and tile_rows == 160
             if pixels % tile_rows == 0 and cg % 4 == 0 and 32 % cg == 0 and (
-                    ksplit == 1 or (256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout)):
+                    ksplit == 1 or fused or (256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout)):
                 nchunk = pixels // tile_rows
                 stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), 8, pixels

@@ -93,6 +93,12 @@ typedef struct lfdm_conv_params {
      the row and writes rstd*(x.W' - mean*ln_wsum) - algebraically LayerNorm(x)*gamma followed by W. */
   const float* ln_wsum;
   float ln_eps;
+  /* Optional in-launch split-K reduction (KSW schedule only): tile_counters_len zero-initialised words, at least one per
+     output tile (lfdm_conv2d_plan's tile_rows x 32/64 columns).  When given, the workgroup that finishes a tile's last
+     K slice sums the slabs in `partial` (fixed order) and runs the epilogue itself - no reduce launch; the counters
+     are left at zero again.  NULL / too short = separate reduce pass. */
+  unsigned int* tile_counters;
+  int tile_counters_len;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);

@@ -42,6 +42,8 @@ def rnd(*shape, seed=0, scale=1.0):
     dict(cin=256, cout=256, k=3, n=2, h=4, w=4, ksplit=4),
     dict(cin=64, cout=64, k=3, n=5, h=8, w=8, residual=True, act=1),            # K-split-across-waves 160x32/64
     dict(cin=96, cout=128, k=3, n=3, h=8, w=10, split_src=32, ksplit=2),         # ksw + split-K, ragged M
+    dict(cin=96, cout=128, k=3, n=3, h=8, w=10, split_src=32, ksplit=3, fused=True, residual=True),   # slabs reduced in-launch
+    dict(cin=256, cout=64, k=3, n=5, h=8, w=8, ksplit=4, fused=True, act=1),
     dict(cin=256, cout=64, k=1, n=5, h=8, w=8),                                  # ksw on a 1x1 (K = 256)
     dict(cin=32, cout=32, k=4, n=5, h=16, w=16, stride=2, pad=1),                # ksw, strided
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
@@ -73,12 +75,16 @@ def test_conv2d(backend, case):
     if case.get("split_src"):
         s = case["split_src"]
         src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
-    out = ops.conv2d_cl(src0, ops.pack_conv_weight(wt).to(dev), cout, k, k, n, h, w, src1=src1,
-                        bias=bias.to(dev), pad=(pad, pad), stride=stride,
-                        upsample=bool(case.get("upsample")), reflect=bool(case.get("reflect")),
-                        residual=None if res is None else to_cl(res).to(dev), act=act,
-                        ksplit=case.get("ksplit", 1))
-    assert_close(from_cl(out.cpu(), n, ref.shape[2], ref.shape[3]), ref, TOL, "conv2d")
+    counters = torch.zeros(64, dtype=torch.int32, device=dev) if case.get("fused") else None
+    for rep in range(2 if counters is not None else 1):      # second launch: the counters must have been left at zero
+        out = ops.conv2d_cl(src0, ops.pack_conv_weight(wt).to(dev), cout, k, k, n, h, w, src1=src1,
+                            bias=bias.to(dev), pad=(pad, pad), stride=stride,
+                            upsample=bool(case.get("upsample")), reflect=bool(case.get("reflect")),
+                            residual=None if res is None else to_cl(res).to(dev), act=act,
+                            ksplit=case.get("ksplit", 1), tile_counters=counters)
+        assert_close(from_cl(out.cpu(), n, ref.shape[2], ref.shape[3]), ref, TOL, "conv2d")
+    if counters is not None:
+        assert int(counters.abs().sum()) == 0
 
 
 def test_conv2d_c2_shapes(backend):
@@ -128,12 +134,12 @@ def test_groupnorm_silu(backend, c, with_ss):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
 
 
-@pytest.mark.parametrize("ksplit", [1, 3])
+@pytest.mark.parametrize("ksplit", [1, 3, -3])
 def test_conv_fused_groupnorm_stats(backend, ksplit):
     """conv epilogue (or the split-K reduce) emits the GroupNorm partial sums; finalize+apply must equal
     conv -> group_norm."""
     dev = backend
-    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 5, 8, 32, 64)
+    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else ((2, 5, 8, 32, 64) if ksplit >= 0 else (2, 5, 8, 64, 64))
     x = rnd(b, cin, t, s, s, seed=1)
     wt = rnd(cout, cin, 1, 3, 3, seed=2, scale=0.06)
     bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
@@ -143,14 +149,18 @@ def test_conv_fused_groupnorm_stats(backend, ksplit):
     ref = F.silu(ref * (ss[:, :cout].view(b, cout, 1, 1, 1) + 1) + ss[:, cout:].view(b, cout, 1, 1, 1)) + res
     w = ops.pack_conv_weight(wt).to(dev)
     xs = unet_to_cl(x).to(dev)
-    pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=ksplit)
+    counters = torch.zeros(512, dtype=torch.int32, device=dev) if ksplit < 0 else None   # -3: split-K reduced in-launch
+    ksplit = abs(ksplit)
+    pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=ksplit, tile_counters=counters)
     rows_per_tile, ks = ops.conv_plan(pp)
+    if counters is not None:
+        assert rows_per_tile == 160
     pixels = t * s * s
     assert ks == ksplit and pixels % rows_per_tile == 0, (ks, rows_per_tile)
     nchunk = pixels // rows_per_tile
     partial = torch.zeros(b * nchunk, 16, device=dev)
     h = ops.conv2d_cl(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), gn_partial=partial,
-                      gn_groups=8, gn_pixels=pixels, ksplit=ksplit)
+                      gn_groups=8, gn_pixels=pixels, ksplit=ksplit, tile_counters=counters)
     out = ops.groupnorm_apply_cl(h, b, gamma.to(dev), beta.to(dev), partial, nchunk, scale_shift=ss.to(dev),
                                  residual=unet_to_cl(res).to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
