@@ -6,6 +6,7 @@
 // per-workgroup partial (sum, sumsq) via wave shuffles -> a tiny finalize kernel that merges the
 // partials in double and folds mean/rstd/gamma/beta/scale/shift into one per-(b,c) FMA ->
 // a streaming apply pass.  Reduction order is fixed (no float atomics): bit-reproducible.
+#include <stdlib.h>
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -294,7 +295,13 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
                      const float* scale_shift, int ss_ld, float eps, int silu, const float* residual,
                      hipStream_t stream) {
   const int64_t per_b = (int64_t)pixels * (channels / 4);
-  int64_t nb = (per_b + 256 * 4 - 1) / (256 * 4);       // ~4 float4 per thread
+  static int f4 = -1;
+  if (f4 < 0) {
+    const char* e = getenv("LFDM_GN_F4");             // experiment knob: float4 per thread
+    f4 = e ? atoi(e) : 2;
+    if (f4 < 1) f4 = 2;
+  }
+  int64_t nb = (per_b + 256 * f4 - 1) / (256 * f4);
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
   LFDM_LAUNCH(gn_apply_kernel, dim3((unsigned)nb, batch), dim3(256), 0, stream, x, out, pixels, channels,

@@ -546,3 +546,154 @@ def sample_one_video(dsd, gsd, img, cond, num_frames, latent_size, sampling_time
         "sample_out_vid": torch.stack(outs, dim=2), "sample_warped_vid": torch.stack(warps, dim=2),
         "sample_img_fea": fea,
     }
+
+
+# --------------------------------------------------------------------------------------
+# Training rows: frozen LFAE motion predictors + Generator.forward + the DM training step
+# (LFAE/modules/{region_predictor,bg_motion_predictor,pixelwise_flow_predictor,util}.py,
+#  DM/modules/video_flow_diffusion.py:848-903, DM/modules/video_flow_diffusion_model.py:116-188)
+# Restated per frame, exactly in the reference's order of operations (incl. its broadcast matmuls and
+# torch.inverse / torch.svd calls), so it is the slow-but-literal counterpart of cvpr23_lfdm_amd/lfae_predictors.py.
+# --------------------------------------------------------------------------------------
+
+
+def make_coordinate_grid(h, w):
+    """util.py:51-67."""
+    x = 2 * (torch.arange(w).float() / (w - 1)) - 1
+    y = 2 * (torch.arange(h).float() / (h - 1)) - 1
+    return torch.cat((x.view(1, -1).repeat(h, 1).unsqueeze(2), y.view(-1, 1).repeat(1, w).unsqueeze(2)), 2)
+
+
+def anti_alias_down(x, weight, scale=0.25):
+    """AntiAliasInterpolation2d.forward (util.py:254-264)."""
+    ks = weight.shape[-1]
+    ka = ks // 2
+    kb = ka - 1 if ks % 2 == 0 else ka
+    out = F.conv2d(F.pad(x, (ka, kb, ka, kb)), weight=weight, groups=x.shape[1])
+    s = int(1 / scale)
+    return out[:, :, ::s, ::s]
+
+
+def hourglass(x, sd, prefix, num_blocks=5, decoder=True):
+    """Encoder / Decoder (util.py:153-214): DownBlock2d = conv3x3 -> BN -> ReLU -> AvgPool2 (util.py:115-133),
+    UpBlock2d = interpolate x2 -> conv3x3 -> BN -> ReLU (util.py:95-112); decoder concatenates the skips."""
+    outs = [x]
+    for i in range(num_blocks):
+        q = "%sencoder.down_blocks.%d." % (prefix, i)
+        y = F.relu(_bn_eval(_conv(outs[-1], sd, q + "conv.", 1), sd, q + "norm."))
+        outs.append(F.avg_pool2d(y, 2))
+    if not decoder:
+        return outs
+    out = outs.pop()
+    for j in range(num_blocks):
+        q = "%sdecoder.up_blocks.%d." % (prefix, j)
+        out = F.interpolate(out, scale_factor=2)
+        out = F.relu(_bn_eval(_conv(out, sd, q + "conv.", 1), sd, q + "norm."))
+        out = torch.cat([out, outs.pop()], dim=1)
+    return out
+
+
+def region_predictor(rsd, x, temperature=0.1, scale=0.25, pad=3):
+    """RegionPredictor.forward, pca_based (region_predictor.py:52-117)."""
+    x = anti_alias_down(x, rsd["down.weight"], scale)
+    fmap = hourglass(x, rsd, "predictor.")
+    pred = F.conv2d(fmap, rsd["regions.weight"], rsd["regions.bias"], padding=pad)
+    shp = pred.shape
+    region = F.softmax(pred.view(shp[0], shp[1], -1) / temperature, dim=2).view(*shp)
+    grid = make_coordinate_grid(shp[2], shp[3]).unsqueeze(0).unsqueeze(0)
+    r = region.unsqueeze(-1)
+    mean = (r * grid).sum(dim=(2, 3))
+    mean_sub = grid - mean.unsqueeze(-2).unsqueeze(-2)
+    covar = torch.matmul(mean_sub.unsqueeze(-1), mean_sub.unsqueeze(-2)) * r.unsqueeze(-1)
+    covar = covar.sum(dim=(2, 3))
+    u, s, _ = torch.svd(covar.view(-1, 2, 2))
+    affine = torch.matmul(u, torch.diag_embed(s ** 0.5)).view(*covar.shape)
+    return {"shift": mean, "covar": covar, "affine": affine, "heatmap": region}
+
+
+def bg_predictor(bsd, source, driving):
+    """BGMotionPredictor.forward, bg_type 'affine' (bg_motion_predictor.py:42-57)."""
+    feats = hourglass(torch.cat([source, driving], dim=1), bsd, "", decoder=False)
+    pred = F.linear(feats[-1].mean(dim=(2, 3)), bsd["fc.weight"], bsd["fc.bias"])
+    out = torch.eye(3).unsqueeze(0).repeat(source.shape[0], 1, 1)
+    out[:, :2, :] = pred.view(-1, 2, 3)
+    return out
+
+
+def region2gaussian(center, covar, h, w):
+    """util.py:22-48 (matrix covariance)."""
+    grid = make_coordinate_grid(h, w).view(1, 1, h, w, 2)
+    d = grid - center.view(*center.shape[:2], 1, 1, 2)
+    inv = torch.inverse(covar).view(*covar.shape[:2], 1, 1, 2, 2)
+    under = torch.matmul(torch.matmul(d.unsqueeze(-2), inv), d.unsqueeze(-1))
+    return torch.exp(-0.5 * under.sum(dim=(-1, -2)))
+
+
+def pixelwise_flow_predictor(gsd, source_image, driving, source, bg_params, num_regions=10, scale=0.25):
+    """PixelwiseFlowPredictor.forward with use_covar_heatmap, use_deformed_source, revert_axis_swap, occlusion
+    (pixelwise_flow_predictor.py:48-137)."""
+    p = "pixelwise_flow_predictor."
+    img = anti_alias_down(source_image, gsd[p + "down.weight"], scale)
+    bs, c, h, w = img.shape
+    k = num_regions
+    heat = region2gaussian(driving["shift"], driving["covar"], h, w) - region2gaussian(source["shift"], source["covar"], h, w)
+    heat = torch.cat([torch.zeros(bs, 1, h, w), heat], dim=1).unsqueeze(2)
+    ident = make_coordinate_grid(h, w).view(1, 1, h, w, 2)
+    cg = ident - driving["shift"].view(bs, k, 1, 1, 2)
+    affine = torch.matmul(source["affine"], torch.inverse(driving["affine"]))
+    affine = affine * torch.sign(affine[:, :, 0:1, 0:1])
+    affine = affine.unsqueeze(-3).unsqueeze(-3).repeat(1, 1, h, w, 1, 1)
+    cg = torch.matmul(affine, cg.unsqueeze(-1)).squeeze(-1)
+    d2s = cg + source["shift"].view(bs, k, 1, 1, 2)
+    bg = ident.repeat(bs, 1, 1, 1, 1)
+    bg = torch.cat([bg, torch.ones_like(bg[..., :1])], dim=-1)
+    bg = torch.matmul(bg_params.view(bs, 1, 1, 1, 3, 3), bg.unsqueeze(-1)).squeeze(-1)
+    bg = bg[..., :2] / bg[..., 2:]
+    sparse = torch.cat([bg, d2s], dim=1)
+    rep = img.unsqueeze(1).unsqueeze(1).repeat(1, k + 1, 1, 1, 1, 1).view(bs * (k + 1), -1, h, w)
+    deformed = F.grid_sample(rep, sparse.view(bs * (k + 1), h, w, -1), align_corners=False).view(bs, k + 1, -1, h, w)
+    inp = torch.cat([heat, deformed], dim=2).view(bs, -1, h, w)
+    pred = hourglass(inp, gsd, p + "hourglass.")
+    mask = F.softmax(F.conv2d(pred, gsd[p + "mask.weight"], gsd[p + "mask.bias"], padding=3), dim=1).unsqueeze(2)
+    deformation = (sparse.permute(0, 1, 4, 2, 3) * mask).sum(dim=1).permute(0, 2, 3, 1)
+    occ = torch.sigmoid(F.conv2d(pred, gsd[p + "occlusion.weight"], gsd[p + "occlusion.bias"], padding=3))
+    return {"optical_flow": deformation, "occlusion_map": occ}
+
+
+def generator_forward(gsd, img, driving, source, bg_params):
+    """Generator.forward (generator.py:90-128)."""
+    motion = pixelwise_flow_predictor(gsd, img, driving, source, bg_params)
+    out = generator_forward_with_flow(gsd, img, motion["optical_flow"], motion["occlusion_map"])
+    out.update(motion)
+    out["bottle_neck_feat"] = generator_compute_fea(gsd, img)
+    return out
+
+
+def pseudo_ground_truth(gsd, rsd, bsd, ref_img, real_vid):
+    """The no-grad loop of FlowDiffusion.forward (video_flow_diffusion_model.py:124-141), one frame at a time."""
+    src = region_predictor(rsd, ref_img)
+    grids, confs, outs, warps = [], [], [], []
+    for idx in range(real_vid.shape[2]):
+        frame = real_vid[:, :, idx]
+        drv = region_predictor(rsd, frame)
+        bg = bg_predictor(bsd, ref_img, frame)
+        g = generator_forward(gsd, ref_img, drv, src, bg)
+        grids.append(g["optical_flow"].permute(0, 3, 1, 2))
+        confs.append(g["occlusion_map"])
+        outs.append(g["prediction"])
+        warps.append(g["deformed"])
+    return {"real_vid_grid": torch.stack(grids, dim=2), "real_vid_conf": torch.stack(confs, dim=2),
+            "real_out_vid": torch.stack(outs, dim=2), "real_warped_vid": torch.stack(warps, dim=2),
+            "ref_img_fea": g["bottle_neck_feat"]}
+
+
+def p_losses(dsd, x_start, t, fea, cond, noise, null_mask=None):
+    """GaussianDiffusion.p_losses (video_flow_diffusion.py:856-895), loss_type 'l2', dynamic threshold.
+    -> (loss, pred_x0); differentiable w.r.t. every floating entry of dsd that requires grad."""
+    b = x_start.shape[0]
+    x_noisy = _bc(dsd["sqrt_alphas_cumprod"][t], b) * x_start + _bc(dsd["sqrt_one_minus_alphas_cumprod"][t], b) * noise
+    fea_rep = fea.unsqueeze(2).repeat(1, 1, x_start.shape[2], 1, 1)
+    pred_noise = unet_forward(dsd, torch.cat([x_noisy, fea_rep], dim=1), t, cond, null_mask)
+    loss = F.mse_loss(noise, pred_noise)
+    pred_x0 = dynamic_threshold(predict_start_from_noise(dsd, x_noisy, t, pred_noise.detach()))
+    return loss, pred_x0

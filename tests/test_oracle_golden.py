@@ -74,3 +74,30 @@ def test_sample_one_video(name):
         assert_close(out[k], g[k], 2e-5, k)
     for k in ("sample_out_vid", "sample_warped_vid"):
         assert_close(out[k][:, :, vf], g[k], 2e-5, k)
+
+
+def test_training_rows_of_the_oracle_match_the_reference_fixture():
+    """oracle pseudo ground truth (region / bg / pixelwise-flow predictors, Generator.forward) and the diffusion loss
+    against the reference's own training step (tests/golden/train_step_128.npz, first sample only: CPU time)."""
+    import numpy as np
+    g = np.load(os.path.join(GOLD, "train_step_128.npz"))
+    b, t, hw = int(g["b"]), int(g["t"]), int(g["hw"])
+    ref_img, real_vid, cond, tt, noise = synth.train_inputs(b, t, hw)
+    gsd, rsd, bsd = synth.generator_state(), synth.region_state(), synth.bg_state()
+    with torch.no_grad():
+        pg = O.pseudo_ground_truth(gsd, rsd, bsd, ref_img[:1], real_vid[:1])
+    T = lambda k: torch.from_numpy(g[k])
+    assert_close(pg["real_vid_grid"], T("real_vid_grid")[:1], 2e-4, "pseudo-GT flow")
+    assert_close(pg["real_vid_conf"], T("real_vid_conf")[:1], 2e-4, "pseudo-GT occlusion")
+    assert_close(pg["real_out_vid"][:, :, -1], T("real_out_vid")[:1], 2e-4, "real_out_vid")
+    assert_close(pg["real_warped_vid"][:, :, -1], T("real_warped_vid")[:1], 2e-4, "real_warped_vid")
+    # the diffusion loss needs both samples (mean over the batch): use the fixture's own pseudo ground truth
+    dsd = {"denoise_fn." + k: v for k, v in synth.unet_state().items()}
+    dsd.update(O.make_schedule(1000))
+    x0 = torch.cat((T("real_vid_grid"), T("real_vid_conf") * 2 - 1), dim=1)
+    with torch.no_grad():
+        pg_all = O.pseudo_ground_truth(gsd, rsd, bsd, ref_img, real_vid[:, :, :1])       # ref_img_fea of both samples
+        loss, pred_x0 = O.p_losses(dsd, x0, tt, pg_all["ref_img_fea"], cond, noise,
+                                   null_mask=torch.from_numpy(g["null_cond_mask"]))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-4 * max(1.0, abs(float(g["loss"])))
+    assert_close(pred_x0, T("pred_x0"), 5e-4, "pred_x0")
