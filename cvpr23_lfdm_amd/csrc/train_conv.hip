@@ -147,6 +147,47 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(const float* in, float
   }
 }
 
+// same, 16 bytes per lane (n % 4 == 0, 16-byte aligned): the weight-gradient slabs are tens of MB
+__global__ __launch_bounds__(256) void sum_leading4_kernel(const float4* in, float4* out, int64_t n4, int s) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = 0; k < s; ++k) {
+      const float4 v = in[(int64_t)k * n4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    out[i] = acc;
+  }
+}
+
+// float4 variant: 16 float4 columns (64 channels) x 16 row lanes per workgroup
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* x, int64_t rows, int c, int ld, float* partial,
+                                                      int rows_per_blk) {
+  __shared__ __attribute__((aligned(16))) float red[16][64];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * c4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk;
+  if (r1 > rows) r1 = rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < c)
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + col);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  *reinterpret_cast<float4*>(&red[rl][4 * c4]) = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < c) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += red[k][threadIdx.x];
+      partial[(int64_t)blockIdx.y * c + cc] = sum;
+    }
+  }
+}
+
 // partial[blk][c] = sum over the block's rows of x[r][c]; 64 columns per workgroup column strip
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t rows, int c, int ld, float* partial,
                                                      int rows_per_blk) {
@@ -252,6 +293,13 @@ extern "C" size_t lfdm_conv2d_wgrad_ws_bytes(const lfdm_wgrad_params* p) {
 extern "C" int lfdm_sum_leading_f32(const float* in, float* out, int64_t n, int s, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !out || n <= 0 || s <= 0) { lfdm_set_error("sum_leading: bad arguments"); return LFDM_EINVAL; }
+  if (n % 4 == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) {
+    int64_t nb = (n / 4 + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    LFDM_LAUNCH(sum_leading4_kernel, dim3((unsigned)nb), dim3(256), 0, stream, reinterpret_cast<const float4*>(in),
+                reinterpret_cast<float4*>(out), n / 4, s);
+    return lfdm_check_launch("sum_leading");
+  }
   int64_t nb = (n + 255) / 256;
   if (nb > 65536) nb = 65536;
   LFDM_LAUNCH(sum_leading_kernel, dim3((unsigned)nb), dim3(256), 0, stream, in, out, n, s);
@@ -305,8 +353,12 @@ extern "C" int lfdm_colsum_f32(const float* x, int64_t rows, int c, int ld, floa
   if (nblk > 512) nblk = 512;
   if (!ws || ws_bytes < (size_t)nblk * c * sizeof(float)) { lfdm_set_error("colsum: workspace too small"); return LFDM_EWORKSPACE; }
   const int rows_per_blk = (int)((rows + nblk - 1) / nblk);
-  LFDM_LAUNCH(colsum_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)nblk), dim3(256), 0, stream, x, rows, c, ld, (float*)ws,
-              rows_per_blk);
+  if (c % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0)
+    LFDM_LAUNCH(colsum4_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)nblk), dim3(256), 0, stream, x, rows, c, ld, (float*)ws,
+                rows_per_blk);
+  else
+    LFDM_LAUNCH(colsum_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)nblk), dim3(256), 0, stream, x, rows, c, ld, (float*)ws,
+                rows_per_blk);
   int rc = lfdm_check_launch("colsum");
   if (rc) return rc;
   return lfdm_sum_leading_f32((const float*)ws, out, c, (int)nblk, stream_);
