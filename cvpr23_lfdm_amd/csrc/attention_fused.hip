@@ -28,6 +28,98 @@ constexpr int HEADS = 8;
 constexpr int DH = 32;
 constexpr int OUT_LD = HEADS * DH;      // 256
 
+// Attention of one (sequence, head) from operand-layout fragments (see the header comment): scores transposed,
+// softmax in registers, P V, store.  qf/kf[ti][4*fi + r] = feature 16*fi + 4*lq + r of token 16*ti + l15 (q scaled and
+// rotated, k rotated); vf[half][4*ti + r] = v[token 16*ti + 4*lq + r][16*half + l15].
+template <int NT>
+__device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const float (&kf)[NT][8], const float (&vf)[2][4 * NT],
+                                             int head, int L, int l15, int lq, const float* __restrict__ bias, bool bias_vec,
+                                             float* __restrict__ out, int64_t row0, int hw) {
+  // ---- S^T = K Q^T: lane = query token 16*ti + l15, registers = key tokens 16*tj + 4*lq + r.  In this orientation the
+  // softmax over the keys of a query is a reduction over the lane's registers plus two shuffles (the four k-slots),
+  // and the result is ALREADY the A operand of P V for the token order t(lq, s) = 16*(s>>2) + 4*lq + (s&3): no LDS. ----
+  f32x4 st[NT][NT];                                   // [ti (query tile)][tj (key tile)]
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(kf[tj][s], qf[ti][s], acc);
+      st[ti][tj] = acc;
+    }
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    const int qt = ti * 16 + l15;                     // this lane's query token
+    float m = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      const int key0 = tj * 16 + lq * 4;
+      if (bias && qt < L && key0 < L) {
+        const float* bp = bias + ((int64_t)head * L + qt) * L + key0;
+        if (bias_vec) {                                 // four consecutive keys of one query row: one 16-byte load
+          const float4 b4 = *reinterpret_cast<const float4*>(bp);
+          bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = (key0 + r < L) ? bp[r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = st[ti][tj][r];
+        if (key0 + r >= L) v = -3.0e38f;
+        else v += bv[r];
+        st[ti][tj][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = tj * 16 + lq * 4 + r;
+        const float e = key < L ? expf(st[ti][tj][r] - m) : 0.f;
+        st[ti][tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] / sum;
+  }
+
+  // ---- O = P V ----
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    f32x4 o[2];
+    o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o[1] = o[0];
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[0] = mfma_16x16x4(st[ti][tj][r], vf[0][4 * tj + r], o[0]);
+        o[1] = mfma_16x16x4(st[ti][tj][r], vf[1][4 * tj + r], o[1]);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = ti * 16 + lq * 4 + r;
+      if (t < L) {
+        float* dst = out + (row0 + (int64_t)t * hw) * OUT_LD + head * DH;
+        dst[l15] = o[0][r];
+        dst[16 + l15] = o[1][r];
+      }
+    }
+  }
+}
+
 template <int LP, int C>
 __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float* __restrict__ x, int ldx, int heads_per_block,
                                                                  const float* __restrict__ wqkv,   // (768, C), gamma folded
@@ -150,66 +242,6 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
           }
       }
     }
-    // ---- S^T = K Q^T: lane = query token 16*ti + l15, registers = key tokens 16*tj + 4*lq + r.  In this orientation the
-    // softmax over the keys of a query is a reduction over the lane's registers plus two shuffles (the four k-slots),
-    // and the result is ALREADY the A operand of P V for the token order t(lq, s) = 16*(s>>2) + 4*lq + (s&3): no LDS. ----
-    f32x4 st[NT][NT];                                   // [ti (query tile)][tj (key tile)]
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(kf[tj][s], qf[ti][s], acc);
-        st[ti][tj] = acc;
-      }
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-      const int qt = ti * 16 + l15;                     // this lane's query token
-      float m = -3.0e38f;
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        const int key0 = tj * 16 + lq * 4;
-        if (bias && qt < L && key0 < L) {
-          const float* bp = bias + ((int64_t)head * L + qt) * L + key0;
-          if (bias_vec) {                                 // four consecutive keys of one query row: one 16-byte load
-            const float4 b4 = *reinterpret_cast<const float4*>(bp);
-            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (key0 + r < L) ? bp[r] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = st[ti][tj][r];
-          if (key0 + r >= L) v = -3.0e38f;
-          else v += bv[r];
-          st[ti][tj][r] = v;
-          m = fmaxf(m, v);
-        }
-      }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float sum = 0.f;
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = tj * 16 + lq * 4 + r;
-          const float e = key < L ? expf(st[ti][tj][r] - m) : 0.f;
-          st[ti][tj][r] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] / sum;
-    }
-
     // ---- V: rows = tokens, cols = features; vf[half][4*ti + r] = v[token 16*ti + 4*lq + r][16*half + l15] ----
     float vf[2][4 * NT];
     {
@@ -239,30 +271,148 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
       }
     }
 
-    // ---- O = P V ----
+    attend_store<NT>(qf, kf, vf, head, L, l15, lq, bias, bias_vec, out, row0, hw);
+  }
+}
+
+// Wide variant (C = 128, 256, ...): the channels are streamed in blocks of 64 with persistent Q^T / K^T / V
+// accumulators, so the register budget does not grow with C; the sequence's rows are re-read from L1/L2 for every head
+// and channel block (10-40 KB) and normalised on the fly with the token's mean / rstd computed once up front.
+template <int LP>
+__global__ __launch_bounds__(64, 1) void temporal_attn_fused_wide_kernel(const float* __restrict__ x, int ldx, int channels,
+                                                                      int heads_per_block, const float* __restrict__ wqkv,
+                                                                      float* __restrict__ out, int batch, int frames, int hw,
+                                                                      const float* __restrict__ bias,
+                                                                      const float* __restrict__ rot_cos,
+                                                                      const float* __restrict__ rot_sin, float eps) {
+  constexpr int NT = LP / 16;
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int L = frames;
+  const int64_t seq = blockIdx.x;
+  const int64_t b = seq / hw, pix = seq - b * hw;
+  const int64_t row0 = b * frames * hw + pix;
+  const float scale = 0.17677669529663687f;
+  const int ncb = channels / 64;
+
+  float mean[NT], rstd[NT];
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-      f32x4 o[2];
-      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      o[1] = o[0];
+  for (int ti = 0; ti < NT; ++ti) {
+    const int t = ti * 16 + l15;
+    float s1 = 0.f, s2 = 0.f;
+    if (t < L) {
+      const float* src = x + (row0 + (int64_t)t * hw) * ldx + 16 * lq;
+      for (int cb = 0; cb < ncb; ++cb)
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(src + 64 * cb + 4 * q);
+          s1 += (v.x + v.y) + (v.z + v.w);
+          s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float m = s1 / (float)channels;
+    float var = s2 / (float)channels - m * m;
+    if (var < 0.f) var = 0.f;
+    mean[ti] = m;
+    rstd[ti] = 1.0f / sqrtf(var + eps);
+  }
+  const bool bias_vec = bias && (L % 4 == 0) && ((((uintptr_t)bias) & 15) == 0);
+
+  const int head_begin = blockIdx.y * heads_per_block;
+#pragma unroll 1
+  for (int head = head_begin; head < head_begin + heads_per_block; ++head) {
+    f32x4 aq[2][NT], ak[2][NT], av[2][NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[0] = mfma_16x16x4(st[ti][tj][r], vf[0][4 * tj + r], o[0]);
-          o[1] = mfma_16x16x4(st[ti][tj][r], vf[1][4 * tj + r], o[1]);
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) aq[g][ti] = ak[g][ti] = av[g][ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cb = 0; cb < ncb; ++cb) {
+      // weight-row fragments of this channel block: k-slot lq <-> channels 64*cb + 16*lq + s
+      float w[6][16];
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        const float* wsrc = wqkv + ((int64_t)((g >> 1) * OUT_LD + head * DH + 16 * (g & 1) + l15)) * channels + 64 * cb + 16 * lq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + 4 * q);
+          w[g][4 * q] = v.x; w[g][4 * q + 1] = v.y; w[g][4 * q + 2] = v.z; w[g][4 * q + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        const int t = ti * 16 + l15;
+        float xf[16];
+        if (t < L) {
+          const float* src = x + (row0 + (int64_t)t * hw) * ldx + 64 * cb + 16 * lq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+            xf[4 * q] = (v.x - mean[ti]) * rstd[ti]; xf[4 * q + 1] = (v.y - mean[ti]) * rstd[ti];
+            xf[4 * q + 2] = (v.z - mean[ti]) * rstd[ti]; xf[4 * q + 3] = (v.w - mean[ti]) * rstd[ti];
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) xf[s2] = 0.f;
         }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = ti * 16 + lq * 4 + r;
-        if (t < L) {
-          float* dst = out + (row0 + (int64_t)t * hw) * OUT_LD + head * DH;
-          dst[l15] = o[0][r];
-          dst[16 + l15] = o[1][r];
+        for (int s2 = 0; s2 < 16; ++s2) {
+          aq[0][ti] = mfma_16x16x4(w[0][s2], xf[s2], aq[0][ti]);      // Q^T, K^T: rows = features, cols = tokens
+          aq[1][ti] = mfma_16x16x4(w[1][s2], xf[s2], aq[1][ti]);
+          ak[0][ti] = mfma_16x16x4(w[2][s2], xf[s2], ak[0][ti]);
+          ak[1][ti] = mfma_16x16x4(w[3][s2], xf[s2], ak[1][ti]);
+          av[0][ti] = mfma_16x16x4(xf[s2], w[4][s2], av[0][ti]);      // V: rows = tokens, cols = features
+          av[1][ti] = mfma_16x16x4(xf[s2], w[5][s2], av[1][ti]);
         }
       }
     }
+    float qf[NT][8], kf[NT][8], vf[2][4 * NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qf[ti][4 * fi + r] = aq[fi][ti][r] * scale;
+          kf[ti][4 * fi + r] = ak[fi][ti][r];
+          vf[fi][4 * ti + r] = av[fi][ti][r];
+        }
+    if (rot_cos) {
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        const int t = ti * 16 + l15;
+        const int tt = t < L ? t : 0;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const float c = rot_cos[tt * 16 + 8 * fi + 2 * lq + pr], sn = rot_sin[tt * 16 + 8 * fi + 2 * lq + pr];
+            const float qx = qf[ti][4 * fi + 2 * pr], qy = qf[ti][4 * fi + 2 * pr + 1];
+            const float kx = kf[ti][4 * fi + 2 * pr], ky = kf[ti][4 * fi + 2 * pr + 1];
+            qf[ti][4 * fi + 2 * pr] = qx * c - qy * sn;
+            qf[ti][4 * fi + 2 * pr + 1] = qy * c + qx * sn;
+            kf[ti][4 * fi + 2 * pr] = kx * c - ky * sn;
+            kf[ti][4 * fi + 2 * pr + 1] = ky * c + kx * sn;
+          }
+      }
+    }
+    attend_store<NT>(qf, kf, vf, head, L, l15, lq, bias, bias_vec, out, row0, hw);
   }
+}
+
+int launch_fused_wide(const float* x, int ldx, int channels, const float* wqkv, float* out, int batch, int frames, int hw,
+                      const float* bias, const float* rot_cos, const float* rot_sin, float eps, hipStream_t stream) {
+  const int64_t nseq = (int64_t)batch * hw;
+  int hpb = 8;
+  while (hpb > 1 && nseq * (HEADS / hpb) < 2048) hpb >>= 1;
+  const dim3 grid((unsigned)nseq, (unsigned)(HEADS / hpb)), block(64);
+  if (frames <= 16) LFDM_LAUNCH((temporal_attn_fused_wide_kernel<16>), grid, block, 0, stream, x, ldx, channels, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (frames <= 32) LFDM_LAUNCH((temporal_attn_fused_wide_kernel<32>), grid, block, 0, stream, x, ldx, channels, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (frames <= 48) LFDM_LAUNCH((temporal_attn_fused_wide_kernel<48>), grid, block, 0, stream, x, ldx, channels, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  else LFDM_LAUNCH((temporal_attn_fused_wide_kernel<64>), grid, block, 0, stream, x, ldx, channels, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
+  return lfdm_check_launch("temporal_attention_fused_wide");
 }
 
 template <int C>
@@ -288,10 +438,10 @@ extern "C" int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !wqkv || !out || batch <= 0 || frames <= 0 || frames > 64 || hw <= 0 || ldx < channels || ldx % 4 != 0 ||
       (((uintptr_t)x | (uintptr_t)wqkv) & 15) || ((rot_cos == nullptr) != (rot_sin == nullptr)) ||
-      (channels != 64 && channels != 128)) {
-    lfdm_set_error("temporal_attention_fused: needs C in {64, 128}, frames <= 64, 16-byte aligned rows");
+      channels < 64 || channels % 64 != 0) {
+    lfdm_set_error("temporal_attention_fused: needs C % 64 == 0, frames <= 64, 16-byte aligned rows");
     return LFDM_EINVAL;
   }
   if (channels == 64) return launch_fused<64>(x, ldx, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
-  return launch_fused<128>(x, ldx, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  return launch_fused_wide(x, ldx, channels, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
 }

@@ -263,7 +263,7 @@ int lfdm_planar_to_cl_f32(const float* x, float* out, int n_img, int channels, i
 int lfdm_cl_to_planar_f32(const float* x, float* out, int n_img, int channels, int hw, int ldx,
                           lfdm_stream_t stream);
 
-/* PreNorm LayerNorm + to_qkv + temporal Attention (without to_out) in one launch, for C in {64, 128}:
+/* PreNorm LayerNorm + to_qkv + temporal Attention (without to_out) in one launch, for C % 64 == 0:
  * video_flow_diffusion.py:170-189 (LayerNorm, PreNorm), :270-283 (einops re-layout), :303-361 (Attention incl.
  * rotary :329-331 and relative position bias :339-340).  x: CL rows (B*T*HW, C) stride ldx; wqkv: the to_qkv weight
  * (768, C) row-major with the LayerNorm gamma folded in (w[n][c] * gamma[c]); out: rows of 256 (heads merged).

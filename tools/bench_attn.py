@@ -59,3 +59,17 @@ out = torch.empty(rows, 256, device="cuda")
 ws = torch.empty(16 << 20, device="cuda")
 us = timeit(lambda: ops.linear_attention_fused_cl(x, wq, t, s * s, out=out, ws=ws))
 print("res %2d C=%3d: fused %7.1f us" % (s, c, us))
+
+print("wide fused temporal attention (C = 128 @16, 256 @8) vs separate:")
+for s, c in ((16, 128), (8, 256), (4, 512)):
+    rows = t * s * s
+    x = torch.randn(rows, c, device="cuda")
+    wq = torch.randn(768, c, device="cuda") * 0.1
+    gamma = torch.ones(c, device="cuda")
+    out = torch.empty(rows, 256, device="cuda")
+    us = timeit(lambda: ops.temporal_attention_fused_cl(x, wq, 1, t, s * s, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
+    packed, wsum = ops.pack_ln_conv_weight(wq, gamma)
+    qkv = torch.empty(rows, 768, device="cuda")
+    us_a = timeit(lambda: ops.conv2d_cl(x, packed, 768, 1, 1, t, s, s, ln_wsum=wsum, out=qkv))
+    us_b = timeit(lambda: ops.attention_cl(qkv, 1, t, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=out))
+    print("res %2d C=%3d: fused %7.1f us   separate %7.1f + %7.1f us" % (s, c, us, us_a, us_b))
