@@ -17,6 +17,7 @@ typedef emu_f32x4 f32x4;
   emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
 static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return emu_mfma_32x32x2(a, b, c); }
 static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return emu_mfma_16x16x4(a, b, c); }
+static inline f32x4 mfma_4x4x1(float a, float b, f32x4 c) { return emu_mfma_4x4x1(a, b, c); }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,6 +31,11 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 // lane l: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D col = l&15, row = (l>>4)*4 + r
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// 16 independent 4x4 blocks (K = 1): block b = l>>2, A_b[i] from lane 4b+i, B_b[j] from lane 4b+j; D_b[i][j] = register i
+// of lane 4b+j.  Full MFMA rate with only FOUR output columns per block: the shape for skinny-N contractions.
+__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 #endif
 

@@ -110,6 +110,10 @@ class Generator(ParamTree):
         pk["final.w"] = ops.pack_conv_weight(torch.cat((wf, wf.new_zeros(cpad, *wf.shape[1:])), dim=0).contiguous())
         pk["final.b"] = torch.cat((bf, bf.new_zeros(cpad))).contiguous()
         pk["final.cout"] = wf.shape[0] + cpad
+        # <= 4 output channels: sixteen 4x4 MFMA blocks per instruction (lane = pixel) instead of a 32-column tile
+        pk["final.small"] = None
+        if wf.shape[0] <= 4 and wf.shape[1] % 16 == 0 and wf.shape[2] == wf.shape[3] and wf.shape[2] % 2 == 1 and wf.shape[2] <= 7:
+            pk["final.small"] = ops.pack_smalln_weight(wf, bf)
         return pk
 
     def _feat(self, i):
@@ -183,8 +187,14 @@ class Generator(ParamTree):
             res_h, res_w = res_h * 2, res_w * 2
         blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
                               out=self._buf("dec.wf", n * res_h * res_w, skips[0].shape[1]), **wk)
-        rgb = ops.conv2d_cl(blended, pk["final.w"], pk["final.cout"], 7, 7, n, res_h, res_w, bias=pk["final.b"],
-                            act=ops.ACT_SIGMOID, out=self._buf("dec.rgb", n * res_h * res_w, pk["final.cout"]))[:, :c]
+        rgb_buf = self._buf("dec.rgb", n * res_h * res_w, pk["final.cout"])
+        if pk["final.small"] is not None:
+            wsm, bsm = pk["final.small"]
+            rgb = ops.conv2d_smalln_cl(blended, wsm, bsm, c, int(round(wsm.shape[0] ** 0.5)), n, res_h, res_w,
+                                       act=ops.ACT_SIGMOID, out=rgb_buf)[:, :c]
+        else:
+            rgb = ops.conv2d_cl(blended, pk["final.w"], pk["final.cout"], 7, 7, n, res_h, res_w, bias=pk["final.b"],
+                                act=ops.ACT_SIGMOID, out=rgb_buf)[:, :c]
         prediction = ops.warp_planar(img, frames, flow_x, flow_y, occ, fh, fw, fsb, fst, prev=rgb, prev_is_cl=True,
                                      occ_scale=occ_scale, occ_bias=occ_bias)
         return prediction, deformed

@@ -190,6 +190,29 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     return out
 
 
+def pack_smalln_weight(w, bias=None):
+    """(Cout <= 4, Cin, k, k) -> ([k*k][Cin][4] filters innermost, zero padded; bias padded to 4)."""
+    cout, cin, kh, kw = w.shape
+    assert cout <= 4 and kh == kw
+    wp = torch.zeros(kh * kw, cin, 4, dtype=torch.float32, device=w.device)
+    wp[:, :, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    bp = torch.zeros(4, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        bp[:cout] = bias
+    return wp.contiguous(), bp
+
+
+def conv2d_smalln_cl(x, wpacked, bias4, cout, k, n_img, h, w, *, act=ACT_NONE, out=None):
+    """Convolution with <= 4 output channels (4x4x1 MFMA blocks); out rows have stride out.stride(0) >= cout."""
+    lib = _lib()
+    _chk(lib, x, wpacked, bias4, out)
+    if out is None:
+        out = torch.empty(n_img * h * w, 4, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_conv2d_smalln_cl_f32(_p(x), x.stride(0), x.shape[1], n_img, h, w, _p(wpacked), _p(bias4), _p(out),
+                                            out.stride(0), cout, k, act, _stream(lib)), "lfdm_conv2d_smalln_cl_f32")
+    return out
+
+
 def deconv4x4s2_cl(src, packs, cout, n_img, hi, wi, *, bias=None, out=None):
     """ConvTranspose (1,4,4) stride (1,2,2) pad (0,1,1) as four parity 2x2 convolutions."""
     if out is None:

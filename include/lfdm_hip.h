@@ -281,6 +281,14 @@ int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, co
                                        int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                        lfdm_stream_t stream);
 
+/* Convolution with at most 4 output channels on v_mfma_f32_4x4x1 (sixteen 4x4 blocks per instruction, lane = output
+ * pixel): the LFAE generator's final Conv2d(64 -> 3, 7x7) + sigmoid (LFAE/modules/generator.py:54,161-162).
+ * x: CL rows (n_img*h*w, cin) stride ldx; wgt: [k*k][cin][4] (tap-major, filters innermost, zero padded to 4);
+ * bias: 4 floats or NULL; out: CL rows stride ldo (only `cout` columns are written); stride 1, zero padding k/2. */
+int lfdm_conv2d_smalln_cl_f32(const float* x, int ldx, int cin, int n_img, int h, int w, const float* wgt,
+                              const float* bias, float* out, int ldo, int cout, int k, int act,
+                              lfdm_stream_t stream);
+
 /* ==========================================================================================
  * TRAINING (backward) kernels - the DM gradient step of
  * DM/modules/video_flow_diffusion_model.py:181-188 (loss.backward(); optimizer_diff.step()).

@@ -151,6 +151,26 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks, K = 1.  Block b = lane>>2: A_b[i] from lane 4b+i,
+// B_b[j] from lane 4b+j; D_b[i][j]: register i of lane 4b+j.
+static inline emu_f32x4 emu_mfma_4x4x1(float a, float b, emu_f32x4 c) {
+  emu::WaveState& w = emu::my_wave();
+  unsigned lane = emu::lane_id();
+  float ab[2] = {a, b};
+  memcpy(w.slot[lane], ab, 8);
+  emu::wave_sync();
+  const unsigned blk = lane >> 2;
+  float bv;
+  memcpy(&bv, w.slot[lane] + 4, 4);                 // B_b[j = lane&3] is this lane's own b
+  for (int i = 0; i < 4; ++i) {
+    float av;
+    memcpy(&av, w.slot[4 * blk + i], 4);
+    c[i] = fmaf(av, bv, c[i]);
+  }
+  emu::wave_sync();
+  return c;
+}
+
 // v_mfma_f32_16x16x4_f32: A[i][k] from lane i+16k, B[k][j] from lane j+16k;
 // D: col = lane&15, row = (lane>>4)*4 + reg.
 static inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {

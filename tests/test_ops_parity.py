@@ -488,3 +488,19 @@ def test_linear_attention_fused(backend, hw):
     wf = (wq * gamma.reshape(1, -1)).contiguous()
     out = ops.linear_attention_fused_cl(x.reshape(-1, c).to(dev), wf.to(dev), nf, hw)
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + linear attention")
+
+
+@pytest.mark.parametrize("cin,k,h,w", [(16, 7, 20, 18), (64, 7, 16, 16), (32, 3, 5, 33)])
+def test_conv2d_smalln(backend, cin, k, h, w):
+    """<= 4 output channels on the 4x4x1 MFMA blocks (LFAE final 7x7 RGB conv + sigmoid); ragged tiles."""
+    dev = backend
+    n = 2
+    if big(dev) and cin == 64:
+        n, h, w = 8, 128, 128
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(3, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    bias = rnd(3, seed=3)
+    ref = torch.sigmoid(F.conv2d(x, wt, bias, padding=k // 2))
+    wp, bp = ops.pack_smalln_weight(wt, bias)
+    out = ops.conv2d_smalln_cl(to_cl(x).to(dev), wp.to(dev), bp.to(dev), 3, k, n, h, w, act=ops.ACT_SIGMOID)
+    assert_close(from_cl(out[:, :3].contiguous().cpu(), n, h, w), ref, TOL, "small-N conv")
