@@ -7,6 +7,7 @@
 // LDS-privatised histograms merged by integer atomics (order independent -> deterministic).
 // All step-dependent scalars come from a device table indexed by a device counter so the captured
 // hipGraph of one step can be replayed for every step.
+#include <stdlib.h>
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -25,28 +26,34 @@ struct Ranks {
 // All 256 threads call it; result is broadcast through LDS.
 __device__ void find_bin(const unsigned* hist, int nbins, unsigned k, unsigned& bin, unsigned& krem,
                          unsigned* s_part /*[256]*/, unsigned* s_res /*[2]*/) {
-  const int tid = threadIdx.x;
-  const int per = nbins / 256;
-  unsigned local = 0;
-  for (int i = 0; i < per; ++i) local += hist[tid * per + i];
-  s_part[tid] = local;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned run = 0;
-    int seg = 255;
-    for (int i = 0; i < 256; ++i) {
-      if (run + s_part[i] > k) { seg = i; break; }
-      run += s_part[i];
+  // one wavefront: each lane sums nbins/64 consecutive bins, a shuffle scan locates the lane holding rank k, that lane
+  // walks its own bins.  (The first version let thread 0 walk 256 partial sums serially - 6 of these per workgroup cost
+  // more than streaming the data.)
+  (void)s_part;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int per = nbins / 64;
+    unsigned local = 0;
+    for (int i = 0; i < per; ++i) local += hist[lane * per + i];
+    unsigned incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned up = __shfl(incl, lane >= d ? lane - d : lane);
+      if (lane >= d) incl += up;
     }
-    unsigned b = seg * per;
-    for (int i = 0; i < per; ++i) {
-      const unsigned c = hist[seg * per + i];
-      b = seg * per + i;
-      if (run + c > k) break;
-      if (i + 1 < per) run += c;
+    const unsigned excl = incl - local;
+    if (k >= excl && k < incl) {
+      unsigned run = excl;
+      int b = lane * per;
+      for (int i = 0; i < per; ++i) {
+        const unsigned c = hist[lane * per + i];
+        b = lane * per + i;
+        if (run + c > k) break;
+        run += c;
+      }
+      s_res[0] = (unsigned)b;
+      s_res[1] = k - run;
     }
-    s_res[0] = b;
-    s_res[1] = k - run;
   }
   __syncthreads();
   bin = s_res[0];
@@ -291,12 +298,12 @@ extern "C" int lfdm_sampler_step_f32(float* x, const float* eps, const float* no
   }
   unsigned* hists = reinterpret_cast<unsigned*>(ws);
   float* x0buf = reinterpret_cast<float*>(hists + (size_t)batch * HIST_PER_SAMPLE);
+  const Ranks rk = make_ranks(n, quantile);
   {
     const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
     LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream,
                 hists, nz);
   }
-  const Ranks rk = make_ranks(n, quantile);
   const dim3 grid(blocks_for(n), batch), block(256);
   LFDM_LAUNCH(quantile_pass0_kernel, grid, block, 0, stream, (const float*)x, eps, x0buf, n, coef,
               (const int32_t*)step_dev, hists);

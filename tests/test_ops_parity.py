@@ -309,12 +309,17 @@ def test_abs_quantile(backend, n):
     assert torch.equal(out.cpu(), ref), (out.cpu(), ref)
 
 
-@pytest.mark.parametrize("mode", ["ddim", "ddim_last", "ddpm"])
+@pytest.mark.parametrize("mode", ["ddim", "ddim_last", "ddpm", "ddim_c5"])
 def test_sampler_step(backend, mode):
+    """mode ddim_c5: 64x64 latent (491 520 elements per sample)."""
     dev = backend
     b, shape = 2, (3, 4, 8, 8)
     if big(dev):
         shape = (3, 40, 32, 32)
+    if mode == "ddim_c5":
+        if not big(dev):
+            pytest.skip("large latent: GPU only")
+        shape, mode = (3, 40, 64, 64), "ddim"
     x, eps, noise = rnd(b, *shape, seed=1), rnd(b, *shape, seed=2), rnd(b, *shape, seed=3)
     sd = O.make_schedule(1000)
     time = 640
