@@ -45,15 +45,24 @@ def build_hip(force=False, verbose=False):
     objdir = os.path.join(PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [d for d in _deps() if d.endswith(".h")]
-    objs = []
+    objs, todo = [], []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            out = _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
-                        "-o", obj, "-Wno-unused-result"])
-            if verbose and out.strip():
-                print(out)
+            todo.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        return _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
+                     "-o", obj, "-Wno-unused-result"])
+
+    if todo:      # independent translation units: compile a few at a time
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(6, len(todo), os.cpu_count() or 1)) as pool:
+            for out in pool.map(compile_one, todo):
+                if verbose and out.strip():
+                    print(out)
     if force or _stale(HIP_LIB, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
     return HIP_LIB
