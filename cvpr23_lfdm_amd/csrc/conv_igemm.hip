@@ -630,7 +630,6 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     const int64_t mt = (M + 159) / 160;
     const int64_t t64 = mt * ((p.coutp + 63) / 64), t32 = mt * ((p.coutp + 31) / 32);
     pl.bn = (t64 >= 224 && p.coutp > 32) ? 64 : 32;      // <= 32 (padded) output channels: the 64-column tile would be half empty
-    if (const char* e = getenv("LFDM_KSW_BN")) pl.bn = atoi(e);   // experiment knob
     int k = 1;
     if (t64 < 224 && t32 < 224) {
       k = (int)(256 / t32);

@@ -295,12 +295,7 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
                      const float* scale_shift, int ss_ld, float eps, int silu, const float* residual,
                      hipStream_t stream) {
   const int64_t per_b = (int64_t)pixels * (channels / 4);
-  static int f4 = -1;
-  if (f4 < 0) {
-    const char* e = getenv("LFDM_GN_F4");             // experiment knob: float4 per thread
-    f4 = e ? atoi(e) : 2;
-    if (f4 < 1) f4 = 2;
-  }
+  constexpr int f4 = 2;       // float4 per thread (measured: 2 beats 4..32; the finalize prologue is cheap, occupancy is not)
   int64_t nb = (per_b + 256 * f4 - 1) / (256 * f4);
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;

@@ -281,8 +281,9 @@ class Unet3D(ParamTree):
             pixels = m // batch
             cg = cout // 8
             fused = ksplit > 1 and tile_rows == 160
-            if pixels % tile_rows == 0 and cg % 4 == 0 and 32 % cg == 0 and (
-                    ksplit == 1 or fused or (256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout)):
+            in_tile = (ksplit == 1 or fused) and 32 % cg == 0             # statistics from the conv epilogue (group inside a 32-column tile)
+            in_reduce = ksplit > 1 and not fused and 256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout    # ... from the split-K reduce pass (any group width)
+            if pixels % tile_rows == 0 and cg % 4 == 0 and (in_tile or in_reduce):
                 nchunk = pixels // tile_rows
                 stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), 8, pixels

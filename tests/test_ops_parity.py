@@ -134,12 +134,14 @@ def test_groupnorm_silu(backend, c, with_ss):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
 
 
-@pytest.mark.parametrize("ksplit", [1, 3, -3])
+@pytest.mark.parametrize("ksplit", [1, 3, -3, 512])
 def test_conv_fused_groupnorm_stats(backend, ksplit):
     """conv epilogue (or the split-K reduce) emits the GroupNorm partial sums; finalize+apply must equal
     conv -> group_norm."""
     dev = backend
     b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else ((2, 5, 8, 32, 64) if ksplit >= 0 else (2, 5, 8, 64, 64))
+    if ksplit == 512:       # 64-channel groups (C_out = 512, the 4x4 level): statistics come from the split-K reduce pass
+        b, t, s, cin, cout, ksplit = (1, 40, 4, 256, 512, 4) if big(dev) else (2, 2, 4, 64, 512, 2)
     x = rnd(b, cin, t, s, s, seed=1)
     wt = rnd(cout, cin, 1, 3, 3, seed=2, scale=0.06)
     bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
