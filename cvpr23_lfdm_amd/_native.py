@@ -40,7 +40,7 @@ class ConvParams(C.Structure):
         ("gn_partial", f32p),
         ("gn_groups", i32), ("gn_pixels", i32),
         ("ln_wsum", f32p), ("ln_eps", f32),
-        ("tile_counters", C.c_void_p), ("tile_counters_len", i32),
+        ("tile_counters", C.c_void_p), ("tile_counters_len", i32), ("weight_wino", C.c_void_p),
     ]
 
 

@@ -577,6 +577,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, hipStream_t stream);          // conv_wino.hip
 
 namespace {
 
@@ -584,7 +585,8 @@ struct ConvPlan;
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p);
 
 struct ConvPlan {
-  int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip)
+  int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip),
+                   // 2 = Winograd F(2x2,3x3), 128-pixel x 32-column tiles (conv_wino.hip)
   int bm, bn, ksplit;
   bool fast, simple;
 };
@@ -604,6 +606,11 @@ int conv_force() {   // debugging aid for tools/bench_conv.py: LFDM_CONV_FORCE=i
 //    about 256 workgroups (one per CU) exist;
 //  - otherwise the 2x2-wave kernel: 128x128 tiles when they give >= 256 workgroups, else 64x64, with
 //    split-K for the low-resolution levels.
+bool wino_enabled() {   // on by default (faster than the direct kernels on every 3x3 shape of tools/bench_conv.py); LFDM_WINO=0
+  const char* e = getenv("LFDM_WINO");       // forces the direct form.  Read per call: tests and tools toggle it at run time
+  return !(e && e[0] == '0');
+}
+
 ConvPlan make_plan(const lfdm_conv_params& p) {
   ConvPlan pl;
   const int cin = p.c0 + p.c1;
@@ -624,6 +631,27 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160 && !p.ln_wsum && fits32 && vec_ok;
   if (conv_force() == 0) ksw = false;
   if (conv_force() == 1 && pl.fast && pl.simple && !p.ln_wsum && fits32 && vec_ok) ksw = true;
+  const bool wino = p.weight_wino && wino_enabled() && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 &&
+                    pl.simple && p.hq == p.hi && p.wq == p.wi && p.hi % 2 == 0 && p.wi % 2 == 0 && p.c0 % 16 == 0 &&
+                    p.c1 % 16 == 0 && p.ld0 % 4 == 0 && (p.c1 == 0 || p.ld1 % 4 == 0) && (((uintptr_t)p.src0 & 15) == 0) &&
+                    (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0) && (((uintptr_t)p.weight_wino) & 15) == 0 && !p.ln_wsum &&
+                    p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64;
+  if (wino) {
+    pl.kind = 2;
+    pl.bm = 128;
+    pl.bn = 32;
+    const int64_t blocks = (((int64_t)p.n_img * (p.hi / 2) * (p.wi / 2) + 31) / 32) * ((p.coutp + 31) / 32);
+    const int nch = cin / 16;
+    int k = 1;
+    if (blocks < 224) {
+      k = (int)(256 / blocks);
+      if (k > nch / 4) k = nch / 4;
+      if (k < 1) k = 1;
+    }
+    pl.ksplit = user_k >= 1 ? user_k : k;
+    if (pl.ksplit > nch) pl.ksplit = nch;
+    return pl;
+  }
   if (ksw) {
     pl.kind = 1;
     pl.bm = 160;
@@ -729,6 +757,8 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   int rc;
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
+  } else if (pl.kind == 2) {
+    rc = lfdm_conv_wino_launch(p, stream);
   } else {
     const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit);
     if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);

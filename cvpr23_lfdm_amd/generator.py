@@ -102,6 +102,9 @@ class Generator(ParamTree):
             w, b = conv_bn(p + "conv1.", p + "norm2.")       # conv1 -> norm2 folded, ReLU in the epilogue
             pk["r%d.w1" % i], pk["r%d.bb1" % i] = ops.pack_conv_weight(w), b
             pk["r%d.w2" % i] = ops.pack_conv_weight(g(p + "conv2.weight").contiguous())
+            # Winograd F(2x2,3x3) forms of the same filters (the library chooses the schedule)
+            pk["r%d.ww1" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
+            pk["r%d.ww2" % i] = ops.pack_wino_weight(g(p + "conv2.weight")) if w.shape[1] % 16 == 0 else None
             pk["r%d.b2" % i] = g(p + "conv2.bias").contiguous()
         # output channels padded to a multiple of 4 (zero filters): float4 epilogue -> the 32-column KSW tile instead of
         # a 64-column tile for 3 real channels
@@ -171,9 +174,9 @@ class Generator(ParamTree):
             t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
                                    out=self._buf("dec.t0", n * lh * lw, cb))
             t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
-                               out=self._buf("dec.t1", n * lh * lw, cb))
+                               out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
             out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
-                                out=out)
+                                out=out, weight_wino=pk["r%d.ww2" % i])
         res_h, res_w = lh, lw
         for i in range(self.num_down_blocks):                # apply_optical(skip, prev) + UpBlock2d (:152-155)
             skip = skips[-(i + 1)]

@@ -101,6 +101,21 @@ def pack_ln_conv_weight(w, gamma):
     return packed, wsum
 
 
+def pack_wino_weight(w, coutp=None):
+    """(Cout, Cin, 3, 3) -> Winograd F(2x2,3x3) filters U = G g G^T as [16][Cin/16][coutp][16] (position, channel
+    chunk, output channel, channel in chunk) - the operand order conv_wino.hip loads (lfdm_conv_params.weight_wino)."""
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 16 == 0
+    coutp = coutp or (cout + 31) // 32 * 32
+    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64, device=w.device)
+    u = torch.einsum("ia,ocab,jb->ijoc", G, w.double(), G).reshape(16, cout, cin)          # [pos][cout][cin]
+    out = torch.zeros(16, cin // 16, coutp, 16, dtype=torch.float32, device=w.device)
+    out[:, :, :cout] = u.view(16, cout, cin // 16, 16).permute(0, 2, 1, 3).float()
+    return out.contiguous()
+
+
 def pack_planar_in_weight(w):
     """(Cout, Cin, kh, kw) -> [kh*kw*Cin][Cout] (tap-major, then channel) for conv_planar_in_cl."""
     if w.dim() == 5:
@@ -116,7 +131,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None):
+                tile_counters=None, weight_wino=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -155,7 +170,12 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         p.tile_counters, p.tile_counters_len = tile_counters.data_ptr(), tile_counters.numel()
     if ln_wsum is not None:
         p.ksplit = 1
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters)      # keep the tensors alive with the struct
+    p.weight_wino = None
+    if weight_wino is not None:
+        _chk(lib, weight_wino)
+        assert kh == 3 and kw == 3 and weight_wino.shape == (16, cin // 16, coutp, 16), weight_wino.shape
+        p.weight_wino = weight_wino.data_ptr()
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino)   # keep the tensors alive with the struct
     return p, out
 
 

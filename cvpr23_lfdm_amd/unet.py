@@ -139,6 +139,9 @@ class Unet3D(ParamTree):
 
         def block(prefix):
             pk[prefix + "proj.w"] = ops.pack_conv_weight(g(prefix + "proj.weight"))
+            wp = g(prefix + "proj.weight")
+            # the same 3x3 filter in Winograd F(2x2,3x3) form: the library picks the 16/36-multiplication schedule
+            pk[prefix + "proj.ww"] = ops.pack_wino_weight(wp) if wp.shape[1] % 16 == 0 else None
             pk[prefix + "proj.b"] = g(prefix + "proj.bias")
             pk[prefix + "norm.w"] = g(prefix + "norm.weight")
             pk[prefix + "norm.b"] = g(prefix + "norm.bias")
@@ -262,11 +265,11 @@ class Unet3D(ParamTree):
 
     # ------------------------------------------------------------------ building blocks
     def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, gn=None,
-              scratch="splitk", **kw):
+              scratch="splitk", ww=None, **kw):
         """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
-                               out=out, **kw)
+                               out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         if self.fuse_splitk:     # split-K slabs reduced inside the launch (measured neutral-to-slower on MI355X: off)
             cnt = self._tile_counters()
             p.tile_counters, p.tile_counters_len = cnt.data_ptr(), cnt.numel()
@@ -310,7 +313,7 @@ class Unet3D(ParamTree):
                                out=self._buf("rb.res", rows, cout), scratch="splitk.side")
         h1 = self._buf("rb.h1", rows, cout)
         _, st = self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
-                           bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,))
+                           bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,), ww=pk[prefix + "block1.proj.ww"])
         sshift = None
         if ss is not None and (prefix + "ss_off") in pk:
             o = pk[prefix + "ss_off"]
@@ -318,7 +321,7 @@ class Unet3D(ParamTree):
         self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
         out = self._buf(outname, rows, cout)
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
-                           out=out, gn=(batch,))
+                           out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
         if has_res and side is not None:
             torch.cuda.current_stream().wait_stream(side)

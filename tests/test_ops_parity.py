@@ -511,3 +511,56 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     wp, bp = ops.pack_smalln_weight(wt, bias)
     out = ops.conv2d_smalln_cl(to_cl(x).to(dev), wp.to(dev), bp.to(dev), 3, k, n, h, w, act=ops.ACT_SIGMOID)
     assert_close(from_cl(out[:, :3].contiguous().cpu(), n, h, w), ref, TOL, "small-N conv")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(cin=32, cout=64, n=2, h=8, w=8),
+    dict(cin=64, cout=40, n=3, h=6, w=10, residual=True, act=1),               # ragged tile block, cout not /32
+    dict(cin=48, cout=64, n=2, h=8, w=8, split_src=16, residual=True),         # fused concat
+    dict(cin=128, cout=32, n=1, h=4, w=4, ksplit=2, act=1),                    # split-K slabs + reduce pass
+    dict(cin=64, cout=64, n=8, h=8, w=8, gn=True),                           # GroupNorm partial sums from the epilogue
+    dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
+    dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv2d_winograd(backend, case, monkeypatch):
+    """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    monkeypatch.setenv("LFDM_WINO", "1")
+    cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
+    bias = rnd(cout, seed=3)
+    ref = conv_out = F.conv2d(x, wt, bias, padding=1)
+    res = None
+    if case.get("residual"):
+        res = rnd(*ref.shape, seed=4)
+        ref = ref + res
+    act = case.get("act", 0)
+    if act == 1:
+        ref = F.relu(ref)
+    xs = to_cl(x).to(dev)
+    src0, src1 = xs, None
+    if case.get("split_src"):
+        s = case["split_src"]
+        src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
+    wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt).to(dev)
+    kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act,
+              ksplit=case.get("ksplit", 1), weight_wino=ww)
+    pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
+    rows, ks = ops.conv_plan(pp)
+    assert rows == (128 if ks == 1 else 16), "the Winograd plan was not selected"
+    partial = None
+    if case.get("gn"):
+        pixels = h * w * n // 2                    # two samples
+        partial = torch.zeros(2 * (pixels // rows), 16, device=dev)
+        kw.update(gn_partial=partial, gn_groups=8, gn_pixels=pixels)
+    out = ops.conv2d_cl(src0, wd, cout, 3, 3, n, h, w, **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "winograd conv")
+    if partial is not None:
+        y = conv_out.view(2, n // 2, 8, cout // 8, h, w).permute(0, 2, 1, 3, 4, 5).reshape(2, 8, -1).double()
+        got = partial.cpu().view(2, pixels // rows, 8, 2).double().sum(dim=1)
+        assert_close(got[..., 0].float(), y.sum(-1).float(), TOL, "gn sum")
+        assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")

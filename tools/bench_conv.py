@@ -31,36 +31,52 @@ def main():
     helper = unet_mod.Unet3D.__new__(unet_mod.Unet3D)      # only for the split-K heuristic
     tot_ms = 0.0
     tot_gf = 0.0
+    tot_wino = 0.0
     print("%-28s %9s %8s %8s %8s %5s" % ("shape", "GFLOP", "us", "TF/s", "ksplit", "rows"))
     for name, cin, cout, k, s, count in SHAPES:
         n_img = FRAMES if "8f" not in name else 8
         m = n_img * s * s
         x = torch.randn(m, cin, device=dev)
-        w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device=dev) * 0.05)
         b = torch.randn(cout, device=dev)
         out = torch.empty(m, cout, device=dev)
-        pp, _ = ops.conv_params(x, w, cout, k, k, n_img, s, s, bias=b, out=out, ksplit=int(os.environ.get("KSPLIT", "0")))
-        rows_per_tile, ksplit = ops.conv_plan(pp)
-        if ksplit > 1:
-            partial = torch.empty(ksplit * m * w.shape[1], device=dev)
-            pp.partial = partial.data_ptr()
-        run = lambda: ops.conv_launch(pp)
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 20
-        e0.record()
-        for _ in range(iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
+        raw = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        w = ops.pack_conv_weight(raw)
+        ww = ops.pack_wino_weight(raw) if (k == 3 and cin % 16 == 0) else None
         gf = 2.0 * m * cout * cin * k * k / 1e9
-        print("%-28s %9.2f %8.1f %8.1f %8d %5d" % (name, gf, us, gf / us * 1e3, ksplit, rows_per_tile))
+        cols = []
+        for wino in ([False, True] if ww is not None else [False]):
+            os.environ["LFDM_WINO"] = "1" if wino else "0"
+            pp, _ = ops.conv_params(x, w, cout, k, k, n_img, s, s, bias=b, out=out, ksplit=int(os.environ.get("KSPLIT", "0")),
+                                    weight_wino=ww)
+            rows_per_tile, ksplit = ops.conv_plan(pp)
+            if ksplit > 1:
+                partial = torch.empty(ksplit * m * w.shape[1], device=dev)
+                pp.partial = partial.data_ptr()
+            run = lambda: ops.conv_launch(pp)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 20
+            e0.record()
+            for _ in range(iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            cols.append((e0.elapsed_time(e1) * 1e3 / iters, ksplit, rows_per_tile))
+        os.environ["LFDM_WINO"] = "0"
+        us, ksplit, rows_per_tile = cols[0]
+        extra = ""
+        if len(cols) > 1:
+            extra = "   | winograd %8.1f us  k=%d  (x%.2f)" % (cols[1][0], cols[1][1], us / cols[1][0])
+            tot_wino += min(us, cols[1][0]) * count / 1e3
+        else:
+            tot_wino += us * count / 1e3
+        print("%-28s %9.2f %8.1f %8.1f %8d %5d%s" % (name, gf, us, gf / us * 1e3, ksplit, rows_per_tile, extra))
         tot_ms += us * count / 1e3
         tot_gf += gf * count
     print("weighted per UNet step: %.1f GFLOP in %.3f ms -> %.1f TF/s" % (tot_gf, tot_ms, tot_gf / tot_ms))
+    print("with the faster of direct / Winograd per shape: %.3f ms" % tot_wino)
 
 
 if __name__ == "__main__":
