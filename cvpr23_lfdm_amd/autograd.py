@@ -19,6 +19,12 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):
+    """Geometry the Winograd F(2x2,3x3) schedule covers (lfdm_conv_params.weight_wino); chans = reduction-channel counts."""
+    return (kh == 3 and kw == 3 and stride == 1 and tuple(pad) == (1, 1) and hi % 2 == 0 and wi % 2 == 0 and
+            all(c % 16 == 0 for c in chans))
+
+
 class ConvCL(Function):
     """y = conv(cat(x0, x1), weight) + bias (+ residual).  weight in the reference layout (Cout, Cin, [1,] kh, kw)
     (or ConvTranspose (Cin, Cout, [1,] 4, 4) when geom['kind'] == 'deconv').  geom: n_img, hi, wi, stride, pad."""
@@ -35,8 +41,12 @@ class ConvCL(Function):
         if kind == "conv":
             stride = geom.get("stride", 1)
             pad = geom.get("pad", (kh // 2, kw // 2))
+            ww = None
+            if _wino_ok(kh, kw, stride, pad, hi, wi, x0.shape[1], 0 if x1 is None else x1.shape[1]):
+                ww = ops.pack_wino_weight(_c(w4))
             y = ops.conv2d_cl(_c(x0.detach()), ops.pack_conv_weight(w4), w4.shape[0], kh, kw, n_img, hi, wi,
-                              src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad)
+                              src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
+                              weight_wino=ww)
             hq = (hi + 2 * pad[0] - kh) // stride + 1
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
@@ -52,7 +62,7 @@ class ConvCL(Function):
         x0, x1, weight = ctx.saved_tensors
         kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, has_bias, has_res = ctx.meta
         dy = _c(dy)
-        w4 = weight.detach().reshape(weight.shape[0], weight.shape[1], kh, kw)
+        w4 = _c(weight.detach().reshape(weight.shape[0], weight.shape[1], kh, kw))
         need = ctx.needs_input_grad
         dx0 = dx1 = dw = db = None
         if has_bias and need[3]:
@@ -75,8 +85,9 @@ class ConvCL(Function):
                 ws = w4[:, lo:hi_c]
                 if stride == 1:
                     wd = ws.transpose(0, 1).flip(-2, -1).contiguous()                         # (cin, cout, kh, kw)
+                    ww = ops.pack_wino_weight(ws, dgrad=True) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
                     g = ops.conv2d_cl(dy, ops.pack_conv_weight(wd), hi_c - lo, kh, kw, n_img, hq, wq,
-                                      pad=(kh - 1 - pad[0], kw - 1 - pad[1]))
+                                      pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)
                 else:
                     assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
                     g = ops.deconv4x4s2_cl(dy, ops.pack_deconv_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)

@@ -4,10 +4,13 @@
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 4x4 input patch d / 2x2 output tile Y and (c_in, c_out) pair:
 // 16 independent "frequency positions", each an ordinary GEMM over c_in: M[pos][tile][co] = sum_ci V[pos][tile][ci] U[pos][ci][co]
 // -> 16/36 of the multiplications of the direct form.  One workgroup owns 32 output tiles (128 pixels) x 32 output channels;
-// per 16-channel chunk 128 threads transform the patches (B^T d B, float4 over channels) into LDS, then wave w runs the
-// MFMAs of positions 4w..4w+3 (A operand = V from LDS, B operand = the pre-transformed weights straight from global memory in
-// operand order, prefetched one chunk ahead); the four waves' accumulators meet in LDS for the output transform A^T M A, which
-// feeds the same epilogue as the direct kernels (bias, GroupNorm partial sums, residual, activation) or the split-K slabs.
+// per 16-channel chunk every thread transforms one (tile, channel pair) patch (B^T d B) into LDS, then wave i runs the MFMAs
+// of position row i (positions 4i..4i+3; A operand = V from LDS, B operand = the pre-transformed weights straight from global
+// memory in operand order, each fragment re-loaded for the next chunk as soon as its MFMAs are issued).  The output
+// transform A^T M A is split: the sum over the position column j happens in the wave's accumulator registers, the sum over
+// the row i (across waves) through 8 LDS planes; it feeds the same epilogue as the direct kernels (bias, GroupNorm partial
+// sums, residual, activation) or the split-K slabs.  ~168 VGPRs and 40 KB LDS: three workgroups per CU, so one
+// workgroup's transform overlaps the others' MFMAs.
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -17,35 +20,59 @@ constexpr int WT = 32;            // tiles per workgroup
 constexpr int WN = 32;            // output channels per workgroup
 constexpr int WKC = 16;           // input channels per chunk
 constexpr int LDV = WKC + 4;      // LDS row stride of V
-constexpr int LDM = WN + 1;       // LDS row stride of M in the output transform
+constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M planes in the epilogue
 
+// Operands are prefetched one chunk ahead; ~150 VGPRs / 43 KB LDS -> three workgroups per CU hide each other's phases.
+// Per chunk and CU the vector-memory path moves 32 KB of patches + 32 KB of weight fragments for 2048 matrix-pipe cycles
+// per SIMD; rocprofv3 (profiles/r01_n_wino_pmc.txt) shows ~2000-2500 L1 accesses per chunk and the busiest TA ~40 % busy:
+// the kernel is co-limited by the L1 path, which is why the variants below changed nothing.  Measured and removed (no
+// faster on any shape of tools/bench_conv.py): double-buffered LDS with the next chunk's transform placed between the
+// positions' MFMAs; patches and weight fragments fetched two chunks ahead at two workgroups per CU; A-fragment LDS reads
+// pinned one position ahead with sched_group_barrier.  What would help next: 32-channel chunks with 16-byte patch loads
+// (half the TA cycles per patch byte) or a 64-column tile (half the patch bytes per MFMA) - both cost occupancy.
 template <bool ACT>
-__global__ __launch_bounds__(256) void conv_wino_kernel(lfdm_conv_params p) {
-  __shared__ __attribute__((aligned(16))) float smem[16 * WT * LDM];      // >= 16*WT*LDV: V during the loop, M in the epilogue
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
+  constexpr int LD = LDV;
+  constexpr int VSZ = 16 * WT * LD;
+  __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
+  static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ int s_n[WT], s_ty[WT], s_tx[WT];
   __shared__ float s_gn[2][8][WN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int th = p.hi >> 1, tw = p.wi >> 1;                 // tiles per image (H, W even: host check)
-  const int64_t ntiles = (int64_t)p.n_img * th * tw;
-  const int64_t t0 = (int64_t)blockIdx.x * WT;
-  const int n0 = blockIdx.y * WN;
+  const unsigned ntiles = (unsigned)p.n_img * th * tw;       // < 2^31 / 4 (host check on the pixel count)
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order.  The
+  // default order puts the column tiles of one tile block on one XCD (gridDim.x % 8 == 0: they share the input patches).
+  // Where the Winograd filters outweigh the input (16*coutp*cin vs pixels*cin floats: the 8x8 / 4x4 levels) it is the
+  // filter slice that must not be fetched into all eight L2s: XCD k then owns the column tiles k, k+8, ...
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.y & 7u) == 0 && 16ll * p.coutp > (int64_t)p.n_img * p.hi * p.wi) {
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned j = L >> 3, ny8 = gridDim.y >> 3;
+    by = (L & 7u) + 8u * (j % ny8);
+    const unsigned rest = j / ny8;
+    bx = rest % gridDim.x;
+    bz = rest / gridDim.x;
+  }
+  const unsigned t0 = bx * WT;
+  const int n0 = by * WN;
   const int cin = p.c0 + p.c1;
   const int nchunks_all = cin / WKC;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-  const int kc_begin = (int)((int64_t)nchunks_all * blockIdx.z / ksplit);
-  const int kc_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / ksplit);
+  const int kc_begin = (int)((int64_t)nchunks_all * bz / ksplit);
+  const int kc_end = (int)((int64_t)nchunks_all * (bz + 1) / ksplit);
   const int64_t M = (int64_t)p.n_img * p.hi * p.wi;
 
   if (tid < WT) {
-    const int64_t t = t0 + tid;
+    const unsigned t = t0 + tid;
     int n = -1, ty = 0, tx = 0;
     if (t < ntiles) {
-      n = (int)(t / (th * tw));
-      const int rem = (int)(t - (int64_t)n * th * tw);
-      ty = rem / tw;
-      tx = rem - ty * tw;
+      n = (int)(t / (unsigned)(th * tw));
+      const unsigned rem = t - (unsigned)n * (th * tw);
+      ty = (int)(rem / (unsigned)tw);
+      tx = (int)(rem - (unsigned)ty * tw);
     }
     s_n[tid] = n;
     s_ty[tid] = ty;
@@ -54,51 +81,49 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(lfdm_conv_params p) {
   __syncthreads();
 
   // ---- transform threads: (tile, float4 of channels) ----
-  const bool xform = tid < WT * (WKC / 4);
-  const int x_tile = tid >> 2, x_c4 = tid & 3;
+  const int x_tile = tid >> 3, x_c2 = tid & 7;              // 32 tiles x 8 channel pairs = 256 threads
   const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
   const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
   const lfdm_buf buf1 = p.c1 > 0 ? lfdm_make_buf(p.src1, (uint32_t)(((in_rows - 1) * p.ld1 + p.c1) * 4)) : buf0;
-  int pix_base = 0;                  // pixel index of the patch's (0,0) corner (may be outside the image)
+  // 32-bit byte offsets (the plan guarantees rows * ld * 4 < 2^32): off = base + uniform per-(py,px) delta + chunk; `base`
+  // may wrap for the patch corner outside the image - those taps are masked to the out-of-range offset anyway
+  uint32_t base0 = 0, base1 = 0;     // byte offset of the patch's (0,0) corner + this thread's channel pair, per source
   unsigned valid_mask = 0;           // bit (py*4+px): patch pixel inside the image
-  if (xform && s_n[x_tile] >= 0) {
+  if (s_n[x_tile] >= 0) {
     const int n = s_n[x_tile], ty = s_ty[x_tile], tx = s_tx[x_tile];
-    pix_base = (n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1;
+    const uint32_t pix = (uint32_t)((n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1);
+    base0 = (pix * (uint32_t)p.ld0 + 2u * x_c2) * 4u;
+    base1 = (pix * (uint32_t)p.ld1 + 2u * x_c2) * 4u;
+    const unsigned rows = 0xFu & ~(ty == 0 ? 1u : 0u) & ~(ty == th - 1 ? 8u : 0u);     // only the first / last patch row or
+    const unsigned cols = 0xFu & ~(tx == 0 ? 1u : 0u) & ~(tx == tw - 1 ? 8u : 0u);     // column can fall outside
+#pragma unroll
     for (int py = 0; py < 4; ++py)
-      for (int px = 0; px < 4; ++px) {
-        const int iy = 2 * ty - 1 + py, ix = 2 * tx - 1 + px;
-        if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi) valid_mask |= 1u << (py * 4 + px);
-      }
+      if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
-  float4 patch[16];
-  auto fetch_patch = [&](int chunk) {
+  float2 patch[16];
+  auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
     int cc = chunk * WKC;
     const bool second = cc >= p.c0;
     if (second) cc -= p.c0;
     const lfdm_buf buf = second ? buf1 : buf0;
-    const int ld = second ? p.ld1 : p.ld0;
+    const uint32_t ld4 = (uint32_t)(second ? p.ld1 : p.ld0) * 4u;
+    const uint32_t base = (second ? base1 : base0) + (uint32_t)cc * 4u;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int py = q >> 2, px = q & 3;
-      const uint32_t off = ((valid_mask >> q) & 1u)
-                               ? (uint32_t)((((int64_t)pix_base + py * p.wi + px) * ld + cc + 4 * x_c4) * 4)
-                               : LFDM_BUF_OOB;
-      patch[q] = lfdm_buf_load_f4(buf, off);
+      const uint32_t delta = (uint32_t)((q >> 2) * p.wi + (q & 3)) * ld4;          // uniform: scalar registers
+      patch[q] = lfdm_buf_load_f2(buf, ((valid_mask >> q) & 1u) ? base + delta : LFDM_BUF_OOB);
     }
   };
   // ---- weight fragments: lane (co = n0 + l31, k-slot kh) holds U[pos][16*chunk + 8*kh + s][co], s = 0..7 ----
   const lfdm_buf bufw = lfdm_make_buf(p.weight_wino, (uint32_t)((int64_t)16 * nchunks_all * p.coutp * WKC * 4));
-  float4 bcur[4][2], bnext[4][2];
-  auto fetch_b = [&](float4 (&dst)[4][2], int chunk) {
-#pragma unroll
-    for (int pi = 0; pi < 4; ++pi) {
-      const int pos = 4 * wave + pi;
-      const uint32_t off = (n0 + l31 < p.coutp)
-                               ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * p.coutp + n0 + l31) * WKC + 8 * kh) * 4)
-                               : LFDM_BUF_OOB;
-      dst[pi][0] = lfdm_buf_load_f4(bufw, off);
-      dst[pi][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
-    }
+  float4 bfrag[4][2];
+  auto fetch_b = [&](int pi, int chunk) {
+    const int pos = 4 * wave + pi;
+    const uint32_t off = (n0 + l31 < p.coutp)
+                             ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * p.coutp + n0 + l31) * WKC + 8 * kh) * 4)
+                             : LFDM_BUF_OOB;
+    bfrag[pi][0] = lfdm_buf_load_f4(bufw, off);
+    bfrag[pi][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
   };
 
   f32x16 acc[4];
@@ -107,68 +132,69 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(lfdm_conv_params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[pi][r] = 0.f;
 
-  float* const Vs = smem;           // [16 pos][WT tiles][LDV]
-  if (xform) fetch_patch(kc_begin);
-  fetch_b(bcur, kc_begin);
+  // B^T d B on a channel pair: part i = row i of the position grid (positions 4i..4i+3)
+  auto xform_part = [&](const float2 (&d)[16], int i, float* V) {
+    float2 r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float2 d0 = d[c], d1 = d[4 + c], d2 = d[8 + c], d3 = d[12 + c];
+      r[c] = i == 0 ? make_float2(d0.x - d2.x, d0.y - d2.y)
+           : i == 1 ? make_float2(d1.x + d2.x, d1.y + d2.y)
+           : i == 2 ? make_float2(d2.x - d1.x, d2.y - d1.y)
+                    : make_float2(d1.x - d3.x, d1.y - d3.y);
+    }
+    float* dst = V + ((4 * i) * WT + x_tile) * LD + 2 * x_c2;
+    *reinterpret_cast<float2*>(dst) = make_float2(r[0].x - r[2].x, r[0].y - r[2].y);
+    *reinterpret_cast<float2*>(dst + WT * LD) = make_float2(r[1].x + r[2].x, r[1].y + r[2].y);
+    *reinterpret_cast<float2*>(dst + 2 * WT * LD) = make_float2(r[2].x - r[1].x, r[2].y - r[1].y);
+    *reinterpret_cast<float2*>(dst + 3 * WT * LD) = make_float2(r[1].x - r[3].x, r[1].y - r[3].y);
+  };
+  auto load_a = [&](const float* V, int pi, float4& a0, float4& a1) {        // A fragment of position 4*wave + pi
+    const float* va = V + ((4 * wave + pi) * WT + l31) * LD + 8 * kh;
+    a0 = *reinterpret_cast<const float4*>(va);
+    a1 = *reinterpret_cast<const float4*>(va + 4);
+  };
+  auto mfma_pos = [&](const float4& a0, const float4& a1, int pi) {           // its 8 k-steps on this chunk
+    acc[pi] = mfma_32x32x2(a0.x, bfrag[pi][0].x, acc[pi]);
+    acc[pi] = mfma_32x32x2(a0.y, bfrag[pi][0].y, acc[pi]);
+    acc[pi] = mfma_32x32x2(a0.z, bfrag[pi][0].z, acc[pi]);
+    acc[pi] = mfma_32x32x2(a0.w, bfrag[pi][0].w, acc[pi]);
+    acc[pi] = mfma_32x32x2(a1.x, bfrag[pi][1].x, acc[pi]);
+    acc[pi] = mfma_32x32x2(a1.y, bfrag[pi][1].y, acc[pi]);
+    acc[pi] = mfma_32x32x2(a1.z, bfrag[pi][1].z, acc[pi]);
+    acc[pi] = mfma_32x32x2(a1.w, bfrag[pi][1].w, acc[pi]);
+  };
+  const int kc_last = kc_end - 1;
+  auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
+
+  float* const Vs = smem;           // [16 pos][WT tiles][LD]
+  fetch_patch(patch, kc_begin);
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) fetch_b(pi, kc_begin);
   for (int kc = kc_begin; kc < kc_end; ++kc) {
-    // ---- B^T d B on float4 (4 channels), rows then columns ----
-    if (xform) {
-      float4 r[16];
+    const int nxt = clampc(kc + 1);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 d0 = patch[c], d1 = patch[4 + c], d2 = patch[8 + c], d3 = patch[12 + c];
-        r[c] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-        r[4 + c] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-        r[8 + c] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-        r[12 + c] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 a = r[4 * i], b = r[4 * i + 1], c = r[4 * i + 2], d = r[4 * i + 3];
-        float* dst = Vs + ((4 * i) * WT + x_tile) * LDV + 4 * x_c4;
-        *reinterpret_cast<float4*>(dst) = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
-        *reinterpret_cast<float4*>(dst + WT * LDV) = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
-        *reinterpret_cast<float4*>(dst + 2 * WT * LDV) = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
-        *reinterpret_cast<float4*>(dst + 3 * WT * LDV) = make_float4(b.x - d.x, b.y - d.y, b.z - d.z, b.w - d.w);
-      }
-    }
+    for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
     __syncthreads();
-    {
-      const int nxt = kc + 1 < kc_end ? kc + 1 : kc;           // clamped: harmless re-fetch after the last chunk
-      if (xform) fetch_patch(nxt);
-      fetch_b(bnext, nxt);
-    }
+    fetch_patch(patch, nxt);                                   // in flight under this chunk's MFMAs
 #pragma unroll
     for (int pi = 0; pi < 4; ++pi) {
-      const float* va = Vs + ((4 * wave + pi) * WT + l31) * LDV + 8 * kh;
-      const float4 a0 = *reinterpret_cast<const float4*>(va);
-      const float4 a1 = *reinterpret_cast<const float4*>(va + 4);
-      acc[pi] = mfma_32x32x2(a0.x, bcur[pi][0].x, acc[pi]);
-      acc[pi] = mfma_32x32x2(a0.y, bcur[pi][0].y, acc[pi]);
-      acc[pi] = mfma_32x32x2(a0.z, bcur[pi][0].z, acc[pi]);
-      acc[pi] = mfma_32x32x2(a0.w, bcur[pi][0].w, acc[pi]);
-      acc[pi] = mfma_32x32x2(a1.x, bcur[pi][1].x, acc[pi]);
-      acc[pi] = mfma_32x32x2(a1.y, bcur[pi][1].y, acc[pi]);
-      acc[pi] = mfma_32x32x2(a1.z, bcur[pi][1].z, acc[pi]);
-      acc[pi] = mfma_32x32x2(a1.w, bcur[pi][1].w, acc[pi]);
+      float4 a0, a1;
+      load_a(Vs, pi, a0, a1);
+      mfma_pos(a0, a1, pi);
+      fetch_b(pi, nxt);                                        // refilled in place for the next chunk
     }
     __syncthreads();
-#pragma unroll
-    for (int pi = 0; pi < 4; ++pi) {
-      bcur[pi][0] = bnext[pi][0];
-      bcur[pi][1] = bnext[pi][1];
-    }
   }
 
-  // ---- M[pos][tile][co] -> LDS, output transform A^T M A, epilogue ----
-  float* const Ms = smem;           // [16][WT][LDM]
+  // ---- output transform A^T M A: the column sum (over j) in registers, the row sum (over i = wave) through LDS ----
+  float* const Ms = smem;           // [8 = 2*i + j'][WT][LDM]
 #pragma unroll
-  for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      Ms[((4 * wave + pi) * WT + tile) * LDM + l31] = acc[pi][r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    Ms[((2 * wave) * WT + tile) * LDM + l31] = acc[0][r] + acc[1][r] + acc[2][r];
+    Ms[((2 * wave + 1) * WT + tile) * LDM + l31] = acc[1][r] - acc[2][r] - acc[3][r];
+  }
   __syncthreads();
   const int co = n0 + l31;
   float gs = 0.f, gq = 0.f;
@@ -178,29 +204,20 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(lfdm_conv_params p) {
     const int tile = (tid >> 5) + 8 * it;
     const int n = s_n[tile];
     if (n < 0 || co >= p.coutp) continue;
-    float m[16];
+    float m[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) m[q] = Ms[(q * WT + tile) * LDM + l31];
+    for (int q = 0; q < 8; ++q) m[q] = Ms[(q * WT + tile) * LDM + l31];
     float y[4];
-    {
-      float tt[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        tt[0][j] = m[j] + m[4 + j] + m[8 + j];
-        tt[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        y[2 * i] = tt[i][0] + tt[i][1] + tt[i][2];
-        y[2 * i + 1] = tt[i][1] - tt[i][2] - tt[i][3];
-      }
-    }
+    y[0] = m[0] + m[2] + m[4];       // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
+    y[1] = m[1] + m[3] + m[5];
+    y[2] = m[2] - m[4] - m[6];
+    y[3] = m[3] - m[5] - m[7];
+    const int64_t orow0 = ((int64_t)n * p.hi + 2 * s_ty[tile]) * p.wi + 2 * s_tx[tile];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int oy = 2 * s_ty[tile] + (q >> 1), ox = 2 * s_tx[tile] + (q & 1);
-      const int64_t orow = ((int64_t)n * p.hi + oy) * p.wi + ox;
+      const int64_t orow = orow0 + (q >> 1) * p.wi + (q & 1);
       if (ksplit > 1) {
-        p.partial[((int64_t)blockIdx.z * M + orow) * p.coutp + co] = y[q];
+        p.partial[((int64_t)bz * M + orow) * p.coutp + co] = y[q];
       } else if (co < p.cout) {
         float v = y[q] + bb;
         gs += v;
@@ -224,14 +241,62 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(lfdm_conv_params p) {
           s += s_gn[0][w8][tid * cg + c];
           q += s_gn[1][w8][tid * cg + c];
         }
-      float* dst = p.gn_partial + ((int64_t)blockIdx.x * p.gn_groups + (n0 / cg + tid)) * 2;
+      float* dst = p.gn_partial + ((int64_t)bx * p.gn_groups + (n0 / cg + tid)) * 2;
       dst[0] = s;
       dst[1] = q;
     }
   }
 }
 
+// U = G g G^T, one thread per (reduction channel k, output channel n) pair of the convolution the result is used for
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
+                                                        int dgrad, float* __restrict__ out) {
+  const int K = dgrad ? cout : cin;                     // reduction channels of the target convolution
+  const int N = dgrad ? cin : cout;                     // its output channels
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)K * coutp) return;
+  const int n = (int)(idx % coutp), k = (int)(idx / coutp);
+  float g[9];
+  if (n < N) {
+    const float* src = dgrad ? w + (int64_t)k * ld_o + (int64_t)n * 9 : w + (int64_t)n * ld_o + (int64_t)k * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = dgrad ? src[8 - t] : src[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = 0.f;
+  }
+  float r[4][3];                                        // G g
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    r[0][b] = g[b];
+    r[1][b] = 0.5f * (g[b] + g[3 + b] + g[6 + b]);
+    r[2][b] = 0.5f * (g[b] - g[3 + b] + g[6 + b]);
+    r[3][b] = g[6 + b];
+  }
+  const int nch = K / WKC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u[4] = {r[i][0], 0.5f * (r[i][0] + r[i][1] + r[i][2]), 0.5f * (r[i][0] - r[i][1] + r[i][2]), r[i][2]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      out[((((int64_t)(4 * i + j)) * nch + k / WKC) * coutp + n) * WKC + (k % WKC)] = u[j];
+  }
+}
+
 }  // namespace
+
+extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
+                                         lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int K = dgrad ? cout : cin, N = dgrad ? cin : cout;
+  if (!w || !out || cout <= 0 || cin <= 0 || K % WKC != 0 || coutp < N || coutp % 32 != 0 || ld_o < cin * 9) {
+    lfdm_set_error("pack_wino_weight: reduction channels must be a multiple of 16 and coutp a multiple of 32 >= the output channels");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)K * coutp;
+  LFDM_LAUNCH(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, ld_o, cout, cin, coutp, dgrad, out);
+  return lfdm_check_launch("pack_wino_weight");
+}
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, hipStream_t stream) {

@@ -55,6 +55,11 @@ static inline float4 lfdm_buf_load_f4(lfdm_buf b, uint32_t off) {
   if ((uint64_t)off + 16u <= (uint64_t)b.bytes) memcpy(&v, b.base + off, 16);
   return v;
 }
+static inline float2 lfdm_buf_load_f2(lfdm_buf b, uint32_t off) {
+  float2 v = make_float2(0.f, 0.f);
+  if ((uint64_t)off + 8u <= (uint64_t)b.bytes) memcpy(&v, b.base + off, 8);
+  return v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t lfdm_buf;
 typedef int lfdm_i32x4 __attribute__((ext_vector_type(4)));
@@ -69,6 +74,11 @@ __device__ __forceinline__ float4 lfdm_buf_load_f4(lfdm_buf b, uint32_t off) {
   f.z = __int_as_float(v.z);
   f.w = __int_as_float(v.w);
   return f;
+}
+typedef int lfdm_i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 lfdm_buf_load_f2(lfdm_buf b, uint32_t off) {
+  const lfdm_i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0);
+  return make_float2(__int_as_float(v.x), __int_as_float(v.y));
 }
 #endif
 #define LFDM_BUF_OOB 0xFFFFFFF0u

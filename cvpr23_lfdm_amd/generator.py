@@ -104,7 +104,7 @@ class Generator(ParamTree):
             pk["r%d.w2" % i] = ops.pack_conv_weight(g(p + "conv2.weight").contiguous())
             # Winograd F(2x2,3x3) forms of the same filters (the library chooses the schedule)
             pk["r%d.ww1" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
-            pk["r%d.ww2" % i] = ops.pack_wino_weight(g(p + "conv2.weight")) if w.shape[1] % 16 == 0 else None
+            pk["r%d.ww2" % i] = ops.pack_wino_weight(g(p + "conv2.weight").contiguous()) if w.shape[1] % 16 == 0 else None
             pk["r%d.b2" % i] = g(p + "conv2.bias").contiguous()
         # output channels padded to a multiple of 4 (zero filters): float4 epilogue -> the 32-column KSW tile instead of
         # a 64-column tile for 3 real channels

@@ -101,19 +101,25 @@ def pack_ln_conv_weight(w, gamma):
     return packed, wsum
 
 
-def pack_wino_weight(w, coutp=None):
-    """(Cout, Cin, 3, 3) -> Winograd F(2x2,3x3) filters U = G g G^T as [16][Cin/16][coutp][16] (position, channel
-    chunk, output channel, channel in chunk) - the operand order conv_wino.hip loads (lfdm_conv_params.weight_wino)."""
+def pack_wino_weight(w, coutp=None, dgrad=False):
+    """(Cout, Cin, 3, 3) -> Winograd F(2x2,3x3) filters U = G g G^T as [16][K/16][coutp][16] (position, reduction-channel
+    chunk, output channel, channel in chunk) - the operand order conv_wino.hip loads (lfdm_conv_params.weight_wino).
+    dgrad=True: the filters of the data-gradient convolution dY -> dX (channel roles exchanged, taps flipped);
+    `w` may be a slice w[:, lo:hi] of the input-channel axis (no copy).  lfdm_pack_wino_weight_f32."""
+    lib = _lib()
     if w.dim() == 5:
         w = w[:, :, 0]
     cout, cin, kh, kw = w.shape
-    assert kh == 3 and kw == 3 and cin % 16 == 0
-    coutp = coutp or (cout + 31) // 32 * 32
-    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64, device=w.device)
-    u = torch.einsum("ia,ocab,jb->ijoc", G, w.double(), G).reshape(16, cout, cin)          # [pos][cout][cin]
-    out = torch.zeros(16, cin // 16, coutp, 16, dtype=torch.float32, device=w.device)
-    out[:, :, :cout] = u.view(16, cout, cin // 16, 16).permute(0, 2, 1, 3).float()
-    return out.contiguous()
+    assert kh == 3 and kw == 3 and w.dtype == torch.float32
+    assert w.stride(3) == 1 and w.stride(2) == 3 and w.stride(1) == 9, "input-channel slices of a contiguous filter only"
+    _chk(lib, w)
+    k, n = (cout, cin) if dgrad else (cin, cout)
+    assert k % 16 == 0
+    coutp = coutp or (n + 31) // 32 * 32
+    out = torch.empty(16, k // 16, coutp, 16, dtype=torch.float32, device=w.device)
+    lib.check(lib.lfdm_pack_wino_weight_f32(_p(w), w.stride(0), cout, cin, coutp, int(dgrad), _p(out), _stream(lib)),
+              "lfdm_pack_wino_weight_f32")
+    return out
 
 
 def pack_planar_in_weight(w):

@@ -286,6 +286,16 @@ int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, co
                                        int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                        lfdm_stream_t stream);
 
+/* Winograd F(2x2,3x3) filter transform U = G g G^T into the operand layout of lfdm_conv_params.weight_wino:
+ * out[16][cin/16][coutp][16] (zero for output channels >= cout).  w: 3x3 filters of the reference layout
+ * (Cout, Cin, 3, 3) (video_flow_diffusion.py:197 Block.proj / LFAE util.py:73-76 ResBlock2d); element (o, i, a, b) at
+ * w[o*ld_o + i*9 + a*3 + b], so a channel slice [lo, hi) of the input axis is w + lo*9 with ld_o = Cin_total*9.
+ * dgrad != 0 builds the filters of the data-gradient convolution instead (roles of the channel axes exchanged, taps
+ * flipped): the result convolves dY (cout channels) into dX (cin channels); then cout % 16 == 0 is required and
+ * coutp >= cin.  dgrad == 0 requires cin % 16 == 0 and coutp >= cout; coutp % 32 == 0. */
+int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
+                              lfdm_stream_t stream);
+
 /* Convolution with at most 4 output channels on v_mfma_f32_4x4x1 (sixteen 4x4 blocks per instruction, lane = output
  * pixel): the LFAE generator's final Conv2d(64 -> 3, 7x7) + sigmoid (LFAE/modules/generator.py:54,161-162).
  * x: CL rows (n_img*h*w, cin) stride ldx; wgt: [k*k][cin][4] (tap-major, filters innermost, zero padded to 4);

@@ -519,12 +519,15 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=40, n=3, h=6, w=10, residual=True, act=1),               # ragged tile block, cout not /32
     dict(cin=48, cout=64, n=2, h=8, w=8, split_src=16, residual=True),         # fused concat
     dict(cin=128, cout=32, n=1, h=4, w=4, ksplit=2, act=1),                    # split-K slabs + reduce pass
+    dict(cin=32, cout=256, n=1, h=4, w=4),                                      # filters outweigh the input: XCD k owns column tile k
+    dict(cin=80, cout=512, n=1, h=4, w=2, ksplit=2),                            # ... with split-K and two column tiles per XCD
     dict(cin=64, cout=64, n=8, h=8, w=8, gn=True),                           # GroupNorm partial sums from the epilogue
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
 def test_conv2d_winograd(backend, case, monkeypatch):
-    """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d."""
+    """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
+    tile order of the low-resolution levels."""
     dev = backend
     if case.get("gpu_only") and not big(dev):
         pytest.skip("full-size shapes run on the GPU")
@@ -546,7 +549,7 @@ def test_conv2d_winograd(backend, case, monkeypatch):
     if case.get("split_src"):
         s = case["split_src"]
         src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
-    wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt).to(dev)
+    wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
     kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act,
               ksplit=case.get("ksplit", 1), weight_wino=ww)
     pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
@@ -564,3 +567,31 @@ def test_conv2d_winograd(backend, case, monkeypatch):
         got = partial.cpu().view(2, pixels // rows, 8, 2).double().sum(dim=1)
         assert_close(got[..., 0].float(), y.sum(-1).float(), TOL, "gn sum")
         assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")
+
+
+def test_pack_wino_weight(backend):
+    """lfdm_pack_wino_weight_f32 against U = G g G^T in float64; the dgrad form against autograd's dX."""
+    dev = backend
+    cout, cin = 40, 48
+    wt = rnd(cout, cin, 3, 3, seed=1)
+    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+    u = torch.einsum("ia,ocab,jb->ijoc", G, wt.double(), G).reshape(16, cout, cin)
+    ref = torch.zeros(16, cin // 16, 64, 16, dtype=torch.float64)
+    ref[:, :, :cout] = u.view(16, cout, cin // 16, 16).permute(0, 2, 1, 3)
+    got = ops.pack_wino_weight(wt.to(dev))
+    assert got.shape == ref.shape
+    assert_close(got.cpu(), ref.float(), 1e-6, "pack_wino")
+    # data gradient of y = conv(x, w[:, 16:48]) w.r.t. x: a Winograd convolution of dy with the dgrad-packed slice
+    cout = 32
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=0.1)
+    n, h, w = 2, 6, 8
+    x = rnd(n, 32, h, w, seed=3).requires_grad_(True)
+    dy = rnd(n, cout, h, w, seed=4)
+    F.conv2d(x, wt[:, 16:48], padding=1).backward(dy)
+    wslice = wt.to(dev)[:, 16:48]
+    ww = ops.pack_wino_weight(wslice, dgrad=True)
+    wd = ops.pack_conv_weight(wslice.transpose(0, 1).flip(-2, -1).contiguous())
+    pp, _ = ops.conv_params(to_cl(dy).to(dev), wd, 32, 3, 3, n, h, w, weight_wino=ww)
+    assert ops.conv_plan(pp)[0] == 128
+    dx = ops.conv2d_cl(to_cl(dy).to(dev), wd, 32, 3, 3, n, h, w, weight_wino=ww)
+    assert_close(from_cl(dx.cpu(), n, h, w), x.grad, TOL, "winograd dgrad")
