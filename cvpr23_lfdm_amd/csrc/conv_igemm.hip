@@ -631,8 +631,10 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   bool ksw = pl.fast && pl.simple && nchunks >= 8 && M >= 160 && !p.ln_wsum && fits32 && vec_ok;
   if (conv_force() == 0) ksw = false;
   if (conv_force() == 1 && pl.fast && pl.simple && !p.ln_wsum && fits32 && vec_ok) ksw = true;
+  const int up = p.upsample ? 2 : 1;
   const bool wino = p.weight_wino && wino_enabled() && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 &&
-                    pl.simple && p.hq == p.hi && p.wq == p.wi && p.hi % 2 == 0 && p.wi % 2 == 0 && p.c0 % 16 == 0 &&
+                    p.pad_mode == 0 && fits32 && (int64_t)p.n_img * p.hq * p.wq < (1ll << 31) - (1 << 20) &&
+                    p.hq == up * p.hi && p.wq == up * p.wi && p.hq % 2 == 0 && p.wq % 2 == 0 && p.c0 % 16 == 0 &&
                     p.c1 % 16 == 0 && p.ld0 % 4 == 0 && (p.c1 == 0 || p.ld1 % 4 == 0) && (((uintptr_t)p.src0 & 15) == 0) &&
                     (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0) && (((uintptr_t)p.weight_wino) & 15) == 0 && !p.ln_wsum &&
                     p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64;
@@ -640,7 +642,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.kind = 2;
     pl.bm = 128;
     pl.bn = 32;
-    const int64_t blocks = (((int64_t)p.n_img * (p.hi / 2) * (p.wi / 2) + 31) / 32) * ((p.coutp + 31) / 32);
+    const int64_t blocks = (((int64_t)p.n_img * (p.hq / 2) * (p.wq / 2) + 31) / 32) * ((p.coutp + 31) / 32);
     const int nch = cin / 16;
     int k = 1;
     if (blocks < 224) {

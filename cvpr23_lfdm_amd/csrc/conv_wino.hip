@@ -41,14 +41,17 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int th = p.hi >> 1, tw = p.wi >> 1;                 // tiles per image (H, W even: host check)
+  // p.upsample: the input is read through a virtual nearest x2 upsample (UpBlock2d, LFAE util.py:120-133): the logical
+  // image is (hq, wq) = (2*hi, 2*wi) and logical pixel (y, x) is physical (y >> 1, x >> 1)
+  const int up = p.upsample ? 1 : 0;
+  const int th = p.hq >> 1, tw = p.wq >> 1;                 // tiles per image (hq, wq even: host check)
   const unsigned ntiles = (unsigned)p.n_img * th * tw;       // < 2^31 / 4 (host check on the pixel count)
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order.  The
   // default order puts the column tiles of one tile block on one XCD (gridDim.x % 8 == 0: they share the input patches).
   // Where the Winograd filters outweigh the input (16*coutp*cin vs pixels*cin floats: the 8x8 / 4x4 levels) it is the
   // filter slice that must not be fetched into all eight L2s: XCD k then owns the column tiles k, k+8, ...
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if ((gridDim.y & 7u) == 0 && 16ll * p.coutp > (int64_t)p.n_img * p.hi * p.wi) {
+  if ((gridDim.y & 7u) == 0 && 16ll * p.coutp > (int64_t)p.n_img * p.hi * p.wi) {     // (physical input pixels)
     const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned j = L >> 3, ny8 = gridDim.y >> 3;
     by = (L & 7u) + 8u * (j % ny8);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
   const int kc_begin = (int)((int64_t)nchunks_all * bz / ksplit);
   const int kc_end = (int)((int64_t)nchunks_all * (bz + 1) / ksplit);
-  const int64_t M = (int64_t)p.n_img * p.hi * p.wi;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
 
   if (tid < WT) {
     const unsigned t = t0 + tid;
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
   unsigned valid_mask = 0;           // bit (py*4+px): patch pixel inside the image
   if (s_n[x_tile] >= 0) {
     const int n = s_n[x_tile], ty = s_ty[x_tile], tx = s_tx[x_tile];
-    const uint32_t pix = (uint32_t)((n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1);
+    // physical pixel of the patch corner: logical (2ty-1, 2tx-1); through the upsample that is (ty-1, tx-1)
+    const uint32_t pix = up ? (uint32_t)((n * p.hi + ty - 1) * p.wi + tx - 1)
+                            : (uint32_t)((n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1);
     base0 = (pix * (uint32_t)p.ld0 + 2u * x_c2) * 4u;
     base1 = (pix * (uint32_t)p.ld1 + 2u * x_c2) * 4u;
     const unsigned rows = 0xFu & ~(ty == 0 ? 1u : 0u) & ~(ty == th - 1 ? 8u : 0u);     // only the first / last patch row or
@@ -110,7 +115,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
     const uint32_t base = (second ? base1 : base0) + (uint32_t)cc * 4u;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const uint32_t delta = (uint32_t)((q >> 2) * p.wi + (q & 3)) * ld4;          // uniform: scalar registers
+      // uniform (scalar registers); upsampled: logical rows 2ty-1..2ty+2 are physical rows ty-1, ty, ty, ty+1
+      const int py = up ? ((q >> 2) + 1) >> 1 : (q >> 2), px = up ? ((q & 3) + 1) >> 1 : (q & 3);
+      const uint32_t delta = (uint32_t)(py * p.wi + px) * ld4;
       patch[q] = lfdm_buf_load_f2(buf, ((valid_mask >> q) & 1u) ? base + delta : LFDM_BUF_OOB);
     }
   };
@@ -212,10 +219,10 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
     y[1] = m[1] + m[3] + m[5];
     y[2] = m[2] - m[4] - m[6];
     y[3] = m[3] - m[5] - m[7];
-    const int64_t orow0 = ((int64_t)n * p.hi + 2 * s_ty[tile]) * p.wi + 2 * s_tx[tile];
+    const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[tile]) * p.wq + 2 * s_tx[tile];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t orow = orow0 + (q >> 1) * p.wi + (q & 1);
+      const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
       if (ksplit > 1) {
         p.partial[((int64_t)bz * M + orow) * p.coutp + co] = y[q];
       } else if (co < p.cout) {
@@ -300,7 +307,7 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, hipStream_t stream) {
-  const int64_t ntiles = (int64_t)p.n_img * (p.hi / 2) * (p.wi / 2);
+  const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + WN - 1) / WN), p.ksplit > 1 ? p.ksplit : 1);
   if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino_kernel<true>), grid, dim3(256), 0, stream, p);
   else LFDM_LAUNCH((conv_wino_kernel<false>), grid, dim3(256), 0, stream, p);

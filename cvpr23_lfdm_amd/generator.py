@@ -92,9 +92,11 @@ class Generator(ParamTree):
         for i in range(self.num_down_blocks):
             w, b = conv_bn("down_blocks.%d.conv." % i, "down_blocks.%d.norm." % i)
             pk["down%d.w" % i], pk["down%d.b" % i] = ops.pack_conv_weight(w), b
+            pk["down%d.ww" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
         for i in range(self.num_down_blocks):
             w, b = conv_bn("up_blocks.%d.conv." % i, "up_blocks.%d.norm." % i)
             pk["up%d.w" % i], pk["up%d.b" % i] = ops.pack_conv_weight(w), b
+            pk["up%d.ww" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
         for i in range(self.num_bottleneck_blocks):
             p = "bottleneck.r%d." % i
             a1, b1 = bn_affine(p + "norm1.")                 # pre-activation BN + ReLU (util.py:85-86)
@@ -136,7 +138,7 @@ class Generator(ParamTree):
         for i in range(self.num_down_blocks):
             co = self._feat(i + 1)
             y = ops.conv2d_cl(out, pk["down%d.w" % i], co, 3, 3, b, res_h, res_w, bias=pk["down%d.b" % i],
-                              act=ops.ACT_RELU, out=self._buf("enc.t", b * res_h * res_w, co))
+                              act=ops.ACT_RELU, out=self._buf("enc.t", b * res_h * res_w, co), weight_wino=pk["down%d.ww" % i])
             res_h, res_w = res_h // 2, res_w // 2
             out = ops.avgpool2_cl(y, b, res_h * 2, res_w * 2, out=self._buf("enc%d" % (i + 1), b * res_h * res_w, co))
             skips.append(out)
@@ -185,7 +187,7 @@ class Generator(ParamTree):
                                   out=self._buf("dec.w%d" % i, n * res_h * res_w, ci), **wk)
             co = self._feat(self.num_down_blocks - i - 1)
             out = ops.conv2d_cl(blended, pk["up%d.w" % i], co, 3, 3, n, res_h, res_w, bias=pk["up%d.b" % i],
-                                upsample=True, act=ops.ACT_RELU,
+                                upsample=True, act=ops.ACT_RELU, weight_wino=pk["up%d.ww" % i],
                                 out=self._buf("dec.u%d" % i, n * 4 * res_h * res_w, co))
             res_h, res_w = res_h * 2, res_w * 2
         blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,

@@ -25,7 +25,9 @@ def _fold(tree, cprefix, nprefix):
     a = g(nprefix + "weight") / torch.sqrt(g(nprefix + "running_var") + BN_EPS)
     b = g(nprefix + "bias") - g(nprefix + "running_mean") * a
     w = g(cprefix + "weight") * a.view(-1, 1, 1, 1)
-    return ops.pack_conv_weight(w.contiguous()), (g(cprefix + "bias") * a + b).contiguous(), w.shape[0]
+    w = w.contiguous()
+    ww = ops.pack_wino_weight(w) if (w.shape[1] % 16 == 0 and w.shape[-1] == 3) else None     # Winograd form of the same filter
+    return ops.pack_conv_weight(w), (g(cprefix + "bias") * a + b).contiguous(), w.shape[0], ww
 
 
 class HourglassExec:
@@ -55,9 +57,9 @@ class HourglassExec:
         """-> list of (rows, C) CL feature maps at h, h/2, ... (outs[0] = the input)."""
         pk = self._packed()
         outs = [(x_cl, h, w)]
-        for wp, b, co in pk["down"]:
+        for wp, b, co, wino in pk["down"]:
             src, hh, ww = outs[-1]
-            y = ops.conv2d_cl(src, wp, co, 3, 3, n, hh, ww, bias=b, act=ops.ACT_RELU)
+            y = ops.conv2d_cl(src, wp, co, 3, 3, n, hh, ww, bias=b, act=ops.ACT_RELU, weight_wino=wino)
             outs.append((ops.avgpool2_cl(y, n, hh, ww), hh // 2, ww // 2))
         return outs
 
@@ -67,8 +69,10 @@ class HourglassExec:
         outs = self.encode(x_cl, n, h, w)
         out, hh, ww = outs.pop()
         src1 = None
-        for wp, b, co in pk["up"]:
-            out = ops.conv2d_cl(out, wp, co, 3, 3, n, hh, ww, src1=src1, bias=b, upsample=True, act=ops.ACT_RELU)
+        for wp, b, co, wino in pk["up"]:
+            ok = wino is not None and out.shape[1] % 16 == 0 and (src1 is None or src1.shape[1] % 16 == 0)
+            out = ops.conv2d_cl(out, wp, co, 3, 3, n, hh, ww, src1=src1, bias=b, upsample=True, act=ops.ACT_RELU,
+                                weight_wino=wino if ok else None)
             hh, ww = hh * 2, ww * 2
             src1 = outs.pop()[0]
         return out, src1

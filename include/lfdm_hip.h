@@ -99,7 +99,8 @@ typedef struct lfdm_conv_params {
      are left at zero again.  NULL / too short = separate reduce pass. */
   unsigned int* tile_counters;
   int tile_counters_len;
-  /* Optional Winograd F(2x2,3x3) form of the SAME filter (3x3, stride 1, zero pad 1, even H and W, C0 % 16 == C1 % 16 == 0):
+  /* Optional Winograd F(2x2,3x3) form of the SAME filter (3x3, stride 1, zero pad 1, even H and W, C0 % 16 == C1 % 16 == 0;
+     also through the virtual nearest x2 upsample):
      U = G g G^T laid out [16 positions][Cin/16][coutp][16] (cvpr23_lfdm_amd.ops.pack_wino_weight).  When given and the
      geometry qualifies the library may run the 16/36-multiplication schedule (conv_wino.hip); results differ from the
      direct form by fp32 rounding only (~1e-6 relative).  LFDM_WINO=0 in the environment forces the direct form. */

@@ -521,6 +521,9 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=128, cout=32, n=1, h=4, w=4, ksplit=2, act=1),                    # split-K slabs + reduce pass
     dict(cin=32, cout=256, n=1, h=4, w=4),                                      # filters outweigh the input: XCD k owns column tile k
     dict(cin=80, cout=512, n=1, h=4, w=2, ksplit=2),                            # ... with split-K and two column tiles per XCD
+    dict(cin=32, cout=64, n=2, h=4, w=6, upsample=True, act=1),                  # UpBlock2d: read through the virtual nearest x2 upsample
+    dict(cin=48, cout=32, n=3, h=3, w=4, upsample=True, split_src=32, act=1),    # ... hourglass decoder: fused concat, odd physical height
+    dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),
     dict(cin=64, cout=64, n=8, h=8, w=8, gn=True),                           # GroupNorm partial sums from the epilogue
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
@@ -536,7 +539,9 @@ def test_conv2d_winograd(backend, case, monkeypatch):
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
     bias = rnd(cout, seed=3)
-    ref = conv_out = F.conv2d(x, wt, bias, padding=1)
+    up = bool(case.get("upsample"))
+    ref = conv_out = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest") if up else x, wt, bias, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
     res = None
     if case.get("residual"):
         res = rnd(*ref.shape, seed=4)
@@ -551,7 +556,7 @@ def test_conv2d_winograd(backend, case, monkeypatch):
         src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
     wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
     kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act,
-              ksplit=case.get("ksplit", 1), weight_wino=ww)
+              ksplit=case.get("ksplit", 1), weight_wino=ww, upsample=up)
     pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
     rows, ks = ops.conv_plan(pp)
     assert rows == (128 if ks == 1 else 16), "the Winograd plan was not selected"
@@ -561,7 +566,7 @@ def test_conv2d_winograd(backend, case, monkeypatch):
         partial = torch.zeros(2 * (pixels // rows), 16, device=dev)
         kw.update(gn_partial=partial, gn_groups=8, gn_pixels=pixels)
     out = ops.conv2d_cl(src0, wd, cout, 3, 3, n, h, w, **kw)
-    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "winograd conv")
+    assert_close(from_cl(out.cpu(), n, ho, wo), ref, TOL, "winograd conv")
     if partial is not None:
         y = conv_out.view(2, n // 2, 8, cout // 8, h, w).permute(0, 2, 1, 3, 4, 5).reshape(2, 8, -1).double()
         got = partial.cpu().view(2, pixels // rows, 8, 2).double().sum(dim=1)
