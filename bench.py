@@ -110,7 +110,7 @@ def conv_roofline(model, img, cond):
     ms = sum(r[1].elapsed_time(r[2]) for r in records)
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    tf = os.path.join(REPO_ROOT, "profiles", "r01_k_traffic.json")
+    tf = os.path.join(REPO_ROOT, "profiles", "r01_o_traffic.json")
     if os.path.exists(tf):          # PMC counters cannot be read from inside the process: committed rocprofv3 pass
         with open(tf) as f:
             tj = json.load(f)
