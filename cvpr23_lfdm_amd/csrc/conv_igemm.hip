@@ -577,7 +577,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, hipStream_t stream);          // conv_wino.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);  // conv_wino.hip
 
 namespace {
 
@@ -642,7 +642,9 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.kind = 2;
     pl.bm = 128;
     pl.bn = 32;
-    const int64_t blocks = (((int64_t)p.n_img * (p.hq / 2) * (p.wq / 2) + 31) / 32) * ((p.coutp + 31) / 32);
+    if (const char* e = getenv("LFDM_WINO_BN"))          // experiment knob (tools/bench_conv.py): 64-column workgroups
+      if (e[0] == '6' && p.coutp % 64 == 0) pl.bn = 64;
+    const int64_t blocks = (((int64_t)p.n_img * (p.hq / 2) * (p.wq / 2) + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
     const int nch = cin / 16;
     int k = 1;
     if (blocks < 224) {
@@ -760,7 +762,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
-    rc = lfdm_conv_wino_launch(p, stream);
+    rc = lfdm_conv_wino_launch(p, pl.bn, stream);
   } else {
     const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit);
     if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);

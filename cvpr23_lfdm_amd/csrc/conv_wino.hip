@@ -30,14 +30,17 @@ constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M pl
 // positions' MFMAs; patches and weight fragments fetched two chunks ahead at two workgroups per CU; A-fragment LDS reads
 // pinned one position ahead with sched_group_barrier.  What would help next: 32-channel chunks with 16-byte patch loads
 // (half the TA cycles per patch byte) or a 64-column tile (half the patch bytes per MFMA) - both cost occupancy.
-template <bool ACT>
-__global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
+// NT = column tiles (32 output channels each) per workgroup: 2 halves the patch loads / transforms per MFMA at two
+// workgroups per CU (~250 VGPRs).
+template <bool ACT, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+  constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
   __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ int s_n[WT], s_ty[WT], s_tx[WT];
-  __shared__ float s_gn[2][8][WN];
+  __shared__ float s_gn[2][8][WNB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
     bz = rest / gridDim.x;
   }
   const unsigned t0 = bx * WT;
-  const int n0 = by * WN;
+  const int n0 = by * WNB;
   const int cin = p.c0 + p.c1;
   const int nchunks_all = cin / WKC;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
@@ -123,21 +126,27 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
   };
   // ---- weight fragments: lane (co = n0 + l31, k-slot kh) holds U[pos][16*chunk + 8*kh + s][co], s = 0..7 ----
   const lfdm_buf bufw = lfdm_make_buf(p.weight_wino, (uint32_t)((int64_t)16 * nchunks_all * p.coutp * WKC * 4));
-  float4 bfrag[4][2];
+  float4 bfrag[4][NT][2];
   auto fetch_b = [&](int pi, int chunk) {
     const int pos = 4 * wave + pi;
-    const uint32_t off = (n0 + l31 < p.coutp)
-                             ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * p.coutp + n0 + l31) * WKC + 8 * kh) * 4)
-                             : LFDM_BUF_OOB;
-    bfrag[pi][0] = lfdm_buf_load_f4(bufw, off);
-    bfrag[pi][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const int n = n0 + WN * ct + l31;
+      const uint32_t off = (n < p.coutp)
+                               ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * p.coutp + n) * WKC + 8 * kh) * 4)
+                               : LFDM_BUF_OOB;
+      bfrag[pi][ct][0] = lfdm_buf_load_f4(bufw, off);
+      bfrag[pi][ct][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
+    }
   };
 
-  f32x16 acc[4];
+  f32x16 acc[4][NT];
 #pragma unroll
   for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[pi][r] = 0.f;
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pi][ct][r] = 0.f;
 
   // B^T d B on a channel pair: part i = row i of the position grid (positions 4i..4i+3)
   auto xform_part = [&](const float2 (&d)[16], int i, float* V) {
@@ -161,15 +170,16 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
     a0 = *reinterpret_cast<const float4*>(va);
     a1 = *reinterpret_cast<const float4*>(va + 4);
   };
-  auto mfma_pos = [&](const float4& a0, const float4& a1, int pi) {           // its 8 k-steps on this chunk
-    acc[pi] = mfma_32x32x2(a0.x, bfrag[pi][0].x, acc[pi]);
-    acc[pi] = mfma_32x32x2(a0.y, bfrag[pi][0].y, acc[pi]);
-    acc[pi] = mfma_32x32x2(a0.z, bfrag[pi][0].z, acc[pi]);
-    acc[pi] = mfma_32x32x2(a0.w, bfrag[pi][0].w, acc[pi]);
-    acc[pi] = mfma_32x32x2(a1.x, bfrag[pi][1].x, acc[pi]);
-    acc[pi] = mfma_32x32x2(a1.y, bfrag[pi][1].y, acc[pi]);
-    acc[pi] = mfma_32x32x2(a1.z, bfrag[pi][1].z, acc[pi]);
-    acc[pi] = mfma_32x32x2(a1.w, bfrag[pi][1].w, acc[pi]);
+  auto mfma_pos = [&](const float4& a0, const float4& a1, int pi) {           // its 8 k-steps on this chunk (NT chains)
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const float4 bq = bfrag[pi][ct][s8 >> 2];
+        const float b = (s8 & 3) == 0 ? bq.x : (s8 & 3) == 1 ? bq.y : (s8 & 3) == 2 ? bq.z : bq.w;
+        acc[pi][ct] = mfma_32x32x2(a[s8], b, acc[pi][ct]);
+      }
   };
   const int kc_last = kc_end - 1;
   auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
@@ -195,52 +205,61 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(lfdm_conv_params p) {
   }
 
   // ---- output transform A^T M A: the column sum (over j) in registers, the row sum (over i = wave) through LDS ----
-  float* const Ms = smem;           // [8 = 2*i + j'][WT][LDM]
+  float* const Ms = smem;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
+  float gs[NT], gq[NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
-    Ms[((2 * wave) * WT + tile) * LDM + l31] = acc[0][r] + acc[1][r] + acc[2][r];
-    Ms[((2 * wave + 1) * WT + tile) * LDM + l31] = acc[1][r] - acc[2][r] - acc[3][r];
-  }
-  __syncthreads();
-  const int co = n0 + l31;
-  float gs = 0.f, gq = 0.f;
-  const float bb = (p.bias && ksplit == 1 && co < p.cout) ? p.bias[co] : 0.f;
+  for (int ct = 0; ct < NT; ++ct) {
+    if (ct > 0) __syncthreads();    // the previous column tile's planes have been consumed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Ms[((2 * wave) * WT + tile) * LDM + l31] = acc[0][ct][r] + acc[1][ct][r] + acc[2][ct][r];
+      Ms[((2 * wave + 1) * WT + tile) * LDM + l31] = acc[1][ct][r] - acc[2][ct][r] - acc[3][ct][r];
+    }
+    __syncthreads();
+    const int co = n0 + WN * ct + l31;
+    gs[ct] = 0.f;
+    gq[ct] = 0.f;
+    const float bb = (p.bias && ksplit == 1 && co < p.cout) ? p.bias[co] : 0.f;
 #pragma unroll 1
-  for (int it = 0; it < WT / 8; ++it) {
-    const int tile = (tid >> 5) + 8 * it;
-    const int n = s_n[tile];
-    if (n < 0 || co >= p.coutp) continue;
-    float m[8];
+    for (int it = 0; it < WT / 8; ++it) {
+      const int tile = (tid >> 5) + 8 * it;
+      const int n = s_n[tile];
+      if (n < 0 || co >= p.coutp) continue;
+      float m[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) m[q] = Ms[(q * WT + tile) * LDM + l31];
-    float y[4];
-    y[0] = m[0] + m[2] + m[4];       // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
-    y[1] = m[1] + m[3] + m[5];
-    y[2] = m[2] - m[4] - m[6];
-    y[3] = m[3] - m[5] - m[7];
-    const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[tile]) * p.wq + 2 * s_tx[tile];
+      for (int q = 0; q < 8; ++q) m[q] = Ms[(q * WT + tile) * LDM + l31];
+      float y[4];
+      y[0] = m[0] + m[2] + m[4];       // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
+      y[1] = m[1] + m[3] + m[5];
+      y[2] = m[2] - m[4] - m[6];
+      y[3] = m[3] - m[5] - m[7];
+      const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[tile]) * p.wq + 2 * s_tx[tile];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
-      if (ksplit > 1) {
-        p.partial[((int64_t)bz * M + orow) * p.coutp + co] = y[q];
-      } else if (co < p.cout) {
-        float v = y[q] + bb;
-        gs += v;
-        gq += v * v;
-        if (p.residual) v += p.residual[orow * p.ldr + co];
-        if (ACT) v = apply_act(v, p.act);
-        p.out[orow * p.ldo + co] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
+        if (ksplit > 1) {
+          p.partial[((int64_t)bz * M + orow) * p.coutp + co] = y[q];
+        } else if (co < p.cout) {
+          float v = y[q] + bb;
+          gs[ct] += v;
+          gq[ct] += v * v;
+          if (p.residual) v += p.residual[orow * p.ldr + co];
+          if (ACT) v = apply_act(v, p.act);
+          p.out[orow * p.ldo + co] = v;
+        }
       }
     }
   }
   if (p.gn_partial && ksplit == 1) {
-    s_gn[0][tid >> 5][l31] = gs;
-    s_gn[1][tid >> 5][l31] = gq;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      s_gn[0][tid >> 5][WN * ct + l31] = gs[ct];
+      s_gn[1][tid >> 5][WN * ct + l31] = gq[ct];
+    }
     __syncthreads();
     const int cg = p.cout / p.gn_groups;
-    const int gpt = WN / cg;                      // groups inside this column tile (cg divides 32: host check)
+    const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32: host check)
     if (tid < gpt && n0 + tid * cg < p.cout) {
       float s = 0.f, q = 0.f;
       for (int c = 0; c < cg; ++c)
@@ -306,10 +325,13 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, hipStream_t stream) {
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
-  const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + WN - 1) / WN), p.ksplit > 1 ? p.ksplit : 1);
-  if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino_kernel<true>), grid, dim3(256), 0, stream, p);
-  else LFDM_LAUNCH((conv_wino_kernel<false>), grid, dim3(256), 0, stream, p);
+  const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
+  const bool act = p.act != LFDM_ACT_NONE;
+  if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
+  else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
+  else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);
+  else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p);
   return lfdm_check_launch("conv_wino");
 }

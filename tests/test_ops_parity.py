@@ -528,13 +528,15 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-def test_conv2d_winograd(backend, case, monkeypatch):
+@pytest.mark.parametrize("bn", ["32", "64"], ids=["n32", "n64"])
+def test_conv2d_winograd(backend, case, bn, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
     tile order of the low-resolution levels."""
     dev = backend
     if case.get("gpu_only") and not big(dev):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
+    monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
