@@ -9,8 +9,10 @@ device->host copy for `torch.svd(covar.cpu())` in every iteration); here the N =
 in ONE pass.  All convolutions (the three hourglass networks, 98 % of the FLOPs) run on the native implicit-GEMM
 kernels with eval-BatchNorm folded into the weights, channels-last, skip concatenations passed as two-source
 convolutions.  What is left in torch are the few-KB closed-form pieces (soft-argmax moments, 2x2 inverses, Gaussian
-heat-maps, the 11-way softmax blend) and ONE batched `torch.svd` on the host per training step - kept on the same
-LAPACK path as the reference so that the (sign-ambiguous) U factors match it.
+heat-maps, the 11-way softmax blend) and the 2x2 SVD of the region covariances.  The reference takes that SVD on the host
+(`torch.svd(covar.cpu())`, LAPACK xGESDD) and uses U * sqrt(S), so the sign convention of U matters; `svd2x2_sym_lapack`
+replays xGESDD's 2x2 path (xGEBRD Householder -> xBDSQR/xLASV2 -> sort) in closed form on the device: same signs as LAPACK
+on 800 k random + edge-case covariances (tests/test_svd2x2.py), and no device->host sync in the training step.
 """
 import torch
 import torch.nn.functional as F
@@ -122,6 +124,88 @@ def inv2x2(m):
     return torch.stack((torch.stack((d, -b), dim=-1), torch.stack((-c, a), dim=-1)), dim=-2) / det.unsqueeze(-1).unsqueeze(-1)
 
 
+def _sign1(x):
+    """Fortran SIGN(1, x): +1 for x >= 0."""
+    return torch.where(x < 0, -torch.ones_like(x), torch.ones_like(x))
+
+
+def _lasv2(f, g, h):
+    """LAPACK xLASV2: SVD of [[f, g], [0, h]] -> (ssmin, ssmax, snl, csl), vectorised; every branch of the routine is
+    evaluated and selected with torch.where (few-KB tensors)."""
+    one, zero = torch.ones_like(f), torch.zeros_like(f)
+    fa, ha = f.abs(), h.abs()
+    swap = ha > fa
+    ft, ht = torch.where(swap, h, f), torch.where(swap, f, h)
+    fa, ha = torch.where(swap, ha, fa), torch.where(swap, fa, ha)
+    gt, ga = g, g.abs()
+    diag = ga == 0
+    eps = torch.finfo(f.dtype).eps / 2                      # xLAMCH('E')
+    gbig = (~diag) & (ga > fa)
+    ft_ = torch.where(ft == 0, one, ft)                     # guards for the lanes whose branch is not taken
+    ga_ = torch.where(diag, one, ga)
+    gt_ = torch.where(diag, one, gt)
+    large = gbig & ((fa / ga_) < eps)
+    d = fa - ha
+    l = torch.where(d == fa, one, d / torch.where(fa == 0, one, fa))
+    m = gt / ft_
+    t = 2 - l
+    mm, tt = m * m, t * t
+    sq = torch.sqrt(tt + mm)
+    r = torch.where(l == 0, m.abs(), torch.sqrt(l * l + mm))
+    a = 0.5 * (sq + r)
+    ssmin, ssmax = ha / a, fa * a
+    d_ = torch.where(d == 0, one, d)
+    t_tiny = torch.where(l == 0, 2 * _sign1(ft) * _sign1(gt), gt / (d_.abs() * _sign1(ft)) + m / t)
+    rl = torch.where(r + l == 0, one, r + l)
+    t_norm = (m / (sq + t) + m / rl) * (1 + a)
+    t2 = torch.where(mm == 0, t_tiny, t_norm)
+    l2 = torch.sqrt(t2 * t2 + 4)
+    crt, srt = 2 / l2, t2 / l2
+    clt = (crt + srt * m) / a
+    slt = (ht / ft_) * srt / a
+    clt, slt = torch.where(large, one, clt), torch.where(large, ht / gt_, slt)
+    srt, crt = torch.where(large, one, srt), torch.where(large, ft / gt_, crt)
+    ssmax = torch.where(large, ga, ssmax)
+    ssmin = torch.where(large, torch.where(ha > 1, fa / (ga_ / torch.where(ha == 0, one, ha)), (fa / ga_) * ha), ssmin)
+    clt, crt = torch.where(diag, one, clt), torch.where(diag, one, crt)
+    slt, srt = torch.where(diag, zero, slt), torch.where(diag, zero, srt)
+    ssmax, ssmin = torch.where(diag, fa, ssmax), torch.where(diag, ha, ssmin)
+    csl, snl = torch.where(swap, srt, clt), torch.where(swap, crt, slt)
+    return ssmin.abs(), ssmax.abs(), snl, csl
+
+
+def svd2x2_sym_lapack(a, b, c):
+    """(U, S) of the symmetric [[a, b], [b, c]] exactly as torch.svd / LAPACK xGESDD return them for a 2x2 input (path 5:
+    xGEBRD = one Householder reflection H1 of the first column, xBDSQR on the upper-bidiagonal H1*A: a negligible
+    off-diagonal splits, else xLASV2 rotates; singular values sorted by one selection-sort swap).  Only U's sign
+    convention needs all this - the reference multiplies U by sqrt(S) (LFAE/modules/region_predictor.py:16-25)."""
+    one, zero = torch.ones_like(a), torch.zeros_like(a)
+    r = torch.sqrt(a * a + b * b)
+    beta = -_sign1(a) * r
+    noref = b == 0                                        # xLARFG: nothing to annihilate -> H1 = I
+    safe = torch.where(noref, one, beta)
+    h00, h01 = torch.where(noref, one, a / safe), torch.where(noref, zero, b / safe)
+    h11 = torch.where(noref, one, -a / safe)
+    d1 = torch.where(noref, a, beta)
+    e1 = h00 * b + h01 * c
+    d2 = h01 * b + h11 * c
+    ssmin, ssmax, snl, csl = _lasv2(d1, e1, d2)
+    eps = torch.finfo(a.dtype).eps / 2
+    tol = max(10.0, min(100.0, eps ** (-0.125))) * eps
+    ad1, ad2, ae = d1.abs(), d2.abs(), e1.abs()
+    mu = ad2 * (ad1 / torch.where(ad1 + ae == 0, one, ad1 + ae))
+    sminoa = torch.where(ad1 == 0, zero, torch.minimum(ad1, mu)) / (2.0 ** 0.5)
+    split = ae <= torch.clamp(tol * sminoa, min=24 * torch.finfo(a.dtype).tiny)
+    csl, snl = torch.where(split, one, csl), torch.where(split, zero, snl)
+    s1, s2 = torch.where(split, ad1, ssmax), torch.where(split, ad2, ssmin)
+    u00, u01 = h00 * csl + h01 * snl, -h00 * snl + h01 * csl
+    u10, u11 = h01 * csl + h11 * snl, -h01 * snl + h11 * csl
+    sw = s2 > s1
+    u = torch.stack((torch.stack((torch.where(sw, u01, u00), torch.where(sw, u00, u01)), dim=-1),
+                     torch.stack((torch.where(sw, u11, u10), torch.where(sw, u10, u11)), dim=-1)), dim=-2)
+    return u, torch.stack((torch.where(sw, s2, s1), torch.where(sw, s1, s2)), dim=-1)
+
+
 def region2gaussian(center, covar, h, w):
     """util.py:22-48 for a (N, K, 2) centre and a (N, K, 2, 2) covariance (or a float)."""
     grid = coordinate_grid(h, w, center.device).view(1, 1, h, w, 2)
@@ -141,6 +225,7 @@ class RegionPredictorExec:
     def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3):
         self.tree, self.temperature, self.scale_factor, self.pca_based, self.pad = tree, temperature, scale_factor, pca_based, pad
         self.hg = HourglassExec(tree, "predictor.", num_blocks)
+        self.host_svd = False
 
     @torch.no_grad()
     def __call__(self, x):
@@ -163,11 +248,15 @@ class RegionPredictorExec:
         cxx, cxy, cyy = (mx * mx * region).sum(dim=(2, 3)), (mx * my * region).sum(dim=(2, 3)), (my * my * region).sum(dim=(2, 3))
         covar = torch.stack((torch.stack((cxx, cxy), dim=-1), torch.stack((cxy, cyy), dim=-1)), dim=-2)
         params["covar"] = covar
-        # one batched host SVD for all frames (the reference: one per frame, region_predictor.py:16-25)
-        u, s, _ = torch.svd(covar.reshape(-1, 2, 2).cpu())
-        u, s = u.to(covar.device), s.to(covar.device)
+        # the reference: torch.svd(covar.cpu()) per frame (region_predictor.py:16-25); here LAPACK's 2x2 path in closed form
+        # on the device for all frames at once (host_svd=True keeps the LAPACK call for A/B checks)
+        if self.host_svd:
+            u, s, _ = torch.svd(covar.reshape(-1, 2, 2).cpu())
+            u, s = u.to(covar.device), s.to(covar.device)
+        else:
+            u, s = svd2x2_sym_lapack(cxx.reshape(-1), cxy.reshape(-1), cyy.reshape(-1))
         d = torch.diag_embed(s ** 0.5)
-        params["affine"] = torch.matmul(u, d).view(*covar.shape)
+        params["affine"] = (u * (s ** 0.5).unsqueeze(-2)).view(*covar.shape)          # U @ diag(sqrt(S))
         params["u"], params["d"] = u, d
         return params
 
