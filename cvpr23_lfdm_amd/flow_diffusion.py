@@ -7,6 +7,8 @@ The DM training step (a29) = frozen-LFAE pseudo ground truth batched over all fr
 diffusion loss through the native UNet forward/backward (unet_train.py, autograd.py) -> fused Adam (optim.py), with
 an optional one-process-per-GPU gradient all-reduce (`enable_data_parallel`).
 """
+import os
+
 import torch
 import yaml
 from torch import nn
@@ -57,7 +59,10 @@ class FlowDiffusion(nn.Module):
                  ddim_sampling_eta=1., timesteps=1000, dim_mults=(1, 2, 4, 8), lr=1e-4,
                  adam_betas=(0.9, 0.99), is_train=True, only_use_flow=True, use_residual_flow=False,
                  learn_null_cond=False, use_deconv=True, padding_mode="zeros", pretrained_pth="",
-                 config_pth=""):
+                 config_pth="", bert_path=None):
+        """Reference signature (video_flow_diffusion_model.py:19-37) + `bert_path`: a local Hugging Face directory of
+        bert-base-cased for `cond=list[str]` (the reference downloads it with torch.hub; see text.py).  LFDM_BERT_PATH in
+        the environment is the default, so unchanged caller scripts pick it up."""
         super().__init__()
         self.use_residual_flow = use_residual_flow
         self.only_use_flow = only_use_flow
@@ -83,6 +88,10 @@ class FlowDiffusion(nn.Module):
                                            sampling_timesteps=sampling_timesteps, timesteps=timesteps,
                                            loss_type='l2', use_dynamic_thres=True,
                                            null_cond_prob=null_cond_prob, ddim_sampling_eta=ddim_sampling_eta)
+        bert_path = bert_path or os.environ.get("LFDM_BERT_PATH")
+        if bert_path:
+            from .text import BertTextEncoder
+            self.diffusion.text_encoder = BertTextEncoder(bert_path, use_cls=self.diffusion.text_use_bert_cls)
         for attr in ('ref_img', 'ref_img_fea', 'real_vid', 'real_out_vid', 'real_warped_vid', 'real_vid_grid',
                      'real_vid_conf', 'fake_out_vid', 'fake_warped_vid', 'fake_vid_grid', 'fake_vid_conf',
                      'sample_out_vid', 'sample_warped_vid', 'sample_vid_grid', 'sample_vid_conf'):
