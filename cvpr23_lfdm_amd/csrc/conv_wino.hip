@@ -9,15 +9,16 @@
 // memory in operand order, each fragment re-loaded for the next chunk as soon as its MFMAs are issued).  The output
 // transform A^T M A is split: the sum over the position column j happens in the wave's accumulator registers, the sum over
 // the row i (across waves) through 8 LDS planes; it feeds the same epilogue as the direct kernels (bias, GroupNorm partial
-// sums, residual, activation) or the split-K slabs.  ~168 VGPRs and 40 KB LDS: three workgroups per CU, so one
-// workgroup's transform overlaps the others' MFMAs.
+// sums, residual, activation) or the split-K slabs.  ~150 VGPRs and 43 KB LDS: three workgroups per CU, so one
+// workgroup's transform overlaps the others' MFMAs.  The same kernel reads its input through a virtual nearest x2 upsample
+// (UpBlock2d) and, with the data-gradient form of the filters, computes dX of the training step.
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
 namespace {
 
 constexpr int WT = 32;            // tiles per workgroup
-constexpr int WN = 32;            // output channels per workgroup
+constexpr int WN = 32;            // output channels per column tile (NT of them per workgroup)
 constexpr int WKC = 16;           // input channels per chunk
 constexpr int LDV = WKC + 4;      // LDS row stride of V
 constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M planes in the epilogue
@@ -29,9 +30,10 @@ constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M pl
 // faster on any shape of tools/bench_conv.py): double-buffered LDS with the next chunk's transform placed between the
 // positions' MFMAs; patches and weight fragments fetched two chunks ahead at two workgroups per CU; A-fragment LDS reads
 // pinned one position ahead with sched_group_barrier.  What would help next: 32-channel chunks with 16-byte patch loads
-// (half the TA cycles per patch byte) or a 64-column tile (half the patch bytes per MFMA) - both cost occupancy.
-// NT = column tiles (32 output channels each) per workgroup: 2 halves the patch loads / transforms per MFMA at two
-// workgroups per CU (~250 VGPRs).
+// (half the TA cycles per patch byte), raw pixels staged once in LDS (the patches overlap 4x).
+// NT = column tiles per workgroup: NT = 2 (64 columns, opt-in LFDM_WINO_BN=64) halves the patch loads / transforms per MFMA at
+// two workgroups per CU (244 VGPRs): 2-5 % faster on the large-M decoder shapes, slower wherever it leaves a CU fewer than
+// ~3 workgroups (profiles/r01_o_conv_shapes_wino_bn64.txt).
 template <bool ACT, int NT>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   }
   __syncthreads();
 
-  // ---- transform threads: (tile, float4 of channels) ----
+  // ---- input transform: one (tile, channel pair) patch per thread ----
   const int x_tile = tid >> 3, x_c2 = tid & 7;              // 32 tiles x 8 channel pairs = 256 threads
   const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
   const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
