@@ -6,9 +6,22 @@ import numpy as np
 import pytest
 import torch
 
+import sys
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden", "text_embed.npz")
 BERT = os.path.join(HERE, "golden", "tiny_bert")
+
+
+@pytest.fixture(autouse=True)
+def _no_reference_import_shims(monkeypatch):
+    """tests/test_oracle_vs_reference.py (this container only) imports the reference through oracle/ref_shims, whose stub
+    `torchvision` makes `transformers` believe torchvision is installed.  Hide the shims while these tests run."""
+    shims = os.path.join(os.path.dirname(HERE), "oracle", "ref_shims")
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if os.path.abspath(p) != shims])
+    for name, mod in list(sys.modules.items()):
+        if os.path.abspath(getattr(mod, "__file__", None) or "").startswith(shims):
+            monkeypatch.delitem(sys.modules, name)
 
 
 def test_tokenize_and_pooling_match_reference():
