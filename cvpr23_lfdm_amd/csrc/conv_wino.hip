@@ -34,9 +34,19 @@ constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M pl
 // NT = column tiles per workgroup: NT = 2 (64 columns, opt-in LFDM_WINO_BN=64) halves the patch loads / transforms per MFMA at
 // two workgroups per CU (244 VGPRs): 2-5 % faster on the large-M decoder shapes, slower wherever it leaves a CU fewer than
 // ~3 workgroups (profiles/r01_o_conv_shapes_wino_bn64.txt).
-template <bool ACT, int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+// STAGE (opt-in LFDM_WINO_STAGE=1, not yet measured on the GPU): the 4x4 patches of horizontally adjacent tiles share two
+// of their four columns, and 8-byte patch loads use half of the TA's bytes per cycle.  With STAGE the workgroup first
+// loads, per tile-row segment, the UNIQUE pixels of the 4-row band its tiles read (16-byte loads, 264-384 pixels instead of
+// 512 patch pixels per chunk) into LDS and the transform threads build their patches from there: 1.6-1.9x fewer patch bytes
+// at full TA width, for ~30 KB more LDS (two workgroups per CU) and 16 more ds_read_b64 per thread and chunk.
+constexpr int RS = 20;              // floats per staged pixel (16 channels + pad: 16-byte aligned, 2-way bank conflicts at most)
+constexpr int SPMAX = 384;          // staged pixels at most (2 tiles per image row)
+constexpr int STG = 6;              // float4 stage loads per thread: ceil(SPMAX * 4 / 256)
+
+template <bool ACT, int NT, bool STAGE>
+__global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
+  __shared__ __attribute__((aligned(16))) float raw[STAGE ? SPMAX * RS : 4];
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
   __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
@@ -110,7 +120,54 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     for (int py = 0; py < 4; ++py)
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
+  // ---- STAGE: unique pixels of each tile-row segment's band -> LDS ----
+  // segment r = tiles [r*TPR, (r+1)*TPR) of this workgroup (one image row of tiles or 32 of them); its band = logical rows
+  // 2ty-1..2ty+2 x logical columns 2tx0-1..2(tx0+TPR): staged pixel q = (r*4 + py)*BW + bx
+  const int TPR = tw < WT ? tw : WT, BW = 2 * TPR + 2, SP4 = (WT / TPR) * 4 * BW * 4;     // SP4 = float4 items to stage
+  uint32_t spix[STAGE ? STG : 1];    // physical pixel index of this thread's item j (0xFFFFFFFF: outside the image)
+  if constexpr (STAGE) {
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int item = tid + 256 * j;
+      spix[j] = 0xFFFFFFFFu;
+      if (item < SP4) {
+        const int q = item >> 2;
+        const int r = q / (4 * BW), rem = q - r * 4 * BW;
+        const int py = rem / BW, bxx = rem - py * BW;
+        const int n = s_n[r * TPR];
+        const int iy = 2 * s_ty[r * TPR] - 1 + py, ix = 2 * s_tx[r * TPR] - 1 + bxx;
+        if (n >= 0 && iy >= 0 && iy < p.hq && ix >= 0 && ix < p.wq)
+          spix[j] = (uint32_t)((n * p.hi + (iy >> up)) * p.wi + (ix >> up));
+      }
+    }
+  }
+  float4 stg[STAGE ? STG : 1];
+  auto fetch_stage = [&](int chunk) {
+    int cc = chunk * WKC;
+    const bool second = cc >= p.c0;
+    if (second) cc -= p.c0;
+    const lfdm_buf buf = second ? buf1 : buf0;
+    const uint32_t ld4 = (uint32_t)(second ? p.ld1 : p.ld0) * 4u;
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const uint32_t c4 = (uint32_t)((tid + 256 * j) & 3);
+      stg[j] = lfdm_buf_load_f4(buf, spix[j] != 0xFFFFFFFFu ? spix[j] * ld4 + ((uint32_t)cc + 4u * c4) * 4u : LFDM_BUF_OOB);
+    }
+  };
+  auto write_stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int item = tid + 256 * j;
+      if (item < SP4) *reinterpret_cast<float4*>(raw + (item >> 2) * RS + 4 * (item & 3)) = stg[j];
+    }
+  };
+  const int seg = x_tile / TPR;
+  const float* const raw_patch = raw + ((seg * 4) * BW + 2 * (x_tile - seg * TPR)) * RS + 2 * x_c2;   // patch (0,0) of this thread
   float2 patch[16];
+  auto patch_from_stage = [&](float2 (&patch)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) patch[q] = *reinterpret_cast<const float2*>(raw_patch + ((q >> 2) * BW + (q & 3)) * RS);
+  };
   auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
     int cc = chunk * WKC;
     const bool second = cc >= p.c0;
@@ -187,23 +244,45 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
 
   float* const Vs = smem;           // [16 pos][WT tiles][LD]
-  fetch_patch(patch, kc_begin);
 #pragma unroll
   for (int pi = 0; pi < 4; ++pi) fetch_b(pi, kc_begin);
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const int nxt = clampc(kc + 1);
+  if constexpr (STAGE) {
+    fetch_stage(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      const int nxt = clampc(kc + 1);
+      write_stage();
+      __syncthreads();               // the band is in LDS; every wave has left the previous chunk's MFMA phase (V is free)
+      patch_from_stage(patch);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
-    __syncthreads();
-    fetch_patch(patch, nxt);                                   // in flight under this chunk's MFMAs
+      for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
+      __syncthreads();               // V complete; all reads of the staged band done
+      fetch_stage(nxt);              // in flight under this chunk's MFMAs
 #pragma unroll
-    for (int pi = 0; pi < 4; ++pi) {
-      float4 a0, a1;
-      load_a(Vs, pi, a0, a1);
-      mfma_pos(a0, a1, pi);
-      fetch_b(pi, nxt);                                        // refilled in place for the next chunk
+      for (int pi = 0; pi < 4; ++pi) {
+        float4 a0, a1;
+        load_a(Vs, pi, a0, a1);
+        mfma_pos(a0, a1, pi);
+        fetch_b(pi, nxt);
+      }
     }
-    __syncthreads();
+    __syncthreads();                 // the epilogue reuses the V buffer
+  } else {
+    fetch_patch(patch, kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      const int nxt = clampc(kc + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
+      __syncthreads();
+      fetch_patch(patch, nxt);                                   // in flight under this chunk's MFMAs
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        float4 a0, a1;
+        load_a(Vs, pi, a0, a1);
+        mfma_pos(a0, a1, pi);
+        fetch_b(pi, nxt);                                        // refilled in place for the next chunk
+      }
+      __syncthreads();
+    }
   }
 
   // ---- output transform A^T M A: the column sum (over j) in registers, the row sum (over i = wave) through LDS ----
@@ -331,9 +410,19 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream)
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
-  else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
-  else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);
-  else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p);
+  const int tw = p.wq / 2;
+  bool stage = false;                // experiment knob (tools/sweep_conv.sh): unique-pixel staging through LDS
+  if (const char* e = getenv("LFDM_WINO_STAGE")) stage = e[0] == '1' && tw >= 2 && ((tw <= WT && WT % tw == 0) || tw % WT == 0);
+  if (stage) {
+    if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
+    else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, true>), grid, dim3(256), 0, stream, p);
+    else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<false, 1, true>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false>), grid, dim3(256), 0, stream, p);
+    else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, false>), grid, dim3(256), 0, stream, p);
+    else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<false, 1, false>), grid, dim3(256), 0, stream, p);
+  }
   return lfdm_check_launch("conv_wino");
 }

@@ -524,12 +524,14 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=32, cout=64, n=2, h=4, w=6, upsample=True, act=1),                  # UpBlock2d: read through the virtual nearest x2 upsample
     dict(cin=48, cout=32, n=3, h=3, w=4, upsample=True, split_src=32, act=1),    # ... hourglass decoder: fused concat, odd physical height
     dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),
+    dict(cin=16, cout=32, n=1, h=4, w=32, residual=True),                        # 16 tiles per image row: two row segments per workgroup
+    dict(cin=32, cout=32, n=2, h=2, w=128, act=1),                               # 64 tiles per image row: a workgroup is half a row
     dict(cin=64, cout=64, n=8, h=8, w=8, gn=True),                           # GroupNorm partial sums from the epilogue
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn", ["32", "64"], ids=["n32", "n64"])
-def test_conv2d_winograd(backend, case, bn, monkeypatch):
+@pytest.mark.parametrize("bn,stage", [("32", "0"), ("64", "0"), ("32", "1"), ("64", "1")], ids=["n32", "n64", "n32-staged", "n64-staged"])
+def test_conv2d_winograd(backend, case, bn, stage, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
     tile order of the low-resolution levels."""
     dev = backend
@@ -537,6 +539,7 @@ def test_conv2d_winograd(backend, case, bn, monkeypatch):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
     monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
+    monkeypatch.setenv("LFDM_WINO_STAGE", stage)    # 1: unique pixels of each tile row staged through LDS (experiment knob)
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
