@@ -605,3 +605,48 @@ def test_pack_wino_weight(backend):
     assert ops.conv_plan(pp)[0] == 128
     dx = ops.conv2d_cl(to_cl(dy).to(dev), wd, 32, 3, 3, n, h, w, weight_wino=ww)
     assert_close(from_cl(dx.cpu(), n, h, w), x.grad, TOL, "winograd dgrad")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
+    """Seeded random geometries through every Winograd variant (tile raggedness, odd image counts, two-source splits,
+    forced split-K, upsampled input, 64-column workgroups, LDS staging) against F.conv2d."""
+    import os
+    import random
+    dev = backend
+    if dev == "cuda" and os.environ.get("LFDM_FUZZ_GPU", "0") != "1":
+        pytest.skip("written after the round's GPU minutes were spent: first GPU run is opt-in (LFDM_FUZZ_GPU=1)")
+    rnd_ = random.Random(1000 + seed)
+    for trial in range(6 if dev == "cpu" else 12):
+        cin = 16 * rnd_.randint(1, 5)
+        cout = rnd_.choice([8, 24, 32, 40, 64, 96])
+        n = rnd_.randint(1, 5)
+        up = rnd_.random() < 0.3
+        h, w = rnd_.choice([1, 2, 3, 4]) * (1 if up else 2), rnd_.choice([1, 2, 3, 4, 8, 16]) * (1 if up else 2)
+        ksplit = rnd_.choice([1, 1, 2, 3])
+        ksplit = min(ksplit, cin // 16)
+        split = rnd_.choice([0, 16]) if cin > 16 else 0
+        monkeypatch.setenv("LFDM_WINO", "1")
+        monkeypatch.setenv("LFDM_WINO_BN", rnd_.choice(["32", "64"]))
+        monkeypatch.setenv("LFDM_WINO_STAGE", rnd_.choice(["0", "1"]))
+        x = rnd(n, cin, h, w, seed=10 * seed + trial)
+        wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
+        bias = rnd(cout, seed=5)
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest") if up else x, wt, bias, padding=1)
+        res = rnd(*ref.shape, seed=6) if rnd_.random() < 0.5 else None
+        if res is not None:
+            ref = ref + res
+        act = rnd_.choice([0, 1])
+        if act:
+            ref = F.relu(ref)
+        xs = to_cl(x).to(dev)
+        src0, src1 = (xs[:, :split].contiguous(), xs[:, split:].contiguous()) if split else (xs, None)
+        kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act, ksplit=ksplit,
+                  weight_wino=ops.pack_wino_weight(wt.to(dev)), upsample=up)
+        wd = ops.pack_conv_weight(wt).to(dev)
+        pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
+        rows, ks = ops.conv_plan(pp)
+        assert rows == (128 if ks == 1 else 16), "the Winograd plan was not selected"
+        out = ops.conv2d_cl(src0, wd, cout, 3, 3, n, h, w, **kw)
+        assert_close(from_cl(out.cpu(), n, ref.shape[2], ref.shape[3]), ref, TOL,
+                     "winograd cin=%d cout=%d n=%d h=%d w=%d up=%s ks=%d split=%d" % (cin, cout, n, h, w, up, ks, split))
