@@ -12,6 +12,9 @@
 // sums, residual, activation) or the split-K slabs.  ~150 VGPRs and 43 KB LDS: three workgroups per CU, so one
 // workgroup's transform overlaps the others' MFMAs.  The same kernel reads its input through a virtual nearest x2 upsample
 // (UpBlock2d) and, with the data-gradient form of the filters, computes dX of the training step.
+#include <cstdio>
+#include <cstdlib>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -406,13 +409,23 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
+bool lfdm_conv_wino_wide_ok(const lfdm_conv_params& p);                       // conv_wino_wide.hip
+int lfdm_conv_wino_wide_launch(const lfdm_conv_params& p, hipStream_t stream);
+
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
+  const bool trace = getenv("LFDM_WINO_TRACE") != nullptr;       // which schedule ran (stderr): sweeps and tests
+  if (const char* e = getenv("LFDM_WINO_WIDE"))          // experiment knob: 64-tile workgroups, staged input, 8-channel chunks
+    if (e[0] == '1' && bn == 32 && lfdm_conv_wino_wide_ok(p)) {
+      if (trace) fprintf(stderr, "conv_wino: wide\n");
+      return lfdm_conv_wino_wide_launch(p, stream);
+    }
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
   const int tw = p.wq / 2;
   bool stage = false;                // experiment knob (tools/sweep_conv.sh): unique-pixel staging through LDS
   if (const char* e = getenv("LFDM_WINO_STAGE")) stage = e[0] == '1' && tw >= 2 && ((tw <= WT && WT % tw == 0) || tw % WT == 0);
+  if (trace) fprintf(stderr, "conv_wino: bn=%d%s\n", bn, stage ? " staged" : "");
   if (stage) {
     if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
     else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, true>), grid, dim3(256), 0, stream, p);

@@ -6,6 +6,7 @@ backend=emu (the kernel sources under the x86 fiber emulator, tiny shapes - inde
 Tolerance: 1e-4 relative to the output scale per op (fp32 kernels with a different summation
 order than ATen; the north-star budget for the whole chain is 1e-3)."""
 import math
+import os
 
 import pytest
 import torch
@@ -526,11 +527,16 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),
     dict(cin=16, cout=32, n=1, h=4, w=32, residual=True),                        # 16 tiles per image row: two row segments per workgroup
     dict(cin=32, cout=32, n=2, h=2, w=128, act=1),                               # 64 tiles per image row: a workgroup is half a row
+    dict(cin=32, cout=40, n=3, h=6, w=16, split_src=16, residual=True, act=1),    # 8 tiles per row: wide schedule, ragged second workgroup
+    dict(cin=16, cout=64, n=2, h=8, w=16, gn=True),                               # ... whose two halves lie in different samples
+    dict(cin=16, cout=32, n=1, h=4, w=8, upsample=True),                          # ... through the upsample
+    dict(cin=32, cout=32, n=1, h=4, w=16, ksplit=2),                              # ... with split-K slabs
     dict(cin=64, cout=64, n=8, h=8, w=8, gn=True),                           # GroupNorm partial sums from the epilogue
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn,stage", [("32", "0"), ("64", "0"), ("32", "1"), ("64", "1")], ids=["n32", "n64", "n32-staged", "n64-staged"])
+@pytest.mark.parametrize("bn,stage", [("32", "0"), ("64", "0"), ("32", "1"), ("64", "1"), ("32", "wide")],
+                         ids=["n32", "n64", "n32-staged", "n64-staged", "wide"])
 def test_conv2d_winograd(backend, case, bn, stage, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
     tile order of the low-resolution levels."""
@@ -539,7 +545,10 @@ def test_conv2d_winograd(backend, case, bn, stage, monkeypatch):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
     monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
-    monkeypatch.setenv("LFDM_WINO_STAGE", stage)    # 1: unique pixels of each tile row staged through LDS (experiment knob)
+    monkeypatch.setenv("LFDM_WINO_STAGE", "1" if stage == "1" else "0")    # unique pixels of each tile row staged through LDS (experiment knob)
+    monkeypatch.setenv("LFDM_WINO_WIDE", "1" if stage == "wide" else "0")  # conv_wino_wide.hip: 64-tile workgroups (>= 8 tiles per row, else the default)
+    if stage == "wide" and dev == "cuda" and os.environ.get("LFDM_FUZZ_GPU", "0") != "1":
+        pytest.skip("written after the round's GPU minutes were spent: first GPU run is opt-in (LFDM_FUZZ_GPU=1)")
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
@@ -629,6 +638,7 @@ def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
         monkeypatch.setenv("LFDM_WINO", "1")
         monkeypatch.setenv("LFDM_WINO_BN", rnd_.choice(["32", "64"]))
         monkeypatch.setenv("LFDM_WINO_STAGE", rnd_.choice(["0", "1"]))
+        monkeypatch.setenv("LFDM_WINO_WIDE", rnd_.choice(["0", "1"]))
         x = rnd(n, cin, h, w, seed=10 * seed + trial)
         wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
         bias = rnd(cout, seed=5)
