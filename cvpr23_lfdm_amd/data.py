@@ -79,12 +79,22 @@ class FrameFolderVideos(data.Dataset):
     def __getitem__(self, index):
         label, vid, paths = self.videos[index]
         idx = sample_indices(len(paths), self.num_frames, self.sampling)
-        frames = [imread(paths[i])[:, :, :3] for i in idx]
+        frames = [_rgb(imread(paths[i])) for i in idx]
         if self.jitter:
             frames = color_jitter(frames)
         frames = [resize(np.asarray(f, np.float32), self.image_size, interpolation=INTER_AREA) - self.mean for f in frames]
         video = np.stack([np.transpose(f, (2, 0, 1)) for f in frames], axis=1)
         return np.array(video / 255.0, dtype=np.float32), label, "%s_%s" % (label, vid)
+
+
+def _rgb(a):
+    """(H,W) grayscale / (H,W,1) / (H,W,4) RGBA frames -> (H,W,3), as the datasets' cv2.imread(..., IMREAD_COLOR) yields."""
+    a = np.asarray(a)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.shape[2] == 1:
+        a = np.repeat(a, 3, axis=2)
+    return a[:, :, :3]
 
 
 class SyntheticVideos(data.Dataset):

@@ -199,6 +199,10 @@ class GaussianDiffusion(nn.Module):
                 "ws": ops.sampler_ws(batch, n, dev), "graph": None, "pk": pk,
             }
             self._plans = {key: plan}      # keep one plan (static buffers are large)
+        if plan["graph"] is not None and plan.get("buf_gen") != unet._buf_gen:
+            # an eager call in between (Unet3D.forward, p_losses in eval mode, a larger batch) re-allocated scratch
+            # arenas whose raw pointers the captured graph holds: capture again on the current arenas
+            plan["graph"] = None
         x, eps, noise, step_dev, ss = plan["x"], plan["eps"], plan["noise"], plan["step"], plan["ss"]
         if len(variants) > 1:
             fea_term = torch.cat((fea_term, fea_term), dim=0).contiguous()       # rows of samples [cond | null]
@@ -240,6 +244,7 @@ class GaussianDiffusion(nn.Module):
             x.copy_(x_saved)
             step_dev.zero_()
             plan["graph"] = graph
+            plan["buf_gen"] = unet._buf_gen
             plan["static_bind"] = bind
         if use_graph:
             # the captured kernels hold the pointers of the first call's tables: refresh them in place

@@ -206,6 +206,7 @@ class FlowDiffusion(nn.Module):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self._dp = GradAllReduce(self.optimizer_diff, bucket_bytes=bucket_bytes)
+            self._dp.sync_replicas()          # rank 0's parameters + Adam moments -> all ranks, once
         return self
 
     def optimize_parameters(self):

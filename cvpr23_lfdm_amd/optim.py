@@ -12,6 +12,7 @@ import torch
 
 from . import _native
 from .ops import _chk, _lib, _p, _stream
+from .params import bump_weights_epoch
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -100,6 +101,7 @@ class FlatAdam(torch.optim.Optimizer):
                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                              float(group["weight_decay"]), step, float(self.grad_scale), _stream(lib)),
                       "lfdm_adam_step_f32")
+        bump_weights_epoch()      # the kernel wrote the parameters behind torch's back: packed weight caches must rebuild
         return loss
 
 
@@ -121,6 +123,32 @@ class GradAllReduce:
         self._hooks = []
         self._buckets = None
         self._flat_id = None
+
+    def sync_replicas(self, src=0):
+        """Broadcast rank `src`'s flat parameter buffer and Adam moments (one collective each per group) so that the
+        replicas start from identical state whatever seeds / restores happened before; afterwards identical averaged
+        gradients keep them identical (checked by `replica_checksum`).  The reference's nn.DataParallel re-broadcasts
+        the weights from GPU 0 on every forward (DM/train_video_flow_diffusion_mhad_multiGPU.py:207) - here once."""
+        if self.world <= 1:
+            return
+        for group, fl in zip(self.opt.param_groups, self.opt.ensure_flat()):
+            for key in ("p", "m", "v"):
+                self.dist.broadcast(fl[key], src=src, group=self.group)
+            step = torch.tensor([float(self.opt.state[fl["params"][0]]["step"])], device=fl["p"].device)
+            self.dist.broadcast(step, src=src, group=self.group)
+            for p in fl["params"]:
+                self.opt.state[p]["step"] = torch.tensor(float(step.item()))
+        bump_weights_epoch()
+
+    def replica_checksum(self):
+        """(max - min) over ranks of the fp64 sum of the flat parameter buffer: 0.0 iff the replicas agree."""
+        tot = torch.stack([fl["p"].double().sum() for fl in self.opt.ensure_flat()]).sum().reshape(1)
+        if self.world <= 1:
+            return 0.0
+        hi, lo = tot.clone(), tot.clone()
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        return float((hi - lo).item())
 
     def _setup(self):
         flats = self.opt.ensure_flat()

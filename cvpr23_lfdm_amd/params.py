@@ -13,6 +13,18 @@ import torch
 from torch import nn
 
 
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch():
+    """Counter of parameter writes torch's `_version` cannot see (raw-pointer kernels, i.e. FlatAdam.step)."""
+    return _WEIGHTS_EPOCH[0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
 class ParamTree(nn.Module):
     def _walk(self, parts, create):
         node = self

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .params import ParamTree, build_tree, unet_spec
+from .params import ParamTree, build_tree, unet_spec, weights_epoch
 
 BERT_MODEL_DIM = 768
 
@@ -75,6 +75,7 @@ class Unet3D(ParamTree):
         self._pk = None
         self._pk_sig = None
         self._bufs = {}
+        self._buf_gen = 0
         self.fuse_splitk = False
         self.overlap_res_conv = False      # measured slower on MI355X (negative results)
         self._side = None
@@ -87,13 +88,17 @@ class Unet3D(ParamTree):
             self.null_cond_emb = fn(self.null_cond_emb)
         self._pk = None
         self._bufs = {}
+        self._buf_gen = getattr(self, "_buf_gen", 0) + 1
         return out
 
     def _signature(self):
+        """Identity of the weights the pack was built from.  `_version` sees every torch-side write (copy_, optimizer
+        foreach ops, load_state_dict); writes through raw pointers (FlatAdam's fused HIP step) are invisible to it, so
+        they bump `params.weights_epoch()` instead."""
         sig = 0
         for p in self.parameters():
             sig += p._version
-        return (sig, next(self.parameters()).device)
+        return (sig, weights_epoch(), next(self.parameters()).device)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -116,6 +121,9 @@ class Unet3D(ParamTree):
         if cur is None or cur.numel() < need or cur.device != dev or cur.dtype != dtype:
             cur = torch.empty(need, dtype=dtype, device=dev)
             self._bufs[name] = cur
+            # a captured hipGraph holds raw pointers into these arenas: a (re)allocation invalidates every plan built
+            # on the old ones (diffusion._plans keys carry this generation)
+            self._buf_gen += 1
         return cur[:need].view(rows, ch)
 
     @property
@@ -457,9 +465,19 @@ class Unet3D(ParamTree):
         if prob_focus_present != 0 or (focus_present_mask is not None and bool(focus_present_mask.any())):
             raise NotImplementedError("focus_present_mask: the LFDM scripts never enable it")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError(
-                "Unet3D.forward under autograd: the native backward kernels are not built yet "
-                "(SURVEY.md 8(f)); call under torch.no_grad() / .eval() for inference")
+            # training mode under autograd: the differentiable executor (native forward AND backward kernels).  It takes
+            # the reference image features as ONE (B,256,S,S) map - which is what the LFDM pipeline feeds (:901 repeats
+            # one frame's features over T); per-frame features are refused rather than silently averaged
+            from .unet_train import unet_train_forward
+            n_dyn = self.channels - 256 if self.channels > 256 else self.channels
+            if self.channels == n_dyn:
+                raise NotImplementedError("Unet3D.forward under autograd needs the [x | fea] input of the LFDM pipeline")
+            fea = x[:, n_dyn:]
+            if fea.shape[2] > 1 and not bool((fea == fea[:, :, :1]).all()):
+                raise NotImplementedError("Unet3D.forward under autograd: `fea` must be constant over the frame axis "
+                                          "(video_flow_diffusion.py:901)")
+            return unet_train_forward(self, x[:, :n_dyn].float(), fea[:, :, 0].contiguous().float(), time, cond,
+                                      null_cond_prob=null_cond_prob, none_cond_mask=none_cond_mask)
         pk = self.packed()
         x = x.contiguous().float()
         batch, _, frames, s, _ = x.shape

@@ -55,6 +55,29 @@ def test_flat_adam_matches_torch(backend):
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
 
 
+def test_packed_weights_follow_flat_adam(backend):
+    """FlatAdam updates the parameters through a raw-pointer kernel, invisible to torch's `_version`.
+    The sampling executor's packed-weight cache (and with it the captured hipGraph plan) must still rebuild."""
+    import synth
+    from cvpr23_lfdm_amd import Unet3D
+    dev = backend
+    u = Unet3D(dim=64, channels=259, out_grid_dim=2, out_conf_dim=1, use_bert_text_cond=True)
+    u.load_state_dict(synth.unet_state())
+    u.to(dev)
+    pk = u.packed()
+    assert u.packed() is pk                                      # cached while nothing changes
+    opt = FlatAdam(u.parameters(), lr=1e-2)
+    for p in u.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    pk2 = u.packed()
+    assert pk2 is not pk
+    assert_close(pk2["init.b"], u.get("init_conv.bias"), 1e-7, "packed bias after the step")
+    assert float((pk["init.b"] - u.get("init_conv.bias")).abs().max()) > 5e-3      # the old pack is stale
+    opt.step()
+    assert u.packed() is not pk2
+
+
 WORKER = r'''
 import json, os, sys
 sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests"))
@@ -66,9 +89,12 @@ from util import rnd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 shapes = [(7, 5), (13,), (4, 3, 3, 3), (1,), (64, 9)]
-ps = [torch.nn.Parameter(rnd(*s, seed=i)) for i, s in enumerate(shapes)]
+ps = [torch.nn.Parameter(rnd(*s, seed=i + 100 * rank)) for i, s in enumerate(shapes)]   # ranks start DIFFERENT ...
 opt = FlatAdam(ps, lr=1e-2, betas=(0.9, 0.99))
 dp = GradAllReduce(opt, bucket_bytes=256)          # tiny buckets -> several all-reduces
+drift0 = dp.replica_checksum()
+dp.sync_replicas()                                 # ... rank 0's parameters / moments are broadcast once
+assert drift0 > 0 and dp.replica_checksum() == 0.0, (drift0, dp.replica_checksum())
 for it in range(3):
     opt.zero_grad()
     dp.prepare()
@@ -76,6 +102,7 @@ for it in range(3):
     loss.backward()
     dp.finish()
     opt.step()
+assert dp.replica_checksum() == 0.0
 out = [p.detach().reshape(-1).tolist() for p in ps]
 gathered = [None] * world
 dist.all_gather_object(gathered, out)

@@ -57,8 +57,10 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         dist.init_process_group("nccl")                      # RCCL
-    torch.manual_seed(args.seed + rank)
-    np.random.seed(args.seed + rank)
+    # every rank must build the SAME initial UNet (parameters are initialised from torch's global generator and the
+    # data-parallel step only averages gradients): common seed for construction, per-rank streams afterwards
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
     os.makedirs(args.out, exist_ok=True)
 
     model = FlowDiffusion(lr=args.lr, is_train=True, img_size=args.size // 4, num_frames=args.frames,
@@ -82,7 +84,11 @@ def main():
             model.optimizer_diff.load_state_dict(ck["optimizer_diff"])
         print("=> loaded checkpoint '%s' (step %d)" % (args.restore_from, start_step))
     if world > 1:
-        model.enable_data_parallel()            # bucketed RCCL all-reduce of the flat gradient, overlapped with backward
+        # bucketed RCCL all-reduce of the flat gradient, overlapped with backward; rank 0's parameters and Adam
+        # moments are broadcast once so the replicas start identical whatever happened above (restore on one rank ...)
+        model.enable_data_parallel()
+    torch.manual_seed(args.seed + 1 + rank)     # per-rank streams for t / noise / null-cond mask / data order
+    np.random.seed(args.seed + 1 + rank)
 
     ds = SyntheticVideos(n=256, image_size=args.size, num_frames=args.frames) if args.synthetic else \
         FrameFolderVideos(args.data, image_size=args.size, num_frames=args.frames, sampling="random", jitter=True)
