@@ -41,6 +41,7 @@ class ConvParams(C.Structure):
         ("gn_groups", i32), ("gn_pixels", i32),
         ("ln_wsum", f32p), ("ln_eps", f32),
         ("tile_counters", C.c_void_p), ("tile_counters_len", i32), ("weight_wino", C.c_void_p),
+        ("deconv4", i32), ("groups", i32),
     ]
 
 
@@ -94,7 +95,7 @@ _SIGNATURES = {
     "lfdm_sinusoidal_f32": (i32, [C.c_void_p, i32, f32p, f32p, i32, i32, i32, stream_t]),
     "lfdm_conv_planar_in_cl_f32": (i32, [f32p, i32, i32, i32, i32, i32, i32, f32p, i32, i32, i32,
                                         f32p, f32p, f32p, i32, i32, stream_t]),
-    "lfdm_heads_cl_to_planar_f32": (i32, [f32p, f32p, i32, f32p, f32p, f32p, f32p, f32p, i32, i32,
+    "lfdm_heads_cl_to_planar_f32": (i32, [f32p, f32p, i32, i32, f32p, f32p, f32p, f32p, f32p, i32, i32,
                                          i32, stream_t]),
     "lfdm_sampler_ws_bytes": (sz, [i32, i64]),
     "lfdm_sampler_step_f32": (i32, [f32p, f32p, f32p, f32p, i32, i64, f32p, C.c_void_p, f32, i32,

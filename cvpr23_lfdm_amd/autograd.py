@@ -51,7 +51,7 @@ class ConvCL(Function):
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
             assert x1 is None and residual is None and kh == 4 and kw == 4
-            y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_deconv_weight(w4), w4.shape[1], n_img, hi, wi, bias=b)
+            y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_deconv4_weight(w4), w4.shape[1], n_img, hi, wi, bias=b)
             stride, pad, hq, wq = 2, (1, 1), 2 * hi, 2 * wi
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
@@ -90,7 +90,7 @@ class ConvCL(Function):
                                       pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)
                 else:
                     assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
-                    g = ops.deconv4x4s2_cl(dy, ops.pack_deconv_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)
+                    g = ops.deconv4x4s2_cl(dy, ops.pack_deconv4_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)
                 grads.append(g)
             dx0 = grads[0]
             dx1 = grads[1] if x1 is not None else None

@@ -83,6 +83,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   const int cin = p.c0 + p.c1;
   const int ntaps = p.kh * p.kw;
   const int ktotal = ntaps * cin;
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  int zk = blockIdx.z;                             // K slice of this workgroup
+  if (p.deconv4) {                                  // grid z = parity * ksplit + slice (see lfdm_conv_params.deconv4)
+    const int par = zk / ksplit;
+    zk -= par * ksplit;
+    p.pad_y = 1 - (par >> 1);
+    p.pad_x = 1 - (par & 1);
+    p.out_off_y = par >> 1;
+    p.out_off_x = par & 1;
+    p.weight += (int64_t)par * ((ktotal + 31) / 32) * p.coutp * 32;
+  }
 
   for (int r = tid; r < BM; r += 256) {
     int64_t m = m0 + r;
@@ -125,9 +136,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks_all = (ktotal + BK - 1) / BK;
-  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-  const int kc_begin = (int)((int64_t)nchunks_all * blockIdx.z / ksplit);
-  const int kc_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / ksplit);
+  const int kc_begin = (int)((int64_t)nchunks_all * zk / ksplit);
+  const int kc_end = (int)((int64_t)nchunks_all * (zk + 1) / ksplit);
 
   float4 ra4[FAST ? A_F4 : 1];
   float ra1[FAST ? 1 : A_F1];
@@ -478,6 +488,12 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_param
   const int cq0 = blockIdx.y * cw;
   const int m0 = blockIdx.x * SPLITK_ROWS;
   const int items = SPLITK_ROWS * cw;
+  if (p.deconv4) {                                  // grid z = parity: slabs [4][ksplit][M][coutp]
+    const int par = blockIdx.z;
+    p.partial += (int64_t)par * p.ksplit * M * p.coutp;
+    p.out_off_y = par >> 1;
+    p.out_off_x = par & 1;
+  }
   float gs = 0.f, gq = 0.f;           // with 256 % cw == 0 a thread always sees the same column quad
   for (int it = tid; it < items; it += 256) {
     const int r = it / cw;
@@ -637,7 +653,8 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                     p.hq == up * p.hi && p.wq == up * p.wi && p.hq % 2 == 0 && p.wq % 2 == 0 && p.c0 % 16 == 0 &&
                     p.c1 % 16 == 0 && p.ld0 % 4 == 0 && (p.c1 == 0 || p.ld1 % 4 == 0) && (((uintptr_t)p.src0 & 15) == 0) &&
                     (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0) && (((uintptr_t)p.weight_wino) & 15) == 0 && !p.ln_wsum &&
-                    p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64;
+                    p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64 &&
+                    !p.deconv4 && vec_ok;      // (float4 epilogue)
   if (wino) {
     pl.kind = 2;
     pl.bm = 128;
@@ -645,11 +662,16 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     if (const char* e = getenv("LFDM_WINO_BN"))          // experiment knob (tools/bench_conv.py): 64-column workgroups
       if (e[0] == '6' && p.coutp % 64 == 0) pl.bn = 64;
     const int64_t blocks = (((int64_t)p.n_img * (p.hq / 2) * (p.wq / 2) + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
-    const int nch = cin / 16;
+    const int nch = cin / 16 / (p.groups > 1 ? p.groups : 1);      // chunks of one output channel's reduction
+    // Split-K from tools/sweep_ksplit.sh (profiles/r02_c_ksplit_sweep.txt): a workgroup that is alone on its CU runs a
+    // chunk in ~1.8 us (the matrix pipe needs 1.0), fixed costs are ~8 us per workgroup, and in the sampler the filters
+    // arrive cold from HBM - so below two workgroups per CU slices of ~5 chunks win although the slabs need a reduce pass
+    // (256->256 @8x8: 34.9 -> 31.7 us warm, 44 -> 28 us in the captured step); 8-chunk convolutions are best unsplit.
     int k = 1;
-    if (blocks < 224) {
-      k = (int)(256 / blocks);
-      if (k > nch / 4) k = nch / 4;
+    if (blocks < 512 && nch >= 16) {
+      k = nch / 5;
+      if (k > 1024 / blocks) k = (int)(1024 / blocks);
+      if (k > 8) k = 8;
       if (k < 1) k = 1;
     }
     pl.ksplit = user_k >= 1 ? user_k : k;
@@ -659,7 +681,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   if (ksw) {
     pl.kind = 1;
     pl.bm = 160;
-    const int64_t mt = (M + 159) / 160;
+    const int64_t mt = (M + 159) / 160 * (p.deconv4 ? 4 : 1);      // deconv4: four problems share the launch
     const int64_t t64 = mt * ((p.coutp + 63) / 64), t32 = mt * ((p.coutp + 31) / 32);
     pl.bn = (t64 >= 224 && p.coutp > 32) ? 64 : 32;      // <= 32 (padded) output channels: the 64-column tile would be half empty
     int k = 1;
@@ -676,7 +698,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.bm = wide ? 128 : (small_m ? 64 : 128);
     pl.bn = wide ? 128 : 64;
     int k = 1;
-    const int64_t tiles = ((M + pl.bm - 1) / pl.bm) * ((p.coutp + pl.bn - 1) / pl.bn);
+    const int64_t tiles = ((M + pl.bm - 1) / pl.bm) * ((p.coutp + pl.bn - 1) / pl.bn) * (p.deconv4 ? 4 : 1);
     if (tiles < 256 && nchunks >= 8) {
       k = (int)(512 / tiles);
       if (k > nchunks / 4) k = nchunks / 4;
@@ -692,7 +714,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
 
 // in-launch slab reduction: KSW schedule with enough zeroed tile counters
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
-  if (pl.kind != 1 || pl.ksplit <= 1 || !p.tile_counters) return false;
+  if (pl.kind != 1 || pl.ksplit <= 1 || !p.tile_counters || p.deconv4) return false;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   const int64_t tiles = ((M + 159) / 160) * ((p.coutp + pl.bn - 1) / pl.bn);
   return (int64_t)p.tile_counters_len >= tiles;
@@ -712,7 +734,7 @@ extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p) return 0;
   const ConvPlan pl = make_plan(*p);
   if (pl.ksplit <= 1) return 0;
-  return (size_t)pl.ksplit * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
+  return (size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
@@ -733,7 +755,17 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
       return LFDM_EINVAL;
     }
   }
+  if (p.deconv4 && (p.kh != 2 || p.kw != 2 || p.stride != 1 || p.out_scale != 2 || p.upsample || p.pad_mode != 0 || p.ln_wsum ||
+                    p.gn_partial || p.hq != p.hi || p.wq != p.wi || p.ho != 2 * p.hi || p.wo != 2 * p.wi)) {
+    lfdm_set_error("conv2d: deconv4 = the four 2x2 parity convolutions of a ConvTranspose k4 s2 p1 (kh = kw = 2, out_scale 2, no fused norms)");
+    return LFDM_EINVAL;
+  }
+  if (p.groups > 1 && !(p.weight_wino && p.c1 == 0 && p.c0 % (16 * p.groups) == 0 && p.cout % (32 * p.groups) == 0 && p.cout == p.coutp)) {
+    lfdm_set_error("conv2d: groups > 1 needs the Winograd form, one source, c0/groups % 16 == 0 and cout/groups % 32 == 0");
+    return LFDM_EINVAL;
+  }
   const ConvPlan pl = make_plan(p);
+  if (p.groups > 1 && pl.kind != 2) { lfdm_set_error("conv2d: groups > 1 is only built for the Winograd schedule (3x3, stride 1, zero pad)"); return LFDM_EINVAL; }
   p.ksplit = pl.ksplit;
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
@@ -764,7 +796,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   } else if (pl.kind == 2) {
     rc = lfdm_conv_wino_launch(p, pl.bn, stream);
   } else {
-    const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit);
+    const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit * (p.deconv4 ? 4 : 1));
     if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);
     else if (pl.bm == 64) launch_conv<64, 64>(p, pl.fast, pl.simple, grid, stream);
     else launch_conv<128, 64>(p, pl.fast, pl.simple, grid, stream);
@@ -773,7 +805,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (rc) return rc;
   if (p.ksplit > 1 && !splitk_fused(pl, p)) {
     LFDM_LAUNCH(conv_splitk_reduce_kernel,
-                dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M)), dim3(256), 0,
+                dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M), p.deconv4 ? 4 : 1), dim3(256), 0,
                 stream, p);
     rc = lfdm_check_launch("conv_splitk_reduce");
   }

@@ -46,6 +46,17 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   const int n0 = blockIdx.y * BN;
   const int cin = p.c0 + p.c1;
   const int ntaps = p.kh * p.kw;
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  int zk = blockIdx.z;                             // K slice of this workgroup
+  if (p.deconv4) {                                  // grid z = parity * ksplit + slice: the four 2x2 parity problems of a
+    const int par = zk / ksplit;                    // ConvTranspose k4 s2 p1 in one launch (p is this workgroup's copy)
+    zk -= par * ksplit;
+    p.pad_y = 1 - (par >> 1);
+    p.pad_x = 1 - (par & 1);
+    p.out_off_y = par >> 1;
+    p.out_off_x = par & 1;
+    p.weight += (int64_t)par * (ntaps * (cin / 32)) * p.coutp * 32;
+  }
 
   for (int r = tid; r < BM; r += 256) {
     const int64_t m = m0 + r;
@@ -84,9 +95,8 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks_all = ntaps * (cin / BK);
-  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-  const int kc_begin = (int)((int64_t)nchunks_all * blockIdx.z / ksplit);
-  const int kc_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / ksplit);
+  const int kc_begin = (int)((int64_t)nchunks_all * zk / ksplit);
+  const int kc_end = (int)((int64_t)nchunks_all * (zk + 1) / ksplit);
   const int nk = kc_end - kc_begin;
 
   // Branch-free main loop: every load goes through a buffer descriptor and an invalid tap is an
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   float* const scratch = smem;                     // [4 waves][32][LD]
   const int trow = tid >> 3, c4 = tid & 7;
   const int ntiles = (int)(gridDim.x * gridDim.y);
-  const bool fuse = ksplit > 1 && p.tile_counters != nullptr && p.tile_counters_len >= ntiles;   // in-launch slab reduction
+  const bool fuse = ksplit > 1 && p.tile_counters != nullptr && p.tile_counters_len >= ntiles && !p.deconv4;   // in-launch slab reduction
   // (the host only selects this kernel when float4 epilogue accesses are legal)
   float gs[TN][4], gq[TN][4];
 #pragma unroll
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
 // bn = 64 or 32; grid z = ksplit.  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
-  const dim3 grid((unsigned)((M + 159) / 160), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
+  const dim3 grid((unsigned)((M + 159) / 160), (unsigned)((p.coutp + bn - 1) / bn), (p.ksplit > 1 ? p.ksplit : 1) * (p.deconv4 ? 4 : 1));
   const bool act = p.act != LFDM_ACT_NONE;
   if (bn == 64) {
     if (act) LFDM_LAUNCH((conv_ksw_kernel<5, 2, true>), grid, dim3(256), 0, stream, p);

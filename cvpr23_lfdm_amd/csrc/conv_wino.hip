@@ -24,7 +24,7 @@ constexpr int WT = 32;            // tiles per workgroup
 constexpr int WN = 32;            // output channels per column tile (NT of them per workgroup)
 constexpr int WKC = 16;           // input channels per chunk
 constexpr int LDV = WKC + 4;      // LDS row stride of V
-constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M planes in the epilogue
+constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M planes in the epilogue (16-byte aligned rows: ds_read_b128)
 
 // Operands are prefetched one chunk ahead; ~150 VGPRs / 43 KB LDS -> three workgroups per CU hide each other's phases.
 // Per chunk and CU the vector-memory path moves 32 KB of patches + 32 KB of weight fragments for 2048 matrix-pipe cycles
@@ -37,28 +37,29 @@ constexpr int LDM = WN + 1;       // LDS row stride of the half-transformed M pl
 // NT = column tiles per workgroup: NT = 2 (64 columns, opt-in LFDM_WINO_BN=64) halves the patch loads / transforms per MFMA at
 // two workgroups per CU (244 VGPRs): 2-5 % faster on the large-M decoder shapes, slower wherever it leaves a CU fewer than
 // ~3 workgroups (profiles/r01_o_conv_shapes_wino_bn64.txt).
-// STAGE (opt-in LFDM_WINO_STAGE=1, not yet measured on the GPU): the 4x4 patches of horizontally adjacent tiles share two
-// of their four columns, and 8-byte patch loads use half of the TA's bytes per cycle.  With STAGE the workgroup first
-// loads, per tile-row segment, the UNIQUE pixels of the 4-row band its tiles read (16-byte loads, 264-384 pixels instead of
-// 512 patch pixels per chunk) into LDS and the transform threads build their patches from there: 1.6-1.9x fewer patch bytes
-// at full TA width, for ~30 KB more LDS (two workgroups per CU) and 16 more ds_read_b64 per thread and chunk.
-constexpr int RS = 20;              // floats per staged pixel (16 channels + pad: 16-byte aligned, 2-way bank conflicts at most)
-constexpr int SPMAX = 384;          // staged pixels at most (2 tiles per image row)
-constexpr int STG = 6;              // float4 stage loads per thread: ceil(SPMAX * 4 / 256)
-
-template <bool ACT, int NT, bool STAGE>
-__global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+// Measured and removed in round 2 (tools/sweep_conv.sh, profiles/r02_a_sweep_conv.txt): staging the unique pixels of each tile-row
+// band in LDS with 16-byte loads (3-25 % SLOWER on every shape) and a 64-tile / 8-channel-chunk workgroup (conv_wino_wide.hip,
+// 10-30 % slower): the L1 path is not what limits this kernel - per-workgroup phase stamps (tools/probe_wino_phases.py) show the
+// K loop AT the matrix-pipe bound whenever three workgroups share a CU; the time is in the set-up, the first patch's latency
+// and the epilogue, which all co-resident workgroups go through in lockstep.
+template <bool ACT, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
-  __shared__ __attribute__((aligned(16))) float raw[STAGE ? SPMAX * RS : 4];
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
   __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ int s_n[WT], s_ty[WT], s_tx[WT];
-  __shared__ float s_gn[2][8][WNB];
+  __shared__ float s_gn[2][4][WNB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
+#ifdef LFDM_WINO_TIMING
+  // probe build only (tools/probe_wino_phases.py): cycle stamps of every workgroup go to p.tile_counters (unused by this schedule)
+  unsigned long long tstamp[6];
+  tstamp[0] = __builtin_readcyclecounter();
+  const unsigned long long wall0 = wall_clock64();
+#endif
   // p.upsample: the input is read through a virtual nearest x2 upsample (UpBlock2d, LFAE util.py:120-133): the logical
   // image is (hq, wq) = (2*hi, 2*wi) and logical pixel (y, x) is physical (y >> 1, x >> 1)
   const int up = p.upsample ? 1 : 0;
@@ -79,7 +80,13 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
   }
   const unsigned t0 = bx * WT;
   const int n0 = by * WNB;
-  const int cin = p.c0 + p.c1;
+  // grouped convolution (lfdm_conv_params.groups): this workgroup's column tile lies inside ONE group (cout/groups % 32 == 0,
+  // NT = 1): it reduces over that group's c0/groups input channels only, with the group's own filter pack
+  const int ngroups = p.groups > 1 ? p.groups : 1;
+  const int wcoutp = ngroups > 1 ? p.cout / ngroups : p.coutp;      // columns of one filter pack
+  const int grp = ngroups > 1 ? n0 / wcoutp : 0;
+  const int cin = (p.c0 + p.c1) / ngroups;
+  const int cbase = grp * cin;                                       // first input channel of the group
   const int nchunks_all = cin / WKC;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
   const int kc_begin = (int)((int64_t)nchunks_all * bz / ksplit);
@@ -123,56 +130,9 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
     for (int py = 0; py < 4; ++py)
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
-  // ---- STAGE: unique pixels of each tile-row segment's band -> LDS ----
-  // segment r = tiles [r*TPR, (r+1)*TPR) of this workgroup (one image row of tiles or 32 of them); its band = logical rows
-  // 2ty-1..2ty+2 x logical columns 2tx0-1..2(tx0+TPR): staged pixel q = (r*4 + py)*BW + bx
-  const int TPR = tw < WT ? tw : WT, BW = 2 * TPR + 2, SP4 = (WT / TPR) * 4 * BW * 4;     // SP4 = float4 items to stage
-  uint32_t spix[STAGE ? STG : 1];    // physical pixel index of this thread's item j (0xFFFFFFFF: outside the image)
-  if constexpr (STAGE) {
-#pragma unroll
-    for (int j = 0; j < STG; ++j) {
-      const int item = tid + 256 * j;
-      spix[j] = 0xFFFFFFFFu;
-      if (item < SP4) {
-        const int q = item >> 2;
-        const int r = q / (4 * BW), rem = q - r * 4 * BW;
-        const int py = rem / BW, bxx = rem - py * BW;
-        const int n = s_n[r * TPR];
-        const int iy = 2 * s_ty[r * TPR] - 1 + py, ix = 2 * s_tx[r * TPR] - 1 + bxx;
-        if (n >= 0 && iy >= 0 && iy < p.hq && ix >= 0 && ix < p.wq)
-          spix[j] = (uint32_t)((n * p.hi + (iy >> up)) * p.wi + (ix >> up));
-      }
-    }
-  }
-  float4 stg[STAGE ? STG : 1];
-  auto fetch_stage = [&](int chunk) {
-    int cc = chunk * WKC;
-    const bool second = cc >= p.c0;
-    if (second) cc -= p.c0;
-    const lfdm_buf buf = second ? buf1 : buf0;
-    const uint32_t ld4 = (uint32_t)(second ? p.ld1 : p.ld0) * 4u;
-#pragma unroll
-    for (int j = 0; j < STG; ++j) {
-      const uint32_t c4 = (uint32_t)((tid + 256 * j) & 3);
-      stg[j] = lfdm_buf_load_f4(buf, spix[j] != 0xFFFFFFFFu ? spix[j] * ld4 + ((uint32_t)cc + 4u * c4) * 4u : LFDM_BUF_OOB);
-    }
-  };
-  auto write_stage = [&]() {
-#pragma unroll
-    for (int j = 0; j < STG; ++j) {
-      const int item = tid + 256 * j;
-      if (item < SP4) *reinterpret_cast<float4*>(raw + (item >> 2) * RS + 4 * (item & 3)) = stg[j];
-    }
-  };
-  const int seg = x_tile / TPR;
-  const float* const raw_patch = raw + ((seg * 4) * BW + 2 * (x_tile - seg * TPR)) * RS + 2 * x_c2;   // patch (0,0) of this thread
   float2 patch[16];
-  auto patch_from_stage = [&](float2 (&patch)[16]) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) patch[q] = *reinterpret_cast<const float2*>(raw_patch + ((q >> 2) * BW + (q & 3)) * RS);
-  };
   auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
-    int cc = chunk * WKC;
+    int cc = chunk * WKC + cbase;
     const bool second = cc >= p.c0;
     if (second) cc -= p.c0;
     const lfdm_buf buf = second ? buf1 : buf0;
@@ -187,15 +147,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
     }
   };
   // ---- weight fragments: lane (co = n0 + l31, k-slot kh) holds U[pos][16*chunk + 8*kh + s][co], s = 0..7 ----
-  const lfdm_buf bufw = lfdm_make_buf(p.weight_wino, (uint32_t)((int64_t)16 * nchunks_all * p.coutp * WKC * 4));
+  const lfdm_buf bufw = lfdm_make_buf(p.weight_wino + (int64_t)grp * 16 * nchunks_all * wcoutp * WKC,
+                                      (uint32_t)((int64_t)16 * nchunks_all * wcoutp * WKC * 4));
   float4 bfrag[4][NT][2];
   auto fetch_b = [&](int pi, int chunk) {
     const int pos = 4 * wave + pi;
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
-      const int n = n0 + WN * ct + l31;
-      const uint32_t off = (n < p.coutp)
-                               ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * p.coutp + n) * WKC + 8 * kh) * 4)
+      const int n = n0 + WN * ct + l31 - grp * wcoutp;          // column inside the (group's) filter pack
+      const uint32_t off = (n < wcoutp)
+                               ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * wcoutp + n) * WKC + 8 * kh) * 4)
                                : LFDM_BUF_OOB;
       bfrag[pi][ct][0] = lfdm_buf_load_f4(bufw, off);
       bfrag[pi][ct][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
@@ -247,34 +208,20 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
   auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
 
   float* const Vs = smem;           // [16 pos][WT tiles][LD]
+#ifdef LFDM_WINO_TIMING
+  tstamp[1] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int pi = 0; pi < 4; ++pi) fetch_b(pi, kc_begin);
-  if constexpr (STAGE) {
-    fetch_stage(kc_begin);
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-      const int nxt = clampc(kc + 1);
-      write_stage();
-      __syncthreads();               // the band is in LDS; every wave has left the previous chunk's MFMA phase (V is free)
-      patch_from_stage(patch);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
-      __syncthreads();               // V complete; all reads of the staged band done
-      fetch_stage(nxt);              // in flight under this chunk's MFMAs
-#pragma unroll
-      for (int pi = 0; pi < 4; ++pi) {
-        float4 a0, a1;
-        load_a(Vs, pi, a0, a1);
-        mfma_pos(a0, a1, pi);
-        fetch_b(pi, nxt);
-      }
-    }
-    __syncthreads();                 // the epilogue reuses the V buffer
-  } else {
+  {
     fetch_patch(patch, kc_begin);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
       const int nxt = clampc(kc + 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
+#ifdef LFDM_WINO_TIMING
+      if (kc == kc_begin) tstamp[2] = __builtin_readcyclecounter();     // first patch arrived + transformed
+#endif
       __syncthreads();
       fetch_patch(patch, nxt);                                   // in flight under this chunk's MFMAs
 #pragma unroll
@@ -288,9 +235,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
     }
   }
 
+#ifdef LFDM_WINO_TIMING
+  tstamp[3] = __builtin_readcyclecounter();
+#endif
   // ---- output transform A^T M A: the column sum (over j) in registers, the row sum (over i = wave) through LDS ----
+  // Read side: thread = (tile, 4 consecutive output channels): 8 ds_read_b128, then the 2x2 output pixels as float4 stores
+  // (8 lanes cover a pixel's 128-byte row segment) - 4x fewer LDS / global instructions than one channel per lane
+  // (epilogue 4.7 -> measured in profiles/r02_*).  The plan only selects this schedule when float4 accesses are legal.
   float* const Ms = smem;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
-  float gs[NT], gq[NT];
+  const int e_tile = tid >> 3, e_c4 = tid & 7;
+  float gs[NT][4], gq[NT][4];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     if (ct > 0) __syncthreads();    // the previous column tile's planes have been consumed
@@ -300,60 +254,89 @@ __global__ __launch_bounds__(256, (NT == 1 && !STAGE) ? 3 : 2) void conv_wino_ke
       Ms[((2 * wave) * WT + tile) * LDM + l31] = acc[0][ct][r] + acc[1][ct][r] + acc[2][ct][r];
       Ms[((2 * wave + 1) * WT + tile) * LDM + l31] = acc[1][ct][r] - acc[2][ct][r] - acc[3][ct][r];
     }
-    __syncthreads();
-    const int co = n0 + WN * ct + l31;
-    gs[ct] = 0.f;
-    gq[ct] = 0.f;
-    const float bb = (p.bias && ksplit == 1 && co < p.cout) ? p.bias[co] : 0.f;
-#pragma unroll 1
-    for (int it = 0; it < WT / 8; ++it) {
-      const int tile = (tid >> 5) + 8 * it;
-      const int n = s_n[tile];
-      if (n < 0 || co >= p.coutp) continue;
-      float m[8];
+    const int co = n0 + WN * ct + 4 * e_c4;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) m[q] = Ms[(q * WT + tile) * LDM + l31];
-      float y[4];
-      y[0] = m[0] + m[2] + m[4];       // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
-      y[1] = m[1] + m[3] + m[5];
-      y[2] = m[2] - m[4] - m[6];
-      y[3] = m[3] - m[5] - m[7];
-      const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[tile]) * p.wq + 2 * s_tx[tile];
+    for (int e = 0; e < 4; ++e) gs[ct][e] = gq[ct][e] = 0.f;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && ksplit == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
+    const int n = s_n[e_tile];
+    const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[e_tile]) * p.wq + 2 * s_tx[e_tile];
+    const bool live = n >= 0 && co < p.coutp;
+    float4 res[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                        // residual rows requested before the barrier
+      res[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && ksplit == 1 && p.residual && co < p.cout)
+        res[q] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.ldr + co);
+    }
+    __syncthreads();
+    if (live) {
+      float4 m[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m[q] = *reinterpret_cast<const float4*>(Ms + (q * WT + e_tile) * LDM + 4 * e_c4);
+      float4 y[4];                   // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
+      y[0] = make_float4(m[0].x + m[2].x + m[4].x, m[0].y + m[2].y + m[4].y, m[0].z + m[2].z + m[4].z, m[0].w + m[2].w + m[4].w);
+      y[1] = make_float4(m[1].x + m[3].x + m[5].x, m[1].y + m[3].y + m[5].y, m[1].z + m[3].z + m[5].z, m[1].w + m[3].w + m[5].w);
+      y[2] = make_float4(m[2].x - m[4].x - m[6].x, m[2].y - m[4].y - m[6].y, m[2].z - m[4].z - m[6].z, m[2].w - m[4].w - m[6].w);
+      y[3] = make_float4(m[3].x - m[5].x - m[7].x, m[3].y - m[5].y - m[7].y, m[3].z - m[5].z - m[7].z, m[3].w - m[5].w - m[7].w);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
         if (ksplit > 1) {
-          p.partial[((int64_t)bz * M + orow) * p.coutp + co] = y[q];
+          *reinterpret_cast<float4*>(p.partial + ((int64_t)bz * M + orow) * p.coutp + co) = y[q];
         } else if (co < p.cout) {
-          float v = y[q] + bb;
-          gs[ct] += v;
-          gq[ct] += v * v;
-          if (p.residual) v += p.residual[orow * p.ldr + co];
-          if (ACT) v = apply_act(v, p.act);
-          p.out[orow * p.ldo + co] = v;
+          float4 v = make_float4(y[q].x + bb.x, y[q].y + bb.y, y[q].z + bb.z, y[q].w + bb.w);
+          gs[ct][0] += v.x; gs[ct][1] += v.y; gs[ct][2] += v.z; gs[ct][3] += v.w;
+          gq[ct][0] += v.x * v.x; gq[ct][1] += v.y * v.y; gq[ct][2] += v.z * v.z; gq[ct][3] += v.w * v.w;
+          v.x += res[q].x; v.y += res[q].y; v.z += res[q].z; v.w += res[q].w;
+          if (ACT) {
+            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+          }
+          *reinterpret_cast<float4*>(p.out + orow * p.ldo + co) = v;
         }
       }
     }
   }
+#ifdef LFDM_WINO_TIMING
+  tstamp[4] = __builtin_readcyclecounter();
+  tstamp[5] = wall_clock64() - wall0;
+  if (tid == 0 && p.tile_counters) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.tile_counters) +
+                              ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
+    for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
+  }
+#endif
   if (p.gn_partial && ksplit == 1) {
+    // per-channel sums over the workgroup's 32 tiles: lanes with equal e_c4 (stride 8) inside the wave, then the four waves
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-      s_gn[0][tid >> 5][WN * ct + l31] = gs[ct];
-      s_gn[1][tid >> 5][WN * ct + l31] = gq[ct];
-    }
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sv = gs[ct][e], qv = gq[ct][e];
+#pragma unroll
+        for (int msk = 8; msk <= 32; msk <<= 1) {
+          sv += __shfl_xor(sv, msk);
+          qv += __shfl_xor(qv, msk);
+        }
+        if (lane < 8) {
+          s_gn[0][wave][WN * ct + 4 * e_c4 + e] = sv;
+          s_gn[1][wave][WN * ct + 4 * e_c4 + e] = qv;
+        }
+      }
     __syncthreads();
     const int cg = p.cout / p.gn_groups;
     const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32: host check)
     if (tid < gpt && n0 + tid * cg < p.cout) {
-      float s = 0.f, q = 0.f;
+      float sv = 0.f, qv = 0.f;
       for (int c = 0; c < cg; ++c)
-        for (int w8 = 0; w8 < 8; ++w8) {
-          s += s_gn[0][w8][tid * cg + c];
-          q += s_gn[1][w8][tid * cg + c];
+        for (int w4 = 0; w4 < 4; ++w4) {
+          sv += s_gn[0][w4][tid * cg + c];
+          qv += s_gn[1][w4][tid * cg + c];
         }
       float* dst = p.gn_partial + ((int64_t)bx * p.gn_groups + (n0 / cg + tid)) * 2;
-      dst[0] = s;
-      dst[1] = q;
+      dst[0] = sv;
+      dst[1] = qv;
     }
   }
 }
@@ -409,33 +392,14 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
-bool lfdm_conv_wino_wide_ok(const lfdm_conv_params& p);                       // conv_wino_wide.hip
-int lfdm_conv_wino_wide_launch(const lfdm_conv_params& p, hipStream_t stream);
-
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
-  const bool trace = getenv("LFDM_WINO_TRACE") != nullptr;       // which schedule ran (stderr): sweeps and tests
-  if (const char* e = getenv("LFDM_WINO_WIDE"))          // experiment knob: 64-tile workgroups, staged input, 8-channel chunks
-    if (e[0] == '1' && bn == 32 && lfdm_conv_wino_wide_ok(p)) {
-      if (trace) fprintf(stderr, "conv_wino: wide\n");
-      return lfdm_conv_wino_wide_launch(p, stream);
-    }
+  if (getenv("LFDM_WINO_TRACE") != nullptr) fprintf(stderr, "conv_wino: bn=%d ksplit=%d groups=%d\n", bn, p.ksplit, p.groups);   // which schedule ran: sweeps and tests
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  const int tw = p.wq / 2;
-  bool stage = false;                // experiment knob (tools/sweep_conv.sh): unique-pixel staging through LDS
-  if (const char* e = getenv("LFDM_WINO_STAGE")) stage = e[0] == '1' && tw >= 2 && ((tw <= WT && WT % tw == 0) || tw % WT == 0);
-  if (trace) fprintf(stderr, "conv_wino: bn=%d%s\n", bn, stage ? " staged" : "");
-  if (stage) {
-    if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
-    else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, true>), grid, dim3(256), 0, stream, p);
-    else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<false, 1, true>), grid, dim3(256), 0, stream, p);
-  } else {
-    if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false>), grid, dim3(256), 0, stream, p);
-    else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, false>), grid, dim3(256), 0, stream, p);
-    else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<false, 1, false>), grid, dim3(256), 0, stream, p);
-  }
+  if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
+  else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
+  else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);
+  else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p);
   return lfdm_check_launch("conv_wino");
 }

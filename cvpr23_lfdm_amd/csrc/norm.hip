@@ -77,6 +77,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C], s_b[GN_MAX_C];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int sub = tid & 31;
+  // the first two float4 of this thread (the host sizes the grid for two per thread) are requested BEFORE the statistics
+  // are merged: their HBM latency runs under the prologue instead of after it
+  const int c4n = channels >> 2;
+  const int64_t per_b = (int64_t)pixels * c4n;
+  const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)b * per_b;
+  float4* ob = reinterpret_cast<float4*>(out) + (int64_t)b * per_b;
+  const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + tid;
+  float4 pre_v[2], pre_r[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int64_t i = i0 + k * stride;
+    pre_v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pre_r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < per_b) {
+      pre_v[k] = xb[i];
+      if (rb) pre_r[k] = rb[i];
+    }
+  }
   for (int g0 = 0; g0 < groups; g0 += 8) {
     const int g = g0 + (tid >> 5);
     double s = 0.0, q = 0.0;
@@ -118,14 +138,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     s_b[c] = bb;
   }
   __syncthreads();
-  const int c4n = channels >> 2;
-  const int64_t per_b = (int64_t)pixels * c4n;
-  const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)b * per_b;
-  float4* ob = reinterpret_cast<float4*>(out) + (int64_t)b * per_b;
-  const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < per_b; i += (int64_t)gridDim.x * 256) {
+  int k = 0;
+  for (int64_t i = i0; i < per_b; i += stride, ++k) {
     const int c4 = (int)(i % c4n);
-    const float4 v = xb[i];
+    const float4 v = k == 0 ? pre_v[0] : k == 1 ? pre_v[1] : xb[i];
     const float4 a = *reinterpret_cast<const float4*>(s_a + 4 * c4);
     const float4 d = *reinterpret_cast<const float4*>(s_b + 4 * c4);
     float4 y;
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
       y.w = siluf_(y.w);
     }
     if (rb) {
-      const float4 r = rb[i];
+      const float4 r = k == 0 ? pre_r[0] : k == 1 ? pre_r[1] : rb[i];
       y.x += r.x;
       y.y += r.y;
       y.z += r.z;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_planar_in_kernel(
 
 // one thread per pixel row; weights (3 x C) in LDS
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_flow,
-                                                    const float* __restrict__ y_occ, int channels,
+                                                    const float* __restrict__ y_occ, int channels, int ld,
                                                     const float* __restrict__ w_flow,
                                                     const float* __restrict__ b_flow,
                                                     const float* __restrict__ w_occ,
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_
   const int64_t total = (int64_t)batch * frames * hw;
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
   if (row >= total) return;
-  const float4* fr = reinterpret_cast<const float4*>(y_flow + row * channels);
-  const float4* orr = reinterpret_cast<const float4*>(y_occ + row * channels);
+  const float4* fr = reinterpret_cast<const float4*>(y_flow + row * ld);
+  const float4* orr = reinterpret_cast<const float4*>(y_occ + row * ld);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int i = 0; i < channels / 4; ++i) {
     const float4 a = fr[i];
@@ -224,18 +224,18 @@ extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, in
   return lfdm_check_launch("conv_planar_in");
 }
 
-extern "C" int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels,
+extern "C" int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels, int ld,
                                            const float* w_flow, const float* b_flow,
                                            const float* w_occ, const float* b_occ, float* out,
                                            int batch, int frames, int hw, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!y_flow || !y_occ || !w_flow || !b_flow || !w_occ || !b_occ || !out || channels <= 0 ||
-      channels > 256 || channels % 4 != 0 || batch <= 0 || frames <= 0 || hw <= 0) {
+      channels > 256 || channels % 4 != 0 || ld < channels || ld % 4 != 0 || batch <= 0 || frames <= 0 || hw <= 0) {
     lfdm_set_error("heads: bad arguments");
     return LFDM_EINVAL;
   }
   const int64_t total = (int64_t)batch * frames * hw;
   LFDM_LAUNCH(heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow,
-              y_occ, channels, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw);
+              y_occ, channels, ld, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw);
   return lfdm_check_launch("heads");
 }

@@ -91,6 +91,19 @@ def pack_deconv_weight(w):
     return packs
 
 
+def pack_deconv4_weight(w):
+    """The four parity packs of pack_deconv_weight stacked in parity order q = 2*py + px: (4, chunks, coutp, 32), the
+    `deconv4=` operand of conv_params (the whole ConvTranspose k4 s2 p1 as ONE launch)."""
+    return torch.stack([pk for _, _, pk in pack_deconv_weight(w)]).contiguous()
+
+
+def pack_wino_weight_grouped(ws):
+    """[(Cout_g, Cin_g, 3, 3)] * G -> (G, 16, Cin_g/16, Cout_g, 16): the filters of a grouped 3x3 convolution
+    (lfdm_conv_params.groups), each group's Winograd pack back to back."""
+    packs = [pack_wino_weight(w.contiguous(), coutp=w.shape[0]) for w in ws]
+    return torch.stack(packs).contiguous()
+
+
 def pack_ln_conv_weight(w, gamma):
     """1x1 conv / linear weight (Cout, Cin[,1,1]) preceded by a channel LayerNorm with scale gamma (Cin,):
     returns (packed W' = W*gamma, ln_wsum (coutp,) = sum_c W'[o][c]) for lfdm_conv_params.ln_wsum."""
@@ -137,14 +150,18 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
     _chk(lib, src0, src1, weight, bias, residual, out, ln_wsum)
     cin = src0.shape[1] + (src1.shape[1] if src1 is not None else 0)
-    assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
-    coutp = weight.shape[1]
+    if groups > 1:      # grouped convolution: Winograd form only, `weight` is not read (lfdm_conv_params.groups)
+        assert weight_wino is not None and src1 is None and weight is weight_wino
+        coutp = cout
+    else:
+        assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
+        coutp = weight.shape[1]
     pad_y, pad_x = (kh // 2, kw // 2) if pad is None else pad
     h_in = hi * 2 if upsample else hi
     w_in = wi * 2 if upsample else wi
@@ -177,11 +194,19 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     if ln_wsum is not None:
         p.ksplit = 1
     p.weight_wino = None
+    p.groups = groups if groups > 1 else 0
     if weight_wino is not None:
         _chk(lib, weight_wino)
-        assert kh == 3 and kw == 3 and weight_wino.shape == (16, cin // 16, coutp, 16), weight_wino.shape
+        want = (16, cin // 16, coutp, 16) if groups <= 1 else (groups, 16, cin // groups // 16, coutp // groups, 16)
+        assert kh == 3 and kw == 3 and weight_wino.shape == want and weight_wino.is_contiguous(), (weight_wino.shape, want)
         p.weight_wino = weight_wino.data_ptr()
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino)   # keep the tensors alive with the struct
+    p.deconv4 = 0
+    if deconv4 is not None:     # the four parity packs of pack_deconv_weight, stacked: ONE launch (lfdm_conv_params.deconv4)
+        _chk(lib, deconv4)
+        assert kh == 2 and kw == 2 and out_scale == 2 and deconv4.is_contiguous() and deconv4.shape == (4,) + tuple(weight.shape) \
+            and deconv4.data_ptr() == weight.data_ptr(), "weight must be deconv4[0]"
+        p.deconv4 = 1
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4)   # keep the tensors alive with the struct
     return p, out
 
 
@@ -206,7 +231,7 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
     _, ks = conv_plan(p)
     if ks > 1:
-        need = ks * n_img * p.hq * p.wq * p.coutp
+        need = ks * n_img * p.hq * p.wq * p.coutp * (4 if p.deconv4 else 1)
         if partial is None or partial.numel() < need:
             partial = torch.empty(need, dtype=torch.float32, device=src0.device)
         p.partial = _p(partial)
@@ -240,9 +265,14 @@ def conv2d_smalln_cl(x, wpacked, bias4, cout, k, n_img, h, w, *, act=ACT_NONE, o
 
 
 def deconv4x4s2_cl(src, packs, cout, n_img, hi, wi, *, bias=None, out=None):
-    """ConvTranspose (1,4,4) stride (1,2,2) pad (0,1,1) as four parity 2x2 convolutions."""
+    """ConvTranspose (1,4,4) stride (1,2,2) pad (0,1,1) as four parity 2x2 convolutions: ONE launch when `packs` is the
+    stacked tensor of pack_deconv4_weight, four launches for the list of pack_deconv_weight."""
     if out is None:
         out = torch.empty(n_img * 4 * hi * wi, cout, dtype=torch.float32, device=src.device)
+    if torch.is_tensor(packs):
+        conv2d_cl(src, packs[0], cout, 2, 2, n_img, hi, wi, bias=bias, pad=(1, 1), out=out, hq=hi, wq=wi, ho=2 * hi, wo=2 * wi,
+                  out_scale=2, deconv4=packs)
+        return out
     for py, px, w in packs:
         conv2d_cl(src, w, cout, 2, 2, n_img, hi, wi, bias=bias, pad=(1 - py, 1 - px), out=out,
                   hq=hi, wq=wi, ho=2 * hi, wo=2 * wi, out_scale=2, out_off=(py, px))
@@ -411,12 +441,14 @@ def conv_planar_in_cl(x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout,
 
 
 def heads_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, batch, frames, hw, *, out=None):
+    """y_flow / y_occ: (rows, C) each, equal row stride (column slices of one (rows, 2C) tensor are fine)."""
     lib = _lib()
     _chk(lib, y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, out)
     ch = y_flow.shape[1]
+    assert y_flow.stride(0) == y_occ.stride(0) and y_flow.stride(1) == 1 and y_occ.stride(1) == 1
     if out is None:
         out = torch.empty(batch, 3, frames, hw, dtype=torch.float32, device=y_flow.device)
-    lib.check(lib.lfdm_heads_cl_to_planar_f32(_p(y_flow), _p(y_occ), ch, _p(w_flow), _p(b_flow),
+    lib.check(lib.lfdm_heads_cl_to_planar_f32(_p(y_flow), _p(y_occ), ch, y_flow.stride(0), _p(w_flow), _p(b_flow),
                                               _p(w_occ), _p(b_occ), _p(out), batch, frames, hw,
                                               _stream(lib)), "lfdm_heads_cl_to_planar_f32")
     return out

@@ -220,7 +220,7 @@ class Unet3D(ParamTree):
             temporal(p + "3.")
             if lvl < nl - 1:
                 if self.use_deconv:
-                    pk[p + "4.packs"] = ops.pack_deconv_weight(g(p + "4.weight"))
+                    pk[p + "4.packs"] = ops.pack_deconv4_weight(g(p + "4.weight"))
                     pk[p + "4.b"] = g(p + "4.bias")
                 else:
                     pk[p + "4.w"] = ops.pack_conv_weight(g(p + "4.1.weight"))
@@ -229,6 +229,17 @@ class Unet3D(ParamTree):
             resblock(head + "0.")
             pk[head + "1.w"] = g(head + "1.weight").reshape(-1, self.dim).contiguous()
             pk[head + "1.b"] = g(head + "1.bias")
+        if self.dim % 32 == 0 and self.has("final_conv.0.res_conv.weight"):      # the two heads as one 2*dim-channel block
+            hp = ("final_conv.0.", "occlusion_map.0.")
+            cat = lambda k: torch.cat([g(h + k) for h in hp], dim=0).contiguous()
+            w1 = cat("block1.proj.weight")
+            pk["heads.block1.w"], pk["heads.block1.ww"] = ops.pack_conv_weight(w1), ops.pack_wino_weight(w1)
+            pk["heads.block1.b"] = cat("block1.proj.bias")
+            pk["heads.block2.ww"] = ops.pack_wino_weight_grouped([g(h + "block2.proj.weight")[:, :, 0] for h in hp])
+            pk["heads.block2.b"] = cat("block2.proj.bias")
+            pk["heads.res.w"], pk["heads.res.b"] = ops.pack_conv_weight(cat("res_conv.weight")), cat("res_conv.bias")
+            for i in (1, 2):
+                pk["heads.norm%d.w" % i], pk["heads.norm%d.b" % i] = cat("block%d.norm.weight" % i), cat("block%d.norm.bias" % i)
         pk["cond.w"] = torch.cat(cond_w, dim=0).contiguous()     # (sum 2C, time_dim + cond_dim)
         pk["cond.b"] = torch.cat(cond_b, dim=0).contiguous()
         pk["cond.n"] = off
@@ -278,34 +289,35 @@ class Unet3D(ParamTree):
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
+        coutp = p.coutp
         if self.fuse_splitk:     # split-K slabs reduced inside the launch (measured neutral-to-slower on MI355X: off)
             cnt = self._tile_counters()
             p.tile_counters, p.tile_counters_len = cnt.data_ptr(), cnt.numel()
         tile_rows, ksplit = ops.conv_plan(p)
         m = n_img * p.hq * p.wq
         if ksplit > 1:
-            part = self._buf(scratch, ksplit * m, w.shape[1])
+            part = self._buf(scratch, ksplit * m * (4 if p.deconv4 else 1), coutp)
             p.partial = part.data_ptr()
         stats = None
         if gn is not None:
-            batch = gn[0]
+            batch, groups = gn[0], (gn[1] if len(gn) > 1 else 8)
             pixels = m // batch
-            cg = cout // 8
+            cg = cout // groups
             fused = ksplit > 1 and tile_rows == 160
             in_tile = (ksplit == 1 or fused) and 32 % cg == 0             # statistics from the conv epilogue (group inside a 32-column tile)
-            in_reduce = ksplit > 1 and not fused and 256 % (w.shape[1] // 4) == 0 and w.shape[1] == cout    # ... from the split-K reduce pass (any group width)
+            in_reduce = ksplit > 1 and not fused and 256 % (coutp // 4) == 0 and coutp == cout    # ... from the split-K reduce pass (any group width)
             if pixels % tile_rows == 0 and cg % 4 == 0 and (in_tile or in_reduce):
                 nchunk = pixels // tile_rows
-                stats = (self._buf("gn.partial", batch * nchunk, 16), nchunk)
-                p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), 8, pixels
+                stats = (self._buf("gn.partial", batch * nchunk, 2 * groups), nchunk)
+                p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), groups, pixels
         ops.conv_launch(p)
         return (y, stats) if gn is not None else y
 
-    def _gn(self, x, batch, gamma, beta, stats, **kw):
+    def _gn(self, x, batch, gamma, beta, stats, groups=8, **kw):
         gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
         if stats is not None:
-            return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, **kw)
-        return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, **kw)
+            return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, groups=groups, **kw)
+        return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, groups=groups, **kw)
 
     def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
         n_img, rows = batch * frames, batch * frames * s * s
@@ -430,17 +442,33 @@ class Unet3D(ParamTree):
             x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, ci, "u%d.d" % lvl, tables)
             if lvl < nl - 1:
                 out_u = self._buf("u%d.up" % lvl, n_img * (res * 2) ** 2, ci)
-                if self.use_deconv:      # ConvTranspose (1,4,4) s2 p1 = four 2x2 parity convolutions
-                    for py, px, wpk in pk[p + "4.packs"]:
-                        self._conv(x, wpk, ci, 2, n_img, res, bias=pk[p + "4.b"], pad=(1 - py, 1 - px), out=out_u,
-                                   hq=res, wq=res, ho=2 * res, wo=2 * res, out_scale=2, out_off=(py, px))
+                if self.use_deconv:      # ConvTranspose (1,4,4) s2 p1 = four 2x2 parity convolutions, ONE launch
+                    w4 = pk[p + "4.packs"]
+                    self._conv(x, w4[0], ci, 2, n_img, res, bias=pk[p + "4.b"], pad=(1, 1), out=out_u,
+                               hq=res, wq=res, ho=2 * res, wo=2 * res, out_scale=2, deconv4=w4)
                     x = out_u
                 else:
                     x = self._conv(x, pk[p + "4.w"], ci, 3, n_img, res, bias=pk[p + "4.b"], upsample=True,
                                    reflect=(self.padding_mode == "reflect"), out=out_u)
                 res *= 2
-        yf = self._resblock(pk, "final_conv.0.", x, r, batch, frames, res, None, dim, "h.flow")
-        yo = self._resblock(pk, "occlusion_map.0.", x, r, batch, frames, res, None, dim, "h.occ")
+        if "heads.block1.w" in pk:
+            # final_conv.0 and occlusion_map.0 (:493-509) are two ResnetBlocks(2*dim -> dim) on the SAME input cat(x, r):
+            # run as ONE block with 2*dim mid channels - block1 / res_conv dense with the filters concatenated along the
+            # output channels, block2 a 2-group convolution, GroupNorm 16 groups of dim/8 - 5 launches instead of 10
+            rows, c2 = n_img * res * res, 2 * dim
+            h1 = self._buf("h.h1", rows, c2)
+            _, st = self._conv(x, pk["heads.block1.w"], c2, 3, n_img, res, src1=r, bias=pk["heads.block1.b"], out=h1,
+                               gn=(batch, 16), ww=pk["heads.block1.ww"])
+            self._gn(h1, batch, pk["heads.norm1.w"], pk["heads.norm1.b"], st, groups=16)
+            y = self._buf("h.y", rows, c2)
+            _, st = self._conv(h1, pk["heads.block2.ww"], c2, 3, n_img, res, bias=pk["heads.block2.b"], out=y,
+                               gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2)
+            self._gn(y, batch, pk["heads.norm2.w"], pk["heads.norm2.b"], st, groups=16)
+            self._conv(x, pk["heads.res.w"], c2, 1, n_img, res, src1=r, bias=pk["heads.res.b"], residual=y, out=y)
+            yf, yo = y[:, :dim], y[:, dim:]
+        else:
+            yf = self._resblock(pk, "final_conv.0.", x, r, batch, frames, res, None, dim, "h.flow")
+            yo = self._resblock(pk, "occlusion_map.0.", x, r, batch, frames, res, None, dim, "h.occ")
         ops.heads_cl_to_planar(yf, yo, pk["final_conv.1.w"], pk["final_conv.1.b"], pk["occlusion_map.1.w"],
                                pk["occlusion_map.1.b"], batch, frames, res * res, out=out)
         return out

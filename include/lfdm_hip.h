@@ -105,6 +105,17 @@ typedef struct lfdm_conv_params {
      geometry qualifies the library may run the 16/36-multiplication schedule (conv_wino.hip); results differ from the
      direct form by fp32 rounding only (~1e-6 relative).  LFDM_WINO=0 in the environment forces the direct form. */
   const float* weight_wino;
+  /* Optional: ConvTranspose k4 s2 p1 (Upsample, video_flow_diffusion.py:158) as ONE launch of its four 2x2 parity
+     convolutions.  weight = the four parity packs back to back ([4][ceil(4*cin/32)][coutp][32], parity q = 2*py + px,
+     cvpr23_lfdm_amd.ops.pack_deconv_weight), kh = kw = 2, stride 1, out_scale 2, (hq, wq) = (hi, wi), (ho, wo) = 2x.
+     Problem q runs with pad = (1 - py, 1 - px) and out_off = (py, px) (the pad_* / out_off_* fields are ignored);
+     grid z = 4 * ksplit and the split-K slabs are [4][ksplit][M][coutp] (lfdm_conv2d_partial_bytes accounts for it). */
+  int deconv4;
+  /* Optional grouped convolution (Winograd schedule only, NULL src1): `groups` > 1 splits the c0 input channels and the
+     cout output channels into equal groups (cout / groups a multiple of 32); weight_wino holds the groups' packs back to
+     back ([groups][16][c0/groups/16][coutp/groups][16]).  Used to run the two output heads' second convolutions
+     (final_conv.0.block2 / occlusion_map.0.block2, video_flow_diffusion.py:493-509) as one launch. */
+  int groups;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
@@ -198,8 +209,10 @@ int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, int cin_total
                                int act, lfdm_stream_t stream);
 
 /* Output heads: the two 1x1x1 convs (video_flow_diffusion.py:495,508,588) from CL features to the
- * PLANAR 3-channel prediction (B, 3, T, H, W): ch 0,1 from y_flow (w_flow (2,C)), ch 2 from y_occ. */
-int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels,
+ * PLANAR 3-channel prediction (B, 3, T, H, W): ch 0,1 from y_flow (w_flow (2,C)), ch 2 from y_occ.
+ * ld = row stride (floats) of both feature tensors: the two heads' ResnetBlocks run as one 2C-channel block, their outputs
+ * are the two column halves of one (rows, 2C) buffer. */
+int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels, int ld,
                                 const float* w_flow, const float* b_flow, const float* w_occ,
                                 const float* b_occ, float* out, int batch, int frames, int hw,
                                 lfdm_stream_t stream);

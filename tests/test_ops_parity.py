@@ -117,6 +117,60 @@ def test_deconv(backend):
     assert_close(from_cl(out.cpu(), n, 2 * h, 2 * w), ref, TOL, "deconv")
 
 
+@pytest.mark.parametrize("case", [dict(n=2, c=32, h=4, w=4, ksplit=0), dict(n=3, c=64, h=2, w=6, ksplit=2),
+                                  dict(n=40, c=256, h=4, w=4, ksplit=0, gpu_only=True), dict(n=40, c=64, h=16, w=16, ksplit=0, gpu_only=True),
+                                  dict(n=2, c=32, h=8, w=8, ksplit=1, force="igemm"), dict(n=2, c=32, h=4, w=4, ksplit=3, force="igemm")],
+                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
+def test_deconv_one_launch(backend, case, monkeypatch):
+    """lfdm_conv_params.deconv4: the four parity convolutions of ConvTranspose k4 s2 p1 as ONE launch (grid z = parity x
+    K slice, both direct schedules, with and without split-K) against F.conv_transpose2d."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    if case.get("force"):
+        monkeypatch.setenv("LFDM_CONV_FORCE", case["force"])
+    n, c, h, w = (case[k] for k in ("n", "c", "h", "w"))
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, c, 4, 4, seed=2, scale=1.0 / math.sqrt(c * 4))
+    bias = rnd(c, seed=3)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2, padding=1)
+    w4 = ops.pack_deconv4_weight(wt).to(dev)
+    out = torch.full((n * 4 * h * w, c), float("nan"), device=dev)
+    ops.conv2d_cl(to_cl(x).to(dev), w4[0], c, 2, 2, n, h, w, bias=bias.to(dev), pad=(1, 1), hq=h, wq=w, ho=2 * h, wo=2 * w,
+                  out_scale=2, deconv4=w4, ksplit=case["ksplit"], out=out)
+    assert_close(from_cl(out.cpu(), n, 2 * h, 2 * w), ref, TOL, "deconv4")
+
+
+@pytest.mark.parametrize("case", [dict(n=2, cg=16, og=32, g=2, h=4, w=8, gn=False), dict(n=4, cg=32, og=32, g=3, h=8, w=8, gn=True),
+                                  dict(n=40, cg=64, og=64, g=2, h=32, w=32, gn=True, gpu_only=True)],
+                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
+def test_conv2d_winograd_grouped(backend, case):
+    """lfdm_conv_params.groups: grouped 3x3 convolution on the Winograd schedule (the two output heads' block2 as one launch)
+    against F.conv2d(groups=), incl. the GroupNorm partial sums of the epilogue over groups * 8 norm groups."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    n, cg, og, g, h, w = (case[k] for k in ("n", "cg", "og", "g", "h", "w"))
+    x = rnd(n, cg * g, h, w, seed=1)
+    wt = rnd(og * g, cg, 3, 3, seed=2, scale=1.0 / math.sqrt(cg * 9))
+    bias = rnd(og * g, seed=3)
+    ref = F.conv2d(x, wt, bias, padding=1, groups=g)
+    ww = ops.pack_wino_weight_grouped([wt[i * og:(i + 1) * og].to(dev) for i in range(g)])
+    kw = dict(bias=bias.to(dev), weight_wino=ww, groups=g)
+    partial, ngn = None, 8 * g
+    if case["gn"]:
+        pixels = h * w * n // 2                    # two samples
+        partial = torch.zeros(2 * (pixels // 128), 2 * ngn, device=dev)
+        kw.update(gn_partial=partial, gn_groups=ngn, gn_pixels=pixels)
+    out = ops.conv2d_cl(to_cl(x).to(dev), ww, og * g, 3, 3, n, h, w, **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "grouped winograd conv")
+    if partial is not None:
+        y = ref.view(2, n // 2, ngn, og * g // ngn, h, w).permute(0, 2, 1, 3, 4, 5).reshape(2, ngn, -1).double()
+        got = partial.cpu().view(2, pixels // 128, ngn, 2).double().sum(dim=1)
+        assert_close(got[..., 0].float(), y.sum(-1).float(), TOL, "gn sum")
+        assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,with_ss", [(64, True), (128, False), (512, True)])
 def test_groupnorm_silu(backend, c, with_ss):
@@ -527,7 +581,7 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),
     dict(cin=16, cout=32, n=1, h=4, w=32, residual=True),                        # 16 tiles per image row: two row segments per workgroup
     dict(cin=32, cout=32, n=2, h=2, w=128, act=1),                               # 64 tiles per image row: a workgroup is half a row
-    dict(cin=32, cout=40, n=3, h=6, w=16, split_src=16, residual=True, act=1),    # 8 tiles per row: wide schedule, ragged second workgroup
+    dict(cin=32, cout=40, n=3, h=6, w=16, split_src=16, residual=True, act=1),    # 8 tiles per row, ragged second workgroup
     dict(cin=16, cout=64, n=2, h=8, w=16, gn=True),                               # ... whose two halves lie in different samples
     dict(cin=16, cout=32, n=1, h=4, w=8, upsample=True),                          # ... through the upsample
     dict(cin=32, cout=32, n=1, h=4, w=16, ksplit=2),                              # ... with split-K slabs
@@ -535,9 +589,8 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn,stage", [("32", "0"), ("64", "0"), ("32", "1"), ("64", "1"), ("32", "wide")],
-                         ids=["n32", "n64", "n32-staged", "n64-staged", "wide"])
-def test_conv2d_winograd(backend, case, bn, stage, monkeypatch):
+@pytest.mark.parametrize("bn", ["32", "64"], ids=["n32", "n64"])
+def test_conv2d_winograd(backend, case, bn, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
     tile order of the low-resolution levels."""
     dev = backend
@@ -545,10 +598,6 @@ def test_conv2d_winograd(backend, case, bn, stage, monkeypatch):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
     monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
-    monkeypatch.setenv("LFDM_WINO_STAGE", "1" if stage == "1" else "0")    # unique pixels of each tile row staged through LDS (experiment knob)
-    monkeypatch.setenv("LFDM_WINO_WIDE", "1" if stage == "wide" else "0")  # conv_wino_wide.hip: 64-tile workgroups (>= 8 tiles per row, else the default)
-    if stage == "wide" and dev == "cuda" and os.environ.get("LFDM_FUZZ_GPU", "0") != "1":
-        pytest.skip("written after the round's GPU minutes were spent: first GPU run is opt-in (LFDM_FUZZ_GPU=1)")
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
@@ -618,13 +667,10 @@ def test_pack_wino_weight(backend):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
-    """Seeded random geometries through every Winograd variant (tile raggedness, odd image counts, two-source splits,
-    forced split-K, upsampled input, 64-column workgroups, LDS staging) against F.conv2d."""
-    import os
+    """Seeded random geometries through the Winograd schedule (tile raggedness, odd image counts, two-source splits,
+    forced split-K, upsampled input, 64-column workgroups) against F.conv2d."""
     import random
     dev = backend
-    if dev == "cuda" and os.environ.get("LFDM_FUZZ_GPU", "0") != "1":
-        pytest.skip("written after the round's GPU minutes were spent: first GPU run is opt-in (LFDM_FUZZ_GPU=1)")
     rnd_ = random.Random(1000 + seed)
     for trial in range(6 if dev == "cpu" else 12):
         cin = 16 * rnd_.randint(1, 5)
@@ -637,8 +683,6 @@ def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
         split = rnd_.choice([0, 16]) if cin > 16 else 0
         monkeypatch.setenv("LFDM_WINO", "1")
         monkeypatch.setenv("LFDM_WINO_BN", rnd_.choice(["32", "64"]))
-        monkeypatch.setenv("LFDM_WINO_STAGE", rnd_.choice(["0", "1"]))
-        monkeypatch.setenv("LFDM_WINO_WIDE", rnd_.choice(["0", "1"]))
         x = rnd(n, cin, h, w, seed=10 * seed + trial)
         wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
         bias = rnd(cout, seed=5)
