@@ -86,7 +86,7 @@ def build_emu(force=False):
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             _run([cxx] + flags + ["-x", "c++", "-c", src, "-o", obj])
-    _run([cxx, "-shared", "-fPIC", "-o", EMU_LIB] + objs)
+    _run([cxx, "-shared", "-fPIC", "-pthread", "-o", EMU_LIB] + objs)
     return EMU_LIB
 
 

@@ -91,8 +91,8 @@ __device__ __forceinline__ float2 lfdm_buf_load_f2(lfdm_buf b, uint32_t off) {
 #define LFDM_DRAIN_STORES() ((void)0)
 #define LFDM_FENCE_RELEASE_AGENT() ((void)0)
 #define LFDM_FENCE_ACQUIRE_AGENT() ((void)0)
-static inline unsigned lfdm_ticket_take(unsigned* c) { const unsigned v = *c; *c = v + 1u; return v; }   // workgroups run one by one
-static inline void lfdm_ticket_reset(unsigned* c) { *c = 0u; }
+static inline unsigned lfdm_ticket_take(unsigned* c) { return __atomic_fetch_add(c, 1u, __ATOMIC_SEQ_CST); }   // workgroups run on several OS threads
+static inline void lfdm_ticket_reset(unsigned* c) { __atomic_store_n(c, 0u, __ATOMIC_SEQ_CST); }
 #else
 #define LFDM_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define LFDM_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")

@@ -1,14 +1,14 @@
 // TEST INFRASTRUCTURE ONLY.
-// A tiny single-OS-thread fiber emulator of the HIP execution model (workgroups, 64-wide
-// wavefronts, LDS, __syncthreads, cross-lane shuffles and the two fp32 MFMA shapes the kernels
-// use).  It lets the kernel sources under cvpr23_lfdm_amd/csrc/ be compiled for x86 and their
+// A tiny fiber emulator of the HIP execution model (workgroups, 64-wide wavefronts, LDS,
+// __syncthreads, cross-lane shuffles and the fp32 MFMA shapes the kernels use).  One fiber per
+// HIP thread (a 7-instruction x86-64 stack switch, no syscall); the workgroups of a launch are
+// dealt to a few OS threads (LFDM_EMU_THREADS, default: the cores, at most 8), each with its own
+// fibers, scheduler state and LDS (`__shared__` = static thread_local).  It lets the kernel sources under cvpr23_lfdm_amd/csrc/ be compiled for x86 and their
 // index arithmetic checked against the CPU oracle in the build container, which has no GPU.
 // It is NOT a backend: the product library (liblfdm_hip.so) is built by hipcc for gfx950 only
 // and never contains this file.  MFMA fragment layouts follow
 // /opt/skills/guides/cdna_hip_programming.md section 3.
 #pragma once
-#include <ucontext.h>
-
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -44,7 +44,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #ifndef __restrict__
 #define __restrict__
@@ -53,7 +53,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 namespace emu {
 
 struct Fiber {
-  ucontext_t ctx;
+  void* sp;         // saved stack pointer while the fiber is not running
   bool done;
   dim3 tid;
   unsigned linear;  // linear thread id in the block
@@ -69,13 +69,13 @@ struct WaveState {
 struct State {
   dim3 bidx, bdim, gdim;
   Fiber* cur = nullptr;
-  ucontext_t sched;
+  void* sched_sp = nullptr;
   unsigned nthreads = 0;
   unsigned bar_arrived = 0, bar_gen = 0;
   std::vector<WaveState> waves;
   unsigned char* dyn_smem = nullptr;
 };
-extern State g;
+extern thread_local State g;
 
 void yield();
 void syncthreads();
@@ -109,11 +109,31 @@ template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { (
 template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; unsigned s = emu::lane_id() + d; return emu::wave_read_from(v, s < 64 ? s : emu::lane_id()); }
 template <class T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return emu::wave_read_from(v, (unsigned)src); }
 
-static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
-static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
-static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
-static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
-static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+// real atomics: workgroups of one launch run on several OS threads
+static inline float atomicAdd(float* p, float v) {
+  unsigned* u = reinterpret_cast<unsigned*>(p);
+  unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED), want;
+  float f;
+  do {
+    memcpy(&f, &old, 4);
+    f += v;
+    memcpy(&want, &f, 4);
+  } while (!__atomic_compare_exchange_n(u, &old, want, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4);
+  return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) {}
+  return o;
+}
+static inline unsigned atomicMin(unsigned* p, unsigned v) {
+  unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) {}
+  return o;
+}
 
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Run one of the reference's caller scripts (demo/demo_*.py, DM/train_video_flow_diffusion_*.py, ...) UNCHANGED - the file
+is read from the reference tree and executed as is - against either the drop-in classes of this repository
+(`--backend ours`: the repository root precedes the reference on sys.path, so `DM.modules.video_flow_diffusion_model`,
+`misc`, `datasets_mug` resolve here) or the reference's own classes (`--backend reference`, torch CPU).
+
+What a launcher has to interpose, because the scripts hard-code their environment:
+  --set NAME=VALUE        module-level constants (checkpoint / data / output paths, N_FRAMES, ...) are rebound right after the
+                          statement that assigns them, before anything derived from them is computed; dotted names
+                          (`args.num_workers=0`) set an attribute of an object the script created
+  --local NAME=VALUE      a literal assigned to a local variable inside a function (`nf = 40` in demo_mug.py:main)
+  --call-arg F.I=VALUE    a literal positional argument of a call (`resize(img, 128, ...)` -> F=resize, I=1)
+  --model-kw K=VALUE      keyword arguments forced on the FlowDiffusion constructor (sampling_timesteps, timesteps, num_frames, ...)
+  --reseed N              torch.manual_seed(N) right after the model is built (the two backends consume the generator
+                          differently while initialising parameters that the checkpoints then overwrite)
+  --record DIR            raw frames of every imageio.mimsave / Image.save call + the model's result tensors -> DIR/*.npz
+  --emu                   drive the kernels through the x86 emulation build (GPU-less container; TEST infrastructure)
+On a box without a GPU `.cuda()` is a no-op (both backends).  Used by tests/test_reference_scripts.py.
+"""
+import argparse
+import ast
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE_ROOT = os.environ.get("LFDM_REFERENCE_ROOT", "/root/reference")
+
+
+def _lit(text):
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def _pairs(items):
+    out = {}
+    for it in items or []:
+        k, v = it.split("=", 1)
+        out[k] = _lit(v)
+    return out
+
+
+class _Rewrite(ast.NodeTransformer):
+    """Literal rebinding inside function bodies (the file on disk stays untouched)."""
+
+    def __init__(self, local, call_arg):
+        self.local, self.call_arg, self.depth, self.hits = local, call_arg, 0, []
+
+    def visit_FunctionDef(self, node):
+        self.depth += 1
+        self.generic_visit(node)
+        self.depth -= 1
+        return node
+
+    def visit_Assign(self, node):
+        self.generic_visit(node)
+        if self.depth > 0 and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                and node.targets[0].id in self.local and isinstance(node.value, ast.Constant):
+            self.hits.append("local %s" % node.targets[0].id)
+            node.value = ast.copy_location(ast.Constant(self.local[node.targets[0].id]), node.value)
+        return node
+
+    def visit_Call(self, node):
+        self.generic_visit(node)
+        name = node.func.id if isinstance(node.func, ast.Name) else getattr(node.func, "attr", None)
+        for key, val in self.call_arg.items():
+            fn, idx = key.rsplit(".", 1)
+            if fn == name and int(idx) < len(node.args) and isinstance(node.args[int(idx)], ast.Constant):
+                self.hits.append("call %s" % key)
+                node.args[int(idx)] = ast.copy_location(ast.Constant(val), node.args[int(idx)])
+        return node
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--script", required=True, help="path relative to the reference root, e.g. demo/demo_mug.py")
+    ap.add_argument("--backend", choices=["ours", "reference"], default="ours")
+    ap.add_argument("--emu", action="store_true")
+    ap.add_argument("--set", action="append")
+    ap.add_argument("--local", action="append")
+    ap.add_argument("--call-arg", action="append")
+    ap.add_argument("--model-kw", action="append")
+    ap.add_argument("--reseed", type=int, default=None)
+    ap.add_argument("--record", default="")
+    ap.add_argument("--bert", default="", help="local Hugging Face BERT directory (hidden size 768) standing in for the "
+                    "torch.hub download of bert-base-cased (DM/modules/text.py:20,27): LFDM_BERT_PATH for this repository's "
+                    "classes, a torch.hub.load replacement for the reference's")
+    ap.add_argument("rest", nargs=argparse.REMAINDER)
+    a = ap.parse_args()
+    sets, local, call_arg, model_kw = _pairs(a.set), _pairs(a.local), _pairs(a.call_arg), _pairs(a.model_kw)
+    script = os.path.join(REFERENCE_ROOT, a.script)
+    script_dir = os.path.dirname(script)
+
+    hub_objects = None
+    if a.bert:
+        os.environ["LFDM_BERT_PATH"] = a.bert
+        if a.backend == "reference":          # loaded BEFORE the import shims (a stub torchvision among them) enter sys.path
+            from transformers import BertModel, BertTokenizer
+            tok = BertTokenizer.from_pretrained(a.bert, local_files_only=True, do_lower_case=False)
+            if not hasattr(tok, "batch_encode_plus"):        # transformers >= 5 dropped the alias text.py:44 calls
+                tok.batch_encode_plus = lambda texts, **kw: tok(texts, **kw)
+            hub_objects = {"tokenizer": tok, "model": BertModel.from_pretrained(a.bert, local_files_only=True).eval()}
+
+    # ---- import resolution -------------------------------------------------------------------------------------------
+    standins = os.path.join(ROOT, "cvpr23_lfdm_amd", "standins")
+    shims = os.path.join(ROOT, "oracle", "ref_shims")
+    keep = [p for p in sys.path if os.path.abspath(p or ".") not in (ROOT, os.path.join(ROOT, "tools"))]
+    if a.backend == "ours":
+        # the script directory comes first for a script run directly (`from datasets_mug import MUG` is script-relative in
+        # the reference); here the repository's DM/ plays that role, then the repository root, and only then the reference
+        sys.path[:] = [os.path.join(ROOT, "DM"), ROOT] + keep + [standins]
+    else:
+        # reference classes; the caller-side vocabulary (misc / datasets / imageio / cv2) is the repository's in BOTH modes
+        # (the reference's own needs cv2, flow_vis, torchvision - not installed), so the two runs differ in the model only
+        sys.path[:] = [shims, REFERENCE_ROOT] + keep + [ROOT, standins]
+        for name, rel in (("misc", "misc.py"), ("datasets_mug", "DM/datasets_mug.py"), ("datasets_mhad", "DM/datasets_mhad.py"),
+                          ("datasets_natops", "DM/datasets_natops.py")):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+        import imageio as _im_std            # the import-only stub of oracle/ref_shims would shadow the working stand-ins
+        for name in ("imageio", "cv2"):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(standins, name + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+        del _im_std
+
+    import numpy as np
+    import torch
+    from torch import nn
+    if not torch.cuda.is_available():
+        nn.Module.cuda = lambda self, *x, **k: self
+        torch.Tensor.cuda = lambda self, *x, **k: self
+    if hub_objects is not None:
+        torch.hub.load = lambda repo, kind, name, *x, **k: hub_objects[kind]
+    if a.backend == "ours" and a.emu:
+        from cvpr23_lfdm_amd import _build, _native
+        _native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))
+
+    # ---- recording hooks --------------------------------------------------------------------------------------------
+    state = {"model": None, "saves": 0}
+    if a.record:
+        os.makedirs(a.record, exist_ok=True)
+        import imageio
+        orig_mimsave = imageio.mimsave
+
+        def mimsave(path, frames, *x, **k):
+            np.savez(os.path.join(a.record, "mimsave_%02d.npz" % state["saves"]), name=os.path.basename(str(path)),
+                     frames=np.stack([np.asarray(f) for f in frames]))
+            state["saves"] += 1
+            return orig_mimsave(path, frames, *x, **k)
+        imageio.mimsave = mimsave
+
+    def wrap_model(cls):
+        def build(*args, **kw):
+            kw.update(model_kw)
+            m = cls(*args, **kw)
+            state["model"] = m
+            if a.reseed is not None:
+                torch.manual_seed(a.reseed)
+            return m
+        return build
+
+    # ---- execute the script statement by statement, rebinding constants as they appear --------------------------------------
+    src = open(script).read()
+    tree = ast.parse(src, filename=script)
+    rw = _Rewrite(local, call_arg)
+    tree = ast.fix_missing_locations(rw.visit(tree))
+    ns = {"__name__": "lfdm_reference_script", "__file__": script}
+    sys.argv = [script] + [r for r in a.rest if r != "--"]
+    applied = set()
+    for node in tree.body:
+        if isinstance(node, ast.If) and "__main__" in ast.dump(node.test):
+            continue                                                       # main() is called below, after the rebinding
+        exec(compile(ast.Module([node], []), script, "exec"), ns)
+        names = [t.id for t in getattr(node, "targets", []) if isinstance(t, ast.Name)]
+        for alias in getattr(node, "names", []) if isinstance(node, (ast.Import, ast.ImportFrom)) else []:
+            names.append(alias.asname or alias.name)
+        for name in names:
+            if name == "FlowDiffusion":
+                ns[name] = wrap_model(ns[name])
+            if name in sets:
+                ns[name] = sets[name]
+                applied.add(name)
+            for key, val in sets.items():                                  # dotted: attribute of an object the script made
+                if "." in key and key.split(".", 1)[0] == name:
+                    setattr(ns[name], key.split(".", 1)[1], val)
+                    applied.add(key)
+    missing = (set(sets) - applied) | {k for k in local if ("local %s" % k) not in rw.hits} | \
+        {k for k in call_arg if ("call %s" % k) not in rw.hits}
+    if missing:
+        sys.exit("run_reference_script: never matched in %s: %s" % (a.script, sorted(missing)))
+    ns["main"]()
+    if a.record and state["model"] is not None:
+        m = state["model"]
+        out = {}
+        for k in ("sample_out_vid", "sample_warped_vid", "sample_vid_grid", "sample_vid_conf", "real_vid_grid", "real_vid_conf",
+                  "real_out_vid", "fake_vid_grid", "fake_out_vid", "loss", "rec_loss", "rec_warp_loss"):
+            v = getattr(m, k, None)
+            if isinstance(v, torch.Tensor):
+                out[k] = v.detach().float().cpu().numpy()
+        if hasattr(m, "diffusion"):
+            sd = m.diffusion.state_dict()
+            for k in ("denoise_fn.init_conv.bias", "denoise_fn.final_conv.1.weight", "denoise_fn.mid_block1.block1.proj.bias"):
+                out["param/" + k] = sd[k].detach().float().cpu().numpy()
+        np.savez(os.path.join(a.record, "model.npz"), **out)
+    print("run_reference_script: %s finished on the %s classes" % (a.script, a.backend))
+
+
+if __name__ == "__main__":
+    main()

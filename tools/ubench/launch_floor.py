@@ -50,7 +50,7 @@ for rows, ch in ((640, 512), (2560, 256), (10240, 128), (40960, 64)):
     y = torch.empty_like(x)
     fn = lambda: ops.groupnorm_silu_cl(x, 1, gamma, beta, out=y, ws=ws)
     print("groupnorm_silu (stats+apply, 2 launches) %5d x %3d: %.2f us per call in a graph" % (rows, ch, timeit(fn, 50, True)))
-    nchunk = rows // 128
-    part = torch.randn(nchunk, 16, device=dev).abs()
-    fn2 = lambda: ops.groupnorm_apply_cl(x, 1, gamma, beta, part, nchunk, out=y, ws=ws)
-    print("groupnorm_apply (1 launch)               %5d x %3d: %.2f us per call in a graph" % (rows, ch, timeit(fn2, 50, True)))
+    for nchunk in (rows // 128, max(1, rows // 1280), 1):
+        part = torch.randn(nchunk, 16, device=dev).abs()
+        fn2 = lambda: ops.groupnorm_apply_cl(x, 1, gamma, beta, part, nchunk, out=y, ws=ws)
+        print("groupnorm_apply (1 launch, %3d partial chunks) %5d x %3d: %.2f us per call in a graph" % (nchunk, rows, ch, timeit(fn2, 50, True)))
