@@ -200,7 +200,7 @@ def train_bench(dev, rank, world, steps, warmup, batch):
         net.eval()
         m.set_requires_grad(net, False)
     m.to(dev)
-    m.enable_data_parallel()
+    m.enable_data_parallel(shard_inputs=False)      # weak scaling: every rank draws its own per-GPU batch
     ref_img, real_vid, cond, _, _ = synth.train_inputs(batch, WORKLOAD["frames"], WORKLOAD["image"], seed=100 + rank)
     m.set_train_input(ref_img=ref_img.to(dev), real_vid=real_vid.to(dev), ref_text=cond.to(dev))
     losses = []

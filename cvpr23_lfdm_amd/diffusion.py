@@ -76,6 +76,9 @@ class GaussianDiffusion(nn.Module):
         self.noise_source = None
         self.pred_x0 = None
         self._plans = {}
+        # (rank, world) under sharded data parallelism (FlowDiffusion.enable_data_parallel): the training step's random
+        # draws are made for the GLOBAL batch on every rank (identical generators) and sliced
+        self.rank_shard = None
 
     # ------------------------------------------------------------------ helpers
     def _embed(self, cond, device):
@@ -305,7 +308,7 @@ class GaussianDiffusion(nn.Module):
                                           "frame (video_flow_diffusion.py:901); pass the (B,256,S,S) feature map")
             fea2d = fea[:, :, 0] if fea.dim() == 5 else fea
             pred_noise = unet_train_forward(unet, x_noisy, fea2d, t, cond, null_cond_prob=self.null_cond_prob,
-                                            none_cond_mask=none_cond_mask)
+                                            none_cond_mask=none_cond_mask, rank_shard=self.rank_shard)
         else:
             was_training = unet.training
             unet.eval()
@@ -339,6 +342,11 @@ class GaussianDiffusion(nn.Module):
     def forward(self, x, fea, text, *args, **kwargs):
         """:897-903."""
         b, device = x.shape[0], x.device
-        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
         fea = fea.unsqueeze(dim=2).expand(-1, -1, x.size(2), -1, -1)      # reference: .repeat (:901); a view is enough
+        if self.rank_shard is not None and "noise" not in kwargs:
+            rank, world = self.rank_shard
+            t = torch.randint(0, self.num_timesteps, (b * world,), device=device).long()[rank * b:(rank + 1) * b]
+            noise = torch.randn_like(x.new_empty((b * world,) + tuple(x.shape[1:])))[rank * b:(rank + 1) * b]     # (:858)
+            return self.p_losses(x, t, fea, cond=text, *args, noise=noise, **kwargs)
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
         return self.p_losses(x, t, fea, cond=text, *args, **kwargs)

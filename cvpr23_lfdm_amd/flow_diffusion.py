@@ -107,6 +107,13 @@ class FlowDiffusion(nn.Module):
             # a torch.optim.Optimizer (state_dict / param_groups / lr schedulers work) whose step is one fused HIP launch
             self.optimizer_diff = FlatAdam(self.diffusion.parameters(), lr=lr, betas=adam_betas)
         self._dp = None
+        self._shard = None            # (rank, world) once data parallelism is on: set_train_input keeps this rank's videos
+        # Launched by torchrun (one process per GPU) from an UNCHANGED training script: there is nobody to call
+        # enable_data_parallel(), so the wrapper does it itself at the first optimize_parameters() - the process takes the
+        # GPU of its LOCAL_RANK here, before the script's `.cuda()`.  LFDM_AUTO_DP=0 switches this off.
+        self._auto_dp = (is_train and int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("LFDM_AUTO_DP", "1") != "0")
+        if self._auto_dp and torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
 
     # ------------------------------------------------------------------ sampling (a28)
     def sample_one_video(self, cond_scale):
@@ -142,7 +149,19 @@ class FlowDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ training (a29) - next row
     def set_train_input(self, ref_img, real_vid, ref_text):
+        """Reference :218-221.  Under data parallelism every rank is handed the SAME global batch (the script's DataLoader
+        is seeded identically everywhere) and keeps its own contiguous slice - what nn.DataParallel's scatter does in the
+        reference (DM/train_video_flow_diffusion_mhad_multiGPU.py:207,249)."""
         dev = next(self.unet.parameters()).device
+        self._start_auto_dp()
+        if self._shard is not None:
+            rank, world = self._shard
+            b = real_vid.shape[0]
+            if b % world != 0:
+                raise ValueError("data parallel: batch %d is not divisible by the %d ranks" % (b, world))
+            lo, hi = rank * (b // world), (rank + 1) * (b // world)
+            ref_img, real_vid = ref_img[lo:hi], real_vid[lo:hi]
+            ref_text = ref_text[lo:hi] if isinstance(ref_text, torch.Tensor) else list(ref_text)[lo:hi]
         self.ref_img = ref_img.to(dev)
         self.real_vid = real_vid.to(dev)
         self.ref_text = ref_text
@@ -200,14 +219,31 @@ class FlowDiffusion(nn.Module):
                 self.rec_loss = (self.real_vid - self.fake_out_vid).abs().mean()
                 self.rec_warp_loss = (self.real_vid - self.fake_warped_vid).abs().mean()
 
-    def enable_data_parallel(self, bucket_bytes=64 << 20):
+    def enable_data_parallel(self, bucket_bytes=64 << 20, shard_inputs=True):
         """One process per GPU (torch.distributed initialised by the launcher): average the DM gradients over the
-        ranks with a bucketed RCCL all-reduce that overlaps backward.  No-op for world size 1."""
+        ranks with a bucketed RCCL all-reduce that overlaps backward.  No-op for world size 1.
+        shard_inputs: every rank receives the same global batch and keeps its slice (set_train_input); the step's random
+        draws (t, noise, null-condition mask) are made for the global batch and sliced, so N ranks reproduce the
+        single-process step on the same batch exactly.  shard_inputs=False: the caller already feeds rank-local batches
+        (tools/train_dm.py with a DistributedSampler)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self._dp = GradAllReduce(self.optimizer_diff, bucket_bytes=bucket_bytes)
             self._dp.sync_replicas()          # rank 0's parameters + Adam moments -> all ranks, once
+            if shard_inputs:
+                self._shard = (dist.get_rank(), dist.get_world_size())
+                self.diffusion.rank_shard = self._shard
         return self
+
+    def _start_auto_dp(self):
+        if not self._auto_dp or self._dp is not None:
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = os.environ.get("LFDM_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")     # "nccl" = RCCL
+            dist.init_process_group(backend)
+        self._auto_dp = False
+        self.enable_data_parallel()
 
     def optimize_parameters(self):
         """:181-188."""

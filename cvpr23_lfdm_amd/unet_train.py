@@ -78,7 +78,7 @@ def _linear_attn(unet, c, prefix, x, res):
                      n_img=n_img, hi=res, wi=res)
 
 
-def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_cond_mask=None):
+def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_cond_mask=None, rank_shard=None):
     """x_dyn (B, 3, T, S, S) noisy flow/occlusion, fea (B, 256, S, S) reference-image features (constant over T),
     time (B,) long, cond (B, 768)  ->  eps_hat (B, 3, T, S, S) with grad to every UNet parameter."""
     g = unet.get
@@ -90,7 +90,10 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     dim = unet.dim
 
     # --- conditioning (B x 1024 vectors: torch) (:549-562)
-    unet.null_cond_mask = prob_mask_like((b,), null_cond_prob, device=dev)
+    if rank_shard is not None:       # sharded data parallelism: the draw of the global batch, this rank's slice
+        unet.null_cond_mask = prob_mask_like((b * rank_shard[1],), null_cond_prob, device=dev)[rank_shard[0] * b:(rank_shard[0] + 1) * b]
+    else:
+        unet.null_cond_mask = prob_mask_like((b,), null_cond_prob, device=dev)
     if none_cond_mask is not None:
         unet.null_cond_mask = torch.logical_or(unet.null_cond_mask, torch.as_tensor(none_cond_mask, device=dev))
     temb = _time_embedding(unet, time)

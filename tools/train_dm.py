@@ -86,7 +86,7 @@ def main():
     if world > 1:
         # bucketed RCCL all-reduce of the flat gradient, overlapped with backward; rank 0's parameters and Adam
         # moments are broadcast once so the replicas start identical whatever happened above (restore on one rank ...)
-        model.enable_data_parallel()
+        model.enable_data_parallel(shard_inputs=False)      # the DistributedSampler below already feeds rank-local batches
     torch.manual_seed(args.seed + 1 + rank)     # per-rank streams for t / noise / null-cond mask / data order
     np.random.seed(args.seed + 1 + rank)
 
