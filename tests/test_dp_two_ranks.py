@@ -58,7 +58,7 @@ out = {"rank": rank, "world": int(os.environ.get("WORLD_SIZE", "1")), "losses": 
        "params": {k: m.unet.get(k).detach().double().flatten()[:4096].cpu().tolist() for k in names},
        "moved": float((m.unet.get("mid_block1.block1.proj.weight").detach().cpu() - p0.cpu()).abs().mean()),
        "checksum_spread": m._dp.replica_checksum() if m._dp is not None else 0.0}
-print("RESULT " + json.dumps(out), flush=True)
+open(os.path.join(os.environ["LFDM_DP_OUT"], "rank%d.json" % rank), "w").write(json.dumps(out))      # (two ranks' long stdout lines interleave)
 import torch.distributed as dist
 if dist.is_initialized():
     dist.barrier(); dist.destroy_process_group()
@@ -68,7 +68,9 @@ if dist.is_initialized():
 def _launch(tmp_path, kind, world):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, LFDM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    outdir = tmp_path / ("out_w%d" % world)
+    outdir.mkdir()
+    env = dict(os.environ, LFDM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", LFDM_DP_OUT=str(outdir))
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
     if world == 1:
         cmd = [sys.executable, str(script), REPO, kind]
@@ -77,7 +79,7 @@ def _launch(tmp_path, kind, world):
                "--master-port", "29581", str(script), REPO, kind]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=3000)
     assert r.returncode == 0, r.stdout[-4000:]
-    outs = [json.loads(l[7:]) for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    outs = [json.loads((outdir / f).read_text()) for f in sorted(os.listdir(outdir))]
     assert len(outs) == world, r.stdout[-2000:]
     return sorted(outs, key=lambda o: o["rank"])
 
