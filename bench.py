@@ -70,62 +70,109 @@ def timed_region(run_step, steps, warmup, world, device_sync):
     return elapsed
 
 
-def conv_roofline(model, img, cond):
-    """One instrumented eager UNet step: every lfdm_conv2d_cl_f32 launch is bracketed by HIP events on the
-    launch stream; achieved = sum(algorithmic 2*M*N*K) / sum(kernel time)."""
+def sampler_step_convs(model):
+    """The lfdm_conv2d_cl_f32 launches of ONE sampler step (stem excluded: it is not a convolution launch), collected from
+    an eager run of the loop the sampler captures (LFDM_NO_GRAPH=1): the parameter structs stay valid afterwards because
+    every pointer in them is a weight pack or one of the executor's persistent arenas."""
     from cvpr23_lfdm_amd import ops
-    records = []
-    orig = ops.conv_launch
+    records, state = [], {"step": 0}
+    orig_conv, orig_step = ops.conv_launch, ops.sampler_step
 
-    def timed_launch(p):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(p)
-        e1.record()
-        rows = p.n_img * p.hq * p.wq
-        kdim = (p.c0 + p.c1) * p.kh * p.kw
-        # algorithmic bytes: input once + packed weights once + output once (fp32)
-        nbytes = 4.0 * (p.n_img * p.hi * p.wi * (p.c0 + p.c1) + kdim * p.cout + p.n_img * p.ho * p.wo * p.cout)
-        # launches given the Winograd F(2x2,3x3) form of the filter run 16 instead of 36 multiplications per output
-        # (conv_wino.hip; LFDM_WINO=0 disables): "achieved" stays the ALGORITHMIC direct-form count, the executed
-        # matrix-pipe work is reported next to it
-        executed = 2.0 * rows * p.cout * kdim * ((16.0 / 36.0) if (p.weight_wino and os.environ.get("LFDM_WINO", "1") != "0") else 1.0)
-        records.append((2.0 * rows * p.cout * kdim, e0, e1, nbytes, executed))
+    def conv_launch(p):
+        if state["step"] == 0:
+            records.append(p)
+        orig_conv(p)
 
-    unet = model.unet
-    b, t, s = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"]
-    x = torch.randn(b, 259, t, s, s, device=img.device)
-    x[:, 3:] = x[:, 3:, :1]
-    tt = torch.full((b,), 500, device=img.device)
-    with torch.no_grad():
-        unet.forward(x, tt, cond=cond)          # warm
-        torch.cuda.synchronize()
-        ops.conv_launch = timed_launch
-        try:
-            unet.forward(x, tt, cond=cond)
-        finally:
-            ops.conv_launch = orig
-        torch.cuda.synchronize()
-    flops = sum(r[0] for r in records)
-    ms = sum(r[1].elapsed_time(r[2]) for r in records)
-    achieved = flops / (ms * 1e-3) / 1e12
+    def sampler_step(*a, **k):
+        state["step"] += 1
+        return orig_step(*a, **k)
+
+    os.environ["LFDM_NO_GRAPH"] = "1"
+    ops.conv_launch, ops.sampler_step = conv_launch, sampler_step
+    try:
+        model.sample_one_video(cond_scale=1.0)
+    finally:
+        ops.conv_launch, ops.sampler_step = orig_conv, orig_step
+        os.environ.pop("LFDM_NO_GRAPH", None)
+    torch.cuda.synchronize()
+    # before the loop: the LFAE encoder's convolutions and the per-video `fea` term (7x7 over the 256 feature channels) - once
+    # per video, not part of a step
+    fea = [i for i, p in enumerate(records) if p.kh == 7 and p.c0 == 256]
+    assert len(fea) == 1, "unexpected launch order"
+    return records[fea[0] + 1:]
+
+
+def conv_work(p):
+    """(algorithmic direct-form FLOPs, algorithmic bytes = input once + filters once + output once) of one launch."""
+    probs = 4 if p.deconv4 else 1                                       # deconv4: four parity problems in the launch
+    kdim = (p.c0 + p.c1) // max(1, p.groups) * p.kh * p.kw
+    m = p.n_img * p.hq * p.wq
+    return (2.0 * m * p.cout * kdim * probs,
+            4.0 * (p.n_img * p.hi * p.wi * (p.c0 + p.c1) + kdim * p.cout * probs + p.n_img * p.ho * p.wo * p.cout))
+
+
+def graph_time(launch_all, replays=30):
+    """Average duration of a launch sequence under the conditions of the real step: captured once, replayed back to back."""
+    launch_all()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch_all()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / replays
+
+
+def conv_roofline(model, ms_per_sampler_step):
+    """Roofline of the dominant kernel, measured live: the Winograd convolution launches (conv_wino_kernel) of one sampler
+    step are re-captured as their own hipGraph - same parameter structs, same arenas, 40 different filter sets so the
+    weights are as cold as in the real step - and replayed; achieved = sum of their ALGORITHMIC (direct-form) FLOPs / that
+    time.  The direct-form schedules (conv_ksw / conv_igemm + split-K reduce) get the same treatment as a second row."""
+    from cvpr23_lfdm_amd import ops
+    convs = sampler_step_convs(model)
+    fam = {"winograd": [], "direct": []}
+    for p in convs:
+        fam["winograd" if (p.weight_wino and p.kh == 3 and os.environ.get("LFDM_WINO", "1") != "0") else "direct"].append(p)
+    rows = {}
+    for name, ps in fam.items():
+        if not ps:
+            continue
+        sec = graph_time(lambda ps=ps: [ops.conv_launch(p) for p in ps])
+        flops = sum(conv_work(p)[0] for p in ps)
+        nbytes = sum(conv_work(p)[1] for p in ps)
+        rows[name] = {"launches": len(ps), "us_per_step": round(sec * 1e6, 1), "us_per_launch": round(sec * 1e6 / len(ps), 2),
+                      "gflop_per_step": round(flops / 1e9, 2), "tflops": round(flops / sec / 1e12, 2),
+                      "frac": round(flops / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_bytes_per_step": round(nbytes)}
+    w = rows["winograd"]
+    executed = w["gflop_per_step"] * 16.0 / 36.0
     traffic, traffic_src = None, None
-    tf = os.path.join(REPO_ROOT, "profiles", "r01_o_traffic.json")
-    if os.path.exists(tf):          # PMC counters cannot be read from inside the process: committed rocprofv3 pass
+    tf = os.path.join(REPO_ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tf):          # PMC counters cannot be read from inside the process: committed rocprofv3 passes of this build
         with open(tf) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj["conv_bytes_per_step"], tj["source"]
-    executed = sum(r[4] for r in records)
-    return {"bound": "mfma", "kernel": "lfdm_conv2d_cl_f32 = conv_wino_kernel (3x3, Winograd F(2x2,3x3)) + conv_ksw_kernel + conv_igemm_kernel "
-                                       "(+ split-K reduce), all launches of one eager UNet step",
-            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM-side bytes per UNet step summed over the same launches (rocprofv3 PMC, not live)",
-            "traffic_source": traffic_src, "algorithmic_bytes_per_step": round(sum(r[3] for r in records)),
-            "launches": len(records), "gflop_per_step": round(flops / 1e9, 2), "ms_per_step_in_kernel": round(ms, 3),
-            "executed_mfma_gflop_per_step": round(executed / 1e9, 2),
-            "executed_mfma_tflops": round(executed / (ms * 1e-3) / 1e12, 3),
-            "note": "achieved/frac count the reference's direct-form FLOPs; the Winograd launches execute 4/9 of theirs on the matrix pipe"}
+        traffic, traffic_src = tj.get("wino_bytes_per_step"), tj.get("source")
+    all_flops = sum(r["gflop_per_step"] for r in rows.values())
+    all_us = sum(r["us_per_step"] for r in rows.values())
+    return {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) - the %d launches of one "
+                                       "sampler step, incl. their split-K reduce passes" % w["launches"],
+            "achieved": w["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": w["frac"],
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per sampler step over the same launches (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not live)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_step": w["algorithmic_bytes_per_step"],
+            "launches": w["launches"], "us_per_launch": w["us_per_launch"], "gflop_per_step": w["gflop_per_step"],
+            "executed_mfma_tflops": round(executed / (w["us_per_step"] * 1e-6) / 1e3, 2),
+            "executed_mfma_frac": round(executed / (w["us_per_step"] * 1e-6) / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "families": rows,
+            "all_convolutions": {"gflop_per_step": round(all_flops, 2), "us_per_step": round(all_us, 1),
+                                 "tflops": round(all_flops / all_us * 1e3, 2), "frac": round(all_flops / all_us * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "sampler_step_us": round(ms_per_sampler_step * 1e3, 1),
+            "note": "achieved / frac count the reference's direct-form FLOPs (SURVEY.md 8d); the Winograd launches execute 16/36 of theirs "
+                    "on the matrix pipe (executed_*); measured by replaying the step's own launches as a hipGraph on this stream"}
 
 
 def warp_bench(model, img, iters=20):
@@ -175,10 +222,16 @@ def warp_bench(model, img, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     gbs = nbytes / sec / 1e9
+    traffic = None
+    tf = os.path.join(REPO_ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tf):
+        with open(tf) as f:
+            traffic = json.load(f).get("warp_bytes_per_video")
     return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 5 launches = all warps of one 40-frame decode)",
             "us_per_video": round(sec * 1e6, 1), "elements": elems,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
+                         "frac": round(gbs / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": nbytes,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/warp_only.py (tools/prof_traffic.sh), not live"}}
 
 
 def train_bench(dev, rank, world, steps, warmup, batch):
@@ -219,9 +272,10 @@ def train_bench(dev, rank, world, steps, warmup, batch):
 
 
 def cpu_baseline():
-    """The CPU oracle (oracle/lfdm_oracle.py, a port of the reference dataflow) on this host, bounded sample:
-    2 UNet forwards at the C2 shape + compute_fea + 2 decoded frames, extrapolated linearly to one video
-    (per-step cost is step independent)."""
+    """The CPU oracle (oracle/lfdm_oracle.py, a torch-CPU port of the reference dataflow; the reference tree itself is not on
+    the GPU box) on this host, bounded sample: the thread count is swept over {8, 16, 32, 64, all} on one UNet forward at the
+    C2 shape, the best setting is then timed on 3 forwards + compute_fea + 3 decoded frames, and extrapolated linearly to
+    one video (per-step cost is step independent)."""
     sys.path.insert(0, os.path.join(REPO_ROOT, "oracle"))
     import lfdm_oracle as O
     import synth
@@ -232,28 +286,42 @@ def cpu_baseline():
     img, cond = synth.inputs(b, hw)
     x = torch.randn(b, 259, t, s, s)
     tt = torch.full((b,), 500, dtype=torch.long)
+    ncpu = os.cpu_count() or 1
+    sweep = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        fea = O.generator_compute_fea(gsd, img)
-        t_fea = time.perf_counter() - t0
         O.unet_forward(dsd, x, tt, cond)        # warm-up (thread pools, allocator)
-        t0 = time.perf_counter()
-        n_unet = 2
-        for _ in range(n_unet):
+        for n in sorted({min(v, ncpu) for v in (8, 16, 32, 64, ncpu)}):
+            torch.set_num_threads(n)
             O.unet_forward(dsd, x, tt, cond)
-        t_unet = (time.perf_counter() - t0) / n_unet
+            t0 = time.perf_counter()
+            O.unet_forward(dsd, x, tt, cond)
+            sweep[n] = time.perf_counter() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        n_unet = 3
+        times = []
+        for _ in range(n_unet):
+            t0 = time.perf_counter()
+            O.unet_forward(dsd, x, tt, cond)
+            times.append(time.perf_counter() - t0)
+        t_unet = sum(times) / n_unet
+        t0 = time.perf_counter()
+        O.generator_compute_fea(gsd, img)
+        t_fea = time.perf_counter() - t0
         flow = torch.rand(b, s, s, 2) * 2 - 1
         occ = torch.rand(b, 1, s, s)
+        O.generator_forward_with_flow(gsd, img, flow, occ)
         t0 = time.perf_counter()
-        n_dec = 2
+        n_dec = 3
         for _ in range(n_dec):
             O.generator_forward_with_flow(gsd, img, flow, occ)
         t_dec = (time.perf_counter() - t0) / n_dec
     per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t * t_dec
-    return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/lfdm_oracle.py on host CPU: %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each, compute_fea %.3f s, "
-                      "%d decode frames = %.3f s each; extrapolated to %d steps + %d frames"
-                      % (n_unet, b, t, s, s, t_unet, t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
+    return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "thread_sweep_s_per_unet_forward": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": "oracle/lfdm_oracle.py on host CPU, %d threads (best of the sweep): %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each "
+                      "(min %.2f, max %.2f), compute_fea %.3f s, %d decode frames = %.3f s each; extrapolated to %d steps + %d frames"
+                      % (best, n_unet, b, t, s, s, t_unet, min(times), max(times), t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
 
 
 def main():
@@ -263,7 +331,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=2, help="timed DM training steps for the extra `train` object (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed DM training steps for the extra `train` object (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=8, help="training videos per GPU per step")
     ap.add_argument("--train-timeout", type=int, default=240, help="seconds before the training measurement is abandoned")
     ap.add_argument("--batch", type=int, default=1,
@@ -318,7 +386,7 @@ def main():
             "whole_job_tflops_reference_dataflow": round(value * GFLOP_PER_VIDEO_REFERENCE / 1e3, 2),
         }
         if not args.no_roofline:
-            line["roofline"] = conv_roofline(model, img, cond)
+            line["roofline"] = conv_roofline(model, 1e3 * elapsed / args.steps / WORKLOAD["sampling_timesteps"])
             line["warp"] = warp_bench(model, img)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
@@ -338,7 +406,7 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            train = train_bench(dev, rank, world, args.train_steps, 1, args.train_batch)
+            train = train_bench(dev, rank, world, args.train_steps, 2, args.train_batch)
         except Exception as e:               # never lose the headline line to the secondary measurement
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         watchdog.cancel()

@@ -19,6 +19,8 @@
 //  * the scores are computed TRANSPOSED too (S^T = K Q^T): lane = query token, registers = key tokens, so the softmax
 //    over the keys is a register reduction + two shuffles and P^T is already the A operand of P V: no LDS at all.
 // Weight fragments (rows of W, contiguous over channels) come from L2 as float4.
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -421,6 +423,10 @@ int launch_fused(const float* x, int ldx, const float* wqkv, float* out, int bat
   const int64_t nseq = (int64_t)batch * hw;
   int hpb = 8;                                       // heads per workgroup: aim at >= 2048 workgroups
   while (hpb > 1 && nseq * (HEADS / hpb) < 2048) hpb >>= 1;
+  if (const char* e = getenv("LFDM_TATTN_HPB")) {    // experiment knob (tools/bench_attn.py)
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) hpb = v;
+  }
   const dim3 grid((unsigned)nseq, (unsigned)(HEADS / hpb)), block(64);
   if (frames <= 16) LFDM_LAUNCH((temporal_attn_fused_kernel<16, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);
   else if (frames <= 32) LFDM_LAUNCH((temporal_attn_fused_kernel<32, C>), grid, block, 0, stream, x, ldx, hpb, wqkv, out, batch, frames, hw, bias, rot_cos, rot_sin, eps);

@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   constexpr int VSZ = 16 * WT * LD;
   __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
-  __shared__ int s_n[WT], s_ty[WT], s_tx[WT];
   __shared__ float s_gn[2][4][WNB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,20 +92,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const int kc_end = (int)((int64_t)nchunks_all * (bz + 1) / ksplit);
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
 
-  if (tid < WT) {
-    const unsigned t = t0 + tid;
-    int n = -1, ty = 0, tx = 0;
+  // every thread derives the coordinates of ITS tile (tid >> 3 - the same tile in the input transform and in the epilogue)
+  // itself: no LDS table, no barrier before the first loads are issued
+  int my_n = -1, my_ty = 0, my_tx = 0;
+  {
+    const unsigned t = t0 + (tid >> 3);
     if (t < ntiles) {
-      n = (int)(t / (unsigned)(th * tw));
-      const unsigned rem = t - (unsigned)n * (th * tw);
-      ty = (int)(rem / (unsigned)tw);
-      tx = (int)(rem - (unsigned)ty * tw);
+      my_n = (int)(t / (unsigned)(th * tw));
+      const unsigned rem = t - (unsigned)my_n * (th * tw);
+      my_ty = (int)(rem / (unsigned)tw);
+      my_tx = (int)(rem - (unsigned)my_ty * tw);
     }
-    s_n[tid] = n;
-    s_ty[tid] = ty;
-    s_tx[tid] = tx;
   }
-  __syncthreads();
 
   // ---- input transform: one (tile, channel pair) patch per thread ----
   const int x_tile = tid >> 3, x_c2 = tid & 7;              // 32 tiles x 8 channel pairs = 256 threads
@@ -117,8 +114,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   // may wrap for the patch corner outside the image - those taps are masked to the out-of-range offset anyway
   uint32_t base0 = 0, base1 = 0;     // byte offset of the patch's (0,0) corner + this thread's channel pair, per source
   unsigned valid_mask = 0;           // bit (py*4+px): patch pixel inside the image
-  if (s_n[x_tile] >= 0) {
-    const int n = s_n[x_tile], ty = s_ty[x_tile], tx = s_tx[x_tile];
+  if (my_n >= 0) {
+    const int n = my_n, ty = my_ty, tx = my_tx;
     // physical pixel of the patch corner: logical (2ty-1, 2tx-1); through the upsample that is (ty-1, tx-1)
     const uint32_t pix = up ? (uint32_t)((n * p.hi + ty - 1) * p.wi + tx - 1)
                             : (uint32_t)((n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1);
@@ -259,8 +256,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     for (int e = 0; e < 4; ++e) gs[ct][e] = gq[ct][e] = 0.f;
     float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && ksplit == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
-    const int n = s_n[e_tile];
-    const int64_t orow0 = ((int64_t)n * p.hq + 2 * s_ty[e_tile]) * p.wq + 2 * s_tx[e_tile];
+    const int n = my_n;                                 // e_tile == x_tile == tid >> 3
+    const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
     const bool live = n >= 0 && co < p.coutp;
     float4 res[4];
 #pragma unroll

@@ -94,17 +94,19 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
     spec += _conv_entries("init_conv.", dim, channels, 1, init_kernel_size, init_kernel_size)
 
     def temporal(prefix, c):
+        # registration order = the reference's named_parameters() order (PreNorm registers `fn` before `norm`, :182-186), so
+        # that a torch.optim state_dict saved by the reference (indexed by parameter position) loads into FlatAdam
         return [
-            (prefix + "fn.norm.gamma", (1, c, 1, 1, 1), ("ones",), False),
             (prefix + "fn.fn.fn.to_qkv.weight", (3 * hidden, c), ("uniform", 1 / math.sqrt(c)), False),
             (prefix + "fn.fn.fn.to_out.weight", (c, hidden), ("uniform", 1 / math.sqrt(hidden)), False),
             (prefix + "fn.fn.fn.rotary_emb.freqs", (dim_head // 2,), ("const", rotary_freqs(dim_head)), True),
+            (prefix + "fn.norm.gamma", (1, c, 1, 1, 1), ("ones",), False),
         ]
 
     def spatial_linear(prefix, c):
-        return ([(prefix + "fn.norm.gamma", (1, c, 1, 1, 1), ("ones",), False)]
-                + _conv_entries(prefix + "fn.fn.to_qkv.", 3 * hidden, c, 1, 1, bias=False)
-                + _conv_entries(prefix + "fn.fn.to_out.", c, hidden, 1, 1))
+        return (_conv_entries(prefix + "fn.fn.to_qkv.", 3 * hidden, c, 1, 1, bias=False)
+                + _conv_entries(prefix + "fn.fn.to_out.", c, hidden, 1, 1)
+                + [(prefix + "fn.norm.gamma", (1, c, 1, 1, 1), ("ones",), False)])
 
     def resblock(prefix, cin, cout, cond=True):
         out = []
@@ -133,13 +135,7 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
         spec += spatial_linear(p + "2.", co) + temporal(p + "3.", co)
         if lvl < n_res - 1:
             spec += _conv_entries(p + "4.", co, co, 1, 4, 4)
-    mid = dims[-1]
-    spec += resblock("mid_block1.", mid, mid)
-    spec += [("mid_spatial_attn.fn.norm.gamma", (1, mid, 1, 1, 1), ("ones",), False),
-             ("mid_spatial_attn.fn.fn.fn.to_qkv.weight", (3 * hidden, mid), ("uniform", 1 / math.sqrt(mid)), False),
-             ("mid_spatial_attn.fn.fn.fn.to_out.weight", (mid, hidden), ("uniform", 1 / math.sqrt(hidden)), False)]
-    spec += temporal("mid_temporal_attn.", mid)
-    spec += resblock("mid_block2.", mid, mid)
+    # (the reference creates `downs` and `ups` before the mid_* modules, :455-456: same registration order here)
     for lvl, (ci, co) in enumerate(reversed(in_out)):
         p = "ups.%d." % lvl
         spec += resblock(p + "0.", co * 2, ci) + resblock(p + "1.", ci, ci)
@@ -151,6 +147,13 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
                          (p + "4.bias", (ci,), ("uniform", b), False)]
             else:
                 spec += _conv_entries(p + "4.1.", ci, ci, 1, 3, 3)
+    mid = dims[-1]
+    spec += resblock("mid_block1.", mid, mid)
+    spec += [("mid_spatial_attn.fn.fn.fn.to_qkv.weight", (3 * hidden, mid), ("uniform", 1 / math.sqrt(mid)), False),
+             ("mid_spatial_attn.fn.fn.fn.to_out.weight", (mid, hidden), ("uniform", 1 / math.sqrt(hidden)), False),
+             ("mid_spatial_attn.fn.norm.gamma", (1, mid, 1, 1, 1), ("ones",), False)]
+    spec += temporal("mid_temporal_attn.", mid)
+    spec += resblock("mid_block2.", mid, mid)
     for head, od in (("final_conv.", out_grid_dim), ("occlusion_map.", out_conf_dim)):
         spec += resblock(head + "0.", dim * 2, dim, cond=False)
         spec += _conv_entries(head + "1.", od, dim, 1, 1, 1)

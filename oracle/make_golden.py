@@ -9,6 +9,7 @@ Only OUTPUTS are stored; inputs and weights are re-derived from the seeds record
 
     python oracle/make_golden.py            # small cases (seconds)
     python oracle/make_golden.py --c2       # + one C2-shape UNet forward and a full C2 DDIM-100 video (minutes)
+    python oracle/make_golden.py --full c3|c4|c5    # full-size cases of BASELINE.json configs[2..4] (compact fixtures)
 """
 import argparse
 import os
@@ -97,7 +98,7 @@ def generator_case(name, b, hw):
     save(name, b=b, hw=hw, fea=fea, prediction=out["prediction"], deformed=out["deformed"])
 
 
-def train_case(name, b, t, hw, labels):
+def train_case(name, b, t, hw, labels, compact=False):
     """One full DM training step of the reference (FlowDiffusion.optimize_parameters, single-GPU class) on synthetic
     frozen-LFAE + UNet checkpoints: pseudo ground truth, losses, per-parameter gradient / updated-weight statistics.
     Randomness (t, noise) is replaced by recorded tensors; null_cond_prob = 0 (labels 'None' exercise none_cond_mask);
@@ -134,6 +135,17 @@ def train_case(name, b, t, hw, labels):
         pnorm.append(float(p.detach().double().norm()))
         if p.numel() <= 128:
             small["grad/" + k] = p.grad.detach()
+    if compact:          # full-T fixture: strided sub-tensors + statistics / projections instead of whole videos
+        sub = lambda v: v[:, :, ::8, ::2, ::2].clone()
+        st_g, pr_g = probes(m.real_vid_grid)
+        st_x, pr_x = probes(m.diffusion.pred_x0)
+        save(name, b=b, t=t, hw=hw, labels=np.array(labels), names=np.array(names), grad_norm=np.array(gnorm),
+             grad_probe=np.array(gprobe), param_norm_after=np.array(pnorm), real_vid_grid=sub(m.real_vid_grid),
+             real_vid_conf=sub(m.real_vid_conf), grid_stats=st_g, grid_probes=pr_g, pred_x0=sub(m.diffusion.pred_x0),
+             pred_x0_stats=st_x, pred_x0_probes=pr_x, real_out_vid=m.real_out_vid[:, :, -1, ::2, ::2], fake_out_vid=m.fake_out_vid[:, :, -1, ::2, ::2],
+             loss=m.loss.detach(), rec_loss=m.rec_loss, rec_warp_loss=m.rec_warp_loss,
+             null_cond_mask=m.diffusion.denoise_fn.null_cond_mask, **small)
+        return
     save(name, b=b, t=t, hw=hw, labels=np.array(labels), names=np.array(names), grad_norm=np.array(gnorm),
          grad_probe=np.array(gprobe), param_norm_after=np.array(pnorm),
          real_vid_grid=m.real_vid_grid, real_vid_conf=m.real_vid_conf, real_out_vid=m.real_out_vid[:, :, -1],
@@ -141,6 +153,64 @@ def train_case(name, b, t, hw, labels):
          fake_warped_vid=m.fake_warped_vid[:, :, -1], ref_img_fea_sum=m.ref_img_fea.double().sum(),
          ref_img_fea_slice=m.ref_img_fea[:, ::32, ::4, ::4], pred_x0=m.diffusion.pred_x0, loss=m.loss.detach(),
          rec_loss=m.rec_loss, rec_warp_loss=m.rec_warp_loss, null_cond_mask=m.diffusion.denoise_fn.null_cond_mask, **small)
+
+
+def probes(x, n=64, seed=5):
+    """Compact but sensitive summary of a big tensor: per-sample (mean, mean |x|, std) + n random projections per sample
+    (numpy PCG64 directions over the flattened sample, unit variance) - what the full-size fixtures store instead of the
+    tensors themselves."""
+    x = x.detach().double().reshape(x.shape[0], -1)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d = torch.from_numpy(rng.standard_normal((n, x.shape[1])))
+    stats = torch.stack((x.mean(1), x.abs().mean(1), x.std(1)), dim=1)
+    return stats, (x @ d.t()) / np.sqrt(x.shape[1])
+
+
+def c3_steps_case(name, b=16, t=40, s=32, steps=(999, 500, 0)):
+    """BASELINE.json configs[2] at FULL size (MHAD, DDPM-1000, batch 16): teacher-forced single sampler steps.  For each
+    timestep the reference's p_sample (:737-746) maps a seeded x_t to x_{t-1} with a seeded noise draw; the fixture keeps a
+    strided sub-tensor, per-sample statistics and random projections of every result."""
+    m = reference_model(s, t, 1000)
+    rng = np.random.Generator(np.random.PCG64(31))
+    fea = torch.from_numpy(rng.standard_normal((b, 256, s, s)).astype(np.float32))
+    cond = torch.from_numpy(rng.standard_normal((b, 768)).astype(np.float32))
+    out = {}
+    for i, step in enumerate(steps):
+        x_t = torch.from_numpy(rng.standard_normal((b, 3, t, s, s)).astype(np.float32))
+        noise = torch.from_numpy(rng.standard_normal((b, 3, t, s, s)).astype(np.float32))
+        randn_like = torch.randn_like
+        torch.randn_like = lambda x, **k: noise.clone()
+        try:
+            y = m.diffusion.p_sample(x_t, torch.full((b,), step, dtype=torch.long), fea, cond=cond, cond_scale=1.0)
+        finally:
+            torch.randn_like = randn_like
+        st, pr = probes(y)
+        out["x_prev_%d" % i], out["stats_%d" % i], out["probes_%d" % i] = y[:, :, ::8, ::4, ::4].clone(), st, pr
+        print("c3 step t=%d done" % step, flush=True)
+    save(name, b=b, t=t, s=s, steps=np.array(steps), input_seed=31, **out)
+
+
+def train_full_case(name, b=4, t=40, hw=128):
+    """BASELINE.json configs[3] per-GPU shape class at full T: one reference training step (B=4, T=40, 128x128)."""
+    labels = ["label a", "None", "label c", "label d"][:b]
+    train_case(name, b, t, hw, labels, compact=True)
+
+
+def c5_case(name, b=1, t=40, s=64, hw=256, steps=10):
+    """BASELINE.json configs[4] geometry at FULL frame count: NATOPS variant (learned null condition, nearest-upsample +
+    reflect-padded Upsample), 64x64 latent, 256x256 frames, 40 frames, DDIM (10 of the 50 steps: minutes on this CPU)."""
+    variant = dict(learn_null_cond=True, use_deconv=False, padding_mode="reflect")
+    m = reference_model(s, t, steps, 1000, **variant)
+    img, cond = synth.inputs(b, hw)
+    m.set_sample_input(sample_img=img, sample_text=cond)
+    with patched_noise(synth.NoiseTape(11)), torch.no_grad():
+        m.sample_one_video(cond_scale=1.0)
+    vf = np.array([0, 20, 39])
+    st, pr = probes(m.sample_out_vid)
+    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=1000, noise_seed=11, video_frames=vf,
+         sample_vid_grid=m.sample_vid_grid[:, :, :, ::2, ::2], sample_vid_conf=m.sample_vid_conf[:, :, :, ::2, ::2],
+         sample_out_vid=m.sample_out_vid[:, :, vf][..., ::2, ::2], sample_warped_vid=m.sample_warped_vid[:, :, vf][..., ::2, ::2],
+         out_stats=st, out_probes=pr)
 
 
 def op_cases():
@@ -165,8 +235,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true")
     ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
+    ap.add_argument("--full", choices=["c3", "c4", "c5"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.full:
+        {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"), "c4": lambda: train_full_case("train_step_c4_b4_t40"),
+         "c5": lambda: c5_case("sample_ddim10_c5_256")}[args.full]()
+        return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])
         return

@@ -1,0 +1,142 @@
+"""FULL-SIZE parity for the other BASELINE.json configurations (configs[2..4]), against compact fixtures minted from the
+unmodified reference at those sizes (oracle/make_golden.py --full c3|c4|c5: strided sub-tensors + per-sample statistics +
+random projections of every result, so batch-16 / 40-frame / 256x256 tensors are pinned without storing them).
+
+  c3  MHAD shape class, DDPM-1000, batch 16, 40 frames: teacher-forced sampler steps at t = 999, 500, 0 through the REAL
+      sampling path (fea term, step tables, stem, trunk, radix-select threshold, update; one captured hipGraph per call)
+  c4  one DM training step at B = 4, T = 40, 128x128 (pseudo ground truth of 160 frames, loss, pred_x0, every gradient norm)
+  c5  NATOPS variant (learned null condition, upsample + reflect), 64x64 latent, 256x256 frames, 40 frames, DDIM-10
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from util import assert_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+pytestmark = pytest.mark.gpu
+
+
+def gold(name):
+    path = os.path.join(GOLD, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % name)
+    return {k: np.asarray(v) for k, v in np.load(path).items()}
+
+
+def probes(x, n=64, seed=5):
+    """oracle/make_golden.py::probes on the device tensor."""
+    x = x.detach().double().reshape(x.shape[0], -1).cpu()
+    d = torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal((n, x.shape[1])))
+    return torch.stack((x.mean(1), x.abs().mean(1), x.std(1)), dim=1), (x @ d.t()) / np.sqrt(x.shape[1])
+
+
+@pytest.fixture(autouse=True)
+def _hip():
+    from cvpr23_lfdm_amd import _native
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _native._set_library_for_tests(None)
+
+
+def test_c3_ddpm_steps_batch16():
+    g = gold("c3_ddpm_steps_b16")
+    b, t, s = int(g["b"]), int(g["t"]), int(g["s"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=1000)
+    dif = m.diffusion
+    rng = np.random.Generator(np.random.PCG64(int(g["input_seed"])))
+    fea = torch.from_numpy(rng.standard_normal((b, 256, s, s)).astype(np.float32)).cuda()
+    cond = torch.from_numpy(rng.standard_normal((b, 768)).astype(np.float32)).cuda()
+    times, coef, _ = dif._step_tables(False)
+    for i, step in enumerate(g["steps"].tolist()):
+        x_t = torch.from_numpy(rng.standard_normal((b, 3, t, s, s)).astype(np.float32))
+        noise = torch.from_numpy(rng.standard_normal((b, 3, t, s, s)).astype(np.float32))
+        k = times.index(step)
+        dif._step_tables = lambda ddim, k=k: ([times[k]], coef[k:k + 1].contiguous(), [True])        # ONE teacher-forced step
+        tape = iter([x_t, noise])
+        dif.noise_source = lambda shape: next(tape)                     # first draw = "x_T" (our x_t), second = the step's noise
+        y = dif.sample(fea, cond=cond, cond_scale=1.0)
+        assert y.shape == (b, 3, t, s, s) and bool(torch.isfinite(y).all())
+        assert_close(y[:, :, ::8, ::4, ::4].cpu(), torch.from_numpy(g["x_prev_%d" % i]), 1e-3, "x_{t-1} sub-tensor, t=%d" % step)
+        st, pr = probes(y)
+        assert_close(st.float(), torch.from_numpy(g["stats_%d" % i]).float(), 1e-3, "per-sample statistics, t=%d" % step)
+        assert_close(pr.float(), torch.from_numpy(g["probes_%d" % i]).float(), 2e-3, "random projections, t=%d" % step)
+
+
+def test_c4_training_step_t40(monkeypatch):
+    g = gold("train_step_c4_b4_t40")
+    b, t, hw = int(g["b"]), int(g["t"]), int(g["hw"])
+    from cvpr23_lfdm_amd import FlowDiffusion
+    m = FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=0.0, is_train=True, lr=1e-3,
+                      config_pth=synth.CONFIG, pretrained_pth="")
+    m.unet.load_state_dict(synth.unet_state())
+    m.generator.load_state_dict(synth.generator_state())
+    m.region_predictor.load_state_dict(synth.region_state())
+    m.bg_predictor.load_state_dict(synth.bg_state())
+    for net in (m.generator, m.region_predictor, m.bg_predictor):
+        net.eval()
+        m.set_requires_grad(net, False)
+    m.to("cuda")
+    ref_img, real_vid, cond, tt, noise = synth.train_inputs(b, t, hw)
+    m.diffusion.text_encoder = lambda texts: cond
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: tt.clone().to(k.get("device", "cpu")))
+    monkeypatch.setattr(torch, "randn_like", lambda x, **k: noise.clone().to(x.device))
+    m.set_train_input(ref_img=ref_img.cuda(), real_vid=real_vid.cuda(), ref_text=[str(x) for x in g["labels"]])
+    m.optimize_parameters()
+    monkeypatch.undo()
+    T = lambda k: torch.from_numpy(g[k])
+    sub = lambda v: v[:, :, ::8, ::2, ::2].cpu()
+    assert_close(sub(m.real_vid_grid), T("real_vid_grid"), 1e-3, "pseudo-GT flow (160 frames)")
+    assert_close(sub(m.real_vid_conf), T("real_vid_conf"), 1e-3, "pseudo-GT occlusion")
+    st, pr = probes(m.real_vid_grid)
+    assert_close(st.float(), T("grid_stats").float(), 1e-3, "flow statistics")
+    assert_close(pr.float(), T("grid_probes").float(), 2e-3, "flow projections")
+    assert bool((m.unet.null_cond_mask.cpu() == T("null_cond_mask")).all())
+    assert_close(sub(m.diffusion.pred_x0), T("pred_x0"), 2e-3, "pred_x0")
+    st, pr = probes(m.diffusion.pred_x0)
+    assert_close(st.float(), T("pred_x0_stats").float(), 2e-3, "pred_x0 statistics")
+    assert_close(pr.float(), T("pred_x0_probes").float(), 3e-3, "pred_x0 projections")
+    assert_close(m.real_out_vid[:, :, -1, ::2, ::2].cpu(), T("real_out_vid"), 1e-3, "real_out_vid")
+    assert_close(m.fake_out_vid[:, :, -1, ::2, ::2].cpu(), T("fake_out_vid"), 2e-3, "fake_out_vid")
+    for k in ("loss", "rec_loss", "rec_warp_loss"):
+        got, want = float(getattr(m, k)), float(g[k])
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (k, got, want)
+    names = [str(n) for n in g["names"]]
+    params = dict(m.diffusion.named_parameters())
+    rng = np.random.Generator(np.random.PCG64(77))
+    worst = ("", 0.0)
+    for i, k in enumerate(names):
+        p = params[k]
+        gr = p.grad.detach().double().cpu()
+        probe = torch.from_numpy(rng.standard_normal(p.numel())).view_as(gr)
+        want = float(g["grad_norm"][i])
+        for tag, e in (("grad norm", abs(float(gr.norm()) - want) / (want + 1e-12)),
+                       ("grad probe", abs(float((gr * probe).sum()) - float(g["grad_probe"][i])) / (want * np.sqrt(p.numel()) + 1e-12)),
+                       ("updated weight norm", abs(float(p.detach().double().norm()) - float(g["param_norm_after"][i])) / (float(g["param_norm_after"][i]) + 1e-12))):
+            if e > worst[1]:
+                worst = ("%s of %s" % (tag, k), e)
+    assert worst[1] < 5e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
+
+
+def test_c5_natops_256_t40():
+    g = gold("sample_ddim10_c5_256")
+    b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=int(g["steps"]), timesteps=int(g["timesteps"]),
+                                         learn_null_cond=True, use_deconv=False, padding_mode="reflect")
+    img, cond = synth.inputs(b, hw)
+    m.diffusion.noise_source = synth.NoiseTape(int(g["noise_seed"]))
+    m.set_sample_input(sample_img=img.cuda(), sample_text=cond.cuda())
+    m.sample_one_video(cond_scale=1.0)
+    vf = torch.from_numpy(g["video_frames"]).long()
+    T = lambda k: torch.from_numpy(g[k])
+    assert m.sample_out_vid.shape == (b, 3, t, hw, hw)
+    assert_close(m.sample_vid_grid[:, :, :, ::2, ::2].cpu(), T("sample_vid_grid"), 1e-3, "flow")
+    assert_close(m.sample_vid_conf[:, :, :, ::2, ::2].cpu(), T("sample_vid_conf"), 1e-3, "occlusion")
+    assert_close(m.sample_out_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_out_vid"), 1e-3, "frames")
+    assert_close(m.sample_warped_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_warped_vid"), 1e-3, "warped frames")
+    st, pr = probes(m.sample_out_vid)
+    assert_close(st.float(), T("out_stats").float(), 1e-3, "video statistics")
+    assert_close(pr.float(), T("out_probes").float(), 2e-3, "video projections")

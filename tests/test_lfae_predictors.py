@@ -1,6 +1,8 @@
 """The frozen LFAE region predictor as the DM training step runs it (cvpr23_lfdm_amd.lfae_predictors.RegionPredictorExec:
 batched frames, native convolutions, the device-side LAPACK-convention 2x2 SVD) against the CPU oracle's restatement of
 LFAE/modules/region_predictor.py:52-117 (which calls torch.svd on the host like the reference)."""
+import os
+
 import pytest
 import torch
 
@@ -35,3 +37,50 @@ def test_region_predictor(backend, pad):
     u, sv, _ = torch.svd(got["covar"].cpu().reshape(-1, 2, 2))
     host = (u @ torch.diag_embed(sv.sqrt())).view(*got["affine"].shape)
     assert_close(got["affine"].cpu(), host, 1e-4, "device closed form vs host LAPACK")
+
+
+def test_bg_motion_predictor(backend):
+    """BGMotionPredictorExec (bg_motion_predictor.py:42-57: encoder-only hourglass over cat(source, driving) -> global
+    average -> fc -> 3x3 affine) directly against the oracle - not only through the training-step fixture."""
+    dev = backend
+    from cvpr23_lfdm_amd import FlowDiffusion
+    m = FlowDiffusion(img_size=32, num_frames=2, sampling_timesteps=5, is_train=False, config_pth=synth.CONFIG, pretrained_pth="")
+    bsd = synth.bg_state()
+    m.bg_predictor.load_state_dict(bsd)
+    net = m.bg_predictor.to(dev).eval()
+    g = torch.Generator().manual_seed(78)
+    n = 3 if dev == "cuda" else 1
+    src, drv = torch.rand(n, 3, 128, 128, generator=g), torch.rand(n, 3, 128, 128, generator=g)
+    with torch.no_grad():
+        ref = O.bg_predictor({k: v.float() for k, v in bsd.items()}, src, drv)
+        got = net(src.to(dev), drv.to(dev))
+    assert got.shape == (n, 3, 3)
+    assert_close(got.cpu(), ref, 1e-3, "background affine")
+    assert float((ref[:, :2] - torch.eye(3)[:2]).abs().max()) > 1e-3          # not the trivial identity
+
+
+def test_pixelwise_flow_predictor(backend):
+    """PixelwiseFlowPredictorExec (pixelwise_flow_predictor.py:48-137: heat-maps, sparse motions through inv(affine), deformed
+    sources, hourglass, softmax mask -> flow + occlusion) directly against the oracle, fed with oracle region parameters."""
+    dev = backend
+    from cvpr23_lfdm_amd import FlowDiffusion
+    from cvpr23_lfdm_amd.lfae_predictors import PixelwiseFlowPredictorExec
+    m = FlowDiffusion(img_size=32, num_frames=2, sampling_timesteps=5, is_train=False, config_pth=synth.CONFIG, pretrained_pth="")
+    gsd, rsd, bsd = synth.generator_state(), synth.region_state(), synth.bg_state()
+    m.generator.load_state_dict(gsd)
+    m.generator.to(dev).eval()
+    g = torch.Generator().manual_seed(79)
+    n = 2
+    src = torch.rand(n, 3, 128, 128, generator=g)
+    drv_img = (0.8 * torch.roll(src, shifts=(5, -3), dims=(2, 3)) + 0.2 * torch.rand(n, 3, 128, 128, generator=g)).clamp(0, 1)
+    f32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    with torch.no_grad():
+        s_par, d_par = O.region_predictor(f32(rsd), src), O.region_predictor(f32(rsd), drv_img)
+        bg = O.bg_predictor(f32(bsd), src, drv_img)
+        ref = O.pixelwise_flow_predictor(f32(gsd), src, d_par, s_par, bg)
+        ex = PixelwiseFlowPredictorExec(m.generator, num_regions=10)
+        to = lambda d: {k: v.to(dev) for k, v in d.items() if k != "heatmap"}
+        got = ex(src.to(dev), to(d_par), to(s_par), bg.to(dev))
+    assert got["optical_flow"].shape == (n, 32, 32, 2) and got["occlusion_map"].shape == (n, 1, 32, 32)
+    assert_close(got["optical_flow"].cpu(), ref["optical_flow"], 1e-3, "pixelwise flow")
+    assert_close(got["occlusion_map"].cpu(), ref["occlusion_map"], 1e-3, "occlusion map")

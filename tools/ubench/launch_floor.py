@@ -43,6 +43,27 @@ def timeit(fn, n, graph):
 
 
 print("tiny kernel, graph replay : %.2f us/launch" % timeit(tiny, N, True))
+# two DIFFERENT tiny kernels alternating (different code, different LDS / register configuration): what a real step looks like
+tdev = torch.zeros(4, dtype=torch.int32, device=dev); freqs = torch.randn(32, device=dev); semb = torch.empty(4, 64, device=dev)
+lin_x = torch.randn(1, 64, device=dev); lin_w = torch.randn(64, 64, device=dev); lin_b = torch.randn(64, device=dev); lin_o = torch.empty(1, 64, device=dev)
+
+
+def two_kinds():
+    ops.step_cond(step_part, sample, step_dev, out)
+    ops.linear_small(lin_x, lin_w, lin_b, out=lin_o)
+
+
+print("two different tiny kernels alternating, graph replay : %.2f us/launch" % (timeit(two_kinds, N // 2, True) / 2))
+xs = torch.randn(640, 512, device=dev); g512 = torch.ones(512, device=dev); b512 = torch.zeros(512, device=dev)
+wsx = torch.empty(256 * 128 + 2048, device=dev); ys = torch.empty_like(xs); pt = torch.randn(5, 16, device=dev).abs()
+
+
+def tiny_then_stream():
+    ops.step_cond(step_part, sample, step_dev, out)
+    ops.groupnorm_apply_cl(xs, 1, g512, b512, pt, 5, out=ys, ws=wsx)
+
+
+print("tiny kernel + 1.3 MB GroupNorm apply alternating : %.2f us per PAIR (apply alone 3.9, tiny alone 1.6)" % timeit(tiny_then_stream, N // 2, True))
 print("tiny kernel, eager        : %.2f us/launch (host %.2f us/launch)" % timeit(tiny, N, False))
 for rows, ch in ((640, 512), (2560, 256), (10240, 128), (40960, 64)):
     x = torch.randn(rows, ch, device=dev); gamma = torch.ones(ch, device=dev); beta = torch.zeros(ch, device=dev)
