@@ -31,6 +31,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 GFLOP_PER_VIDEO_REFERENCE = 24506.0
 
 
+def log(msg):
+    """Progress on stderr (stdout carries exactly ONE JSON line)."""
+    print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def dist_setup(n_gpus):
     """One process per GPU; returns (rank, world, local_rank)."""
     rank = int(os.environ.get("RANK", "0"))
@@ -288,23 +296,33 @@ def cpu_baseline():
     tt = torch.full((b,), 500, dtype=torch.long)
     ncpu = os.cpu_count() or 1
     sweep = {}
+    budget_t0 = time.perf_counter()
+    xs = x[:, :, :8].contiguous()               # the thread-count sweep runs on 8 of the 40 frames (bounded CPU time)
     with torch.no_grad():
-        O.unet_forward(dsd, x, tt, cond)        # warm-up (thread pools, allocator)
+        O.unet_forward(dsd, xs, tt, cond)       # warm-up (thread pools, allocator)
         for n in sorted({min(v, ncpu) for v in (8, 16, 32, 64, ncpu)}):
             torch.set_num_threads(n)
-            O.unet_forward(dsd, x, tt, cond)
+            O.unet_forward(dsd, xs, tt, cond)
             t0 = time.perf_counter()
-            O.unet_forward(dsd, x, tt, cond)
+            O.unet_forward(dsd, xs, tt, cond)
             sweep[n] = time.perf_counter() - t0
+            log("cpu_baseline: %d threads -> %.2f s per 8-frame UNet forward" % (n, sweep[n]))
+            # torch's CPU convolutions get SLOWER with more threads on this host (measured on the 128-CPU GPU box: 0.22 s at 8
+            # threads, 1.1 s at 64, minutes at 128): stop climbing once a setting is clearly worse than the best so far
+            if sweep[n] > 2.0 * min(sweep.values()) or time.perf_counter() - budget_t0 > 45:
+                break
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
-        n_unet = 3
         times = []
-        for _ in range(n_unet):
+        for _ in range(3):
             t0 = time.perf_counter()
             O.unet_forward(dsd, x, tt, cond)
             times.append(time.perf_counter() - t0)
+            if time.perf_counter() - budget_t0 > 150:       # bounded sample: at least one full-shape forward
+                break
+        n_unet = len(times)
         t_unet = sum(times) / n_unet
+        log("cpu_baseline: %d full-shape forwards, %.2f s each" % (n_unet, t_unet))
         t0 = time.perf_counter()
         O.generator_compute_fea(gsd, img)
         t_fea = time.perf_counter() - t0
@@ -318,7 +336,7 @@ def cpu_baseline():
         t_dec = (time.perf_counter() - t0) / n_dec
     per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t * t_dec
     return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": best, "kind": "port", "host_cpus": ncpu,
-            "thread_sweep_s_per_unet_forward": {str(k): round(v, 3) for k, v in sweep.items()},
+            "thread_sweep_s_per_8_frame_unet_forward": {str(k): round(v, 3) for k, v in sweep.items()},
             "sample": "oracle/lfdm_oracle.py on host CPU, %d threads (best of the sweep): %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each "
                       "(min %.2f, max %.2f), compute_fea %.3f s, %d decode frames = %.3f s each; extrapolated to %d steps + %d frames"
                       % (best, n_unet, b, t, s, s, t_unet, min(times), max(times), t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
@@ -364,7 +382,9 @@ def main():
     def run_step():
         model.sample_one_video(cond_scale=1.0)
 
+    log("model built; timing %d + %d sampling steps" % (args.warmup, args.steps))
     elapsed = timed_region(run_step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    log("headline: %.2f ms per video" % (1e3 * elapsed / args.steps))
     videos = args.steps * WORKLOAD["batch"] * world
     value = videos / elapsed
     out = model.sample_out_vid
@@ -387,9 +407,12 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = conv_roofline(model, 1e3 * elapsed / args.steps / WORKLOAD["sampling_timesteps"])
+            log("roofline done")
             line["warp"] = warp_bench(model, img)
+            log("warp done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline done")
     train = None
     if args.train_steps > 0:                 # every rank takes part (gradient all-reduce); after the headline measurement
         del model
@@ -410,6 +433,7 @@ def main():
         except Exception as e:               # never lose the headline line to the secondary measurement
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         watchdog.cancel()
+        log("train done")
     if rank == 0:
         if train is not None:
             line["train"] = train

@@ -19,6 +19,17 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _conv(x0, w4_direct, cout, kh, kw, n_img, hi, wi, *, weight_wino=None, **kw_):
+    """ops.conv2d_cl that skips the direct-form filter pack (a handful of torch kernels per call, every step) whenever the
+    library confirms the Winograd schedule; w4_direct: callable producing the (cout, cin, kh, kw) filter for the fallback."""
+    if weight_wino is not None:
+        try:
+            return ops.conv2d_cl(x0, None, cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
+        except ops.WinogradUnavailable:
+            pass
+    return ops.conv2d_cl(x0, ops.pack_conv_weight(w4_direct()), cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
+
+
 def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):
     """Geometry the Winograd F(2x2,3x3) schedule covers (lfdm_conv_params.weight_wino); chans = reduction-channel counts."""
     return (kh == 3 and kw == 3 and stride == 1 and tuple(pad) == (1, 1) and hi % 2 == 0 and wi % 2 == 0 and
@@ -44,9 +55,9 @@ class ConvCL(Function):
             ww = None
             if _wino_ok(kh, kw, stride, pad, hi, wi, x0.shape[1], 0 if x1 is None else x1.shape[1]):
                 ww = ops.pack_wino_weight(_c(w4))
-            y = ops.conv2d_cl(_c(x0.detach()), ops.pack_conv_weight(w4), w4.shape[0], kh, kw, n_img, hi, wi,
-                              src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
-                              weight_wino=ww)
+            y = _conv(_c(x0.detach()), lambda: w4, w4.shape[0], kh, kw, n_img, hi, wi,
+                      src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
+                      weight_wino=ww)
             hq = (hi + 2 * pad[0] - kh) // stride + 1
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
@@ -84,10 +95,9 @@ class ConvCL(Function):
                     continue
                 ws = w4[:, lo:hi_c]
                 if stride == 1:
-                    wd = ws.transpose(0, 1).flip(-2, -1).contiguous()                         # (cin, cout, kh, kw)
                     ww = ops.pack_wino_weight(ws, dgrad=True) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
-                    g = ops.conv2d_cl(dy, ops.pack_conv_weight(wd), hi_c - lo, kh, kw, n_img, hq, wq,
-                                      pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)
+                    g = _conv(dy, lambda ws=ws: ws.transpose(0, 1).flip(-2, -1).contiguous(), hi_c - lo, kh, kw, n_img, hq, wq,
+                              pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)                # filter (cin, cout, kh, kw)
                 else:
                     assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
                     g = ops.deconv4x4s2_cl(dy, ops.pack_deconv4_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)

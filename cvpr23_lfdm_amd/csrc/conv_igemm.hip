@@ -730,6 +730,11 @@ extern "C" int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* 
   return LFDM_OK;
 }
 
+extern "C" int lfdm_conv2d_schedule(const lfdm_conv_params* p) {
+  if (!p) return LFDM_EINVAL;
+  return make_plan(*p).kind;
+}
+
 extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p) return 0;
   const ConvPlan pl = make_plan(*p);

@@ -10,6 +10,8 @@
 //    channel plane (<= 128x128 fp32 = 64 KB) in LDS once and produces that channel for a block of
 //    frames, so the random-access taps hit LDS and every source byte is read from HBM once per
 //    frame block instead of once per tap.
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -90,17 +92,21 @@ __device__ __forceinline__ PixelTaps pixel_taps(const lfdm_warp_params& p, int b
 // A pixel is served by G = C/(4*R) adjacent lanes; lane j owns the float4 chunks j, j+G, ... (R of
 // them), so the taps / occlusion (12 low-res map reads + the bilinear set-up) are computed once per
 // 4*R channels and every access of the G lanes is one contiguous G*16-byte segment.
+// grid (blocks over one frame's hw * g lane items, frames): the frame index comes from blockIdx.y (scalar unit) and the
+// per-lane decomposition is 32-bit with g = 1, 2, 4, ... a power of two in every LFAE shape (shift instead of divide) - the
+// earlier flat 64-bit index cost three 64-bit divisions per lane item, ~40 % of the kernel's VALU time.
 template <int R>
 __global__ __launch_bounds__(256) void warp_cl_kernel(lfdm_warp_params p) {
   const int g = (p.c >> 2) / R;             // lanes per pixel
   const int hw = p.h * p.w;
-  const int64_t total = (int64_t)p.batch * p.frames * hw * g;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % g) * 4;
-    const int64_t gp = i / g;               // output pixel row
-    const int64_t n = gp / hw;              // frame index b*T + t
-    const int pix = (int)(gp - n * hw);
-    const int b = (int)(n / p.frames), t = (int)(n - (int64_t)b * p.frames);
+  const int per_frame = hw * g;
+  const int gshift = (g & (g - 1)) == 0 ? __builtin_ctz(g) : -1;
+  for (int n = blockIdx.y; n < p.batch * p.frames; n += gridDim.y)
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < per_frame; idx += gridDim.x * 256) {
+    const int pix = gshift >= 0 ? (idx >> gshift) : idx / g;
+    const int c = (idx - pix * g) * 4;
+    const int64_t gp = (int64_t)n * hw + pix;   // output pixel row
+    const int b = n / p.frames, t = n - b * p.frames;
     const int oy = pix / p.w, ox = pix - oy * p.w;
     const PixelTaps tp = pixel_taps(p, b, t, oy, ox);
     const float* sb = p.src + (int64_t)b * hw * p.ld_src + c;
@@ -265,13 +271,21 @@ extern "C" int lfdm_warp_cl_f32(const lfdm_warp_params* pp, lfdm_stream_t stream
     lfdm_set_error("warp_cl: channels and row strides must be multiples of 4");
     return LFDM_EINVAL;
   }
-  const int r = (p.c % 16 == 0) ? 4 : (p.c % 8 == 0 ? 2 : 1);
-  const int64_t total = (int64_t)p.batch * p.frames * p.h * p.w * (p.c / (4 * r));
-  int64_t nb = (total + 255) / 256;
-  if (nb > 262144) nb = 262144;
-  if (r == 4) LFDM_LAUNCH((warp_cl_kernel<4>), dim3((unsigned)nb), dim3(256), 0, stream, p);
-  else if (r == 2) LFDM_LAUNCH((warp_cl_kernel<2>), dim3((unsigned)nb), dim3(256), 0, stream, p);
-  else LFDM_LAUNCH((warp_cl_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  int r = (p.c % 16 == 0) ? 4 : (p.c % 8 == 0 ? 2 : 1);
+  if (const char* e = getenv("LFDM_WARP_R")) {      // experiment knob (bench.py warp object): lanes per pixel = C / (4 r)
+    const int v = atoi(e);
+    if ((v == 1 || v == 2 || v == 4) && p.c % (4 * v) == 0) r = v;
+  }
+  const int64_t per_frame = (int64_t)p.h * p.w * (p.c / (4 * r));
+  if (per_frame >= (1ll << 31) - 256 * 65536) { lfdm_set_error("warp_cl: frame too large"); return LFDM_EINVAL; }
+  int64_t nbx = (per_frame + 255) / 256;
+  if (nbx > 65536) nbx = 65536;
+  int64_t nby = (int64_t)p.batch * p.frames;
+  if (nby > 65535) nby = 65535;
+  const dim3 grid((unsigned)nbx, (unsigned)nby);
+  if (r == 4) LFDM_LAUNCH((warp_cl_kernel<4>), grid, dim3(256), 0, stream, p);
+  else if (r == 2) LFDM_LAUNCH((warp_cl_kernel<2>), grid, dim3(256), 0, stream, p);
+  else LFDM_LAUNCH((warp_cl_kernel<1>), grid, dim3(256), 0, stream, p);
   return lfdm_check_launch("warp_cl");
 }
 

@@ -159,6 +159,9 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     if groups > 1:      # grouped convolution: Winograd form only, `weight` is not read (lfdm_conv_params.groups)
         assert weight_wino is not None and src1 is None and weight is weight_wino
         coutp = cout
+    elif weight is None:     # Winograd-only call (training re-packs filters every step: no direct-form pack); conv2d_cl verifies
+        assert weight_wino is not None and deconv4 is None          # with lfdm_conv2d_schedule that the library agrees
+        weight, coutp = weight_wino, weight_wino.shape[2]
     else:
         assert weight.shape[0] == (kh * kw * cin + 31) // 32 and weight.shape[2] == 32, (weight.shape, kh, kw, cin)
         coutp = weight.shape[1]
@@ -210,6 +213,10 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     return p, out
 
 
+class WinogradUnavailable(RuntimeError):
+    pass
+
+
 def conv_plan(p):
     """(tile_rows, ksplit) the library will use for these params (lfdm_conv2d_plan)."""
     lib = _lib()
@@ -229,6 +236,8 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     lib = _lib()
     _chk(lib, partial, gn_partial)
     p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
+    if weight is None and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
+        raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack")
     _, ks = conv_plan(p)
     if ks > 1:
         need = ks * n_img * p.hq * p.wq * p.coutp * (4 if p.deconv4 else 1)

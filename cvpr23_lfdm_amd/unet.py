@@ -76,9 +76,6 @@ class Unet3D(ParamTree):
         self._pk_sig = None
         self._bufs = {}
         self._buf_gen = 0
-        self.fuse_splitk = False
-        self.overlap_res_conv = False      # measured slower on MI355X (negative results)
-        self._side = None
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
@@ -99,20 +96,6 @@ class Unet3D(ParamTree):
         for p in self.parameters():
             sig += p._version
         return (sig, weights_epoch(), next(self.parameters()).device)
-
-    def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
-        return self._side
-
-    def _tile_counters(self):
-        """Zero-initialised arrival counters of the in-launch split-K reduction (every launch leaves them at zero)."""
-        dev = next(self.parameters()).device
-        cur = self._bufs.get("splitk.counters")
-        if cur is None or cur.device != dev:
-            cur = torch.zeros(4096, dtype=torch.int32, device=dev)
-            self._bufs["splitk.counters"] = cur
-        return cur
 
     def _buf(self, name, rows, ch, dtype=torch.float32):
         need = rows * ch
@@ -285,14 +268,13 @@ class Unet3D(ParamTree):
     # ------------------------------------------------------------------ building blocks
     def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, gn=None,
               scratch="splitk", ww=None, **kw):
+        # (measured and removed: split-K slabs reduced inside the launch by the last-arriving workgroup - neutral to slower -
+        #  and res_conv on a second stream - slower; DESIGN.md "negative results")
         """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         coutp = p.coutp
-        if self.fuse_splitk:     # split-K slabs reduced inside the launch (measured neutral-to-slower on MI355X: off)
-            cnt = self._tile_counters()
-            p.tile_counters, p.tile_counters_len = cnt.data_ptr(), cnt.numel()
         tile_rows, ksplit = ops.conv_plan(p)
         m = n_img * p.hq * p.wq
         if ksplit > 1:
@@ -321,16 +303,6 @@ class Unet3D(ParamTree):
 
     def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
         n_img, rows = batch * frames, batch * frames * s * s
-        # res_conv(x) does not depend on the block1 -> block2 chain: below the finest level, where a convolution leaves
-        # CUs idle, it runs on a second stream (a parallel branch of the captured graph) and its result is added by
-        # the last GroupNorm kernel instead of a serial 1x1 convolution at the end
-        side, r = None, None
-        if (prefix + "res.w") in pk and self.overlap_res_conv and x.is_cuda and rows <= 16384:
-            side = self._side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                r = self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"],
-                               out=self._buf("rb.res", rows, cout), scratch="splitk.side")
         h1 = self._buf("rb.h1", rows, cout)
         _, st = self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
                            bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,), ww=pk[prefix + "block1.proj.ww"])
@@ -343,10 +315,6 @@ class Unet3D(ParamTree):
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
                            out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
-        if has_res and side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st, residual=r)
-            return out
         self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st,
                  residual=None if has_res else x)
         if has_res:
