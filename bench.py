@@ -137,6 +137,30 @@ def graph_time(launch_all, replays=30):
     return e0.elapsed_time(e1) * 1e-3 / replays
 
 
+def in_situ_family_us(model, is_member, ms_per_video_full, videos=3):
+    """Time one launch family INSIDE the real captured step, by subtraction: the sampler is made to capture its step graph
+    once more with that family's launches left out (every other kernel, buffer and dependency unchanged; the samples are
+    garbage and discarded), and (video time with) - (video time without) over the 100 steps is what the family costs where
+    it actually runs - inputs still warm from the producing kernel, filters cold.  Returns microseconds per step."""
+    from cvpr23_lfdm_amd import ops
+    orig = ops.conv_launch
+    ops.conv_launch = lambda p: None if is_member(p) else orig(p)
+    dif = model.diffusion
+    saved_plans, dif._plans = dif._plans, {}
+    try:
+        model.sample_one_video(cond_scale=1.0)          # captures the reduced graph
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(videos):
+            model.sample_one_video(cond_scale=1.0)
+        torch.cuda.synchronize()
+        ms_without = 1e3 * (time.perf_counter() - t0) / videos
+    finally:
+        ops.conv_launch = orig
+        dif._plans = saved_plans
+    return (ms_per_video_full - ms_without) * 1e3 / WORKLOAD["sampling_timesteps"], ms_without
+
+
 def conv_roofline(model, ms_per_sampler_step):
     """Roofline of the dominant kernel, measured live: the Winograd convolution launches (conv_wino_kernel) of one sampler
     step are re-captured as their own hipGraph - same parameter structs, same arenas, 40 different filter sets so the
@@ -157,7 +181,23 @@ def conv_roofline(model, ms_per_sampler_step):
         rows[name] = {"launches": len(ps), "us_per_step": round(sec * 1e6, 1), "us_per_launch": round(sec * 1e6 / len(ps), 2),
                       "gflop_per_step": round(flops / 1e9, 2), "tflops": round(flops / sec / 1e12, 2),
                       "frac": round(flops / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "algorithmic_bytes_per_step": round(nbytes)}
-    w = rows["winograd"]
+    # in-situ (the headline roofline number): the same launches timed inside the real step, by subtraction
+    key = lambda p: (p.src0, p.out, p.weight_wino, p.cout)            # (the LFAE's Winograd launches before / after the loop stay)
+    members = {key(p) for p in fam["winograd"]}
+    is_wino = lambda p: key(p) in members
+    ms_video = ms_per_sampler_step * WORKLOAD["sampling_timesteps"]
+    t0 = time.perf_counter()
+    model.sample_one_video(cond_scale=1.0)
+    model.sample_one_video(cond_scale=1.0)
+    torch.cuda.synchronize()
+    ms_video_now = 1e3 * (time.perf_counter() - t0) / 2          # same un-barriered host timing as the subtraction run
+    wino_us, ms_without = in_situ_family_us(model, is_wino, ms_video_now)
+    w = dict(rows["winograd"])
+    w_iso = rows["winograd"]
+    w.update(us_per_step=round(wino_us, 1), us_per_launch=round(wino_us / w["launches"], 2),
+             tflops=round(w["gflop_per_step"] / wino_us * 1e3, 2), frac=round(w["gflop_per_step"] / wino_us * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4))
+    rows["winograd_in_situ"] = {"us_per_step": w["us_per_step"], "us_per_launch": w["us_per_launch"], "tflops": w["tflops"], "frac": w["frac"],
+                                "ms_per_video_with": round(ms_video_now, 2), "ms_per_video_without": round(ms_without, 2)}
     executed = w["gflop_per_step"] * 16.0 / 36.0
     traffic, traffic_src = None, None
     tf = os.path.join(REPO_ROOT, "profiles", "r02_traffic.json")
@@ -165,8 +205,8 @@ def conv_roofline(model, ms_per_sampler_step):
         with open(tf) as f:
             tj = json.load(f)
         traffic, traffic_src = tj.get("wino_bytes_per_step"), tj.get("source")
-    all_flops = sum(r["gflop_per_step"] for r in rows.values())
-    all_us = sum(r["us_per_step"] for r in rows.values())
+    all_flops = sum(rows[k]["gflop_per_step"] for k in ("winograd", "direct") if k in rows)
+    all_us = sum(rows[k]["us_per_step"] for k in ("winograd", "direct") if k in rows)
     return {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) - the %d launches of one "
                                        "sampler step, incl. their split-K reduce passes" % w["launches"],
             "achieved": w["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": w["frac"],
@@ -179,8 +219,11 @@ def conv_roofline(model, ms_per_sampler_step):
             "all_convolutions": {"gflop_per_step": round(all_flops, 2), "us_per_step": round(all_us, 1),
                                  "tflops": round(all_flops / all_us * 1e3, 2), "frac": round(all_flops / all_us * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "sampler_step_us": round(ms_per_sampler_step * 1e3, 1),
+            "isolated_replay": {"us_per_launch": w_iso["us_per_launch"], "tflops": w_iso["tflops"], "frac": w_iso["frac"]},
             "note": "achieved / frac count the reference's direct-form FLOPs (SURVEY.md 8d); the Winograd launches execute 16/36 of theirs "
-                    "on the matrix pipe (executed_*); measured by replaying the step's own launches as a hipGraph on this stream"}
+                    "on the matrix pipe (executed_*).  us_per_launch = in situ: (video time of the captured step) - (video time of the "
+                    "same step captured without these launches), / 100 steps / launches - agrees with the rocprofv3 kernel table "
+                    "(profiles/); `isolated_replay` = the same launches replayed alone as a hipGraph (inputs cold: slower)"}
 
 
 def warp_bench(model, img, iters=20):

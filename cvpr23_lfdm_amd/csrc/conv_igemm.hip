@@ -335,6 +335,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         sv += __shfl_xor(sv, m);
         qv += __shfl_xor(qv, m);
       }
+      if (ksplit > 1) {
+        // split-K: this workgroup saw only its K slice of the rows - the (sum, sum of squares) slices go behind the slabs
+        // ([ksplit][M][2]) and conv_splitk_reduce_kernel finishes the LayerNorm (one column tile writes them)
+        const int r = (tid >> 3) + 32 * i;
+        if ((tid & 7) == 0 && blockIdx.y == 0 && s_img[r] >= 0) {
+          float* st = p.partial + (int64_t)ksplit * M * p.coutp + ((int64_t)blockIdx.z * M + (m0 + r)) * 2;
+          st[0] = sv;
+          st[1] = qv;
+        }
+        continue;
+      }
       if ((tid & 7) == 0) {
         const float inv_c = 1.0f / (float)cin;
         const float mean = sv * inv_c;
@@ -527,6 +538,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_param
     const int64_t orow = ((int64_t)img * p.ho + qy * p.out_scale + p.out_off_y) * p.wo +
                          qx * p.out_scale + p.out_off_x;
     float vals[4] = {s.x, s.y, s.z, s.w};
+    if (p.ln_wsum) {                                 // fused channel LayerNorm: y = rstd * (x.W' - mean * sum_c W')
+      const float* st = p.partial + (int64_t)p.ksplit * zs + (int64_t)m * 2;
+      float sv = 0.f, qv = 0.f;
+      for (int zz = 0; zz < p.ksplit; ++zz) {
+        sv += st[(int64_t)zz * M * 2];
+        qv += st[(int64_t)zz * M * 2 + 1];
+      }
+      const float inv_c = 1.0f / (float)(p.c0 + p.c1);
+      const float mean = sv * inv_c;
+      float var = qv * inv_c - mean * mean;
+      if (var < 0.f) var = 0.f;
+      const float rs = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vals[e] = rs * (vals[e] - mean * (col + e < p.coutp ? p.ln_wsum[col + e] : 0.f));
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = col + e;
@@ -739,7 +765,8 @@ extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p) return 0;
   const ConvPlan pl = make_plan(*p);
   if (pl.ksplit <= 1) return 0;
-  return (size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * (size_t)p->n_img * p->hq * p->wq * p->coutp * sizeof(float);
+  const size_t rows = (size_t)p->n_img * p->hq * p->wq;
+  return ((size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * rows * p->coutp + (p->ln_wsum ? (size_t)pl.ksplit * rows * 2 : 0)) * sizeof(float);
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
@@ -789,9 +816,9 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     }
   }
   if (p.ln_wsum) {
-    if (!pl.fast || !pl.simple || p.kh != 1 || p.kw != 1 || p.c1 != 0 || p.ksplit != 1 || p.stride != 1 || p.cout % 4 != 0 ||
+    if (!pl.fast || !pl.simple || p.kh != 1 || p.kw != 1 || p.c1 != 0 || p.stride != 1 || p.cout % 4 != 0 ||
         p.ldo % 4 != 0 || (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.ln_wsum) & 15) != 0) {
-      lfdm_set_error("conv2d: fused LayerNorm needs a 1x1 convolution over one source, C % 32 == 0, ksplit == 1");
+      lfdm_set_error("conv2d: fused LayerNorm needs a 1x1 convolution over one source with C % 32 == 0");
       return LFDM_EINVAL;
     }
   }

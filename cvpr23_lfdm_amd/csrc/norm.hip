@@ -316,7 +316,7 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
   constexpr int f4 = 2;       // float4 per thread (measured: 2 beats 4..32; the finalize prologue is cheap, occupancy is not)
   int64_t nb = (per_b + 256 * f4 - 1) / (256 * f4);
   if (nb < 1) nb = 1;
-  if (nb > 2048) nb = 2048;
+  if (nb > 8192) nb = 8192;        // per sample (grid y = batch); the 2C-channel output heads need 5120 at 32x32 x 40 frames
   LFDM_LAUNCH(gn_apply_kernel, dim3((unsigned)nb, batch), dim3(256), 0, stream, x, out, pixels, channels,
               groups, partial, nchunk, gamma, beta, scale_shift, ss_ld, eps, silu, residual);
 }

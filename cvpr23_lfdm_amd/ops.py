@@ -194,8 +194,6 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         assert tile_counters.dtype == torch.int32 and tile_counters.is_contiguous()
         _chk(lib, tile_counters)
         p.tile_counters, p.tile_counters_len = tile_counters.data_ptr(), tile_counters.numel()
-    if ln_wsum is not None:
-        p.ksplit = 1
     p.weight_wino = None
     p.groups = groups if groups > 1 else 0
     if weight_wino is not None:
@@ -211,6 +209,11 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         p.deconv4 = 1
     p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4)   # keep the tensors alive with the struct
     return p, out
+
+
+def conv_partial_floats(p):
+    """Split-K scratch the library wants for these params (slabs [+ LayerNorm row statistics]), in floats."""
+    return _lib().lfdm_conv2d_partial_bytes(C.byref(p)) // 4
 
 
 class WinogradUnavailable(RuntimeError):
@@ -240,7 +243,7 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
         raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack")
     _, ks = conv_plan(p)
     if ks > 1:
-        need = ks * n_img * p.hq * p.wq * p.coutp * (4 if p.deconv4 else 1)
+        need = conv_partial_floats(p)
         if partial is None or partial.numel() < need:
             partial = torch.empty(need, dtype=torch.float32, device=src0.device)
         p.partial = _p(partial)

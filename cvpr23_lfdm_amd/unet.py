@@ -278,7 +278,7 @@ class Unet3D(ParamTree):
         tile_rows, ksplit = ops.conv_plan(p)
         m = n_img * p.hq * p.wq
         if ksplit > 1:
-            part = self._buf(scratch, ksplit * m * (4 if p.deconv4 else 1), coutp)
+            part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
         if gn is not None:

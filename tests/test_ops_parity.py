@@ -236,6 +236,11 @@ def test_conv_fused_layernorm(backend, c):
     packed, wsum = ops.pack_ln_conv_weight(w, gamma.reshape(-1))
     out = ops.conv2d_cl(unet_to_cl(x).to(dev), packed.to(dev), 768, 1, 1, b * t, s, s, ln_wsum=wsum.to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused layernorm + qkv")
+    # split-K with the fused LayerNorm (the 8x8 / 4x4 levels): every K slice writes its part of the row statistics behind the
+    # slabs and the reduce pass finishes the normalisation; ksplit 0 = the library's own choice, 3 = forced (ragged slices)
+    for ks in ((0, 3) if c >= 128 else (2,)):
+        out = ops.conv2d_cl(unet_to_cl(x).to(dev), packed.to(dev), 768, 1, 1, b * t, s, s, ln_wsum=wsum.to(dev), ksplit=ks)
+        assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused layernorm + qkv, ksplit %d" % ks)
 
 
 @pytest.mark.parametrize("c", [64, 128, 512])
