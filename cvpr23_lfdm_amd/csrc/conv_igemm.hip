@@ -687,14 +687,17 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.bn = 32;
     if (const char* e = getenv("LFDM_WINO_BN"))          // experiment knob (tools/bench_conv.py): 64-column workgroups
       if (e[0] == '6' && p.coutp % 64 == 0) pl.bn = 64;
-    const int64_t blocks = (((int64_t)p.n_img * (p.hq / 2) * (p.wq / 2) + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
+    const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+    const int64_t blocks = ((ntiles + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
     const int nch = cin / 16 / (p.groups > 1 ? p.groups : 1);      // chunks of one output channel's reduction
-    // Split-K from tools/sweep_ksplit.sh (profiles/r02_c_ksplit_sweep.txt): a workgroup that is alone on its CU runs a
-    // chunk in ~1.8 us (the matrix pipe needs 1.0), fixed costs are ~8 us per workgroup, and in the sampler the filters
-    // arrive cold from HBM - so below two workgroups per CU slices of ~5 chunks win although the slabs need a reduce pass
-    // (256->256 @8x8: 34.9 -> 31.7 us warm, 44 -> 28 us in the captured step); 8-chunk convolutions are best unsplit.
+    // (16-tile workgroups on v_mfma_f32_16x16x4 - twice the workgroups at half the matrix work, half the split-K factor - were built
+    //  and measured in round 2, profiles/r02_n_tile16_sweep.txt: two-wave form slower everywhere; four-wave form -2..3 us at 16x16,
+    //  +1..2 us at 32x32, equal at 4x4 / 8x8, +0.45 % end to end when selected below 512 workgroups - not worth a second kernel; removed)
     int k = 1;
     if (blocks < 512 && nch >= 16) {
+      // Split-K from tools/sweep_ksplit.sh (profiles/r02_c_ksplit_sweep.txt): a workgroup that is alone on its CU runs a
+      // chunk in ~1.8 us (the matrix pipe needs 1.0), fixed costs are ~8 us per workgroup, and in the sampler the filters
+      // arrive cold from HBM - so below two workgroups per CU slices of ~5 chunks win although the slabs need a reduce pass
       k = nch / 5;
       if (k > 1024 / blocks) k = (int)(1024 / blocks);
       if (k > 8) k = 8;

@@ -150,6 +150,7 @@ def test_conv2d_winograd_grouped(backend, case):
     dev = backend
     if case.get("gpu_only") and not big(dev):
         pytest.skip("full-size shapes run on the GPU")
+    tile_rows = 128
     n, cg, og, g, h, w = (case[k] for k in ("n", "cg", "og", "g", "h", "w"))
     x = rnd(n, cg * g, h, w, seed=1)
     wt = rnd(og * g, cg, 3, 3, seed=2, scale=1.0 / math.sqrt(cg * 9))
@@ -160,13 +161,13 @@ def test_conv2d_winograd_grouped(backend, case):
     partial, ngn = None, 8 * g
     if case["gn"]:
         pixels = h * w * n // 2                    # two samples
-        partial = torch.zeros(2 * (pixels // 128), 2 * ngn, device=dev)
+        partial = torch.zeros(2 * (pixels // tile_rows), 2 * ngn, device=dev)
         kw.update(gn_partial=partial, gn_groups=ngn, gn_pixels=pixels)
     out = ops.conv2d_cl(to_cl(x).to(dev), ww, og * g, 3, 3, n, h, w, **kw)
     assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "grouped winograd conv")
     if partial is not None:
         y = ref.view(2, n // 2, ngn, og * g // ngn, h, w).permute(0, 2, 1, 3, 4, 5).reshape(2, ngn, -1).double()
-        got = partial.cpu().view(2, pixels // 128, ngn, 2).double().sum(dim=1)
+        got = partial.cpu().view(2, pixels // tile_rows, ngn, 2).double().sum(dim=1)
         assert_close(got[..., 0].float(), y.sum(-1).float(), TOL, "gn sum")
         assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")
 
