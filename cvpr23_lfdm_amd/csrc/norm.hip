@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t i0 = (int64_t)blockIdx.x * 256 + tid;
-  float4 pre_v[2], pre_r[2];
+  float4 pre_v[2], pre_r[2];        // (four in flight measured 1.6x SLOWER: the selects below stop being register renames)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int64_t i = i0 + k * stride;
@@ -313,7 +313,7 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
                      const float* scale_shift, int ss_ld, float eps, int silu, const float* residual,
                      hipStream_t stream) {
   const int64_t per_b = (int64_t)pixels * (channels / 4);
-  constexpr int f4 = 2;       // float4 per thread (measured: 2 beats 4..32; the finalize prologue is cheap, occupancy is not)
+  constexpr int f4 = 2;       // float4 per thread (measured in both rounds: 2 beats 4 and 8, with and without the early loads)
   int64_t nb = (per_b + 256 * f4 - 1) / (256 * f4);
   if (nb < 1) nb = 1;
   if (nb > 8192) nb = 8192;        // per sample (grid y = batch); the 2C-channel output heads need 5120 at 32x32 x 40 frames

@@ -49,10 +49,15 @@ __global__ __launch_bounds__(64) void sinusoidal_kernel(const int32_t* __restric
   }
 }
 
-// Direct conv, planar input with few channels -> CL rows.  grid (ceil(B*T*H*W/64), cout/64);
-// thread = (pixel = tid&63, 16 output channels = tid>>6).  Weights [K][64-slice] sit in LDS and
-// are read wave-uniformly (broadcast); the planar input is read coalesced along W.
+// Direct conv, planar input with few channels -> CL rows.  grid (ceil(B*T*H*W/128), cout/64);
+// thread = (pixel = tid&127, 32 output channels = tid>>7).  Weights [K][64-slice] sit in LDS (staged once per 128 pixels with
+// 16-byte loads) and are read wave-uniformly (broadcast ds_read_b128); the planar input is read coalesced along W.
+// (Round 1: 64 pixels x 16 channels per thread - the 37 KB weight staging per 64 pixels dominated: 46 us for the sampler's
+// 3-channel 7x7 stem at 40 x 32 x 32 pixels.)
 constexpr int CPI_MAX_K = 7 * 7 * 4;
+constexpr int CPI_PIX = 128;
+// (A variant that loads the 21 input values of a filter row back to back before their FMAs was measured: 50 vs 42 us - slower;
+// what bounds this kernel is not the load latency.)
 __global__ __launch_bounds__(256) void conv_planar_in_kernel(
     const float* __restrict__ x, int batch, int cin, int cin_total, int frames, int h, int w,
     const float* __restrict__ wgt, int kh, int kw, int cout, const float* __restrict__ bias,
@@ -61,24 +66,31 @@ __global__ __launch_bounds__(256) void conv_planar_in_kernel(
   const int tid = threadIdx.x;
   const int K = kh * kw * cin;
   const int co0 = blockIdx.y * 64;
-  for (int i = tid; i < K * 64; i += 256) {
-    const int kk = i >> 6, j = i & 63;
-    ws[i] = wgt[(int64_t)kk * cout + co0 + j];
+  if ((cout & 3) == 0 && ((((uintptr_t)wgt) & 15) == 0)) {
+    for (int i = tid; i < K * 16; i += 256) {                  // float4 item i: row kk = i / 16, columns 4*(i % 16)
+      const int kk = i >> 4, j4 = i & 15;
+      *reinterpret_cast<float4*>(ws + kk * 64 + 4 * j4) = *reinterpret_cast<const float4*>(wgt + (int64_t)kk * cout + co0 + 4 * j4);
+    }
+  } else {
+    for (int i = tid; i < K * 64; i += 256) {
+      const int kk = i >> 6, j = i & 63;
+      ws[i] = wgt[(int64_t)kk * cout + co0 + j];
+    }
   }
   __syncthreads();
   const int hw = h * w;
   const int64_t total = (int64_t)batch * frames * hw;
-  const int64_t gp = (int64_t)blockIdx.x * 64 + (tid & 63);
+  const int64_t gp = (int64_t)blockIdx.x * CPI_PIX + (tid & (CPI_PIX - 1));
   if (gp >= total) return;
-  const int cg = tid >> 6;
+  const int cg = tid >> 7;                                     // which 32 of the 64 output channels
   const int64_t bt = gp / hw;
   const int pix = (int)(gp - bt * hw);
   const int b = (int)(bt / frames), t = (int)(bt - (int64_t)b * frames);
   const int oy = pix / w, ox = pix - oy * w;
   const int py = kh / 2, px = kw / 2;
-  float acc[16];
+  float acc[32];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 32; ++j) acc[j] = 0.f;
   for (int ky = 0; ky < kh; ++ky) {
     const int iy = oy + ky - py;
     if (iy < 0 || iy >= h) continue;
@@ -87,9 +99,9 @@ __global__ __launch_bounds__(256) void conv_planar_in_kernel(
       if (ix < 0 || ix >= w) continue;
       for (int c = 0; c < cin; ++c) {
         const float v = x[(((int64_t)b * cin_total + c) * frames + t) * hw + iy * w + ix];
-        const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * kw + kx) * cin + c) * 64 + cg * 16);
+        const float4* wp = reinterpret_cast<const float4*>(ws + ((ky * kw + kx) * cin + c) * 64 + cg * 32);
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
+        for (int j4 = 0; j4 < 8; ++j4) {
           const float4 ww = wp[j4];
           acc[4 * j4 + 0] = fmaf(v, ww.x, acc[4 * j4 + 0]);
           acc[4 * j4 + 1] = fmaf(v, ww.y, acc[4 * j4 + 1]);
@@ -99,15 +111,34 @@ __global__ __launch_bounds__(256) void conv_planar_in_kernel(
       }
     }
   }
-  const int cbase = co0 + cg * 16;
+  const int cbase = co0 + cg * 32;
   float* orow = out + gp * ldo + cbase;
   const float* arow = add_term ? add_term + ((int64_t)b * hw + pix) * cout + cbase : nullptr;
+  const bool vec = (ldo & 3) == 0 && (cout & 3) == 0 && ((((uintptr_t)out) & 15) == 0) && (!arow || (((uintptr_t)add_term) & 15) == 0) &&
+                   (!bias || (((uintptr_t)bias) & 15) == 0);
+  if (vec) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    float v = acc[j];
-    if (bias) v += bias[cbase + j];
-    if (arow) v += arow[j];
-    orow[j] = apply_act(v, act);
+    for (int j4 = 0; j4 < 8; ++j4) {
+      float4 v = make_float4(acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]);
+      if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + cbase + 4 * j4);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (arow) {
+        const float4 aa = *reinterpret_cast<const float4*>(arow + 4 * j4);
+        v.x += aa.x; v.y += aa.y; v.z += aa.z; v.w += aa.w;
+      }
+      v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+      *reinterpret_cast<float4*>(orow + 4 * j4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float v = acc[j];
+      if (bias) v += bias[cbase + j];
+      if (arow) v += arow[j];
+      orow[j] = apply_act(v, act);
+    }
   }
 }
 
@@ -218,9 +249,9 @@ extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, in
     return LFDM_EINVAL;
   }
   const int64_t total = (int64_t)batch * frames * h * w;
-  LFDM_LAUNCH(conv_planar_in_kernel, dim3((unsigned)((total + 63) / 64), cout / 64), dim3(256), 0,
-              stream, x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout, bias, add_term, out,
-              ldo, act);
+  const dim3 grid((unsigned)((total + CPI_PIX - 1) / CPI_PIX), cout / 64);
+  LFDM_LAUNCH(conv_planar_in_kernel, grid, dim3(256), 0, stream, x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout, bias,
+              add_term, out, ldo, act);
   return lfdm_check_launch("conv_planar_in");
 }
 
