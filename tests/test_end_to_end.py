@@ -131,6 +131,44 @@ def test_second_call_reuses_graph(backend):
         assert_close(m.sample_out_vid.cpu(), ref["sample_out_vid"], 1e-3, "call with seed %d" % seed)
 
 
+def test_graph_survives_arena_reallocation(backend):
+    """the captured hipGraph holds raw pointers into the executor's scratch arenas.  An eager call that needs LARGER
+    arenas in between (Unet3D.forward on a bigger batch) frees the old storage; the next sample() with the same shapes must
+    re-capture on the new arenas (generation counter) instead of replaying pointers into freed memory - and a training-style
+    weight update through FlatAdam's raw-pointer kernel must reach the sampler's packed weights."""
+    dev = backend
+    _skip_slow_emu(dev)
+    m, dsd, gsd = synth.build_flow_diffusion(dev, img_size=8, num_frames=4, sampling_timesteps=3)
+    sd = dict(dsd)
+    sd.update(O.make_schedule(1000))
+    img, cond = synth.inputs(1, 32, seed=7)
+    ref = O.sample_one_video(sd, gsd, img, cond, 4, 8, 3, noise_fn=synth.NoiseTape(7))
+
+    def sample():
+        m.diffusion.noise_source = synth.NoiseTape(7)
+        m.set_sample_input(sample_img=img.to(dev), sample_text=cond.to(dev))
+        m.sample_one_video(cond_scale=1.0)
+        return m.sample_out_vid.cpu()
+
+    assert_close(sample(), ref["sample_out_vid"], 1e-3, "first call")
+    gen = m.unet._buf_gen
+    xb, tb, cb = synth.unet_inputs(3, 4, 8)                      # batch 3 > 1: every arena has to grow
+    with torch.no_grad():
+        m.unet(xb.to(dev), tb.to(dev), cond=cb.to(dev))
+    assert m.unet._buf_gen > gen
+    for _ in range(3):                                           # fill the freed blocks with something else
+        torch.full((1 << 20,), float("nan"), device=dev)
+    assert_close(sample(), ref["sample_out_vid"], 1e-3, "after the arenas were re-allocated")
+    # ... and the sampler follows parameter writes torch cannot see
+    from cvpr23_lfdm_amd.optim import FlatAdam
+    opt = FlatAdam(m.unet.parameters(), lr=1e-2)
+    for p in m.unet.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    moved = sample()
+    assert float((moved - ref["sample_out_vid"]).abs().max()) > 1e-3
+
+
 def test_c5_shape_natops_variant(backend):
     """BASELINE.json configs[4] geometry (64x64 latent = 256x256 frames, nearest-upsample + reflect-pad Upsample,
     learned null condition; 64-token mid spatial attention, 4x the spatial work per frame) at a reduced frame /
