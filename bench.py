@@ -205,6 +205,20 @@ def conv_roofline(model, ms_per_sampler_step):
         with open(tf) as f:
             tj = json.load(f)
         traffic, traffic_src = tj.get("wino_bytes_per_step"), tj.get("source")
+    # cross-check: the rocprofv3 kernel table committed for this build (tools/gpu_final.sh -> profiles/), same command line
+    rocprof = None
+    for name in sorted(os.listdir(os.path.join(REPO_ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(REPO_ROOT, "profiles")) else []:
+        if name.startswith("r02_") and name.endswith("_kernel_stats.txt") and "train" not in name:
+            for ln in open(os.path.join(REPO_ROOT, "profiles", name)):
+                if ln.startswith("conv_wino_kernel<false"):
+                    f = ln.split()
+                    avg = float(f[-4])
+                    rocprof = {"file": "profiles/" + name, "avg_us_per_launch": avg,
+                               "tflops_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3, 2),
+                               "frac_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                    break
+            if rocprof:
+                break
     all_flops = sum(rows[k]["gflop_per_step"] for k in ("winograd", "direct") if k in rows)
     all_us = sum(rows[k]["us_per_step"] for k in ("winograd", "direct") if k in rows)
     return {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) - the %d launches of one "
@@ -220,6 +234,7 @@ def conv_roofline(model, ms_per_sampler_step):
                                  "tflops": round(all_flops / all_us * 1e3, 2), "frac": round(all_flops / all_us * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "sampler_step_us": round(ms_per_sampler_step * 1e3, 1),
             "isolated_replay": {"us_per_launch": w_iso["us_per_launch"], "tflops": w_iso["tflops"], "frac": w_iso["frac"]},
+            "rocprofv3": rocprof,
             "note": "achieved / frac count the reference's direct-form FLOPs (SURVEY.md 8d); the Winograd launches execute 16/36 of theirs "
                     "on the matrix pipe (executed_*).  us_per_launch = in situ: (video time of the captured step) - (video time of the "
                     "same step captured without these launches), / 100 steps / launches - agrees with the rocprofv3 kernel table "
