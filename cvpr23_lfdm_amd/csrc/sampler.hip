@@ -22,42 +22,67 @@ struct Ranks {
   float frac;
 };
 
-// Finds the bin holding zero-based rank `k` in hist[0..nbins) and the rank inside that bin.
-// All 256 threads call it; result is broadcast through LDS.
-__device__ void find_bin(const unsigned* hist, int nbins, unsigned k, unsigned& bin, unsigned& krem,
-                         unsigned* s_part /*[256]*/, unsigned* s_res /*[2]*/) {
-  // one wavefront: each lane sums nbins/64 consecutive bins, a shuffle scan locates the lane holding rank k, that lane
-  // walks its own bins.  (The first version let thread 0 walk 256 partial sums serially - 6 of these per workgroup cost
-  // more than streaming the data.)
-  (void)s_part;
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const int per = nbins / 64;
-    unsigned local = 0;
-    for (int i = 0; i < per; ++i) local += hist[lane * per + i];
-    unsigned incl = local;
+// A 2048-bin histogram held eight consecutive bins per thread (256 threads).  load_bins only ISSUES the two 16-byte loads: the
+// callers request every histogram they will need before the first one is searched, so a workgroup pays the global round trip
+// once instead of once per search (the histograms were written by the previous kernel's atomics).
+struct Bins {
+  uint4 a, b;
+};
+__device__ __forceinline__ Bins load_bins(const unsigned* hist) {
+  const uint4* p = reinterpret_cast<const uint4*>(hist) + 2 * threadIdx.x;
+  Bins h;
+  h.a = p[0];
+  h.b = p[1];
+  return h;
+}
+
+// Finds, for up to two zero-based ranks (k[0], k[1]; NK = 1 or 2) of the same histogram, the bin holding the rank and the rank
+// inside that bin.  All 256 threads call it: wave-level shuffle scans of the per-thread sums, the four wave totals through LDS,
+// the owning thread walks its eight registers.  (The first version let thread 0 walk 256 partial sums serially, the second one
+// wavefront walk 32 bins per lane with dependent loads - six of those per workgroup cost more than streaming the data.)
+template <int NK>
+__device__ void find_bins(const Bins& h, const unsigned (&k)[NK], unsigned (&bin)[NK], unsigned (&krem)[NK],
+                          unsigned* s_part /*[256]*/, unsigned* s_res /*[4]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned v[8] = {h.a.x, h.a.y, h.a.z, h.a.w, h.b.x, h.b.y, h.b.z, h.b.w};
+  const unsigned local = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  unsigned incl = local;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned up = __shfl(incl, lane >= d ? lane - d : lane);
-      if (lane >= d) incl += up;
-    }
-    const unsigned excl = incl - local;
-    if (k >= excl && k < incl) {
-      unsigned run = excl;
-      int b = lane * per;
-      for (int i = 0; i < per; ++i) {
-        const unsigned c = hist[lane * per + i];
-        b = lane * per + i;
-        if (run + c > k) break;
-        run += c;
-      }
-      s_res[0] = (unsigned)b;
-      s_res[1] = k - run;
-    }
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned up = __shfl(incl, lane >= d ? lane - d : lane);
+    if (lane >= d) incl += up;
   }
+  if (lane == 63) s_part[wave] = incl;
   __syncthreads();
-  bin = s_res[0];
-  krem = s_res[1];
+  unsigned base = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+    if (w < wave) base += s_part[w];
+  incl += base;
+  const unsigned excl = incl - local;
+#pragma unroll
+  for (int q = 0; q < NK; ++q)
+    if (k[q] >= excl && k[q] < incl) {
+      unsigned run = excl, bsel = 7, rsel = 0;
+      bool found = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!found && run + v[i] > k[q]) {
+          found = true;
+          bsel = (unsigned)i;
+          rsel = k[q] - run;
+        }
+        if (!found) run += v[i];
+      }
+      s_res[2 * q] = 8u * (unsigned)tid + bsel;
+      s_res[2 * q + 1] = rsel;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NK; ++q) {
+    bin[q] = s_res[2 * q];
+    krem[q] = s_res[2 * q + 1];
+  }
   __syncthreads();
 }
 
@@ -104,19 +129,31 @@ template <int PASS>
 __global__ __launch_bounds__(256) void quantile_pass_kernel(const float* __restrict__ v, int64_t n,
                                                             Ranks rk, unsigned* __restrict__ hists) {
   __shared__ unsigned ha[NB], hb[NB];
-  __shared__ unsigned s_part[256], s_res[2];
+  __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
   unsigned* hs = hists + (int64_t)b * HIST_PER_SAMPLE;
   for (int i = threadIdx.x; i < NB; i += 256) { ha[i] = 0; hb[i] = 0; }
-  unsigned pa, pb, ka, kb;
-  find_bin(hs, NB, rk.lo, pa, ka, s_part, s_res);
-  find_bin(hs, NB, rk.hi, pb, kb, s_part, s_res);
+  const Bins h0 = load_bins(hs);
+  Bins h1a = h0, h1b = h0;
   if (PASS == 2) {
-    unsigned qa, qb, t0, t1;
-    find_bin(hs + NB, NB, ka, qa, t0, s_part, s_res);
-    find_bin(hs + 2 * NB, NB, kb, qb, t1, s_part, s_res);
-    pa = (pa << 11) | qa;
-    pb = (pb << 11) | qb;
+    h1a = load_bins(hs + NB);
+    h1b = load_bins(hs + 2 * NB);
+  }
+  unsigned pa, pb;
+  {
+    const unsigned k0[2] = {rk.lo, rk.hi};
+    unsigned bin0[2], rem0[2];
+    find_bins<2>(h0, k0, bin0, rem0, s_part, s_res);
+    pa = bin0[0];
+    pb = bin0[1];
+    if (PASS == 2) {
+      const unsigned ka[1] = {rem0[0]}, kb[1] = {rem0[1]};
+      unsigned qa[1], qb[1], t[1];
+      find_bins<1>(h1a, ka, qa, t, s_part, s_res);
+      find_bins<1>(h1b, kb, qb, t, s_part, s_res);
+      pa = (pa << 11) | qa[0];
+      pb = (pb << 11) | qb[0];
+    }
   }
   __syncthreads();
   const float* vb = v + (int64_t)b * n;
@@ -139,21 +176,24 @@ __global__ __launch_bounds__(256) void quantile_pass_kernel(const float* __restr
 
 // resolves the two order statistics from the histograms (all threads of a block)
 __device__ float resolve_quantile(const unsigned* hs, Ranks rk, unsigned* s_part, unsigned* s_res) {
-  unsigned a0, b0, ka, kb, a1, b1, a2, b2, t;
-  find_bin(hs, NB, rk.lo, a0, ka, s_part, s_res);
-  find_bin(hs, NB, rk.hi, b0, kb, s_part, s_res);
-  find_bin(hs + NB, NB, ka, a1, ka, s_part, s_res);
-  find_bin(hs + 2 * NB, NB, kb, b1, kb, s_part, s_res);
-  find_bin(hs + 3 * NB, NB, ka, a2, t, s_part, s_res);
-  find_bin(hs + 4 * NB, NB, kb, b2, t, s_part, s_res);
-  const float lo = __uint_as_float((a0 << 21) | (a1 << 10) | a2);
-  const float hi = __uint_as_float((b0 << 21) | (b1 << 10) | b2);
+  const Bins h0 = load_bins(hs), h1a = load_bins(hs + NB), h1b = load_bins(hs + 2 * NB), h2a = load_bins(hs + 3 * NB),
+             h2b = load_bins(hs + 4 * NB);                   // all five in flight before the first search
+  const unsigned k0[2] = {rk.lo, rk.hi};
+  unsigned bin0[2], rem0[2], a1[1], b1[1], a2[1], b2[1], ra[1], rb[1], t[1];
+  find_bins<2>(h0, k0, bin0, rem0, s_part, s_res);
+  const unsigned ka[1] = {rem0[0]}, kb[1] = {rem0[1]};
+  find_bins<1>(h1a, ka, a1, ra, s_part, s_res);
+  find_bins<1>(h1b, kb, b1, rb, s_part, s_res);
+  find_bins<1>(h2a, ra, a2, t, s_part, s_res);
+  find_bins<1>(h2b, rb, b2, t, s_part, s_res);
+  const float lo = __uint_as_float((bin0[0] << 21) | (a1[0] << 10) | a2[0]);
+  const float hi = __uint_as_float((bin0[1] << 21) | (b1[0] << 10) | b2[0]);
   return lo + rk.frac * (hi - lo);  // aten lerp form for weight < 0.5
 }
 
 __global__ __launch_bounds__(256) void quantile_out_kernel(Ranks rk, const unsigned* __restrict__ hists,
                                                            float* __restrict__ q_out) {
-  __shared__ unsigned s_part[256], s_res[2];
+  __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.x;
   const float q = resolve_quantile(hists + (int64_t)b * HIST_PER_SAMPLE, rk, s_part, s_res);
   if (threadIdx.x == 0) q_out[b] = q;
@@ -168,7 +208,7 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
                                                              const float* __restrict__ coef,
                                                              const int32_t* __restrict__ step_dev,
                                                              Ranks rk, const unsigned* __restrict__ hists) {
-  __shared__ unsigned s_part[256], s_res[2];
+  __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
   float s = resolve_quantile(hists + (int64_t)b * HIST_PER_SAMPLE, rk, s_part, s_res);
   s = fmaxf(s, 1.0f);

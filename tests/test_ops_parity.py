@@ -46,6 +46,12 @@ def rnd(*shape, seed=0, scale=1.0):
     dict(cin=96, cout=128, k=3, n=3, h=8, w=10, split_src=32, ksplit=3, fused=True, residual=True),   # slabs reduced in-launch
     dict(cin=256, cout=64, k=3, n=5, h=8, w=8, ksplit=4, fused=True, act=1),
     dict(cin=256, cout=64, k=1, n=5, h=8, w=8),                                  # ksw on a 1x1 (K = 256)
+    # the reduce pass holds up to 16 slabs in registers (groups of four, then the remainder in order), more take its loop
+    dict(cin=112, cout=64, k=3, n=2, h=4, w=4, ksplit=5, residual=True),
+    dict(cin=112, cout=64, k=3, n=2, h=4, w=4, ksplit=7, act=1),
+    dict(cin=320, cout=32, k=1, n=2, h=4, w=4, ksplit=9),
+    dict(cin=320, cout=32, k=1, n=2, h=4, w=4, ksplit=16, residual=True),
+    dict(cin=320, cout=32, k=1, n=2, h=4, w=4, ksplit=20),
     dict(cin=32, cout=32, k=4, n=5, h=16, w=16, stride=2, pad=1),                # ksw, strided
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
 def test_conv2d(backend, case):
@@ -188,6 +194,27 @@ def test_groupnorm_silu(backend, c, with_ss):
     out = ops.groupnorm_silu_cl(unet_to_cl(x).to(dev), b, gamma.to(dev), beta.to(dev),
                                 scale_shift=None if ss is None else ss.to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "groupnorm")
+
+
+@pytest.mark.parametrize("groups,nchunk,c", [(8, 330, 64), (16, 323, 128), (16, 7, 64), (32, 90, 128), (64, 45, 256)])
+def test_groupnorm_apply_many_partials(backend, groups, nchunk, c):
+    """The apply pass merges the producer's (sum, sumsq) partials with every load in flight at once (ten per lane and round,
+    32 / 16 / 8 / 4 lanes per group): chunk counts that need one ragged round and several, all group counts of one pass."""
+    dev = backend
+    b, rows_per_chunk = 2, 3
+    pixels = nchunk * rows_per_chunk
+    x = rnd(b, pixels, c, seed=11) * 1.5 + 0.3                      # channels-last rows of b samples
+    gamma, beta = rnd(c, seed=12) + 1.0, rnd(c, seed=13)
+    ss = rnd(b, 2 * c, seed=14) * 0.4
+    res = rnd(b, pixels, c, seed=15)
+    xg = x.view(b, nchunk, rows_per_chunk, groups, c // groups)
+    partial = torch.stack([xg.sum(dim=(2, 4)), (xg * xg).sum(dim=(2, 4))], dim=-1)      # (b, nchunk, groups, 2)
+    ref = F.group_norm(x.permute(0, 2, 1), groups, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    ref = F.silu(ref * (ss[:, None, :c] + 1) + ss[:, None, c:]) + res
+    out = ops.groupnorm_apply_cl(x.view(b * pixels, c).to(dev), b, gamma.to(dev), beta.to(dev),
+                                 partial.contiguous().view(b * nchunk, 2 * groups).to(dev), nchunk, groups=groups,
+                                 scale_shift=ss.to(dev), residual=res.view(b * pixels, c).to(dev))
+    assert_close(out.cpu().view(b, pixels, c), ref, TOL, "groupnorm apply, %d groups / %d chunks" % (groups, nchunk))
 
 
 @pytest.mark.parametrize("ksplit", [1, 3, -3, 512])
