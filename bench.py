@@ -29,6 +29,10 @@ WORKLOAD = dict(name="MUG 128x128, 40-frame DDIM-100 sample, batch=1 per GPU (BA
 FP32_MFMA_PEAK_TFLOPS = 157.3
 # reference-dataflow algorithmic work per C2 video: 100*235.10 + 5.14 + 40*24.78 GFLOP
 GFLOP_PER_VIDEO_REFERENCE = 24506.0
+# one training step of the unmodified reference per 40-frame 128x128 video, counted by torch.utils.flop_counter on the CPU run
+# (oracle/make_golden.py --train-flops): 2423.2 forward (per-frame pseudo ground truth incl. the encoder it re-runs per frame,
+# UNet, logged decode of the denoised flow) + 403.7 backward GFLOP
+TRAIN_GFLOP_PER_VIDEO_REFERENCE = 2826.9
 
 
 def log(msg):
@@ -333,6 +337,8 @@ def train_bench(dev, rank, world, steps, warmup, batch):
     return {"value": round(steps * batch * world / elapsed, 3), "unit": "training videos/s (40 frames, 128x128)",
             "ms_per_step": round(1e3 * elapsed / steps, 1), "batch_per_gpu": batch, "global_batch": batch * world,
             "steps": steps, "warmup": warmup, "grad_allreduce": ("%s, bucketed, overlapped with backward" % __import__("torch.distributed").distributed.get_backend()) if world > 1 else "none (1 GPU)",
+            "gflop_per_video_reference_dataflow": TRAIN_GFLOP_PER_VIDEO_REFERENCE,
+            "tflops_reference_dataflow": round(steps * batch * world / elapsed * TRAIN_GFLOP_PER_VIDEO_REFERENCE / 1e3, 1),
             "loss_first": round(vals[0], 5), "loss_last": round(vals[-1], 5),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 

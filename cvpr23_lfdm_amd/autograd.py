@@ -21,13 +21,14 @@ def _c(t):
 
 def _conv(x0, w4_direct, cout, kh, kw, n_img, hi, wi, *, weight_wino=None, **kw_):
     """ops.conv2d_cl that skips the direct-form filter pack (a handful of torch kernels per call, every step) whenever the
-    library confirms the Winograd schedule; w4_direct: callable producing the (cout, cin, kh, kw) filter for the fallback."""
+    library confirms the Winograd schedule; w4_direct: ((O, I, kh, kw) weight, pack mode of ops.pack_conv_weight_dev) for the
+    fallback - one launch."""
     if weight_wino is not None:
         try:
             return ops.conv2d_cl(x0, None, cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
         except ops.WinogradUnavailable:
             pass
-    return ops.conv2d_cl(x0, ops.pack_conv_weight(w4_direct()), cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
+    return ops.conv2d_cl(x0, ops.pack_conv_weight_dev(*w4_direct), cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
 
 
 def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):
@@ -55,14 +56,14 @@ class ConvCL(Function):
             ww = None
             if _wino_ok(kh, kw, stride, pad, hi, wi, x0.shape[1], 0 if x1 is None else x1.shape[1]):
                 ww = ops.pack_wino_weight(_c(w4))
-            y = _conv(_c(x0.detach()), lambda: w4, w4.shape[0], kh, kw, n_img, hi, wi,
+            y = _conv(_c(x0.detach()), (w4, 0), w4.shape[0], kh, kw, n_img, hi, wi,
                       src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
                       weight_wino=ww)
             hq = (hi + 2 * pad[0] - kh) // stride + 1
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
             assert x1 is None and residual is None and kh == 4 and kw == 4
-            y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_deconv4_weight(w4), w4.shape[1], n_img, hi, wi, bias=b)
+            y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_conv_weight_dev(w4, 2), w4.shape[1], n_img, hi, wi, bias=b)
             stride, pad, hq, wq = 2, (1, 1), 2 * hi, 2 * wi
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
@@ -96,11 +97,11 @@ class ConvCL(Function):
                 ws = w4[:, lo:hi_c]
                 if stride == 1:
                     ww = ops.pack_wino_weight(ws, dgrad=True) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
-                    g = _conv(dy, lambda ws=ws: ws.transpose(0, 1).flip(-2, -1).contiguous(), hi_c - lo, kh, kw, n_img, hq, wq,
+                    g = _conv(dy, (ws, 1), hi_c - lo, kh, kw, n_img, hq, wq,
                               pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)                # filter (cin, cout, kh, kw)
                 else:
                     assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
-                    g = ops.deconv4x4s2_cl(dy, ops.pack_deconv4_weight(ws.contiguous()), hi_c - lo, n_img, hq, wq)
+                    g = ops.deconv4x4s2_cl(dy, ops.pack_conv_weight_dev(ws, 2), hi_c - lo, n_img, hq, wq)
                 grads.append(g)
             dx0 = grads[0]
             dx1 = grads[1] if x1 is not None else None
@@ -111,7 +112,7 @@ class ConvCL(Function):
                 dwt = train_ops.conv_wgrad(dy, _c(x0), n_img, hq, wq, hi, wi, 4, 4, stride=2, pad=(1, 1))   # (16, cout, cin)
                 dw = dwt.view(4, 4, cout, cin).permute(3, 2, 0, 1).reshape(weight.shape)
             if need[0]:
-                dx0 = ops.conv2d_cl(dy, ops.pack_conv_weight(w4), cin, 4, 4, n_img, hq, wq, stride=2, pad=(1, 1))
+                dx0 = ops.conv2d_cl(dy, ops.pack_conv_weight_dev(w4, 0), cin, 4, 4, n_img, hq, wq, stride=2, pad=(1, 1))
         dres = dy if (has_res and need[4]) else None
         return dx0, dx1, dw, db, dres, None
 

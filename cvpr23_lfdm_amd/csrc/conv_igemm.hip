@@ -685,9 +685,17 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.kind = 2;
     pl.bm = 128;
     pl.bn = 32;
+    const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
     if (const char* e = getenv("LFDM_WINO_BN"))          // experiment knob (tools/bench_conv.py): 64-column workgroups
       if (e[0] == '6' && p.coutp % 64 == 0) pl.bn = 64;
-    const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+    {
+      // 64-column workgroups (half the patch loads / transforms per MFMA, two workgroups per CU) pay where every CU still gets
+      // several of them: the batched shapes of training / throughput mode (B = 8 training step 157.0 -> 150.6 ms at >= 1536
+      // workgroups = six per CU, 151.7 at 3072, 150.8 at 768: profiles/r02_u_bn64_train.txt), never the B = 1 sampler
+      // (<= 640 such workgroups).  LFDM_WINO_BN64_MIN overrides the threshold, 0 disables.
+      static const long min_blocks64 = [] { const char* e = getenv("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1536l; }();
+      if (min_blocks64 > 0 && p.coutp % 64 == 0 && !(p.groups > 1) && ((ntiles + 31) / 32) * (p.coutp / 64) >= min_blocks64) pl.bn = 64;
+    }
     const int64_t blocks = ((ntiles + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
     const int nch = cin / 16 / (p.groups > 1 ? p.groups : 1);      // chunks of one output channel's reduction
     // (16-tile workgroups on v_mfma_f32_16x16x4 - twice the workgroups at half the matrix work, half the split-K factor - were built

@@ -195,6 +195,35 @@ __global__ __launch_bounds__(256) void step_cond_kernel(const float* __restrict_
   }
 }
 
+// Direct-form filter pack (lfdm_pack_conv_weight_f32): one thread per element of out[(parity)][chunk][n][kk]
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, int n_o, int n_i, int taps,
+                                                               int64_t stride_o, int64_t stride_i, int mode, int K, int N,
+                                                               int np, float* __restrict__ out) {
+  const int64_t per = (int64_t)((K + 31) / 32) * np * 32;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per * (mode == 2 ? 4 : 1)) return;
+  const int q = (int)(idx / per);                      // parity (mode 2)
+  const int64_t r = idx - q * per;
+  const int kk = (int)(r & 31);
+  const int n = (int)((r >> 5) % np);
+  const int k = (int)((r >> 5) / np) * 32 + kk;
+  float v = 0.f;
+  if (k < K && n < N) {
+    if (mode == 0) {
+      const int tap = k / n_i, i = k - tap * n_i;
+      v = w[n * stride_o + i * stride_i + tap];
+    } else if (mode == 1) {
+      const int tap = k / n_o, o = k - tap * n_o;
+      v = w[o * stride_o + n * stride_i + (taps - 1 - tap)];
+    } else {
+      const int t = k / n_o, ci = k - t * n_o;
+      const int ky = (3 - (q >> 1)) - 2 * (t >> 1), kx = (3 - (q & 1)) - 2 * (t & 1);
+      v = w[ci * stride_o + n * stride_i + ky * 4 + kx];
+    }
+  }
+  out[idx] = v;
+}
+
 }  // namespace
 
 extern "C" int lfdm_step_cond_f32(const float* step_table, const float* batch_base,
@@ -269,4 +298,21 @@ extern "C" int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_o
   LFDM_LAUNCH(heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow,
               y_occ, channels, ld, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw);
   return lfdm_check_launch("heads");
+}
+
+extern "C" int lfdm_pack_conv_weight_f32(const float* w, int n_o, int n_i, int taps, int64_t stride_o, int64_t stride_i,
+                                         int mode, float* out, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!w || !out || n_o <= 0 || n_i <= 0 || taps <= 0 || mode < 0 || mode > 2 || (mode == 2 && taps != 16) ||
+      stride_o <= 0 || stride_i <= 0) {
+    lfdm_set_error("pack_conv_weight: bad arguments (mode 0 conv, 1 data gradient, 2 ConvTranspose k4 s2 p1 parity packs)");
+    return LFDM_EINVAL;
+  }
+  const int K = mode == 0 ? taps * n_i : mode == 1 ? taps * n_o : 4 * n_o;
+  const int N = mode == 0 ? n_o : n_i;
+  const int np = (N + 31) / 32 * 32;
+  const int64_t total = (int64_t)((K + 31) / 32) * np * 32 * (mode == 2 ? 4 : 1);
+  LFDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, n_o, n_i, taps,
+              stride_o, stride_i, mode, K, N, np, out);
+  return lfdm_check_launch("pack_conv_weight");
 }

@@ -97,6 +97,29 @@ def pack_deconv4_weight(w):
     return torch.stack([pk for _, _, pk in pack_deconv_weight(w)]).contiguous()
 
 
+def pack_conv_weight_dev(w, mode=0):
+    """The packs of pack_conv_weight (mode 0), of the data-gradient filter w.transpose(0, 1).flip(-2, -1) (mode 1) and of
+    pack_deconv4_weight (mode 2) built by ONE library launch (lfdm_pack_conv_weight_f32) - the training path re-packs every
+    step.  w: (O, I, kh, kw), any strides on the two channel axes (a slice is not copied), the taps contiguous."""
+    lib = _lib()
+    _chk(lib, w)
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    n_o, n_i, kh, kw = w.shape
+    taps = kh * kw
+    if taps > 1 and (w.stride(3) != 1 or w.stride(2) != kw):
+        w = w.contiguous()
+    k = taps * n_i if mode == 0 else taps * n_o if mode == 1 else 4 * n_o
+    n = n_o if mode == 0 else n_i
+    shape = (round_up(k, 32) // 32, round_up(n, 32), 32)
+    out = torch.empty(((4,) + shape) if mode == 2 else shape, dtype=torch.float32, device=w.device)
+    lib.check(lib.lfdm_pack_conv_weight_f32(_p(w), n_o, n_i, taps, w.stride(0), w.stride(1), mode, _p(out), _stream(lib)),
+              "lfdm_pack_conv_weight_f32")
+    return out
+
+
 def pack_wino_weight_grouped(ws):
     """[(Cout_g, Cin_g, 3, 3)] * G -> (G, 16, Cin_g/16, Cout_g, 16): the filters of a grouped 3x3 convolution
     (lfdm_conv_params.groups), each group's Winograd pack back to back."""

@@ -314,6 +314,19 @@ int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, co
 int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
                               lfdm_stream_t stream);
 
+/* Direct-form filter pack of lfdm_conv_params.weight ([ceil(K/32)][coutp][32], k contiguous per output column, zero padded)
+ * from a weight in the reference layout, in ONE launch - training re-packs every filter every step
+ * (video_flow_diffusion_model.py:181-188), the torch formulation costs three to five small kernels per filter.
+ * w: element (o, i, tap) at w[o*stride_o + i*stride_i + tap], taps = kh*kw contiguous (a channel slice of either axis is a
+ * pointer offset).  mode 0: the filter of the convolution itself, w = (Cout = n_o, Cin = n_i): K index tap*n_i + i, column o.
+ * mode 1: the filter of its data-gradient convolution (channel roles exchanged, taps reversed): K index tap*n_o + o,
+ * column i.  mode 2: the four parity packs of a ConvTranspose k4 s2 p1 with w = (Cin = n_o, Cout = n_i, 4, 4) (taps == 16),
+ * stacked (4, 4*n_o/32 chunks, coutp, 32) in parity order 2*py + px = the `deconv4` operand (Upsample :156-158; also the
+ * data gradient of Downsample :166-167 with the channel roles of its weight).  out holds round_up(K,32) * round_up(N,32)
+ * floats (x4 for mode 2). */
+int lfdm_pack_conv_weight_f32(const float* w, int n_o, int n_i, int taps, int64_t stride_o, int64_t stride_i, int mode,
+                              float* out, lfdm_stream_t stream);
+
 /* Convolution with at most 4 output channels on v_mfma_f32_4x4x1 (sixteen 4x4 blocks per instruction, lane = output
  * pixel): the LFAE generator's final Conv2d(64 -> 3, 7x7) + sigmoid (LFAE/modules/generator.py:54,161-162).
  * x: CL rows (n_img*h*w, cin) stride ldx; wgt: [k*k][cin][4] (tap-major, filters innermost, zero padded to 4);

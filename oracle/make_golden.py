@@ -155,6 +155,34 @@ def train_case(name, b, t, hw, labels, compact=False):
          rec_loss=m.rec_loss, rec_warp_loss=m.rec_warp_loss, null_cond_mask=m.diffusion.denoise_fn.null_cond_mask, **small)
 
 
+def train_flops(b=1, t=40, hw=128):
+    """FLOPs of ONE training step of the unmodified reference (FlowDiffusion.optimize_parameters: per-frame frozen-LFAE
+    pseudo ground truth incl. the encoder it re-runs per frame, UNet forward + backward, per-frame decode of the denoised
+    flow) counted by torch.utils.flop_counter on the CPU run: the "reference dataflow" work bench.py prices the training
+    throughput against (2 FLOP per multiply-add; convolutions / matmuls only, as the counter defines it)."""
+    from torch.utils.flop_counter import FlopCounterMode
+    m = ref.vfdm.FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=0.1,
+                               is_train=True, lr=1e-4, config_pth=synth.CONFIG, pretrained_pth="")
+    for net in (m.generator, m.region_predictor, m.bg_predictor):
+        net.eval()
+        m.set_requires_grad(net, False)
+    ref_img, real_vid, cond, _, _ = synth.train_inputs(b, t, hw)
+    ref.vfd.tokenize = lambda texts: texts
+    ref.vfd.bert_embed = lambda tokens, return_cls_repr=False: cond
+    m.set_train_input(ref_img=ref_img, real_vid=real_vid, ref_text=["x"] * b)
+    with FlopCounterMode(display=False) as fc:
+        m.forward()
+        fwd = fc.get_total_flops()
+        m.optimizer_diff.zero_grad()
+        m.loss.backward()
+        m.optimizer_diff.step()
+    total = fc.get_total_flops()
+    print("reference training step, B=%d T=%d %dx%d: forward (pseudo-GT + UNet + logged decode) %.1f GFLOP, "
+          "backward %.1f GFLOP, total %.1f GFLOP per step = %.1f GFLOP per video"
+          % (b, t, hw, hw, fwd / 1e9, (total - fwd) / 1e9, total / 1e9, total / 1e9 / b))
+    return total / b
+
+
 def probes(x, n=64, seed=5):
     """Compact but sensitive summary of a big tensor: per-sample (mean, mean |x|, std) + n random projections per sample
     (numpy PCG64 directions over the flattened sample, unit variance) - what the full-size fixtures store instead of the
@@ -235,6 +263,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true")
     ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
+    ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
     ap.add_argument("--full", choices=["c3", "c4", "c5"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
@@ -244,6 +273,9 @@ def main():
         return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])
+        return
+    if args.train_flops:
+        train_flops()
         return
     op_cases()
     unet_case("unet_tiny_deconv", 2, 4, 8)

@@ -111,6 +111,25 @@ def test_conv2d_c2_shapes(backend):
         assert_close(from_cl(out.cpu(), frames, s, s), ref, TOL, "conv %s" % ((cin, cout, s),))
 
 
+@pytest.mark.parametrize("shape", [(64, 32, 3, 3), (40, 72, 1, 1), (3, 20, 7, 7), (32, 48, 4, 4)])
+def test_pack_conv_weight_one_launch(backend, shape):
+    """lfdm_pack_conv_weight_f32 (the training path's per-step re-pack, one launch) against the load-time torch packers:
+    the filter itself, its data-gradient filter (transposed, taps reversed), a channel slice without a copy, and the four
+    ConvTranspose k4 s2 p1 parity packs."""
+    dev = backend
+    w = rnd(*shape, seed=21)
+    wd = w.to(dev)
+    assert torch.equal(ops.pack_conv_weight_dev(wd, 0).cpu(), ops.pack_conv_weight(w))
+    assert torch.equal(ops.pack_conv_weight_dev(wd, 1).cpu(), ops.pack_conv_weight(w.transpose(0, 1).flip(-2, -1).contiguous()))
+    lo, hi = 4, shape[1] - 4
+    assert torch.equal(ops.pack_conv_weight_dev(wd[:, lo:hi], 1).cpu(),
+                       ops.pack_conv_weight(w[:, lo:hi].transpose(0, 1).flip(-2, -1).contiguous()))
+    assert torch.equal(ops.pack_conv_weight_dev(wd[:, lo:hi], 0).cpu(), ops.pack_conv_weight(w[:, lo:hi].contiguous()))
+    if shape[2] == 4:
+        assert torch.equal(ops.pack_conv_weight_dev(wd, 2).cpu(), ops.pack_deconv4_weight(w))
+        assert torch.equal(ops.pack_conv_weight_dev(wd[:, lo:hi], 2).cpu(), ops.pack_deconv4_weight(w[:, lo:hi].contiguous()))
+
+
 def test_deconv(backend):
     dev = backend
     n, c, h, w = 2, 32, 4, 4
