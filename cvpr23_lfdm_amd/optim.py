@@ -19,7 +19,8 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
-        self._flat = None            # per group: dict(param, grad, m, v, views)
+        self._flat = None            # per group: dict(params, offs, p, g, m, v, gviews)
+        self._staged = False         # gradients already gathered into the flat buffer (GradAllReduce.finish)
         self.grad_scale = 1.0        # GradAllReduce sets 1/world
 
     # ------------------------------------------------------------------ flat storage
@@ -36,14 +37,12 @@ class FlatAdam(torch.optim.Optimizer):
             fg = torch.zeros_like(fp)
             fm = torch.zeros_like(fp)
             fv = torch.zeros_like(fp)
+            gviews = []
             for p, o in zip(ps, offs):
                 k = p.numel()
                 fp[o:o + k].copy_(p.data.reshape(-1))
                 p.data = fp[o:o + k].view(p.shape)
-                g = fg[o:o + k].view(p.shape)
-                if p.grad is not None:
-                    g.copy_(p.grad)
-                p.grad = g
+                gviews.append(fg[o:o + k].view(p.shape))
                 st = self.state[p]
                 if "exp_avg" in st:                    # state loaded before the first step
                     fm[o:o + k].copy_(st["exp_avg"].reshape(-1))
@@ -51,8 +50,9 @@ class FlatAdam(torch.optim.Optimizer):
                 st.setdefault("step", torch.tensor(0.0))
                 st["exp_avg"] = fm[o:o + k].view(p.shape)
                 st["exp_avg_sq"] = fv[o:o + k].view(p.shape)
-            flats.append(dict(params=ps, offs=offs, p=fp, g=fg, m=fm, v=fv))
+            flats.append(dict(params=ps, offs=offs, p=fp, g=fg, m=fm, v=fv, gviews=gviews))
         self._flat = flats
+        self._staged = False
 
     def _valid(self):
         if self._flat is None:
@@ -60,7 +60,7 @@ class FlatAdam(torch.optim.Optimizer):
         for fl in self._flat:
             base = fl["p"].data_ptr()
             for p, o in zip(fl["params"], fl["offs"]):
-                if p.data_ptr() != base + 4 * o or p.grad is None or p.grad.data_ptr() != fl["g"].data_ptr() + 4 * o:
+                if p.data_ptr() != base + 4 * o:
                     return False
         return True
 
@@ -74,9 +74,40 @@ class FlatAdam(torch.optim.Optimizer):
         return [fl["g"] for fl in self.ensure_flat()]
 
     def zero_grad(self, set_to_none=True):
-        """Keeps the gradient views alive: zeroes the flat buffer in place (set_to_none is ignored on purpose)."""
+        """torch semantics.  With set_to_none (the default, what the training scripts get) autograd hands every parameter its
+        gradient tensor as is - no `grad += new` kernel per parameter (302 of them per step when the gradients were kept as
+        views of the flat buffer) - and `stage_grads` gathers them into the flat buffer with a few multi-tensor copies."""
+        self._staged = False
         for fl in self.ensure_flat():
-            fl["g"].zero_()
+            if set_to_none:
+                for p in fl["params"]:
+                    p.grad = None
+            else:
+                gs = [p.grad for p in fl["params"] if p.grad is not None]
+                if gs:
+                    torch._foreach_zero_(gs)
+
+    @torch.no_grad()
+    def stage_grads(self, fl=None, idxs=None):
+        """Gather p.grad of the given parameters (default: all) into their slots of the flat gradient buffer and re-point
+        p.grad at the slot (so p.grad shows what the update / the all-reduce sees; a backward without zero_grad then
+        accumulates in place).  Parameters without a gradient this step get a zero slot."""
+        todo = [(f, range(len(f["params"]))) for f in self.ensure_flat()] if fl is None else [(fl, idxs)]
+        for f, ids in todo:
+            src, dst = [], []
+            for i in ids:
+                p, slot = f["params"][i], f["gviews"][i]
+                g = p.grad
+                if g is None:
+                    slot.zero_()
+                elif g.data_ptr() != slot.data_ptr():
+                    src.append(g if g.shape == slot.shape else g.reshape(slot.shape))
+                    dst.append(slot)
+                p.grad = slot
+            if dst:
+                torch._foreach_copy_(dst, src)
+        if fl is None:
+            self._staged = True
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -90,6 +121,10 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib()
+        self.ensure_flat()
+        if not self._staged:
+            self.stage_grads()
+        self._staged = False
         for group, fl in zip(self.param_groups, self.ensure_flat()):
             st0 = self.state[fl["params"][0]]
             step = int(st0["step"]) + 1
@@ -162,12 +197,15 @@ class GradAllReduce:
             ends = list(fl["offs"][1:]) + [n]
             # buckets from the end of the buffer
             cur_hi, members = n, []
-            items = list(zip(fl["params"], fl["offs"], ends))
-            for p, lo, hi in reversed(items):
+            items = list(zip(range(len(fl["params"])), fl["params"], fl["offs"], ends))
+            idxs = []
+            for i, p, lo, hi in reversed(items):
                 members.append(p)
+                idxs.append(i)
                 if cur_hi - lo >= self.bucket_elems or lo == 0:
-                    self._buckets.append(dict(view=fl["g"][lo:cur_hi], params=members, pending=0, handle=None))
-                    cur_hi, members = lo, []
+                    self._buckets.append(dict(view=fl["g"][lo:cur_hi], params=members, fl=fl, idxs=idxs, pending=0, handle=None,
+                                              staged=False))
+                    cur_hi, members, idxs = lo, [], []
         for bi, b in enumerate(self._buckets):
             for p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -182,6 +220,9 @@ class GradAllReduce:
         return hook
 
     def _launch(self, b):
+        if not b["staged"]:                       # the bucket's gradients -> its slice of the flat buffer (one multi-tensor copy)
+            self.opt.stage_grads(b["fl"], b["idxs"])
+            b["staged"] = True
         if self.world > 1 and b["handle"] is None:
             b["handle"] = self.dist.all_reduce(b["view"], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -191,6 +232,7 @@ class GradAllReduce:
         for b in self._buckets:
             b["pending"] = len(b["params"])
             b["handle"] = None
+            b["staged"] = False
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
@@ -201,3 +243,4 @@ class GradAllReduce:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
+        self.opt._staged = True

@@ -55,6 +55,39 @@ def test_flat_adam_matches_torch(backend):
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
 
 
+def test_flat_adam_gradient_handling(backend):
+    """zero_grad() has torch's set_to_none semantics (autograd then hands over each gradient without a `grad += new` kernel);
+    step() gathers the gradients into the flat buffer, p.grad afterwards aliases its slot; a second backward WITHOUT zero_grad
+    accumulates; a parameter that got no gradient is updated with a zero gradient; set_to_none=False zeroes in place."""
+    dev = backend
+    pa, pb = _params(dev), _params(dev)
+    a, b = FlatAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    for it in range(3):
+        a.zero_grad()
+        b.zero_grad()
+        assert all(p.grad is None for p in pa)
+        for rep in range(2 if it == 1 else 1):                  # it == 1: two backward passes into the same gradients
+            for i, (x, y) in enumerate(zip(pa, pb)):
+                if it == 2 and i == 1:
+                    continue                                    # parameter 1 is unused in the last iteration
+                g = rnd(*x.shape, seed=7 * it + i + rep).to(dev)
+                (x * g).sum().backward()
+                (y * g).sum().backward()
+            if it == 1 and rep == 0:
+                a.stage_grads()                                 # what GradAllReduce does mid-way: p.grad becomes the slot view
+        a.step()
+        if it == 2:
+            pb[1].grad = torch.zeros_like(pb[1])                # torch.optim.Adam skips None; the flat kernel sees zeros
+        b.step()
+        flat = a.flat_grads()[0]
+        for p in pa:
+            assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+    for x, y in zip(pa, pb):
+        assert_close(x, y, 1e-6, "params")
+    a.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in pa)
+
+
 def test_packed_weights_follow_flat_adam(backend):
     """FlatAdam updates the parameters through a raw-pointer kernel, invisible to torch's `_version`.
     The sampling executor's packed-weight cache (and with it the captured hipGraph plan) must still rebuild."""
