@@ -107,6 +107,8 @@ class FlowDiffusion(nn.Module):
             # a torch.optim.Optimizer (state_dict / param_groups / lr schedulers work) whose step is one fused HIP launch
             self.optimizer_diff = FlatAdam(self.diffusion.parameters(), lr=lr, betas=adam_betas)
         self._dp = None
+        self.lazy_real_decode = os.environ.get("LFDM_LAZY_REAL_DECODE", "0") == "1"     # see the real_out_vid property
+        self._real_decode, self._real_out_vid, self._real_warped_vid = None, None, None
         self._shard = None            # (rank, world) once data parallelism is on: set_train_input keeps this rank's videos
         # Launched by torchrun (one process per GPU) from an UNCHANGED training script: there is nobody to call
         # enable_data_parallel(), so the wrapper does it itself at the first optimize_parameters() - the process takes the
@@ -166,7 +168,7 @@ class FlowDiffusion(nn.Module):
         self.real_vid = real_vid.to(dev)
         self.ref_text = ref_text
 
-    def _train_forward(self, real_vid, ref_img, ref_text):
+    def _train_forward(self, real_vid, ref_img, ref_text, lazy_real=False):
         """Shared body of `forward` (reference :116-179) and of the functional *_multiGPU flavour
         (video_flow_diffusion_model_multiGPU.py:89-157): pseudo ground-truth flow / occlusion of every frame from
         the frozen LFAE (all B*T frames in one batched pass), the diffusion loss on it (native UNet forward under
@@ -181,11 +183,14 @@ class FlowDiffusion(nn.Module):
             driving_region_params = self.region_predictor(frames)
             ref_rep = ref.unsqueeze(1).expand(b, nf, *ref.shape[1:]).reshape(b * nf, *ref.shape[1:])
             bg_params = self.bg_predictor(ref_rep, frames)
-            generated = gen.forward_frames(ref, nf, driving_region_params, source_region_params, bg_params)
+            generated = gen.forward_frames(ref, nf, driving_region_params, source_region_params, bg_params, decode=not lazy_real)
         out["real_vid_grid"] = generated["optical_flow"]
         out["real_vid_conf"] = generated["occlusion_map"]
-        out["real_out_vid"] = generated["prediction"]
-        out["real_warped_vid"] = generated["deformed"]
+        if lazy_real:
+            out["real_decode"] = generated["decode"]
+        else:
+            out["real_out_vid"] = generated["prediction"]
+            out["real_warped_vid"] = generated["deformed"]
         out["ref_img_fea"] = generated["bottle_neck_feat"].clone().detach()
         if self.is_train:
             h, w = out["real_vid_grid"].shape[-2:]
@@ -209,15 +214,46 @@ class FlowDiffusion(nn.Module):
 
     def forward(self):
         """Reference :116-179 (inputs from set_train_input, results as attributes)."""
-        out = self._train_forward(self.real_vid, self.ref_img, self.ref_text)
-        for k in ("real_vid_grid", "real_vid_conf", "real_out_vid", "real_warped_vid", "ref_img_fea"):
+        out = self._train_forward(self.real_vid, self.ref_img, self.ref_text, lazy_real=self.lazy_real_decode)
+        for k in ("real_vid_grid", "real_vid_conf", "ref_img_fea"):
             setattr(self, k, out[k])
+        if self.lazy_real_decode:
+            self._real_decode, self._real_out_vid, self._real_warped_vid = out["real_decode"], None, None
+        else:
+            self._real_decode, self._real_out_vid, self._real_warped_vid = None, out["real_out_vid"], out["real_warped_vid"]
         if self.is_train:
             for k in ("loss", "fake_vid_grid", "fake_vid_conf", "fake_out_vid", "fake_warped_vid"):
                 setattr(self, k, out[k])
             with torch.no_grad():
                 self.rec_loss = (self.real_vid - self.fake_out_vid).abs().mean()
                 self.rec_warp_loss = (self.real_vid - self.fake_warped_vid).abs().mean()
+
+    # real_out_vid / real_warped_vid (reference :139-140): the LFAE decode of the pseudo ground truth feeds no loss - the
+    # training scripts only write it to their sample images every `save_img_freq` steps.  By default it is computed in
+    # forward() like the reference does; with `lazy_real_decode = True` (or LFDM_LAZY_REAL_DECODE=1) the 320-frame decode
+    # (a sixth of the B = 8 step) runs when one of the two attributes is first read.
+    def _materialise_real(self):
+        if self._real_out_vid is None and self._real_decode is not None:
+            self._real_out_vid, self._real_warped_vid = self._real_decode()
+            self._real_decode = None
+
+    @property
+    def real_out_vid(self):
+        self._materialise_real()
+        return self._real_out_vid
+
+    @real_out_vid.setter
+    def real_out_vid(self, v):
+        self._real_out_vid = v
+
+    @property
+    def real_warped_vid(self):
+        self._materialise_real()
+        return self._real_warped_vid
+
+    @real_warped_vid.setter
+    def real_warped_vid(self, v):
+        self._real_warped_vid = v
 
     def enable_data_parallel(self, bucket_bytes=64 << 20, shard_inputs=True):
         """One process per GPU (torch.distributed initialised by the launcher): average the DM gradients over the

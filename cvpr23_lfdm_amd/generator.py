@@ -228,12 +228,13 @@ class Generator(ParamTree):
             self._fp = PixelwiseFlowPredictorExec(self, self.num_regions, **self.flow_predictor_cfg)
         return self._fp
 
-    def forward_frames(self, source_image, frames, driving_region_params, source_region_params, bg_params=None):
+    def forward_frames(self, source_image, frames, driving_region_params, source_region_params, bg_params=None, decode=True):
         """Batched Generator.forward for `frames` driving frames per source image (the training loop of
         video_flow_diffusion_model.py:124-137 in one pass).  source_image (B,C,H,W); driving params / bg_params have
         leading dimension B*frames (n = b*frames + t); source params leading dimension B.
         -> dict: optical_flow (B,2,T,h,w), occlusion_map (B,1,T,h,w), prediction / deformed (B,C,T,H,W),
-                 bottle_neck_feat (B,256,h,w)."""
+                 bottle_neck_feat (B,256,h,w).  decode=False: instead of prediction / deformed the dict carries `decode`, a
+                 callable producing that pair on demand (FlowDiffusion.lazy_real_decode)."""
         with torch.no_grad():
             img = source_image.float().contiguous()
             b, c, h, w = img.shape
@@ -250,8 +251,13 @@ class Generator(ParamTree):
             skips = self.encode(img)
             d = 2 ** self.num_down_blocks
             fea = self.compute_fea_from_skips(skips, b, h // d, w // d).clone()
-            pred, deformed = self.decode_video(img, skips, maps[:, 0], maps[:, 1], maps[:, 2], frames, fh, fw,
-                                               3 * frames * fh * fw, fh * fw)
+            def run_decode():
+                with torch.no_grad():
+                    return self.decode_video(img, skips, maps[:, 0], maps[:, 1], maps[:, 2], frames, fh, fw,
+                                             3 * frames * fh * fw, fh * fw)
+            if not decode:
+                return {"optical_flow": maps[:, :2], "occlusion_map": maps[:, 2:3], "decode": run_decode, "bottle_neck_feat": fea}
+            pred, deformed = run_decode()
             return {"optical_flow": maps[:, :2], "occlusion_map": maps[:, 2:3], "prediction": pred,
                     "deformed": deformed, "bottle_neck_feat": fea}
 

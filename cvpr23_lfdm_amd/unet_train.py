@@ -112,10 +112,17 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
 
     # --- init_conv split by linearity (:410, :547): [n_dyn dynamic channels | fea channels]
     w0, b0 = g("init_conv.weight"), g("init_conv.bias")
-    x4 = F.pad(x_dyn.detach().permute(0, 2, 1, 3, 4).reshape(n_img, n_dyn, s * s), (0, 0, 0, 4 - n_dyn))
-    x_cl = ops.planar_to_cl(x4.contiguous(), n_img, 4, s * s)
-    w_dyn = F.pad(w0[:, :n_dyn], (0, 0, 0, 0, 0, 0, 0, 4 - n_dyn))                 # zero weights for the pad channel
-    r = A.conv_cl(x_cl, w_dyn, None, n_img=n_img, hi=s, wi=s, pad=(3, 3))
+    # The n_dyn = 3 dynamic channels as a 1x1 convolution over their unfolded 7x7 patches (n_dyn*49 = 147 -> 160 columns):
+    # as a 7x7 convolution with 3 (4) input channels both the forward (generic gather path) and above all the weight
+    # gradient (49 taps x a 64-channel tile holding 4 channels: 1.7 ms per B = 8 step) waste the matrix pipe; the patches
+    # cost one 200 MB tensor, the input needs no gradient.
+    kk = w0.shape[-1]
+    cols = F.unfold(x_dyn.detach().permute(0, 2, 1, 3, 4).reshape(n_img, n_dyn, s, s).float(), kk, padding=kk // 2)
+    kcols = n_dyn * kk * kk
+    kpad = (kcols + 31) // 32 * 32
+    x_cl = F.pad(cols.permute(0, 2, 1), (0, kpad - kcols)).reshape(n_img * s * s, kpad).contiguous()
+    w_dyn = F.pad(w0[:, :n_dyn].reshape(dim, kcols), (0, kpad - kcols)).view(dim, kpad, 1, 1)     # (c, ky, kx) order = unfold's
+    r = A.conv_cl(x_cl, w_dyn, None, n_img=n_img, hi=s, wi=s, pad=(0, 0))
     fea_cl = ops.planar_to_cl(fea.detach().reshape(b, fea.shape[1], s * s).contiguous(), b, fea.shape[1], s * s)
     term = A.conv_cl(fea_cl, w0[:, n_dyn:], b0, n_img=b, hi=s, wi=s, pad=(3, 3))                      # (B*S*S, dim)
     r = (r.view(b, t, s * s, dim) + term.view(b, 1, s * s, dim)).reshape(n_img * s * s, dim)

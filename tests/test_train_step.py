@@ -115,3 +115,25 @@ def test_functional_multigpu_flavour(monkeypatch):
     assert all(p.grad is not None for p in m.diffusion.parameters())
     s = m.sample_one_video(sample_img=ref_img[:1].to(dev), sample_text=cond[:1].to(dev), cond_scale=1.0)
     assert s["sample_out_vid"].shape == (1, 3, t, hw, hw) and bool(torch.isfinite(s["sample_out_vid"]).all())
+
+
+@pytest.mark.gpu
+def test_lazy_real_decode_is_the_same_video():
+    """FlowDiffusion.lazy_real_decode: real_out_vid / real_warped_vid (no loss reads them) are decoded when first read and
+    equal what forward() computes eagerly; everything else of the step is untouched."""
+    dev = "cuda"
+    vids = {}
+    for lazy in (False, True):
+        m = _build(dev, 2, 4, 128)
+        m.lazy_real_decode = lazy
+        ref_img, real_vid, cond, tt, noise = synth.train_inputs(2, 4, 128)
+        torch.manual_seed(5)
+        m.set_train_input(ref_img=ref_img.to(dev), real_vid=real_vid.to(dev), ref_text=cond.to(dev))
+        m.optimize_parameters()
+        if lazy:
+            assert m._real_out_vid is None and m._real_decode is not None          # nothing decoded yet
+        vids[lazy] = (m.real_out_vid.clone(), m.real_warped_vid.clone(), m.fake_out_vid.clone(), float(m.loss))
+        assert m._real_decode is None
+    for a, b in zip(vids[False][:3], vids[True][:3]):
+        assert torch.equal(a, b)
+    assert vids[False][3] == vids[True][3]

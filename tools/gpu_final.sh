@@ -8,4 +8,4 @@ timeout 600 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.er
 # the training step with the gradient all-reduce across two ranks
 LFDM_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 600 $O/bench_n2_one_gpu.json; echo
 bash tools/prof_sequence.sh $TAG > $O/prof.txt 2>&1; tail -n 1 $O/step_sequence.txt
-bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt $O/train_kernel_stats.txt; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
+bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt gpurun_out/p3/train_top_launches.txt $O/; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
