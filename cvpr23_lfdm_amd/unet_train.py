@@ -116,11 +116,14 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     # as a 7x7 convolution with 3 (4) input channels both the forward (generic gather path) and above all the weight
     # gradient (49 taps x a 64-channel tile holding 4 channels: 1.7 ms per B = 8 step) waste the matrix pipe; the patches
     # cost one 200 MB tensor, the input needs no gradient.
+    # (three torch launches: pad, zero fill, one strided copy of the window view - F.unfold launches an im2col per image)
     kk = w0.shape[-1]
-    cols = F.unfold(x_dyn.detach().permute(0, 2, 1, 3, 4).reshape(n_img, n_dyn, s, s).float(), kk, padding=kk // 2)
     kcols = n_dyn * kk * kk
     kpad = (kcols + 31) // 32 * 32
-    x_cl = F.pad(cols.permute(0, 2, 1), (0, kpad - kcols)).reshape(n_img * s * s, kpad).contiguous()
+    xp = F.pad(x_dyn.detach().permute(0, 2, 1, 3, 4).reshape(n_img, n_dyn, s, s).float(), (kk // 2,) * 4)
+    win = xp.unfold(2, kk, 1).unfold(3, kk, 1)                                       # (n, c, s, s, ky, kx) view
+    x_cl = torch.zeros(n_img * s * s, kpad, dtype=torch.float32, device=dev)
+    x_cl.view(n_img, s, s, kpad)[..., :kcols].unflatten(-1, (n_dyn, kk, kk)).copy_(win.permute(0, 2, 3, 1, 4, 5))
     w_dyn = F.pad(w0[:, :n_dyn].reshape(dim, kcols), (0, kpad - kcols)).view(dim, kpad, 1, 1)     # (c, ky, kx) order = unfold's
     r = A.conv_cl(x_cl, w_dyn, None, n_img=n_img, hi=s, wi=s, pad=(0, 0))
     fea_cl = ops.planar_to_cl(fea.detach().reshape(b, fea.shape[1], s * s).contiguous(), b, fea.shape[1], s * s)
