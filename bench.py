@@ -304,7 +304,7 @@ def warp_bench(model, img, iters=20):
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/warp_only.py (tools/prof_traffic.sh), not live"}}
 
 
-def train_bench(dev, rank, world, steps, warmup, batch):
+def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
     """BASELINE.json configs[3] per GPU: one DM training step = frozen-LFAE pseudo ground truth of all B*T frames +
     UNet forward/backward (native kernels under autograd) + [RCCL gradient all-reduce when world > 1] + fused Adam,
     on `batch` 40-frame 128x128 videos per GPU (the reference script uses 64 videos over 8 GPUs)."""
@@ -336,16 +336,17 @@ def train_bench(dev, rank, world, steps, warmup, batch):
     vals = [float(v) for v in losses]
     # not the headline: the same step with the pseudo-ground-truth decode (real_out_vid / real_warped_vid: read by no loss, only by
     # the scripts' sample images) deferred until it is read (FlowDiffusion.lazy_real_decode)
-    m.lazy_real_decode = True
-    lazy_steps = max(2, steps // 2)
-    lazy_elapsed = timed_region(step, lazy_steps, 1, world, torch.cuda.synchronize)
-    m.lazy_real_decode = False
+    lazy_steps, lazy_elapsed = max(2, steps // 2), None
+    if lazy_extra:
+        m.lazy_real_decode = True
+        lazy_elapsed = timed_region(step, lazy_steps, 1, world, torch.cuda.synchronize)
+        m.lazy_real_decode = False
     return {"value": round(steps * batch * world / elapsed, 3), "unit": "training videos/s (40 frames, 128x128)",
             "ms_per_step": round(1e3 * elapsed / steps, 1), "batch_per_gpu": batch, "global_batch": batch * world,
             "steps": steps, "warmup": warmup, "grad_allreduce": ("%s, bucketed, overlapped with backward" % __import__("torch.distributed").distributed.get_backend()) if world > 1 else "none (1 GPU)",
             "gflop_per_video_reference_dataflow": TRAIN_GFLOP_PER_VIDEO_REFERENCE,
             "tflops_reference_dataflow": round(steps * batch * world / elapsed * TRAIN_GFLOP_PER_VIDEO_REFERENCE / 1e3, 1),
-            "ms_per_step_lazy_real_decode": round(1e3 * lazy_elapsed / lazy_steps, 1),
+            "ms_per_step_lazy_real_decode": round(1e3 * lazy_elapsed / lazy_steps, 1) if lazy_elapsed else None,
             "loss_first": round(vals[0], 5), "loss_last": round(vals[warmup + steps - 1], 5),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
