@@ -87,6 +87,11 @@ _SIGNATURES = {
                                                   stream_t]),
     "lfdm_pack_wino_weight_f32": (i32, [f32p, i32, i32, i32, i32, i32, f32p, stream_t]),
     "lfdm_pack_conv_weight_f32": (i32, [f32p, i32, i32, i32, i64, i64, i32, f32p, stream_t]),
+    "lfdm_lfae_motion_inputs_f32": (i32, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, i32, i32, i32, i32, i32, i32,
+                                          f32p, i32, f32p, stream_t]),
+    "lfdm_lfae_region_stats_f32": (i32, [f32p, i32, i32, i32, i32, i32, C.c_float, f32p, f32p, f32p, f32p, f32p, f32p, stream_t]),
+    "lfdm_svd2x2_sym_f32": (i32, [f32p, i64, f32p, f32p, stream_t]),
+    "lfdm_lfae_motion_combine_f32": (i32, [f32p, i32, f32p, i32, i32, i32, f32p, f32p, stream_t]),
     "lfdm_conv2d_smalln_cl_f32": (i32, [f32p, i32, i32, i32, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, stream_t]),
     "lfdm_linear_attention_fused_ws_bytes": (sz, [i32, i32]),
     "lfdm_linear_attention_fused_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, i32, i32, f32, C.c_void_p, sz, stream_t]),

@@ -55,12 +55,16 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < NT; ++j) db[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t base = (int64_t)blockIdx.x * WPB; base < units; base += (int64_t)gridDim.x * WPB) {
-    const int64_t unit = base + wave;
-    const bool valid = unit < units;
+  // One wavefront per SIMD (the LDS tiles of four sequences fill a CU) means nothing hides a global round trip: the next
+  // unit's Q / K / V / dO rows are requested into registers as soon as the current ones have been staged, and arrive under
+  // the five GEMMs of the current unit.
+  constexpr int NR = LP / 8;
+  const int rr = lane >> 3, c4 = lane & 7;
+  float4 qv[NR], kv[NR], vv[NR], gv[NR];
+  auto geometry = [&](int64_t unit, bool& valid, int& head, int64_t& row0, int64_t& tstride) {
+    valid = unit < units;
     const int64_t seq = valid ? unit / HEADS : 0;
-    const int head = valid ? (int)(unit - seq * HEADS) : 0;
-    int64_t row0, tstride;
+    head = valid ? (int)(unit - seq * HEADS) : 0;
     if (mode == 0) {
       const int64_t b = seq / hw, pix = seq - b * hw;
       row0 = b * frames * hw + pix;
@@ -69,25 +73,39 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
       row0 = seq * hw;
       tstride = 1;
     }
+  };
+  auto fetch = [&](int64_t unit) {
+    bool valid;
+    int head;
+    int64_t row0, tstride;
+    geometry(unit, valid, head, row0, tstride);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int t = rr + 8 * i;
+      qv[i] = kv[i] = vv[i] = gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid && t < L) {
+        const int64_t row = row0 + (int64_t)t * tstride;
+        const float* src = qkv + row * QKV_LD + head * DH + 4 * c4;
+        qv[i] = *reinterpret_cast<const float4*>(src);
+        kv[i] = *reinterpret_cast<const float4*>(src + OUT_LD);
+        vv[i] = *reinterpret_cast<const float4*>(src + 2 * OUT_LD);
+        gv[i] = *reinterpret_cast<const float4*>(dout + row * OUT_LD + head * DH + 4 * c4);
+      }
+    }
+  };
+  constexpr bool PREFETCH = LP <= 48;          // (64 tokens - the mid spatial attention of the 256x256 configuration, a handful of sequences - is at the register limit already: rows fetched at the top of the unit as before)
+  if (PREFETCH) fetch((int64_t)blockIdx.x * WPB + wave);
+
+  for (int64_t base = (int64_t)blockIdx.x * WPB; base < units; base += (int64_t)gridDim.x * WPB) {
+    const int64_t unit = base + wave;
+    bool valid;
+    int head;
+    int64_t row0, tstride;
+    geometry(unit, valid, head, row0, tstride);
+    if (!PREFETCH) fetch(unit);
 
     // ---- stage Q (scaled + rotary), K (rotary), V, dO ----
     {
-      constexpr int NR = LP / 8;
-      const int rr = lane >> 3, c4 = lane & 7;
-      float4 qv[NR], kv[NR], vv[NR], gv[NR];
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int t = rr + 8 * i;
-        qv[i] = kv[i] = vv[i] = gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid && t < L) {
-          const int64_t row = row0 + (int64_t)t * tstride;
-          const float* src = qkv + row * QKV_LD + head * DH + 4 * c4;
-          qv[i] = *reinterpret_cast<const float4*>(src);
-          kv[i] = *reinterpret_cast<const float4*>(src + OUT_LD);
-          vv[i] = *reinterpret_cast<const float4*>(src + 2 * OUT_LD);
-          gv[i] = *reinterpret_cast<const float4*>(dout + row * OUT_LD + head * DH + 4 * c4);
-        }
-      }
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int t = rr + 8 * i;
@@ -111,6 +129,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         *reinterpret_cast<float4*>(Gs + t * SV + 4 * c4) = gv[i];
       }
     }
+    if (PREFETCH && base + (int64_t)gridDim.x * WPB < units) fetch(unit + (int64_t)gridDim.x * WPB);       // in flight under this unit's GEMMs
     __syncthreads();
 
     // ---- S = Q K^T, dP = dO V^T ----

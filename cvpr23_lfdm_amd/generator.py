@@ -240,8 +240,8 @@ class Generator(ParamTree):
             b, c, h, w = img.shape
             n = b * frames
             rep = lambda v: v.unsqueeze(1).expand(b, frames, *v.shape[1:]).reshape(n, *v.shape[1:])
-            src = {k: rep(v) for k, v in source_region_params.items() if k in ("shift", "covar", "affine")}
-            motion = self.flow_predictor()(rep(img), driving_region_params, src, bg_params=bg_params)
+            src = {k: v for k, v in source_region_params.items() if k in ("shift", "covar", "affine")}
+            motion = self.flow_predictor()(img, driving_region_params, src, bg_params=bg_params, frames=frames)
             flow, occ = motion["optical_flow"], motion["occlusion_map"]          # (N,h,w,2), (N,1,h,w)
             fh, fw = flow.shape[1], flow.shape[2]
             maps = torch.empty(b, 3, frames, fh, fw, dtype=torch.float32, device=img.device)

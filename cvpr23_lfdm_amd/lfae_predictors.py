@@ -101,7 +101,7 @@ def _image_rows(x, pad_to=4, full=False):
     return buf if full else view
 
 
-def _head_conv(tree, prefixes, out, skip, n, h, w, pad):
+def _head_conv(tree, prefixes, out, skip, n, h, w, pad, planar=True):
     """The 7x7 head convolutions `prefixes` (same input cat([out, skip])) as ONE launch -> planar (N, sum of couts, H', W'),
     no activation.  The filters are stacked along the output axis and zero-padded to a multiple of 4 outputs: that is what
     lets the library take its 160x32 K-split schedule (float4 epilogue) instead of a 64-column tile for 1 / 10 / 11 outputs -
@@ -122,6 +122,8 @@ def _head_conv(tree, prefixes, out, skip, n, h, w, pad):
     _, wp, bias, cout, k = hit
     coutp = bias.numel()
     y = ops.conv2d_cl(out, wp, coutp, k, k, n, h, w, src1=skip, bias=bias, pad=(pad, pad))
+    if not planar:
+        return y                                              # channels-last rows (N*H'*W', coutp)
     ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
     return ops.cl_to_planar(y, n, coutp, ho * wo).view(n, coutp, ho, wo)[:, :cout]
 
@@ -261,6 +263,12 @@ class RegionPredictorExec:
             x = antialias_down(x.float(), self.tree.get("down.weight"), self.scale_factor)
         n, _, h, w = x.shape
         out, skip = self.hg.forward(_image_rows(x, pad_to=32, full=True), n, h, w)
+        k_regions = self.tree.get("regions.weight").shape[0]
+        ho, wo = h + 2 * self.pad - 6, w + 2 * self.pad - 6                    # 7x7 head
+        if self.pca_based and not self.host_svd and ho * wo <= 4096:
+            # one launch: spatial softmax, centre, covariance, U sqrt(S) (the element-wise formulation below = ~250 tiny launches)
+            rows = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad, planar=False)
+            return ops.lfae_region_stats(rows, n, k_regions, ho, wo, self.temperature)
         pred = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad)
         shp = pred.shape
         region = F.softmax(pred.view(n, shp[1], -1) / self.temperature, dim=2).view(*shp)
@@ -320,12 +328,35 @@ class PixelwiseFlowPredictorExec:
         self.hg = HourglassExec(tree, "pixelwise_flow_predictor.hourglass.", num_blocks, in_pad_to=32)    # 44 channels in a 64-wide buffer
 
     @torch.no_grad()
-    def __call__(self, source_image, driving, source, bg_params=None):
+    def __call__(self, source_image, driving, source, bg_params=None, frames=None):
+        """frames=None: the reference's signature - source_image / source params carry one entry per driving frame (N).
+        frames=T: source_image (B, ...) and source params (B, K, ...) are per VIDEO, the driving params / bg_params per frame
+        (N = B*T, n = b*T + t): nothing is repeated T times (the down-sampled source image in particular)."""
         p = "pixelwise_flow_predictor."
         if self.scale_factor != 1:
             source_image = antialias_down(source_image.float(), self.tree.get(p + "down.weight"), self.scale_factor)
-        n, c, h, w = source_image.shape
         k = self.k
+        if source_image.shape[1] == 3 and self.use_deformed_source and k <= 32:
+            # two library launches around the hourglass instead of ~120 element-wise ATen launches over (N, K+1, h, w[, 2])
+            t = 1 if frames is None else frames
+            b, c, h, w = source_image.shape
+            n = b * t
+            rows, sparse = ops.lfae_motion_inputs(source_image, driving, source, bg_params, t, region_var=self.region_var,
+                                                  revert_axis_swap=self.revert_axis_swap, use_covar=self.use_covar_heatmap)
+            out, skip = self.hg.forward(rows, n, h, w)
+            has_occ = self.tree.has(p + "occlusion.weight")
+            heads = _head_conv(self.tree, (p + "mask.", p + "occlusion.") if has_occ else (p + "mask.",), out, skip, n, h, w, 3,
+                               planar=False)
+            flow, occ = ops.lfae_motion_combine(heads, sparse, has_occ)
+            res = {"optical_flow": flow}
+            if has_occ:
+                res["occlusion_map"] = occ
+            return res
+        if frames is not None and frames != 1:                   # the general formulation below works per driving frame
+            rep = lambda v: v.unsqueeze(1).expand(v.shape[0], frames, *v.shape[1:]).reshape(v.shape[0] * frames, *v.shape[1:])
+            source_image = rep(source_image)
+            source = {kk: rep(v) for kk, v in source.items()}
+        n, c, h, w = source_image.shape
         dev = source_image.device
         # heat-map representation (:48-65)
         cov_d = driving["covar"] if self.use_covar_heatmap else self.region_var

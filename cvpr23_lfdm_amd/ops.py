@@ -120,6 +120,67 @@ def pack_conv_weight_dev(w, mode=0):
     return out
 
 
+def svd2x2_sym(a, b, c):
+    """lfdm_svd2x2_sym_f32: (U (n,2,2), S (n,2)) of [[a, b], [b, c]] with LAPACK's sign convention."""
+    lib = _lib()
+    abc = torch.stack((a, b, c), dim=-1).float().contiguous()
+    _chk(lib, abc)
+    n = abc.shape[0]
+    u = torch.empty(n, 2, 2, dtype=torch.float32, device=abc.device)
+    s = torch.empty(n, 2, dtype=torch.float32, device=abc.device)
+    lib.check(lib.lfdm_svd2x2_sym_f32(_p(abc), n, _p(u), _p(s), _stream(lib)), "lfdm_svd2x2_sym_f32")
+    return u, s
+
+
+def lfae_region_stats(logits, n, k, h, w, temperature):
+    """lfdm_lfae_region_stats_f32 on the `regions` head's channels-last rows -> the RegionPredictor's output dict."""
+    lib = _lib()
+    _chk(lib, logits)
+    dev = logits.device
+    e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    heat, shift, covar, affine, u, d = e(n, k, h, w), e(n, k, 2), e(n, k, 2, 2), e(n, k, 2, 2), e(n * k, 2, 2), e(n * k, 2, 2)
+    lib.check(lib.lfdm_lfae_region_stats_f32(_p(logits), logits.stride(0), n, k, h, w, float(temperature), _p(heat), _p(shift),
+                                             _p(covar), _p(affine), _p(u), _p(d), _stream(lib)), "lfdm_lfae_region_stats_f32")
+    return {"shift": shift, "heatmap": heat, "covar": covar, "affine": affine, "u": u, "d": d}
+
+
+def lfae_motion_inputs(src_img, driving, source, bg, frames, *, region_var, revert_axis_swap, use_covar, pad_to=32):
+    """lfdm_lfae_motion_inputs_f32: -> (rows (N*h*w, ld) = the pixelwise-flow hourglass' channels-last input, sparse (N, K+1, h, w, 2)).
+    src_img (B, 3, h, w); driving: dict of (N = B*frames, K, ...) tensors, source: dict of (B, K, ...) tensors."""
+    lib = _lib()
+    b, c, h, w = src_img.shape
+    n = b * frames
+    k = driving["shift"].shape[1]
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    img = f(src_img)
+    dsh, ssh = f(driving["shift"]), f(source["shift"])
+    dcv, scv = (f(driving["covar"]), f(source["covar"])) if use_covar else (None, None)
+    daf, saf = (f(driving["affine"]), f(source["affine"])) if "affine" in driving else (None, None)
+    bgm = f(bg)
+    _chk(lib, img, dsh, ssh, dcv, scv, daf, saf, bgm)
+    assert c == 3 and dsh.shape[0] == n and ssh.shape[0] == b
+    ld = round_up(4 * (k + 1), pad_to)
+    rows = torch.empty(n * h * w, ld, dtype=torch.float32, device=img.device)
+    sparse = torch.empty(n, k + 1, h, w, 2, dtype=torch.float32, device=img.device)
+    lib.check(lib.lfdm_lfae_motion_inputs_f32(_p(img), _p(dsh), _p(dcv), _p(daf), _p(ssh), _p(scv), _p(saf), _p(bgm),
+                                              float(region_var), int(bool(revert_axis_swap)), b, frames, k, h, w, _p(rows), ld,
+                                              _p(sparse), _stream(lib)), "lfdm_lfae_motion_inputs_f32")
+    return rows, sparse
+
+
+def lfae_motion_combine(heads, sparse, has_occ):
+    """lfdm_lfae_motion_combine_f32: heads = channels-last rows (N*h*w, >= K+1 [+1]) of the mask (+ occlusion) convolutions ->
+    (optical_flow (N, h, w, 2), occlusion_map (N, 1, h, w) or None)."""
+    lib = _lib()
+    _chk(lib, heads, sparse)
+    n, k1, h, w, _ = sparse.shape
+    flow = torch.empty(n, h, w, 2, dtype=torch.float32, device=sparse.device)
+    occ = torch.empty(n, 1, h, w, dtype=torch.float32, device=sparse.device) if has_occ else None
+    lib.check(lib.lfdm_lfae_motion_combine_f32(_p(heads), heads.stride(0), _p(sparse), n, k1 - 1, h * w, _p(flow), _p(occ),
+                                               _stream(lib)), "lfdm_lfae_motion_combine_f32")
+    return flow, occ
+
+
 def pack_wino_weight_grouped(ws):
     """[(Cout_g, Cin_g, 3, 3)] * G -> (G, 16, Cin_g/16, Cout_g, 16): the filters of a grouped 3x3 convolution
     (lfdm_conv_params.groups), each group's Winograd pack back to back."""

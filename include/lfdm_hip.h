@@ -314,6 +314,36 @@ int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, co
 int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
                               lfdm_stream_t stream);
 
+/* PixelwiseFlowPredictor around its hourglass (LFAE/modules/pixelwise_flow_predictor.py:48-128) for all N = batch*frames driving
+ * frames of a training step, frame n = b*frames + t using source image / source regions b:
+ * lfdm_lfae_motion_inputs_f32: heat-map representation (:48-65: Gaussian of the driving minus the source region, covariances
+ * (N|B, K, 2, 2) or - both NULL - the constant region_var), sparse motions (:67-93: identity grid - driving shift, through
+ * src_affine . drv_affine^-1 (times the sign of its [0][0] entry when revert_axis_swap) when the affines are given, + source
+ * shift; region 0 = background: the identity grid through the 3x3 homography bg (N, 3, 3), or as is when NULL) and the K+1
+ * bilinear / zero-padded / align_corners=False samples of the 3-channel source image src_img (B, 3, h, w) (:95-102).
+ * rows: channels-last hourglass input (N*h*w, ld), channel 4*kk + {0: heat, 1..3: warped image}, columns >= 4*(K+1)
+ * zeroed; sparse: (N, K+1, h, w, 2).
+ * lfdm_lfae_motion_combine_f32: (:112-128) heads = channels-last rows (N*hw, ldh) of the mask (columns 0..K) and occlusion
+ * (column K+1, read iff occ != NULL) convolutions: flow (N, h, w, 2) = sum_k softmax_k(mask) * sparse_k,
+ * occ (N, 1, h, w) = sigmoid. */
+int lfdm_lfae_motion_inputs_f32(const float* src_img, const float* drv_shift, const float* drv_covar, const float* drv_affine,
+                                const float* src_shift, const float* src_covar, const float* src_affine, const float* bg,
+                                float region_var, int revert_axis_swap, int batch, int frames, int regions, int h, int w,
+                                float* rows, int ld, float* sparse, lfdm_stream_t stream);
+/* RegionPredictor tail (LFAE/modules/region_predictor.py:16-25,60-96) for n_img frames in one launch.  logits: channels-last
+ * rows (n_img*h*w, ldh) of the `regions` head convolution, column k = region k.  heatmap (n_img, K, h, w) = spatial softmax of
+ * logits / temperature; shift (n_img, K, 2) = its centre on the [-1, 1] grid; covar (n_img, K, 2, 2) = its covariance;
+ * u (n_img*K, 2, 2), d (n_img*K, 2, 2) = diag(sqrt(S)) and affine (n_img, K, 2, 2) = U sqrt(S) from the covariance's SVD with
+ * LAPACK xGESDD's sign convention (what torch.svd returns for a 2x2 input; closed form, no host round trip).  h*w <= 4096. */
+int lfdm_lfae_region_stats_f32(const float* logits, int ldh, int n_img, int regions, int h, int w, float temperature,
+                               float* heatmap, float* shift, float* covar, float* affine, float* u, float* d,
+                               lfdm_stream_t stream);
+/* (U, S) of n symmetric 2x2 matrices [[a, b], [b, c]] given as abc (n, 3), exactly as LAPACK xGESDD / torch.svd return them
+ * (singular values descending, U's signs included) - the closed form lfdm_lfae_region_stats_f32 uses.  u (n, 2, 2), s (n, 2). */
+int lfdm_svd2x2_sym_f32(const float* abc, int64_t n, float* u, float* s, lfdm_stream_t stream);
+int lfdm_lfae_motion_combine_f32(const float* heads, int ldh, const float* sparse, int n_img, int regions, int hw, float* flow,
+                                 float* occ, lfdm_stream_t stream);
+
 /* Direct-form filter pack of lfdm_conv_params.weight ([ceil(K/32)][coutp][32], k contiguous per output column, zero padded)
  * from a weight in the reference layout, in ONE launch - training re-packs every filter every step
  * (video_flow_diffusion_model.py:181-188), the torch formulation costs three to five small kernels per filter.

@@ -84,3 +84,11 @@ def test_pixelwise_flow_predictor(backend):
     assert got["optical_flow"].shape == (n, 32, 32, 2) and got["occlusion_map"].shape == (n, 1, 32, 32)
     assert_close(got["optical_flow"].cpu(), ref["optical_flow"], 1e-3, "pixelwise flow")
     assert_close(got["occlusion_map"].cpu(), ref["occlusion_map"], 1e-3, "occlusion map")
+    # the per-video form (frames=T: one source image / source regions per video, nothing repeated) = the per-frame form on
+    # the repeated source
+    with torch.no_grad():
+        one = lambda d: {k: v[:1] for k, v in to(d).items()}
+        rep2 = lambda d: {k: v[:1].repeat(2, *([1] * (v.dim() - 1))) for k, v in to(d).items()}
+        a = ex(src[:1].to(dev), to(d_par), one(s_par), bg.to(dev), frames=2)
+        b = ex(src[:1].repeat(2, 1, 1, 1).to(dev), to(d_par), rep2(s_par), bg.to(dev))
+    assert torch.equal(a["optical_flow"], b["optical_flow"]) and torch.equal(a["occlusion_map"], b["occlusion_map"])
