@@ -679,7 +679,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                     p.hq == up * p.hi && p.wq == up * p.wi && p.hq % 2 == 0 && p.wq % 2 == 0 && p.c0 % 16 == 0 &&
                     p.c1 % 16 == 0 && p.ld0 % 4 == 0 && (p.c1 == 0 || p.ld1 % 4 == 0) && (((uintptr_t)p.src0 & 15) == 0) &&
                     (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0) && (((uintptr_t)p.weight_wino) & 15) == 0 && !p.ln_wsum &&
-                    p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64 &&
+                    p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && (p.pool2 ? (2 * p.ho == p.hq && 2 * p.wo == p.wq) : (p.ho == p.hq && p.wo == p.wq)) && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64 &&
                     !p.deconv4 && vec_ok;      // (float4 epilogue)
   if (wino) {
     pl.kind = 2;
@@ -713,6 +713,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     }
     pl.ksplit = user_k >= 1 ? user_k : k;
     if (pl.ksplit > nch) pl.ksplit = nch;
+    if (p.pool2) pl.ksplit = 1;                     // the pooled epilogue needs the finished sums
     return pl;
   }
   if (ksw) {
@@ -809,6 +810,13 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   }
   const ConvPlan pl = make_plan(p);
   if (p.groups > 1 && pl.kind != 2) { lfdm_set_error("conv2d: groups > 1 is only built for the Winograd schedule (3x3, stride 1, zero pad)"); return LFDM_EINVAL; }
+  if ((p.in_scale || p.in_shift || p.pool2) &&
+      (pl.kind != 2 || (p.in_scale == nullptr) != (p.in_shift == nullptr) || (((uintptr_t)p.in_scale | (uintptr_t)p.in_shift) & 7) != 0 ||
+       (p.pool2 && (p.residual || p.gn_partial || pp->ksplit > 1)) || p.act == LFDM_ACT_NONE || (p.in_scale && (p.pool2 || p.c0 + p.c1 > 1024)))) {
+    lfdm_set_error("conv2d: in_scale / in_shift / pool2 exist on the Winograd schedule only (3x3, stride 1, zero pad 1, even size, C % 16 == 0; "
+                   "pool2: out = (hq/2, wq/2), no residual / fused GroupNorm / split-K; both need an output activation, exclude each other; <= 1024 input channels) - see lfdm_conv2d_schedule");
+    return LFDM_EINVAL;
+  }
   p.ksplit = pl.ksplit;
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;

@@ -42,7 +42,9 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // 10-30 % slower): the L1 path is not what limits this kernel - per-workgroup phase stamps (tools/probe_wino_phases.py) show the
 // K loop AT the matrix-pipe bound whenever three workgroups share a CU; the time is in the set-up, the first patch's latency
 // and the epilogue, which all co-resident workgroups go through in lockstep.
-template <bool ACT, int NT>
+// INAFF / POOL: lfdm_conv_params.in_scale+in_shift / .pool2 - instantiations of their own, so that the plain kernel keeps its
+// register allocation (the fused forms cost it 34-48 spilled registers when they were run-time branches)
+template <bool ACT, int NT, bool INAFF = false, bool POOL = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
@@ -127,6 +129,30 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     for (int py = 0; py < 4; ++py)
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
+  // p.in_scale / p.in_shift: the convolution reads relu(x * a[c] + b[c]) (ResBlock2d's pre-activation BatchNorm + ReLU): applied to
+  // the raw patch right before the transform; taps outside the image stay zero.  The two tables sit in LDS (a global load per
+  // chunk would stall the transform, registers held across the K loop spill: the kernel is at its allocation limit).
+  constexpr bool in_aff = INAFF;
+  constexpr int AFF_MAX = INAFF ? 1024 : 1;            // input channels (host check)
+  __shared__ __attribute__((aligned(8))) float s_aff[2][AFF_MAX];
+  if (INAFF) {
+    for (int c = tid; c < cin; c += 256) {
+      s_aff[0][c] = p.in_scale[cbase + c];
+      s_aff[1][c] = p.in_shift[cbase + c];
+    }
+    __syncthreads();
+  }
+  auto apply_affine = [&](float2 (&d)[16], int chunk) {
+    const int c = chunk * WKC + 2 * x_c2;                                    // channel inside this workgroup's reduction range
+    const float2 a = *reinterpret_cast<const float2*>(&s_aff[0][c]);
+    const float2 b = *reinterpret_cast<const float2*>(&s_aff[1][c]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool ok = (valid_mask >> q) & 1u;
+      d[q].x = ok ? fmaxf(fmaf(d[q].x, a.x, b.x), 0.f) : 0.f;
+      d[q].y = ok ? fmaxf(fmaf(d[q].y, a.y, b.y), 0.f) : 0.f;
+    }
+  };
   float2 patch[16];
   auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
     int cc = chunk * WKC + cbase;
@@ -214,6 +240,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     fetch_patch(patch, kc_begin);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
       const int nxt = clampc(kc + 1);
+      if (in_aff) apply_affine(patch, kc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
 #ifdef LFDM_WINO_TIMING
@@ -276,6 +303,25 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       y[1] = make_float4(m[1].x + m[3].x + m[5].x, m[1].y + m[3].y + m[5].y, m[1].z + m[3].z + m[5].z, m[1].w + m[3].w + m[5].w);
       y[2] = make_float4(m[2].x - m[4].x - m[6].x, m[2].y - m[4].y - m[6].y, m[2].z - m[4].z - m[6].z, m[2].w - m[4].w - m[6].w);
       y[3] = make_float4(m[3].x - m[5].x - m[7].x, m[3].y - m[5].y - m[7].y, m[3].z - m[5].z - m[7].z, m[3].w - m[5].w - m[7].w);
+      if (POOL) {
+        // DownBlock2d: conv -> act -> 2x2 average pool = the mean of this tile's four outputs: one row of the half-size image
+        if (co < p.cout) {
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(y[q].x + bb.x, y[q].y + bb.y, y[q].z + bb.z, y[q].w + bb.w);
+            if (ACT) {
+              v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+              v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+            }
+            acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+          }
+          const int64_t prow = ((int64_t)n * th + my_ty) * tw + my_tx;
+          *reinterpret_cast<float4*>(p.out + prow * p.ldo + co) =
+              make_float4(0.25f * acc4.x, 0.25f * acc4.y, 0.25f * acc4.z, 0.25f * acc4.w);
+        }
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
@@ -394,7 +440,13 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream)
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
+  if (p.in_scale && act) {                // (both fused forms follow an output activation in every caller: lfdm_conv2d_cl_f32 checks)
+    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true, false>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<true, 1, true, false>), grid, dim3(256), 0, stream, p);
+  } else if (p.pool2 && act) {
+    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, true>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<true, 1, false, true>), grid, dim3(256), 0, stream, p);
+  } else if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
   else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
   else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);
   else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p);

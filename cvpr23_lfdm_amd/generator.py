@@ -137,10 +137,16 @@ class Generator(ParamTree):
         res_h, res_w = h, w
         for i in range(self.num_down_blocks):
             co = self._feat(i + 1)
-            y = ops.conv2d_cl(out, pk["down%d.w" % i], co, 3, 3, b, res_h, res_w, bias=pk["down%d.b" % i],
-                              act=ops.ACT_RELU, out=self._buf("enc.t", b * res_h * res_w, co), weight_wino=pk["down%d.ww" % i])
+            pooled = self._buf("enc%d" % (i + 1), b * (res_h // 2) * (res_w // 2), co)
+            try:          # DownBlock2d's 2x2 average pool in the convolution's epilogue (Winograd schedule)
+                ops.conv2d_cl(out, pk["down%d.w" % i], co, 3, 3, b, res_h, res_w, bias=pk["down%d.b" % i], act=ops.ACT_RELU,
+                              out=pooled, weight_wino=pk["down%d.ww" % i], pool2=True)
+            except ops.WinogradUnavailable:
+                y = ops.conv2d_cl(out, pk["down%d.w" % i], co, 3, 3, b, res_h, res_w, bias=pk["down%d.b" % i],
+                                  act=ops.ACT_RELU, out=self._buf("enc.t", b * res_h * res_w, co), weight_wino=pk["down%d.ww" % i])
+                ops.avgpool2_cl(y, b, res_h, res_w, out=pooled)
             res_h, res_w = res_h // 2, res_w // 2
-            out = ops.avgpool2_cl(y, b, res_h * 2, res_w * 2, out=self._buf("enc%d" % (i + 1), b * res_h * res_w, co))
+            out = pooled
             skips.append(out)
         return skips
 
@@ -173,10 +179,15 @@ class Generator(ParamTree):
         # bottleneck input: warped + masked latent (generator.py:149)
         out = ops.warp_cl(skips[-1], b, frames, lh, lw, flow_x, flow_y, occ, out=self._buf("dec.x", n * lh * lw, cb), **wk)
         for i in range(self.num_bottleneck_blocks):          # ResBlock2d (util.py:84-92)
-            t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
-                                   out=self._buf("dec.t0", n * lh * lw, cb))
-            t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
-                               out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
+            try:          # the pre-activation BatchNorm + ReLU applied where conv1 loads its input (Winograd schedule)
+                t1 = ops.conv2d_cl(out, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
+                                   out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i],
+                                   in_affine=(pk["r%d.a1" % i], pk["r%d.b1" % i]))
+            except ops.WinogradUnavailable:
+                t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
+                                       out=self._buf("dec.t0", n * lh * lw, cb))
+                t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
+                                   out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
             out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
                                 out=out, weight_wino=pk["r%d.ww2" % i])
         res_h, res_w = lh, lw

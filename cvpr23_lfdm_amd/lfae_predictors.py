@@ -71,8 +71,15 @@ class HourglassExec:
         outs = [(x_cl, h, w)]
         for wp, b, co, wino in pk["down"]:
             src, hh, ww = outs[-1]
-            y = ops.conv2d_cl(src, wp, co, 3, 3, n, hh, ww, bias=b, act=ops.ACT_RELU, weight_wino=wino)
-            outs.append((ops.avgpool2_cl(y, n, hh, ww), hh // 2, ww // 2))
+            try:          # DownBlock2d: the 2x2 average pool taken in the convolution's epilogue (Winograd schedule)
+                pooled = ops.conv2d_cl(src, wp, co, 3, 3, n, hh, ww, bias=b, act=ops.ACT_RELU, weight_wino=wino, pool2=True) \
+                    if (wino is not None and hh % 2 == 0 and ww % 2 == 0) else None
+            except ops.WinogradUnavailable:
+                pooled = None
+            if pooled is None:
+                y = ops.conv2d_cl(src, wp, co, 3, 3, n, hh, ww, bias=b, act=ops.ACT_RELU, weight_wino=wino)
+                pooled = ops.avgpool2_cl(y, n, hh, ww)
+            outs.append((pooled, hh // 2, ww // 2))
         return outs
 
     def forward(self, x_cl, n, h, w):
