@@ -42,7 +42,7 @@ class ConvParams(C.Structure):
         ("ln_wsum", f32p), ("ln_eps", f32),
         ("tile_counters", C.c_void_p), ("tile_counters_len", i32), ("weight_wino", C.c_void_p),
         ("deconv4", i32), ("groups", i32),
-        ("in_scale", f32p), ("in_shift", f32p), ("pool2", i32),
+        ("pool2", i32),
     ]
 
 

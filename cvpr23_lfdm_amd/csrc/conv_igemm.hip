@@ -810,11 +810,9 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   }
   const ConvPlan pl = make_plan(p);
   if (p.groups > 1 && pl.kind != 2) { lfdm_set_error("conv2d: groups > 1 is only built for the Winograd schedule (3x3, stride 1, zero pad)"); return LFDM_EINVAL; }
-  if ((p.in_scale || p.in_shift || p.pool2) &&
-      (pl.kind != 2 || (p.in_scale == nullptr) != (p.in_shift == nullptr) || (((uintptr_t)p.in_scale | (uintptr_t)p.in_shift) & 7) != 0 ||
-       (p.pool2 && (p.residual || p.gn_partial || pp->ksplit > 1)) || p.act == LFDM_ACT_NONE || (p.in_scale && (p.pool2 || p.c0 + p.c1 > 1024)))) {
-    lfdm_set_error("conv2d: in_scale / in_shift / pool2 exist on the Winograd schedule only (3x3, stride 1, zero pad 1, even size, C % 16 == 0; "
-                   "pool2: out = (hq/2, wq/2), no residual / fused GroupNorm / split-K; both need an output activation, exclude each other; <= 1024 input channels) - see lfdm_conv2d_schedule");
+  if (p.pool2 && (pl.kind != 2 || p.residual || p.gn_partial || pp->ksplit > 1 || p.act == LFDM_ACT_NONE)) {
+    lfdm_set_error("conv2d: pool2 exists on the Winograd schedule only (3x3, stride 1, zero pad 1, even size, C % 16 == 0): out = (hq/2, wq/2), "
+                   "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
   }
   p.ksplit = pl.ksplit;

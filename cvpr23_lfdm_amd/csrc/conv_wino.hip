@@ -42,9 +42,11 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // 10-30 % slower): the L1 path is not what limits this kernel - per-workgroup phase stamps (tools/probe_wino_phases.py) show the
 // K loop AT the matrix-pipe bound whenever three workgroups share a CU; the time is in the set-up, the first patch's latency
 // and the epilogue, which all co-resident workgroups go through in lockstep.
-// INAFF / POOL: lfdm_conv_params.in_scale+in_shift / .pool2 - instantiations of their own, so that the plain kernel keeps its
-// register allocation (the fused forms cost it 34-48 spilled registers when they were run-time branches)
-template <bool ACT, int NT, bool INAFF = false, bool POOL = false>
+// POOL: lfdm_conv_params.pool2 - an instantiation of its own, so that the plain kernel keeps its register allocation.
+// Measured and removed in round 2: ResBlock2d's pre-activation BatchNorm + ReLU applied to the patches right before the transform
+// (tables in LDS, no spills): the 256 -> 256 bottleneck convolution of a B = 8 training step went from 1650 to 1781 us, more
+// than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).
+template <bool ACT, int NT, bool POOL = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
@@ -129,30 +131,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     for (int py = 0; py < 4; ++py)
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
-  // p.in_scale / p.in_shift: the convolution reads relu(x * a[c] + b[c]) (ResBlock2d's pre-activation BatchNorm + ReLU): applied to
-  // the raw patch right before the transform; taps outside the image stay zero.  The two tables sit in LDS (a global load per
-  // chunk would stall the transform, registers held across the K loop spill: the kernel is at its allocation limit).
-  constexpr bool in_aff = INAFF;
-  constexpr int AFF_MAX = INAFF ? 1024 : 1;            // input channels (host check)
-  __shared__ __attribute__((aligned(8))) float s_aff[2][AFF_MAX];
-  if (INAFF) {
-    for (int c = tid; c < cin; c += 256) {
-      s_aff[0][c] = p.in_scale[cbase + c];
-      s_aff[1][c] = p.in_shift[cbase + c];
-    }
-    __syncthreads();
-  }
-  auto apply_affine = [&](float2 (&d)[16], int chunk) {
-    const int c = chunk * WKC + 2 * x_c2;                                    // channel inside this workgroup's reduction range
-    const float2 a = *reinterpret_cast<const float2*>(&s_aff[0][c]);
-    const float2 b = *reinterpret_cast<const float2*>(&s_aff[1][c]);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const bool ok = (valid_mask >> q) & 1u;
-      d[q].x = ok ? fmaxf(fmaf(d[q].x, a.x, b.x), 0.f) : 0.f;
-      d[q].y = ok ? fmaxf(fmaf(d[q].y, a.y, b.y), 0.f) : 0.f;
-    }
-  };
   float2 patch[16];
   auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
     int cc = chunk * WKC + cbase;
@@ -240,7 +218,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     fetch_patch(patch, kc_begin);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
       const int nxt = clampc(kc + 1);
-      if (in_aff) apply_affine(patch, kc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
 #ifdef LFDM_WINO_TIMING
@@ -440,12 +417,9 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream)
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (p.in_scale && act) {                // (both fused forms follow an output activation in every caller: lfdm_conv2d_cl_f32 checks)
-    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true, false>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<true, 1, true, false>), grid, dim3(256), 0, stream, p);
-  } else if (p.pool2 && act) {
-    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, true>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<true, 1, false, true>), grid, dim3(256), 0, stream, p);
+  if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)
+    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);
   } else if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
   else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
   else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);

@@ -179,15 +179,10 @@ class Generator(ParamTree):
         # bottleneck input: warped + masked latent (generator.py:149)
         out = ops.warp_cl(skips[-1], b, frames, lh, lw, flow_x, flow_y, occ, out=self._buf("dec.x", n * lh * lw, cb), **wk)
         for i in range(self.num_bottleneck_blocks):          # ResBlock2d (util.py:84-92)
-            try:          # the pre-activation BatchNorm + ReLU applied where conv1 loads its input (Winograd schedule)
-                t1 = ops.conv2d_cl(out, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
-                                   out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i],
-                                   in_affine=(pk["r%d.a1" % i], pk["r%d.b1" % i]))
-            except ops.WinogradUnavailable:
-                t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
-                                       out=self._buf("dec.t0", n * lh * lw, cb))
-                t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
-                                   out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
+            t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
+                                   out=self._buf("dec.t0", n * lh * lw, cb))
+            t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
+                               out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
             out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
                                 out=out, weight_wino=pk["r%d.ww2" % i])
         res_h, res_w = lh, lw

@@ -234,7 +234,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, in_affine=None, pool2=False):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -291,15 +291,8 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         assert kh == 2 and kw == 2 and out_scale == 2 and deconv4.is_contiguous() and deconv4.shape == (4,) + tuple(weight.shape) \
             and deconv4.data_ptr() == weight.data_ptr(), "weight must be deconv4[0]"
         p.deconv4 = 1
-    # Winograd schedule only (the library refuses them elsewhere): in_affine = (scale, shift) over the c0 + c1 input channels -> the
-    # convolution reads relu(x * scale + shift); pool2: the 2x2 average pool behind conv -> act, taken in the epilogue
-    p.in_scale, p.in_shift, p.pool2 = None, None, int(bool(pool2))
-    if in_affine is not None:
-        a, b = in_affine
-        _chk(lib, a, b)
-        assert a.numel() == cin and b.numel() == cin and a.is_contiguous() and b.is_contiguous()
-        p.in_scale, p.in_shift = _p(a), _p(b)
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, in_affine)   # keep the tensors alive with the struct
+    p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4)   # keep the tensors alive with the struct
     return p, out
 
 
@@ -331,9 +324,9 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     lib = _lib()
     _chk(lib, partial, gn_partial)
     p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
-    if (weight is None or kw_.get("in_affine") is not None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
+    if (weight is None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
         raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack / "
-                                  "apply the input affine and the pooling as launches of their own")
+                                  "run the pooling as a launch of its own")
     _, ks = conv_plan(p)
     if ks > 1:
         need = conv_partial_floats(p)

@@ -116,16 +116,10 @@ typedef struct lfdm_conv_params {
      back ([groups][16][c0/groups/16][coutp/groups][16]).  Used to run the two output heads' second convolutions
      (final_conv.0.block2 / occlusion_map.0.block2, video_flow_diffusion.py:493-509) as one launch. */
   int groups;
-  /* Optional (Winograd schedule only; lfdm_conv2d_cl_f32 refuses them on a geometry that would run another schedule - ask
-     lfdm_conv2d_schedule first):
-     in_scale / in_shift [c0 + c1]: the convolution reads relu(x * in_scale[c] + in_shift[c]) instead of x (zero padding
-     stays zero) - the pre-activation BatchNorm(eval) + ReLU of ResBlock2d (LFAE/modules/util.py:85-91) without a pass of
-     its own over the activation (both NULL = off).
-     pool2 = 1: the 2x2 average pool that follows conv -> (folded BN) -> act in DownBlock2d (util.py:136-150) is taken in the
-     epilogue: out has (ho, wo) = (hq / 2, wq / 2) rows per image, one Winograd output tile each; no residual, no fused
-     GroupNorm statistics, no split-K. */
-  const float* in_scale;
-  const float* in_shift;
+  /* Optional (Winograd schedule only; lfdm_conv2d_cl_f32 refuses it on a geometry that would run another schedule - ask
+     lfdm_conv2d_schedule first): pool2 = 1: the 2x2 average pool that follows conv -> (folded BN) -> act in DownBlock2d
+     (LFAE/modules/util.py:136-150) is taken in the epilogue: out has (ho, wo) = (hq / 2, wq / 2) rows per image, one Winograd
+     output tile each; needs an output activation, no residual, no fused GroupNorm statistics, no split-K. */
   int pool2;
 } lfdm_conv_params;
 

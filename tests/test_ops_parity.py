@@ -111,34 +111,6 @@ def test_conv2d_c2_shapes(backend):
         assert_close(from_cl(out.cpu(), frames, s, s), ref, TOL, "conv %s" % ((cin, cout, s),))
 
 
-@pytest.mark.parametrize("case", [dict(cin=32, cout=32, n=2, h=8, w=8), dict(cin=64, cout=96, n=3, h=6, w=10, split_src=32),
-                                  dict(cin=48, cout=64, n=1, h=4, w=4, residual=True)])
-def test_winograd_input_affine_relu(backend, case):
-    """lfdm_conv_params.in_scale / in_shift: conv(relu(x * a + b)) with the affine + ReLU applied where the Winograd kernel loads
-    its patches (ResBlock2d's pre-activation BatchNorm + ReLU, util.py:85-91) - zero padding must stay zero."""
-    dev = backend
-    cin, cout, n, h, w = (case[k] for k in ("cin", "cout", "n", "h", "w"))
-    x = rnd(n, cin, h, w, seed=31)
-    wt = rnd(cout, cin, 3, 3, seed=32, scale=1.0 / math.sqrt(cin * 9))
-    bias, a, b = rnd(cout, seed=33), rnd(cin, seed=34) * 0.5 + 1.0, rnd(cin, seed=35) * 0.7 + 0.3      # b > 0: relu(b) != 0 at the border
-    ref = F.relu(F.conv2d(F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)), wt, bias, padding=1))
-    res = None
-    if case.get("residual"):
-        res = rnd(*ref.shape, seed=36)
-        ref = F.relu(F.conv2d(F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)), wt, bias, padding=1) + res)
-    xs = to_cl(x).to(dev)
-    src0, src1 = xs, None
-    if case.get("split_src"):
-        src0, src1 = xs[:, :case["split_src"]].contiguous(), xs[:, case["split_src"]:].contiguous()
-    out = ops.conv2d_cl(src0, ops.pack_conv_weight(wt).to(dev), cout, 3, 3, n, h, w, src1=src1, bias=bias.to(dev), act=1,
-                        weight_wino=ops.pack_wino_weight(wt.to(dev)), in_affine=(a.to(dev), b.to(dev)),
-                        residual=None if res is None else to_cl(res).to(dev))
-    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "conv(relu(ax+b))")
-    with pytest.raises(ops.WinogradUnavailable):            # not a Winograd geometry: refused, the caller keeps its own pass
-        ops.conv2d_cl(xs, ops.pack_conv_weight(wt[:, :, :1, :1].contiguous()).to(dev), cout, 1, 1, n, h, w,
-                      in_affine=(a.to(dev), b.to(dev)))
-
-
 @pytest.mark.parametrize("case", [dict(cin=32, cout=64, n=2, h=8, w=8), dict(cin=16, cout=32, n=3, h=2, w=6), dict(cin=64, cout=128, n=5, h=16, w=16)])
 def test_winograd_pooled_epilogue(backend, case):
     """lfdm_conv_params.pool2: DownBlock2d's conv -> (folded BN) -> ReLU -> AvgPool2d(2) with the pool taken over each Winograd
@@ -153,6 +125,8 @@ def test_winograd_pooled_epilogue(backend, case):
                         weight_wino=ops.pack_wino_weight(wt.to(dev)), pool2=True)
     assert out.shape == (n * (h // 2) * (w // 2), cout)
     assert_close(from_cl(out.cpu(), n, h // 2, w // 2), ref, TOL, "conv + relu + avgpool")
+    with pytest.raises(ops.WinogradUnavailable):            # not a Winograd geometry: refused, the caller keeps its own pooling pass
+        ops.conv2d_cl(to_cl(x).to(dev), ops.pack_conv_weight(wt[:, :, :1, :1].contiguous()).to(dev), cout, 1, 1, n, h, w, act=1, pool2=True)
 
 
 @pytest.mark.parametrize("shape", [(64, 32, 3, 3), (40, 72, 1, 1), (3, 20, 7, 7), (32, 48, 4, 4)])
