@@ -43,7 +43,6 @@ class ConvParams(C.Structure):
         ("tile_counters", C.c_void_p), ("tile_counters_len", i32), ("weight_wino", C.c_void_p),
         ("deconv4", i32), ("groups", i32),
         ("pool2", i32),
-        ("out2", f32p), ("out2_scale", f32p), ("out2_shift", f32p), ("ldo2", i32),
     ]
 
 

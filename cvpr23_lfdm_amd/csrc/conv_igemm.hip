@@ -815,12 +815,6 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
                    "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
   }
-  if (p.out2 && (pl.kind != 2 || pl.ksplit > 1 || p.pool2 || !p.out2_scale || !p.out2_shift || p.ldo2 < p.cout || p.ldo2 % 4 != 0 ||
-                 (((uintptr_t)p.out2 | (uintptr_t)p.out2_scale | (uintptr_t)p.out2_shift) & 15) != 0)) {
-    lfdm_set_error("conv2d: out2 exists on the Winograd schedule without split-K / pool2 only (ask lfdm_conv2d_schedule and lfdm_conv2d_plan); "
-                   "16-byte aligned out2 / out2_scale / out2_shift, ldo2 % 4 == 0");
-    return LFDM_EINVAL;
-  }
   p.ksplit = pl.ksplit;
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;

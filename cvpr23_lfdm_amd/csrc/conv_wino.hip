@@ -42,11 +42,11 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // 10-30 % slower): the L1 path is not what limits this kernel - per-workgroup phase stamps (tools/probe_wino_phases.py) show the
 // K loop AT the matrix-pipe bound whenever three workgroups share a CU; the time is in the set-up, the first patch's latency
 // and the epilogue, which all co-resident workgroups go through in lockstep.
-// POOL / OUT2: lfdm_conv_params.pool2 / .out2 - instantiations of their own, so that the plain kernel keeps its register allocation.
+// POOL: lfdm_conv_params.pool2 - an instantiation of its own, so that the plain kernel keeps its register allocation.
 // Measured and removed in round 2: ResBlock2d's pre-activation BatchNorm + ReLU applied to the patches right before the transform
 // (tables in LDS, no spills): the 256 -> 256 bottleneck convolution of a B = 8 training step went from 1650 to 1781 us, more
 // than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).
-template <bool ACT, int NT, bool POOL = false, bool OUT2 = false>
+template <bool ACT, int NT, bool POOL = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
@@ -314,13 +314,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
             v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
           }
           *reinterpret_cast<float4*>(p.out + orow * p.ldo + co) = v;
-          if (OUT2) {            // relu(v * a[c] + b[c]): the next block's pre-activation, leaving with the tensor it normalises
-            const float4 a2 = *reinterpret_cast<const float4*>(p.out2_scale + co);
-            const float4 b2 = *reinterpret_cast<const float4*>(p.out2_shift + co);
-            *reinterpret_cast<float4*>(p.out2 + orow * p.ldo2 + co) =
-                make_float4(fmaxf(fmaf(v.x, a2.x, b2.x), 0.f), fmaxf(fmaf(v.y, a2.y, b2.y), 0.f),
-                            fmaxf(fmaf(v.z, a2.z, b2.z), 0.f), fmaxf(fmaf(v.w, a2.w, b2.w), 0.f));
-          }
         }
       }
     }
@@ -424,12 +417,7 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream)
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (p.out2) {                           // (lfdm_conv2d_cl_f32 checked: no split-K, no pooling)
-    if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, true>), grid, dim3(256), 0, stream, p);
-    else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2, false, true>), grid, dim3(256), 0, stream, p);
-    else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, true>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<false, 1, false, true>), grid, dim3(256), 0, stream, p);
-  } else if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)
+  if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)
     if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
     else LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);
   } else if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);

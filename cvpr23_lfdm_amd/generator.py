@@ -178,23 +178,11 @@ class Generator(ParamTree):
         cb = self._feat(self.num_down_blocks)
         # bottleneck input: warped + masked latent (generator.py:149)
         out = ops.warp_cl(skips[-1], b, frames, lh, lw, flow_x, flow_y, occ, out=self._buf("dec.x", n * lh * lw, cb), **wk)
-        t0 = None
         for i in range(self.num_bottleneck_blocks):          # ResBlock2d (util.py:84-92)
-            if t0 is None:   # relu(bn1(out)): from the previous block's conv2 when that could emit it (out2), else a pass of its own
-                t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
-                                       out=self._buf("dec.t0", n * lh * lw, cb))
+            t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
+                                   out=self._buf("dec.t0", n * lh * lw, cb))
             t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
                                out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
-            if i + 1 < self.num_bottleneck_blocks:
-                try:
-                    t0n = self._buf("dec.t0", n * lh * lw, cb)
-                    out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out, out=out,
-                                        weight_wino=pk["r%d.ww2" % i], out2=(t0n, pk["r%d.a1" % (i + 1)], pk["r%d.b1" % (i + 1)]))
-                    t0 = t0n
-                    continue
-                except ops.WinogradUnavailable:
-                    pass
-            t0 = None
             out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
                                 out=out, weight_wino=pk["r%d.ww2" % i])
         res_h, res_w = lh, lw

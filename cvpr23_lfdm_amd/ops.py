@@ -234,7 +234,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, out2=None):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -292,14 +292,7 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
             and deconv4.data_ptr() == weight.data_ptr(), "weight must be deconv4[0]"
         p.deconv4 = 1
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
-    # out2 = (rows like out, scale (cout,), shift (cout,)): second output relu(out * scale + shift) (Winograd schedule, no split-K)
-    p.out2, p.out2_scale, p.out2_shift, p.ldo2 = None, None, None, 0
-    if out2 is not None:
-        o2, a2, b2 = out2
-        _chk(lib, o2, a2, b2)
-        assert o2.shape == out.shape and a2.numel() == cout and b2.numel() == cout
-        p.out2, p.out2_scale, p.out2_shift, p.ldo2 = _p(o2), _p(a2), _p(b2), o2.stride(0)
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, out2)   # keep the tensors alive with the struct
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4)   # keep the tensors alive with the struct
     return p, out
 
 
@@ -331,8 +324,6 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     lib = _lib()
     _chk(lib, partial, gn_partial)
     p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
-    if kw_.get("out2") is not None and (lib.lfdm_conv2d_schedule(C.byref(p)) != 2 or conv_plan(p)[1] > 1):
-        raise WinogradUnavailable("the second output needs the Winograd schedule without split-K: run the affine pass as a launch of its own")
     if (weight is None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
         raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack / "
                                   "run the pooling as a launch of its own")

@@ -121,14 +121,6 @@ typedef struct lfdm_conv_params {
      (LFAE/modules/util.py:136-150) is taken in the epilogue: out has (ho, wo) = (hq / 2, wq / 2) rows per image, one Winograd
      output tile each; needs an output activation, no residual, no fused GroupNorm statistics, no split-K. */
   int pool2;
-  /* Optional second output (Winograd schedule, no split-K, no pool2): out2 rows (indexed like out, row stride ldo2) receive
-     relu(v * out2_scale[c] + out2_shift[c]) of every value v written to out - the pre-activation BatchNorm + ReLU of the NEXT
-     ResBlock2d (LFAE/modules/util.py:85-86) leaves with the convolution that produces its input (which the skip connection
-     needs raw), instead of re-reading that tensor in a pass of its own. */
-  float* out2;
-  const float* out2_scale;
-  const float* out2_shift;
-  int ldo2;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);

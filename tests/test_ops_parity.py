@@ -129,33 +129,6 @@ def test_winograd_pooled_epilogue(backend, case):
         ops.conv2d_cl(to_cl(x).to(dev), ops.pack_conv_weight(wt[:, :, :1, :1].contiguous()).to(dev), cout, 1, 1, n, h, w, act=1, pool2=True)
 
 
-@pytest.mark.parametrize("case", [dict(cin=32, cout=32, n=2, h=8, w=8, residual=True), dict(cin=64, cout=96, n=3, h=6, w=10, act=1)])
-def test_winograd_second_output(backend, case):
-    """lfdm_conv_params.out2: besides out = conv(x) + bias (+ residual), the epilogue writes relu(out * a + b) - the next
-    ResBlock2d's pre-activation BatchNorm + ReLU (util.py:85-86) - in the same launch; refused where split-K would run."""
-    dev = backend
-    cin, cout, n, h, w = (case[k] for k in ("cin", "cout", "n", "h", "w"))
-    x = rnd(n, cin, h, w, seed=51)
-    wt = rnd(cout, cin, 3, 3, seed=52, scale=1.0 / math.sqrt(cin * 9))
-    bias, a, b = rnd(cout, seed=53), rnd(cout, seed=54) * 0.5 + 1.0, rnd(cout, seed=55) * 0.5
-    ref = F.conv2d(x, wt, bias, padding=1)
-    res = None
-    if case.get("residual"):
-        res = rnd(*ref.shape, seed=56)
-        ref = ref + res
-    if case.get("act"):
-        ref = F.relu(ref)
-    ref2 = F.relu(ref * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
-    o2 = torch.full((n * h * w, cout), float("nan"), device=dev)
-    kw = dict(bias=bias.to(dev), act=case.get("act", 0), weight_wino=ops.pack_wino_weight(wt.to(dev)),
-              residual=None if res is None else to_cl(res).to(dev))
-    out = ops.conv2d_cl(to_cl(x).to(dev), ops.pack_conv_weight(wt).to(dev), cout, 3, 3, n, h, w, out2=(o2, a.to(dev), b.to(dev)), **kw)
-    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "first output")
-    assert_close(from_cl(o2.cpu(), n, h, w), ref2, TOL, "second output")
-    with pytest.raises(ops.WinogradUnavailable):
-        ops.conv2d_cl(to_cl(x).to(dev), ops.pack_conv_weight(wt).to(dev), cout, 3, 3, n, h, w, out2=(o2, a.to(dev), b.to(dev)), ksplit=2, **kw)
-
-
 @pytest.mark.parametrize("shape", [(64, 32, 3, 3), (40, 72, 1, 1), (3, 20, 7, 7), (32, 48, 4, 4)])
 def test_pack_conv_weight_one_launch(backend, shape):
     """lfdm_pack_conv_weight_f32 (the training path's per-step re-pack, one launch) against the load-time torch packers:
