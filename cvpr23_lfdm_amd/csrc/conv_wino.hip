@@ -45,7 +45,9 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // POOL: lfdm_conv_params.pool2 - an instantiation of its own, so that the plain kernel keeps its register allocation.
 // Measured and removed in round 2: ResBlock2d's pre-activation BatchNorm + ReLU applied to the patches right before the transform
 // (tables in LDS, no spills): the 256 -> 256 bottleneck convolution of a B = 8 training step went from 1650 to 1781 us, more
-// than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).
+// than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).  The same activation
+// written as a SECOND OUTPUT of the producing convolution's epilogue (one more float4 store per pixel) cost 103 us per launch
+// for the same 112 us pass: no gain either, removed (profiles/r02_ac_*).
 template <bool ACT, int NT, bool POOL = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
