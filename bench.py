@@ -211,8 +211,10 @@ def conv_roofline(model, ms_per_sampler_step):
         traffic, traffic_src = tj.get("wino_bytes_per_step"), tj.get("source")
     # cross-check: the rocprofv3 kernel table committed for this build (tools/gpu_final.sh -> profiles/), same command line
     rocprof = None
-    for name in sorted(os.listdir(os.path.join(REPO_ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(REPO_ROOT, "profiles")) else []:
-        if name.startswith("r02_") and name.endswith("_kernel_stats.txt") and "train" not in name:
+    latest = os.path.join(REPO_ROOT, "profiles", "LATEST")            # tag of the evidence run of the current build (tools/gpu_final.sh)
+    tag = open(latest).read().strip() if os.path.exists(latest) else None
+    for name in ([tag + "_kernel_stats.txt"] if tag else []):
+        if os.path.exists(os.path.join(REPO_ROOT, "profiles", name)):
             for ln in open(os.path.join(REPO_ROOT, "profiles", name)):
                 if ln.startswith("conv_wino_kernel<false"):
                     f = ln.split()

@@ -1,5 +1,6 @@
 # end-of-round evidence: the whole -m gpu suite, smoke(), the default bench, a profiled step (kernel table + dispatch sequence),
-# the training kernel table.  Outputs under gpurun_out/$TAG (copy what should be judged into profiles/).
+# the training kernel table.  Outputs under gpurun_out/$TAG (copy what should be judged into profiles/ as ${TAG}_*, and put the tag into profiles/LATEST:
+# bench.py quotes that run's rocprofv3 average beside its live figure).
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -n 4 $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
