@@ -34,7 +34,8 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // positions' MFMAs; patches and weight fragments fetched two chunks ahead at two workgroups per CU; A-fragment LDS reads
 // pinned one position ahead with sched_group_barrier.  What would help next: 32-channel chunks with 16-byte patch loads
 // (half the TA cycles per patch byte), raw pixels staged once in LDS (the patches overlap 4x).
-// NT = column tiles per workgroup: NT = 2 (64 columns, opt-in LFDM_WINO_BN=64) halves the patch loads / transforms per MFMA at
+// NT = column tiles per workgroup: NT = 2 (64 columns; chosen by the plan for launches of >= 1536 such workgroups, i.e. the batched
+// shapes of training / throughput mode - conv_igemm.hip make_plan, LFDM_WINO_BN64_MIN) halves the patch loads / transforms per MFMA at
 // two workgroups per CU (244 VGPRs): 2-5 % faster on the large-M decoder shapes, slower wherever it leaves a CU fewer than
 // ~3 workgroups (profiles/r01_o_conv_shapes_wino_bn64.txt).
 // Measured and removed in round 2 (tools/sweep_conv.sh, profiles/r02_a_sweep_conv.txt): staging the unique pixels of each tile-row

@@ -10,7 +10,6 @@ SURVEY.md 3.4; here: one process per GPU, every rank applies the identical updat
 """
 import torch
 
-from . import _native
 from .ops import _chk, _lib, _p, _stream
 from .params import bump_weights_epoch
 
