@@ -620,6 +620,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);  // conv_wino.hip
+int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
 
 namespace {
 
@@ -628,7 +629,8 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p);
 
 struct ConvPlan {
   int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip),
-                   // 2 = Winograd F(2x2,3x3), 128-pixel x 32-column tiles (conv_wino.hip)
+                   // 2 = Winograd F(2x2,3x3), 128-pixel x 32-column tiles (conv_wino.hip),
+                   // 3 = pointwise register-operand GEMM, 32-row tiles, never split-K (conv_pw.hip)
   int bm, bn, ksplit;
   bool fast, simple;
 };
@@ -681,6 +683,22 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                     (p.c1 == 0 || ((uintptr_t)p.src1 & 15) == 0) && (((uintptr_t)p.weight_wino) & 15) == 0 && !p.ln_wsum &&
                     p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && (p.pool2 ? (2 * p.ho == p.hq && 2 * p.wo == p.wq) : (p.ho == p.hq && p.wo == p.wq)) && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64 &&
                     !p.deconv4 && vec_ok;      // (float4 epilogue)
+  // 1x1 / stride 1 projections (to_qkv with the LayerNorm fold, to_out, res_conv): the register-operand GEMM of conv_pw.hip has no
+  // staging prologue and never needs split-K slabs + a reduce launch.  LFDM_PW=0 disables it, LFDM_PW_MAXM bounds the row count
+  // (default: the B = 1 sampler's levels; the batched shapes keep the LDS-staged schedules until measured otherwise).
+  static const long pw_max_m = [] { const char* e = getenv("LFDM_PW_MAXM"); return e ? atol(e) : 49152l; }();
+  const char* pw_env = getenv("LFDM_PW");
+  const bool pw = !(pw_env && pw_env[0] == '0') && conv_force() < 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && !p.upsample && p.pad_y == 0 &&
+                  p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
+                  p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
+                  M <= pw_max_m && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
+  if (pw) {
+    pl.kind = 3;
+    pl.bm = 32;
+    pl.bn = 32;
+    pl.ksplit = 1;
+    return pl;
+  }
   if (wino) {
     pl.kind = 2;
     pl.bm = 128;
@@ -844,6 +862,8 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
     rc = lfdm_conv_wino_launch(p, pl.bn, stream);
+  } else if (pl.kind == 3) {
+    rc = lfdm_conv_pw_launch(p, stream);
   } else {
     const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit * (p.deconv4 ? 4 : 1));
     if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);

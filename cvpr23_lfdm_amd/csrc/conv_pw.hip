@@ -1,0 +1,225 @@
+// Pointwise (1x1, stride 1) convolution / Linear on channels-last rows as a register-operand fp32-MFMA GEMM
+// (include/lfdm_hip.h: lfdm_conv2d_cl_f32 picks it for the to_qkv / to_out / res_conv projections, schedule 3).
+//
+// Why a third direct schedule: in the B = 1 sampler these projections have K = 64 ... 1024 and M = 640 ... 10 240 rows.  The
+// LDS-staged schedules (conv_igemm / conv_ksw) need ~10 us of fixed cost per launch (index tables, staging prologue, barrier
+// per 32-wide chunk) and, below 256 output tiles, a split-K slab round trip plus a reduce launch - 15-21 us for 0.3-0.5 GFLOP.
+// Here nothing is staged: with the contraction order free, MFMA k-step 4q+e of lane half kh takes k = 8q + 4kh + e for BOTH
+// operands, so a lane's A fragment is 16 contiguous bytes of its row of x and its B fragment 16 contiguous bytes of its
+// output channel's packed filter row ([chunk][cout][32]: k contiguous) - two buffer loads feed four v_mfma_f32_32x32x2_f32.
+// A workgroup owns 32 rows x (4/KW * TN * 32) columns; its four wavefronts split K (KW of them) and the column tiles, every
+// load of a 32-deep K group is issued one group ahead, and there is no barrier before the epilogue.  The K slices are summed
+// through LDS (18 KB), which also turns the accumulator layout into float4 row segments for bias / LayerNorm fold / residual /
+// activation.  No split-K across workgroups, no reduce launch: 32-row tiles give 20 x 16 workgroups even at M = 640.
+// Workgroups are dealt so that the column tiles of one row tile share an XCD (x is read into ONE L2).
+#include <stdlib.h>
+
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+template <int TN, int KW, bool LN>
+__global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx, int ny) {
+  constexpr int NW = 4 / KW;           // wavefronts along N
+  constexpr int LD = 36;               // scratch row stride (floats): conflict-free b128 reads
+  __shared__ __attribute__((aligned(16))) float scratch[4 * 32 * LD];
+  __shared__ float s_ln[2][4][32];     // fused LayerNorm: [sum | sum of squares][wave][row]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % KW, wn = wave / KW;
+  // block id -> (row tile, column tile): ids round-robin over the 8 XCDs, an XCD walks the column tiles of one row tile
+  const int id = blockIdx.x, slot = id >> 3;
+  const int bx = (id & 7) + 8 * (slot / ny), by = slot % ny;
+  if (bx >= gx) return;
+  const int M = p.n_img * p.hq * p.wq;
+  const int m0 = bx * 32;
+  const int n0 = by * (NW * TN * 32);
+  const int K = p.c0 + p.c1;
+  const int kw_len = K / KW;           // this wave's K slice: [wk*kw_len, +kw_len), a multiple of 32
+  const int kbeg = wk * kw_len;
+  const int ng = kw_len >> 5;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((int64_t)(M - 1) * p.ld0 + p.c0) * 4));
+  const lfdm_buf buf1 = p.c1 > 0 ? lfdm_make_buf(p.src1, (uint32_t)(((int64_t)(M - 1) * p.ld1 + p.c1) * 4)) : buf0;
+  const lfdm_buf bufw = lfdm_make_buf(p.weight, (uint32_t)((int64_t)(K >> 5) * p.coutp * 128));
+  const int row = m0 + l31;
+  const bool row_ok = row < M;
+  const uint32_t a_off0 = row_ok ? ((uint32_t)row * (uint32_t)p.ld0 + 4u * kh) * 4u : LFDM_BUF_OOB;
+  const uint32_t a_off1 = row_ok ? ((uint32_t)row * (uint32_t)p.ld1 + 4u * kh) * 4u : LFDM_BUF_OOB;
+  uint32_t b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    b_off[j] = n < p.coutp ? ((uint32_t)n * 32u + 4u * kh) * 4u : LFDM_BUF_OOB;
+  }
+  const uint32_t wgroup_bytes = (uint32_t)p.coutp * 128u;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ln_s = 0.f, ln_q = 0.f;
+
+  float4 ra[4], rb[4][TN];
+  auto fetch = [&](int g) {
+    const int kk = kbeg + 32 * g;
+    const bool second = kk >= p.c0;
+    const lfdm_buf buf = second ? buf1 : buf0;
+    const uint32_t abase = second ? a_off1 + (uint32_t)(kk - p.c0) * 4u : a_off0 + (uint32_t)kk * 4u;
+    const uint32_t wbase = (uint32_t)(kk >> 5) * wgroup_bytes;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ra[u] = lfdm_buf_load_f4(buf, row_ok ? abase + 32u * u : LFDM_BUF_OOB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        rb[u][j] = lfdm_buf_load_f4(bufw, b_off[j] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[j] + 32u * u);
+    }
+  };
+
+  fetch(0);
+  for (int g = 0; g < ng; ++g) {
+    float4 a[4], b[4][TN];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = ra[u];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[u][j] = rb[u][j];
+    }
+    fetch(g + 1 < ng ? g + 1 : g);       // clamped (the last group is re-read): no branch around the loads
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (LN) {
+        ln_s += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+        ln_q += (a[u].x * a[u].x + a[u].y * a[u].y) + (a[u].z * a[u].z + a[u].w * a[u].w);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[j] = mfma_32x32x2(a[u].x, b[u][j].x, acc[j]);
+        acc[j] = mfma_32x32x2(a[u].y, b[u][j].y, acc[j]);
+        acc[j] = mfma_32x32x2(a[u].z, b[u][j].z, acc[j]);
+        acc[j] = mfma_32x32x2(a[u].w, b[u][j].w, acc[j]);
+      }
+    }
+  }
+
+  if (LN) {
+    ln_s += __shfl_xor(ln_s, 32);        // the two lane halves hold the two k quads of every group
+    ln_q += __shfl_xor(ln_q, 32);
+    if (lane < 32) {
+      s_ln[0][wave][l31] = ln_s;
+      s_ln[1][wave][l31] = ln_q;
+    }
+  }
+
+  // ---- K-slice sum + epilogue: one 32x32 tile per pass, thread = (row, float4 of columns) ----
+  const int trow = tid >> 3, c4 = tid & 7;
+  const int orow = m0 + trow;
+  const bool vec_row = orow < M;
+  float mean = 0.f, rstd = 1.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    if (j > 0) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      scratch[wave * (32 * LD) + ((r & 3) + 8 * (r >> 2) + 4 * kh) * LD + l31] = acc[j][r];
+    __syncthreads();
+    if (LN && j == 0) {
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {     // the waves of column group 0 cover K exactly once
+        sv += s_ln[0][k][trow];
+        qv += s_ln[1][k][trow];
+      }
+      const float inv_c = 1.0f / (float)K;
+      mean = sv * inv_c;
+      float var = qv * inv_c - mean * mean;
+      if (var < 0.f) var = 0.f;
+      rstd = 1.0f / sqrtf(var + p.ln_eps);
+    }
+#pragma unroll
+    for (int g = 0; g < NW; ++g) {
+      float4 v = *reinterpret_cast<const float4*>(scratch + (g * KW) * (32 * LD) + trow * LD + 4 * c4);
+#pragma unroll
+      for (int k = 1; k < KW; ++k) {
+        const float4 u = *reinterpret_cast<const float4*>(scratch + (g * KW + k) * (32 * LD) + trow * LD + 4 * c4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      const int col = n0 + (g * TN + j) * 32 + 4 * c4;
+      if (!vec_row || col >= p.cout) continue;
+      if (LN) {                          // y = rstd * (x.W' - mean * sum_c W')
+        const float4 ws = *reinterpret_cast<const float4*>(p.ln_wsum + col);
+        v.x = rstd * (v.x - mean * ws.x); v.y = rstd * (v.y - mean * ws.y);
+        v.z = rstd * (v.z - mean * ws.z); v.w = rstd * (v.w - mean * ws.w);
+      }
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (p.residual) {
+        const float4 rr = *reinterpret_cast<const float4*>(p.residual + (int64_t)orow * p.ldr + col);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      if (p.act) {
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+      }
+      *reinterpret_cast<float4*>(p.out + (int64_t)orow * p.ldo + col) = v;
+    }
+  }
+}
+
+template <int TN, int KW>
+void launch_pw(const lfdm_conv_params& p, int gx, int ny, hipStream_t stream) {
+  const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny)), block(256);
+  if (p.ln_wsum) LFDM_LAUNCH((conv_pw_kernel<TN, KW, true>), grid, block, 0, stream, p, gx, ny);
+  else LFDM_LAUNCH((conv_pw_kernel<TN, KW, false>), grid, block, 0, stream, p, gx, ny);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+// Tile shape for a geometry the caller has already checked (1x1, stride 1, C % 32 == 0, float4-legal epilogue):
+// K across KW wavefronts when the slices stay multiples of 32; the widest column tile that still leaves >= 256 workgroups.
+void lfdm_conv_pw_shape(const lfdm_conv_params& p, int* tn, int* kw) {
+  const int K = p.c0 + p.c1;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  // (two sources: the source is selected per 32-deep K group and c0 % 32 == 0, so a slice only has to be a multiple of 32)
+  int k = K % 128 == 0 ? 4 : K % 64 == 0 ? 2 : 1;
+  const int fk = env_int("LFDM_PW_KW", 0);
+  if ((fk == 1 || fk == 2 || fk == 4) && K % (32 * fk) == 0) k = fk;
+  const int nw = 4 / k;
+  const int64_t gx = (M + 31) / 32;
+  int t = 1;
+  for (int cand = 3; cand >= 2; --cand) {
+    const int bn = nw * cand * 32;
+    const int ny = (p.coutp + bn - 1) / bn;
+    if (ny * bn - p.coutp >= 32 * nw) continue;          // a whole idle wave column: take a narrower tile
+    if (gx * ny >= 256) { t = cand; break; }
+  }
+  const int ft = env_int("LFDM_PW_TN", 0);
+  if (ft >= 1 && ft <= 3) t = ft;
+  *tn = t;
+  *kw = k;
+}
+
+int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream) {
+  int tn, kw;
+  lfdm_conv_pw_shape(p, &tn, &kw);
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  const int gx = (int)((M + 31) / 32);
+  const int bn = (4 / kw) * tn * 32;
+  const int ny = (p.coutp + bn - 1) / bn;
+#define LFDM_PW_CASE(T, W) if (tn == T && kw == W) launch_pw<T, W>(p, gx, ny, stream)
+  LFDM_PW_CASE(1, 4); else LFDM_PW_CASE(2, 4); else LFDM_PW_CASE(3, 4);
+  else LFDM_PW_CASE(1, 2); else LFDM_PW_CASE(2, 2); else LFDM_PW_CASE(3, 2);
+  else LFDM_PW_CASE(1, 1); else LFDM_PW_CASE(2, 1); else LFDM_PW_CASE(3, 1);
+#undef LFDM_PW_CASE
+  return lfdm_check_launch("conv_pw");
+}

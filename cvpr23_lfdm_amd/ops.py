@@ -327,14 +327,14 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     if (weight is None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
         raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack / "
                                   "run the pooling as a launch of its own")
+    if gn_partial is not None:      # before the plan is asked for: the pointwise schedule has no fused statistics
+        p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
     _, ks = conv_plan(p)
     if ks > 1:
         need = conv_partial_floats(p)
         if partial is None or partial.numel() < need:
             partial = torch.empty(need, dtype=torch.float32, device=src0.device)
         p.partial = _p(partial)
-    if gn_partial is not None:
-        p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
     conv_launch(p)
     return out
 

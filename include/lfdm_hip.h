@@ -124,12 +124,15 @@ typedef struct lfdm_conv_params {
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
-/* the schedule the library will use for this geometry: rows of the output tile (64 / 128 / 160) and the
- * split-K factor (the given one if p->ksplit >= 1) */
+/* the schedule the library will use for this geometry: rows of the output tile (32 / 64 / 128 / 160) and the
+ * split-K factor (the given one if p->ksplit >= 1).  Fill in gn_partial (any non-NULL value) BEFORE asking when fused
+ * GroupNorm statistics are wanted: the pointwise schedule (3) has none, so the request changes the plan. */
 int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit);
 /* which schedule lfdm_conv2d_cl_f32 will run for these parameters: 0 = 2x2-wave implicit GEMM (conv_igemm), 1 = K-split
  * across waves (conv_ksw), 2 = Winograd F(2x2,3x3) (conv_wino: reads weight_wino only - `weight` is then never dereferenced, so
- * a caller that re-packs filters every step, i.e. training, can skip the direct-form pack), < 0 = error */
+ * a caller that re-packs filters every step, i.e. training, can skip the direct-form pack), 3 = pointwise register-operand
+ * GEMM (conv_pw: 1x1 / stride 1 projections with C % 32 == 0 - to_qkv incl. the LayerNorm fold, to_out, res_conv,
+ * video_flow_diffusion.py:224,246-247,300-301 - 32-row tiles, never split-K; LFDM_PW=0 in the environment disables it), < 0 = error */
 int lfdm_conv2d_schedule(const lfdm_conv_params* p);
 /* bytes of `partial` needed (0 when the plan does not split K) */
 size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);

@@ -94,6 +94,68 @@ def test_conv2d(backend, case):
         assert int(counters.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("case", [
+    dict(c0=64, c1=0, cout=128, n=3, hw=(5, 7)),                          # K = 64: two K slices, ragged M (105 rows)
+    dict(c0=128, c1=0, cout=96, n=2, hw=(4, 4), residual=True),           # K = 128: four K slices of one group
+    dict(c0=256, c1=256, cout=128, n=5, hw=(4, 4), residual=True),        # ups res_conv: concat of two sources, K = 512
+    dict(c0=32, c1=64, cout=64, n=2, hw=(3, 3), act=3),                   # K = 96: no K split, waves along N, SiLU
+    dict(c0=256, c1=0, cout=512, n=4, hw=(4, 4), bias=False),             # to_out without bias
+    dict(c0=512, c1=0, cout=768, n=2, hw=(4, 4), ln=True),                # PreNorm + to_qkv
+    dict(c0=64, c1=0, cout=64, n=2, hw=(4, 4), tn=3, kw=1),               # forced shapes: a 384-column tile on 64 columns
+    dict(c0=128, c1=0, cout=768, n=2, hw=(4, 4), ln=True, tn=3, kw=2),
+    dict(c0=128, c1=0, cout=768, n=2, hw=(4, 4), ln=True, tn=2, kw=1),
+    dict(c0=256, c1=0, cout=256, n=2, hw=(8, 8), big=True),               # the 8x8 level's to_out at full size (GPU)
+    dict(c0=512, c1=0, cout=768, n=1, hw=(4, 4), ln=True, big=True),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_pointwise(backend, case, monkeypatch):
+    """Schedule 3 (conv_pw.hip): 1x1 / stride-1 projections as a register-operand GEMM - two sources, residual, activation,
+    the LayerNorm fold, ragged row tiles, every (TN, KW) tile shape - against F.conv2d; and the planner picks it."""
+    dev = backend
+    c0, c1, cout, n = case["c0"], case["c1"], case["cout"], case["n"]
+    h, w = case["hw"]
+    if case.get("big"):
+        if not big(dev):
+            pytest.skip("full-size shape runs on the GPU")
+        n *= 40
+    for k_, e_ in (("tn", "LFDM_PW_TN"), ("kw", "LFDM_PW_KW")):
+        if k_ in case:
+            monkeypatch.setenv(e_, str(case[k_]))
+    cin = c0 + c1
+    x = rnd(n, cin, h, w, seed=1) * 1.5 + (0.4 if case.get("ln") else 0.0)
+    wt = rnd(cout, cin, 1, 1, seed=2, scale=1.0 / math.sqrt(cin))
+    bias = None if (case.get("bias") is False or case.get("ln")) else rnd(cout, seed=3)
+    xs = to_cl(x).to(dev)
+    kw = {}
+    if case.get("ln"):
+        gamma = rnd(cin, seed=5) * 0.3 + 1
+        xn = O.channel_layernorm(x.unsqueeze(2), gamma.reshape(1, cin, 1, 1, 1)).squeeze(2)
+        ref = F.conv2d(xn, wt)
+        packed, wsum = ops.pack_ln_conv_weight(wt.reshape(cout, cin), gamma)
+        kw["ln_wsum"] = wsum.to(dev)
+    else:
+        ref = F.conv2d(x, wt, bias)
+        packed = ops.pack_conv_weight(wt)
+    res = None
+    if case.get("residual"):
+        res = rnd(*ref.shape, seed=4)
+        ref = ref + res
+    act = case.get("act", 0)
+    if act == 3:
+        ref = F.silu(ref)
+    src0, src1 = (xs, None) if c1 == 0 else (xs[:, :c0].contiguous(), xs[:, c0:].contiguous())
+    pp, _ = ops.conv_params(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1)
+    assert ops._lib().lfdm_conv2d_schedule(__import__("ctypes").byref(pp)) == 3
+    assert ops.conv_plan(pp) == (32, 1)
+    out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
+                        residual=None if res is None else to_cl(res).to(dev), act=act, **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv")
+    monkeypatch.setenv("LFDM_PW", "0")          # the LDS-staged schedules still serve the same call
+    assert ops._lib().lfdm_conv2d_schedule(__import__("ctypes").byref(pp)) in (0, 1)
+    out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
+                        residual=None if res is None else to_cl(res).to(dev), act=act, **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv, LFDM_PW=0")
+
+
 def test_conv2d_c2_shapes(backend):
     """C2-sized contractions - GPU only."""
     if not big(backend):
