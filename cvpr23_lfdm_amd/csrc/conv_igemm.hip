@@ -684,21 +684,18 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                     p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && (p.pool2 ? (2 * p.ho == p.hq && 2 * p.wo == p.wq) : (p.ho == p.hq && p.wo == p.wq)) && (int64_t)16 * (cin / 16) * p.coutp * 64 < (1ll << 32) - 64 &&
                     !p.deconv4 && vec_ok;      // (float4 epilogue)
   // 1x1 / stride 1 projections (to_qkv with the LayerNorm fold, to_out, res_conv): the register-operand GEMM of conv_pw.hip has no
-  // staging prologue and never needs split-K slabs + a reduce launch.  LFDM_PW=0 disables it, LFDM_PW_MAXM bounds the row count
-  // (default: the B = 1 sampler's levels; the batched shapes keep the LDS-staged schedules until measured otherwise).
-  static const long pw_max_m = [] { const char* e = getenv("LFDM_PW_MAXM"); return e ? atol(e) : 49152l; }();
+  // staging prologue and never needs split-K slabs + a reduce launch.  Measured per shape against the LDS-staged schedules
+  // (tools/bench_pw.py, profiles/r03_a_bench_pw.txt): it wins wherever those would split K (every projection of the 4x4 level,
+  // the K >= 256 ones with few output columns above it) and at M <= 1024 rows; with one K slice and thousands of rows the staged,
+  // fully coalesced tiles are as fast or faster (its fragment-shaped loads cost four L1 line look-ups per 128-byte line).
+  // LFDM_PW=0 disables it, LFDM_PW=2 takes it for every eligible geometry, LFDM_PW_MAXM bounds the row count.
+  static const long pw_max_m = [] { const char* e = getenv("LFDM_PW_MAXM"); return e ? atol(e) : 16384l; }();
   const char* pw_env = getenv("LFDM_PW");
-  const bool pw = !(pw_env && pw_env[0] == '0') && conv_force() < 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && !p.upsample && p.pad_y == 0 &&
-                  p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
-                  p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
-                  M <= pw_max_m && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
-  if (pw) {
-    pl.kind = 3;
-    pl.bm = 32;
-    pl.bn = 32;
-    pl.ksplit = 1;
-    return pl;
-  }
+  const int pw_mode = pw_env ? atoi(pw_env) : 1;
+  const bool pw_ok = pw_mode != 0 && conv_force() < 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && !p.upsample && p.pad_y == 0 &&
+                     p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
+                     p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
+                     M <= pw_max_m && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
   if (wino) {
     pl.kind = 2;
     pl.bm = 128;
@@ -765,6 +762,12 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   }
   if (pl.ksplit > nchunks) pl.ksplit = nchunks;
   if (pl.ksplit < 1) pl.ksplit = 1;
+  if (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1)) {      // see above: where the staged schedules would split K, or few rows
+    pl.kind = 3;
+    pl.bm = 32;
+    pl.bn = 32;
+    pl.ksplit = 1;
+  }
   return pl;
 }
 

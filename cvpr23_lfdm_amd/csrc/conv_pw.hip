@@ -194,15 +194,9 @@ void lfdm_conv_pw_shape(const lfdm_conv_params& p, int* tn, int* kw) {
   int k = K % 128 == 0 ? 4 : K % 64 == 0 ? 2 : 1;
   const int fk = env_int("LFDM_PW_KW", 0);
   if ((fk == 1 || fk == 2 || fk == 4) && K % (32 * fk) == 0) k = fk;
-  const int nw = 4 / k;
-  const int64_t gx = (M + 31) / 32;
-  int t = 1;
-  for (int cand = 3; cand >= 2; --cand) {
-    const int bn = nw * cand * 32;
-    const int ny = (p.coutp + bn - 1) / bn;
-    if (ny * bn - p.coutp >= 32 * nw) continue;          // a whole idle wave column: take a narrower tile
-    if (gx * ny >= 256) { t = cand; break; }
-  }
+  // measured (tools/bench_pw.py): 96-column tiles for the 768-column to_qkv of the 4x4 level (160 workgroups of 3 accumulator
+  // chains beat 480 of one), one 32-column tile per wave everywhere else
+  int t = (M <= 1024 && p.coutp >= 768 && p.coutp % ((4 / k) * 96) == 0) ? 3 : 1;
   const int ft = env_int("LFDM_PW_TN", 0);
   if (ft >= 1 && ft <= 3) t = ft;
   *tn = t;

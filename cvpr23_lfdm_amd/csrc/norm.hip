@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 // mean / rstd / gamma / beta / (scale+1, shift) into one FMA per channel kept in LDS, then streams its
 // slice:  y = silu(x * A[c] + Bc[c]) (+ residual).
 constexpr int GN_MAX_C = 1024;
-__global__ __launch_bounds__(256) void gn_apply_kernel(
+// NT threads per workgroup (256 / 512 / 1024).  Every workgroup repeats the merge of the partials, so fewer, larger workgroups
+// (LFDM_GN_BLOCK, LFDM_GN_F4) trade memory-level parallelism for less redundant L2 traffic: with 320 partial chunks x 16
+// groups (the merged output heads) the 2560 256-thread workgroups of round 2 read 100 MB of partials for a 21 MB tensor.
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(
     const float* __restrict__ x, float* __restrict__ out, int pixels, int channels, int groups,
     const float* __restrict__ partial, int nchunk, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ scale_shift, int ss_ld, float eps, int silu,
@@ -76,16 +80,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C], s_b[GN_MAX_C];
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int sub = tid & 31;
-  // the first two float4 of this thread (the host sizes the grid for two per thread) are requested BEFORE the statistics
-  // are merged: their HBM latency runs under the prologue instead of after it
+  // the first two float4 of this thread are requested BEFORE the statistics are merged: their HBM latency runs under the
+  // prologue instead of after it
   const int c4n = channels >> 2;
   const int64_t per_b = (int64_t)pixels * c4n;
   const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)b * per_b;
   float4* ob = reinterpret_cast<float4*>(out) + (int64_t)b * per_b;
   const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t i0 = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  const int64_t i0 = (int64_t)blockIdx.x * NT + tid;
   float4 pre_v[2], pre_r[2];        // (four in flight measured 1.6x SLOWER: the selects below stop being register renames)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -99,18 +102,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   }
   // (a coalesced float2 walk with one thread per (chunk, group) item + an LDS tree was measured: 9.2 vs 9.1 us at 320 chunks and
   // 8.0 vs 6.8 us at 32 - the extra barrier costs more than the strided loads; removed)
-  for (int g0 = 0; g0 < groups; g0 += 8) {
-    const int g = g0 + (tid >> 5);
+  // LPG lanes walk one group's chunks: a whole wavefront per group once the workgroup has 64 threads per group
+  const int lpg = (NT >= 64 * groups) ? 64 : 32;
+  const int gpp = NT / lpg;           // groups per pass
+  const int sub = tid & (lpg - 1);
+  for (int g0 = 0; g0 < groups; g0 += gpp) {
+    const int g = g0 + tid / lpg;
     double s = 0.0, q = 0.0;
     if (g < groups) {
-      for (int k = sub; k < nchunk; k += 32) {
+      for (int k = sub; k < nchunk; k += lpg) {
         const float* src = partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
         s += (double)src[0];
         q += (double)src[1];
       }
     }
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
+    for (int m = lpg >> 1; m >= 1; m >>= 1) {
       s += __shfl_xor(s, m);
       q += __shfl_xor(q, m);
     }
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   }
   __syncthreads();
   const int cg = channels / groups;
-  for (int c = tid; c < channels; c += 256) {
+  for (int c = tid; c < channels; c += NT) {
     const int g = c / cg;
     const float a = s_rstd[g] * gamma[c];
     float bb = beta[c] - s_mean[g] * a;
@@ -313,12 +319,32 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
                      const float* scale_shift, int ss_ld, float eps, int silu, const float* residual,
                      hipStream_t stream) {
   const int64_t per_b = (int64_t)pixels * (channels / 4);
-  constexpr int f4 = 2;       // float4 per thread (measured in both rounds: 2 beats 4 and 8, with and without the early loads)
-  int64_t nb = (per_b + 256 * f4 - 1) / (256 * f4);
+  // float4 per thread and threads per workgroup: two per thread in 256-thread workgroups measured best in rounds 1 and 2 for the
+  // 64 ... 512-channel tensors with <= 8 groups; LFDM_GN_F4 / LFDM_GN_BLOCK override (tools/bench_gn.py sweeps them)
+  static const int env_f4 = [] { const char* e = getenv("LFDM_GN_F4"); return e ? atoi(e) : 0; }();
+  static const int env_nt = [] { const char* e = getenv("LFDM_GN_BLOCK"); return e ? atoi(e) : 0; }();
+  int f4 = 2, nt = 256;
+  // many partials: merge them in fewer, larger workgroups (tools/bench_gn.py sweep, profiles/r03_a_sweep_gn.txt: the merged output
+  // heads' 21 MB tensor with 320 x 16 partials 33.1 -> 16.8 us at 1024 threads x 8 float4; 640 x 8 partials on 2.6 MB 6.5 -> 5.6 us at 512)
+  if ((int64_t)nchunk * groups >= 4096) {
+    nt = per_b >= (1 << 20) ? 1024 : 512;
+    f4 = per_b >= (1 << 20) ? 8 : 2;
+  }
+  if (env_f4 > 0) f4 = env_f4;
+  if (env_nt == 256 || env_nt == 512 || env_nt == 1024) nt = env_nt;
+  int64_t nb = (per_b + (int64_t)nt * f4 - 1) / ((int64_t)nt * f4);
   if (nb < 1) nb = 1;
   if (nb > 8192) nb = 8192;        // per sample (grid y = batch); the 2C-channel output heads need 5120 at 32x32 x 40 frames
-  LFDM_LAUNCH(gn_apply_kernel, dim3((unsigned)nb, batch), dim3(256), 0, stream, x, out, pixels, channels,
-              groups, partial, nchunk, gamma, beta, scale_shift, ss_ld, eps, silu, residual);
+  const dim3 grid((unsigned)nb, batch);
+  if (nt == 1024)
+    LFDM_LAUNCH(gn_apply_kernel<1024>, grid, dim3(1024), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
+                scale_shift, ss_ld, eps, silu, residual);
+  else if (nt == 512)
+    LFDM_LAUNCH(gn_apply_kernel<512>, grid, dim3(512), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
+                scale_shift, ss_ld, eps, silu, residual);
+  else
+    LFDM_LAUNCH(gn_apply_kernel<256>, grid, dim3(256), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
+                scale_shift, ss_ld, eps, silu, residual);
 }
 
 }  // namespace

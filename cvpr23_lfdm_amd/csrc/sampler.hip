@@ -210,8 +210,11 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
                                                              Ranks rk, const unsigned* __restrict__ hists) {
   __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
-  float s = resolve_quantile(hists + (int64_t)b * HIST_PER_SAMPLE, rk, s_part, s_res);
-  s = fmaxf(s, 1.0f);
+  float s = 1.0f;                       // rk.frac < 0: static clipping, x0.clamp(-1, 1) (use_dynamic_thres=False, :729-732)
+  if (rk.frac >= 0.f) {
+    s = resolve_quantile(hists + (int64_t)b * HIST_PER_SAMPLE, rk, s_part, s_res);
+    s = fmaxf(s, 1.0f);
+  }
   const float* c = coef + (int64_t)(*step_dev) * 6;
   const float k_x0 = c[2], k_eps = c[3], k_x = c[4], k_noise = c[5];
   float* xb = x + (int64_t)b * n;
@@ -338,7 +341,13 @@ extern "C" int lfdm_sampler_step_f32(float* x, const float* eps, const float* no
   }
   unsigned* hists = reinterpret_cast<unsigned*>(ws);
   float* x0buf = reinterpret_cast<float*>(hists + (size_t)batch * HIST_PER_SAMPLE);
-  const Ranks rk = make_ranks(n, quantile);
+  const bool dynamic = quantile >= 0.f;           // quantile < 0: static clipping to [-1, 1] (GaussianDiffusion's own default)
+  if (dynamic && quantile > 1.f) {
+    lfdm_set_error("sampler_step: quantile must lie in [0, 1] (or be negative for the static clamp to [-1, 1])");
+    return LFDM_EINVAL;
+  }
+  Ranks rk = make_ranks(n, dynamic ? quantile : 0.f);
+  if (!dynamic) rk.frac = -1.f;
   {
     const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
     LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream,
@@ -346,8 +355,8 @@ extern "C" int lfdm_sampler_step_f32(float* x, const float* eps, const float* no
   }
   const dim3 grid(blocks_for(n), batch), block(256);
   LFDM_LAUNCH(quantile_pass0_kernel, grid, block, 0, stream, (const float*)x, eps, x0buf, n, coef,
-              (const int32_t*)step_dev, hists);
-  run_select(x0buf, batch, n, rk, hists, stream);
+              (const int32_t*)step_dev, hists);         // (also the x0 = c_x*x - c_eps*eps pass)
+  if (dynamic) run_select(x0buf, batch, n, rk, hists, stream);
   LFDM_LAUNCH(sampler_update_kernel, grid, block, 0, stream, x, eps, noise, x0buf, x0_out, n, coef,
               (const int32_t*)step_dev, rk, (const unsigned*)hists);
   if (advance) LFDM_LAUNCH(advance_step_kernel, dim3(1), dim3(64), 0, stream, step_dev);

@@ -156,8 +156,6 @@ class GaussianDiffusion(nn.Module):
         dev = next(unet.parameters()).device
         batch, ch, frames, s, _ = shape
         n = ch * frames * s * s
-        if not self.use_dynamic_thres:
-            raise NotImplementedError("static clipping (use_dynamic_thres=False): LFDM always enables it")
         times, coef, draws = self._step_tables(ddim)
         steps = len(times)
 
@@ -227,7 +225,7 @@ class GaussianDiffusion(nn.Module):
                 r = unet.stem(pk, x2, b["fea_term"], 2 * batch, frames, s)
                 unet.run_trunk(pk, r, ss2, 2 * batch, frames, s, eps2)
                 ops.cfg_combine(eps2[:batch], eps2[batch:], b["scale"], eps)      # null + (cond - null) * scale
-            ops.sampler_step(x, eps, noise, b["coef"], step_dev, quantile=self.dynamic_thres_percentile,
+            ops.sampler_step(x, eps, noise, b["coef"], step_dev, quantile=self.dynamic_thres_percentile if self.use_dynamic_thres else -1.0,
                              ws=plan["ws"])
 
         use_graph = (_native.library().kind == "hip" and os.environ.get("LFDM_NO_GRAPH", "0") != "1")

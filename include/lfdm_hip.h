@@ -236,6 +236,7 @@ int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int cha
  * table indexed by a device step counter, so the whole step can be replayed from a hipGraph:
  *   coef[step] = { c_x (sqrt_recip_alphas_cumprod), c_eps (sqrt_recipm1_alphas_cumprod),
  *                  k_x0, k_eps, k_x, k_noise }:  x <- k_x0*x0 + k_eps*eps + k_x*x + k_noise*noise
+ * quantile < 0 selects the static branch of the reference instead (use_dynamic_thres=False: x0.clamp(-1, 1), :729-732).
  * x (in/out), eps, noise: planar (B, n) with n = 3*T*S*S. x0_out optional (B, n).
  * ws: lfdm_sampler_ws_bytes(batch, n).  advance != 0 increments *step_dev at the end.
  */

@@ -117,6 +117,7 @@ def test_conv_pointwise(backend, case, monkeypatch):
         if not big(dev):
             pytest.skip("full-size shape runs on the GPU")
         n *= 40
+    monkeypatch.setenv("LFDM_PW", "2")          # every eligible geometry (the planner's own choice: test_conv_pointwise_plan)
     for k_, e_ in (("tn", "LFDM_PW_TN"), ("kw", "LFDM_PW_KW")):
         if k_ in case:
             monkeypatch.setenv(e_, str(case[k_]))
@@ -154,6 +155,40 @@ def test_conv_pointwise(backend, case, monkeypatch):
     out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
                         residual=None if res is None else to_cl(res).to(dev), act=act, **kw)
     assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv, LFDM_PW=0")
+
+
+def test_conv_pointwise_plan():
+    """Where the planner takes schedule 3 by itself (no launch: lfdm_conv2d_schedule only reads the geometry): every 1x1 projection
+    of the 4x4 level, above it the ones the LDS-staged schedules would split K for; never with fused GroupNorm statistics."""
+    import ctypes
+    from cvpr23_lfdm_amd import _native
+    _native._set_library_for_tests(None)
+    try:
+        lib = _native.library()
+    except Exception:
+        from cvpr23_lfdm_amd import _build
+        lib = _native.NativeLibrary(_build.build_emu(), "emu")
+        _native._set_library_for_tests(lib)
+    try:
+        def kind(m_rows, cin, cout, ln=False, gn=False):
+            x = torch.zeros(m_rows, cin)
+            w = torch.zeros((cin + 31) // 32, (cout + 31) // 32 * 32, 32)
+            old = ops._chk
+            ops._chk = lambda *a, **k: None          # geometry only: no tensor reaches a kernel
+            try:
+                pp, _ = ops.conv_params(x, w, cout, 1, 1, m_rows // 16, 4, 4, ln_wsum=torch.zeros(768) if ln else None)
+            finally:
+                ops._chk = old
+            if gn:
+                pp.gn_partial, pp.gn_groups, pp.gn_pixels = x.data_ptr(), 8, 16
+            return lib.lfdm_conv2d_schedule(ctypes.byref(pp))
+        assert kind(640, 512, 768, ln=True) == 3 and kind(640, 256, 512) == 3 and kind(640, 1024, 256) == 3
+        assert kind(2560, 256, 256) == 3                 # the staged plan would split K
+        assert kind(2560, 256, 768, ln=True) != 3        # one K slice, thousands of rows: staged tiles
+        assert kind(40960, 256, 64) != 3
+        assert kind(640, 256, 512, gn=True) != 3
+    finally:
+        _native._set_library_for_tests(None)
 
 
 def test_conv2d_c2_shapes(backend):
