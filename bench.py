@@ -57,8 +57,30 @@ def dist_setup(n_gpus):
     return rank, world, local
 
 
-def timed_region(run_step, steps, warmup, world, device_sync):
-    """W untimed + exactly K timed steps, bracketed by barrier + device sync; returns max-over-ranks seconds."""
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (backend nccl = RCCL
+    over xGMI), the same command line; rank 0's ONE JSON line passes through on stdout.  With fewer visible GPUs than ranks (a
+    one-GPU test box) the ranks share devices and the collective backend falls back to gloo (RCCL refuses duplicate devices)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n_gpus:
+        env.setdefault("LFDM_DIST_BACKEND", "gloo")
+        log("self-launch: %d ranks on %d visible GPU(s): ranks share devices, backend gloo (NOT a scaling measurement)" % (n_gpus, ndev))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_region(run_step, steps, warmup, world, device_sync, per_rank=None):
+    """W untimed + exactly K timed steps, bracketed by barrier + device sync; returns max-over-ranks seconds
+    (per_rank, if a list, receives every rank's own seconds)."""
     import torch.distributed as dist
     for _ in range(warmup):
         run_step()
@@ -77,8 +99,14 @@ def timed_region(run_step, steps, warmup, world, device_sync):
     if world > 1:
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if per_rank is not None:
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank[:] = [float(v.item()) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    elif per_rank is not None:
+        per_rank[:] = [elapsed]
     return elapsed
 
 
@@ -370,8 +398,18 @@ def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
         m.optimize_parameters()
         losses.append(m.loss.detach())
 
-    elapsed = timed_region(step, steps, warmup, world, torch.cuda.synchronize)
+    if m._dp is not None:
+        m._dp.profile = True
+    per_rank = []
+    elapsed = timed_region(step, steps, warmup, world, torch.cuda.synchronize, per_rank)
     vals = [float(v) for v in losses]
+    comm = None
+    if m._dp is not None:       # what the gradient exchange looks like and how much of it backward did not hide
+        exposed = m._dp.exposed_ms(last=steps) or []
+        comm = dict(m._dp.describe(), exposed_allreduce_ms_per_step=round(sum(exposed) / max(1, len(exposed)), 3),
+                    exposed_allreduce_ms_max=round(max(exposed), 3) if exposed else None,
+                    note="exposed = time the compute stream waited in GradAllReduce.finish() (events around the bucket waits), rank 0")
+        m._dp.profile = False
     # not the headline: the same step with the pseudo-ground-truth decode (real_out_vid / real_warped_vid: read by no loss, only by
     # the scripts' sample images) deferred until it is read (FlowDiffusion.lazy_real_decode)
     lazy_steps, lazy_elapsed = max(2, steps // 2), None
@@ -381,7 +419,8 @@ def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
         m.lazy_real_decode = False
     return {"value": round(steps * batch * world / elapsed, 3), "unit": "training videos/s (40 frames, 128x128)",
             "ms_per_step": round(1e3 * elapsed / steps, 1), "batch_per_gpu": batch, "global_batch": batch * world,
-            "steps": steps, "warmup": warmup, "grad_allreduce": ("%s, bucketed, overlapped with backward" % __import__("torch.distributed").distributed.get_backend()) if world > 1 else "none (1 GPU)",
+            "steps": steps, "warmup": warmup, "ms_per_step_per_rank": [round(1e3 * v / steps, 1) for v in per_rank],
+            "allreduce": comm, "grad_allreduce": ("%s, bucketed, overlapped with backward" % __import__("torch.distributed").distributed.get_backend()) if world > 1 else "none (1 GPU)",
             "gflop_per_video_reference_dataflow": TRAIN_GFLOP_PER_VIDEO_REFERENCE,
             "tflops_reference_dataflow": round(steps * batch * world / elapsed * TRAIN_GFLOP_PER_VIDEO_REFERENCE / 1e3, 1),
             "ms_per_step_lazy_real_decode": round(1e3 * lazy_elapsed / lazy_steps, 1) if lazy_elapsed else None,
@@ -466,7 +505,17 @@ def main():
                     help="videos per GPU per step; 1 = BASELINE.json configs[1] (latency mode), >1 = throughput mode")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:      # plain `python bench.py --gpus N`: become the launcher
+        sys.exit(self_launch(args.gpus))
     rank, world, local = dist_setup(args.gpus)
+    if os.environ.get("LFDM_BENCH_DRYRUN") == "1":      # test hook (tests/test_host_and_abi.py): launcher + rendezvous + timing protocol only
+        el = timed_region(lambda: time.sleep(0.005 * (rank + 1)), args.steps, args.warmup, world, lambda: None)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "elapsed": el}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.batch != 1:
         WORKLOAD["batch"] = args.batch
         WORKLOAD["name"] = WORKLOAD["name"].replace("batch=1 per GPU (BASELINE.json configs[1])",
@@ -493,7 +542,8 @@ def main():
         model.sample_one_video(cond_scale=1.0)
 
     log("model built; timing %d + %d sampling steps" % (args.warmup, args.steps))
-    elapsed = timed_region(run_step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    per_rank = []
+    elapsed = timed_region(run_step, args.steps, args.warmup, world, torch.cuda.synchronize, per_rank)
     log("headline: %.2f ms per video" % (1e3 * elapsed / args.steps))
     videos = args.steps * WORKLOAD["batch"] * world
     value = videos / elapsed
@@ -507,6 +557,7 @@ def main():
             "metric": "40-frame 128x128 videos/sec (DDIM-100)",
             "value": round(value, 4), "unit": "videos/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "ms_per_step_per_rank": [round(1e3 * v / args.steps, 2) for v in per_rank],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (random-init weights, rand image, randn cond; seeds 1234/7/1237)",
             "config": {"workload": WORKLOAD["name"], "global_batch": WORKLOAD["batch"] * world,

@@ -28,6 +28,15 @@ def is_list_str(x):
     return isinstance(x, (list, tuple)) and all(type(e) == str for e in x)
 
 
+def shard_bounds(rank_shard, b_local):
+    """(lo, hi, global batch) of this rank's videos: rank_shard is that triple (FlowDiffusion.set_train_input, any split) or
+    the older (rank, world) of equal shards."""
+    if len(rank_shard) == 3:
+        return rank_shard
+    rank, world = rank_shard
+    return rank * b_local, (rank + 1) * b_local, b_local * world
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, denoise_fn, *, image_size, num_frames, text_use_bert_cls=False, channels=3,
                  timesteps=1000, sampling_timesteps=250, ddim_sampling_eta=1., loss_type='l1',
@@ -79,6 +88,14 @@ class GaussianDiffusion(nn.Module):
         # (rank, world) under sharded data parallelism (FlowDiffusion.enable_data_parallel): the training step's random
         # draws are made for the GLOBAL batch on every rank (identical generators) and sliced
         self.rank_shard = None
+
+    def skip_step_draws(self, total, sample_shape, device):
+        """Advance the default generator exactly as one training step over `total` videos does (t :899, noise :858, the null
+        condition mask :55-61) without running the model - a data-parallel rank whose shard is empty this step."""
+        torch.randint(0, self.num_timesteps, (total,), device=device)
+        torch.randn_like(torch.empty((total,) + tuple(sample_shape), device=device))
+        if 0 < self.null_cond_prob < 1:
+            torch.zeros((total,), device=device).float().uniform_(0, 1)
 
     # ------------------------------------------------------------------ helpers
     def _embed(self, cond, device):
@@ -342,9 +359,9 @@ class GaussianDiffusion(nn.Module):
         b, device = x.shape[0], x.device
         fea = fea.unsqueeze(dim=2).expand(-1, -1, x.size(2), -1, -1)      # reference: .repeat (:901); a view is enough
         if self.rank_shard is not None and "noise" not in kwargs:
-            rank, world = self.rank_shard
-            t = torch.randint(0, self.num_timesteps, (b * world,), device=device).long()[rank * b:(rank + 1) * b]
-            noise = torch.randn_like(x.new_empty((b * world,) + tuple(x.shape[1:])))[rank * b:(rank + 1) * b]     # (:858)
+            lo, hi, total = shard_bounds(self.rank_shard, b)
+            t = torch.randint(0, self.num_timesteps, (total,), device=device).long()[lo:hi]
+            noise = torch.randn_like(x.new_empty((total,) + tuple(x.shape[1:])))[lo:hi]     # (:858)
             return self.p_losses(x, t, fea, cond=text, *args, noise=noise, **kwargs)
         t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
         return self.p_losses(x, t, fea, cond=text, *args, **kwargs)

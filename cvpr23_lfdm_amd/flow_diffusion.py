@@ -110,6 +110,7 @@ class FlowDiffusion(nn.Module):
         self.lazy_real_decode = os.environ.get("LFDM_LAZY_REAL_DECODE", "0") == "1"     # see the real_out_vid property
         self._real_decode, self._real_out_vid, self._real_warped_vid = None, None, None
         self._shard = None            # (rank, world) once data parallelism is on: set_train_input keeps this rank's videos
+        self._slice = None            # (lo, hi, global batch) of the current step's shard
         # Launched by torchrun (one process per GPU) from an UNCHANGED training script: there is nobody to call
         # enable_data_parallel(), so the wrapper does it itself at the first optimize_parameters() - the process takes the
         # GPU of its LOCAL_RANK here, before the script's `.cuda()`.  LFDM_AUTO_DP=0 switches this off.
@@ -156,12 +157,16 @@ class FlowDiffusion(nn.Module):
         reference (DM/train_video_flow_diffusion_mhad_multiGPU.py:207,249)."""
         dev = next(self.unet.parameters()).device
         self._start_auto_dp()
+        self._slice = None
         if self._shard is not None:
+            # torch.tensor_split semantics, like nn.DataParallel's scatter: any batch size works (the reference scripts use
+            # BATCH_SIZE = 5 and no drop_last); the first b % world ranks get one video more, a rank may get none
             rank, world = self._shard
             b = real_vid.shape[0]
-            if b % world != 0:
-                raise ValueError("data parallel: batch %d is not divisible by the %d ranks" % (b, world))
-            lo, hi = rank * (b // world), (rank + 1) * (b // world)
+            lo = rank * (b // world) + min(rank, b % world)
+            hi = lo + b // world + (1 if rank < b % world else 0)
+            self._slice = (lo, hi, b)
+            self.diffusion.rank_shard = self._slice
             ref_img, real_vid = ref_img[lo:hi], real_vid[lo:hi]
             ref_text = ref_text[lo:hi] if isinstance(ref_text, torch.Tensor) else list(ref_text)[lo:hi]
         self.ref_img = ref_img.to(dev)
@@ -282,15 +287,32 @@ class FlowDiffusion(nn.Module):
         self.enable_data_parallel()
 
     def optimize_parameters(self):
-        """:181-188."""
+        """:181-188.  Under sharded data parallelism the rank's loss is the mean over ITS videos: it is weighted by
+        shard_size * world / global_batch before backward, so that the all-reduced sum times 1/world (folded into the Adam
+        kernel) is the gradient of the mean over the global batch for any split; a rank without videos this step skips the
+        model, advances the random generator like everybody else and contributes zero gradients."""
+        weight, empty = 1.0, False
+        if self._dp is not None and getattr(self, "_slice", None) is not None:
+            lo, hi, total = self._slice
+            weight, empty = (hi - lo) * self._shard[1] / float(total), hi == lo
+        if empty:
+            dev = next(self.unet.parameters()).device
+            s = self.diffusion.image_size
+            self.diffusion.skip_step_draws(self._slice[2], (3, self.diffusion.num_frames, s, s), dev)
+            self.unet.null_cond_mask = torch.zeros(0, dtype=torch.bool, device=dev)
+            self.loss = torch.zeros((), device=dev)
+            self.rec_loss, self.rec_warp_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)
+            self.optimizer_diff.zero_grad()
+            self._dp.prepare()
+            self._dp.finish()
+            self.optimizer_diff.step()
+            return
         self.forward()
         self.optimizer_diff.zero_grad()
         if self._dp is not None:
             self._dp.prepare()
-        if self.only_use_flow:
-            self.loss.backward()
-        else:
-            (self.loss + self.rec_loss + self.rec_warp_loss).backward()
+        total_loss = self.loss if self.only_use_flow else self.loss + self.rec_loss + self.rec_warp_loss
+        (total_loss * weight if weight != 1.0 else total_loss).backward()
         if self._dp is not None:
             self._dp.finish()
         self.optimizer_diff.step()

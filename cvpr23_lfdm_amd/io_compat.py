@@ -8,6 +8,7 @@ path; it exists so a user of the reference finds the surrounding script vocabula
   misc.py:96 resize      misc.py:113 resample   misc.py:137 get_grid
   imageio.v2.imread / imageio.mimsave / imageio.imsave  -> imread / mimsave / imsave
 """
+import os
 import sys
 
 import numpy as np
@@ -22,7 +23,9 @@ class Logger(object):
 
     def __init__(self, filename="default.log", stream=sys.stdout):
         self.terminal = stream
-        self.log = open(filename, "w")
+        # one process per GPU runs the whole unchanged script: only rank 0 owns the script's log file, the others write theirs next to it
+        rank = int(os.environ.get("RANK", "0"))
+        self.log = open(filename if rank == 0 else "%s.rank%d" % (filename, rank), "w")
 
     def write(self, message):
         self.terminal.write(message)

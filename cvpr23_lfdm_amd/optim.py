@@ -157,6 +157,10 @@ class GradAllReduce:
         self._hooks = []
         self._buckets = None
         self._flat_id = None
+        # profile = True: finish() brackets its waits with events on the compute stream; exposed_ms() then reports how long the
+        # compute stream stood still for the exchange per step (the part of the all-reduce NOT hidden under backward)
+        self.profile = False
+        self._wait_events = []
 
     def sync_replicas(self, src=0):
         """Broadcast rank `src`'s flat parameter buffer and Adam moments (one collective each per group) so that the
@@ -238,8 +242,29 @@ class GradAllReduce:
         for b in self._buckets:
             if b["handle"] is None:
                 self._launch(b)
+        timed = self.profile and self.world > 1 and torch.cuda.is_available() and self._buckets and self._buckets[0]["view"].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in self._buckets:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         self.opt._staged = True
+
+    def describe(self):
+        """Bucket layout of the exchange: count and bytes (after the first prepare())."""
+        if not self._buckets:
+            return {"buckets": 0, "bytes": []}
+        return {"buckets": len(self._buckets), "bytes": [int(b["view"].numel()) * 4 for b in self._buckets]}
+
+    def exposed_ms(self, last=None):
+        """Per-step milliseconds the compute stream waited in finish() (profile = True), newest `last` steps."""
+        ev = self._wait_events[-last:] if last else self._wait_events
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in ev]

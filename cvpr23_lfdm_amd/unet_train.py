@@ -91,7 +91,9 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
 
     # --- conditioning (B x 1024 vectors: torch) (:549-562)
     if rank_shard is not None:       # sharded data parallelism: the draw of the global batch, this rank's slice
-        unet.null_cond_mask = prob_mask_like((b * rank_shard[1],), null_cond_prob, device=dev)[rank_shard[0] * b:(rank_shard[0] + 1) * b]
+        from .diffusion import shard_bounds
+        lo, hi, total = shard_bounds(rank_shard, b)
+        unet.null_cond_mask = prob_mask_like((total,), null_cond_prob, device=dev)[lo:hi]
     else:
         unet.null_cond_mask = prob_mask_like((b,), null_cond_prob, device=dev)
     if none_cond_mask is not None:

@@ -75,9 +75,12 @@ def unet_case(name, b, t, s, **variant):
     save(name, b=b, t=t, s=s, **outs)
 
 
-def sampler_case(name, b, t, s, hw, steps, timesteps, video_frames=None):
-    """video_frames: keep only these frame indices of the image-resolution outputs (fixture size)."""
-    m = reference_model(s, t, steps, timesteps)
+def sampler_case(name, b, t, s, hw, steps, timesteps, video_frames=None, static_clip=False, **variant):
+    """video_frames: keep only these frame indices of the image-resolution outputs (fixture size).  static_clip: the
+    GaussianDiffusion default use_dynamic_thres=False (x0.clamp(-1, 1), :729-732) instead of the wrapper's dynamic threshold."""
+    m = reference_model(s, t, steps, timesteps, **variant)
+    if static_clip:
+        m.diffusion.use_dynamic_thres = False
     img, cond = synth.inputs(b, hw)
     m.set_sample_input(sample_img=img, sample_text=cond)
     with patched_noise(synth.NoiseTape(11)), torch.no_grad():
@@ -98,13 +101,13 @@ def generator_case(name, b, hw):
     save(name, b=b, hw=hw, fea=fea, prediction=out["prediction"], deformed=out["deformed"])
 
 
-def train_case(name, b, t, hw, labels, compact=False):
+def train_case(name, b, t, hw, labels, compact=False, null_cond_prob=0.0, **variant):
     """One full DM training step of the reference (FlowDiffusion.optimize_parameters, single-GPU class) on synthetic
     frozen-LFAE + UNet checkpoints: pseudo ground truth, losses, per-parameter gradient / updated-weight statistics.
     Randomness (t, noise) is replaced by recorded tensors; null_cond_prob = 0 (labels 'None' exercise none_cond_mask);
     text -> embedding is a fixed tensor (the reference's BERT download is unavailable)."""
-    m = ref.vfdm.FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=0.0,
-                               is_train=True, lr=1e-3, config_pth=synth.CONFIG, pretrained_pth="")
+    m = ref.vfdm.FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=null_cond_prob,
+                               is_train=True, lr=1e-3, config_pth=synth.CONFIG, pretrained_pth="", **variant)
     m.unet.load_state_dict(synth.unet_state())
     m.generator.load_state_dict(synth.generator_state())
     m.region_predictor.load_state_dict(synth.region_state())
@@ -115,14 +118,17 @@ def train_case(name, b, t, hw, labels, compact=False):
     ref_img, real_vid, cond, tt, noise = synth.train_inputs(b, t, hw)
     ref.vfd.tokenize = lambda texts: texts
     ref.vfd.bert_embed = lambda tokens, return_cls_repr=False: cond
-    randint, randn_like = torch.randint, torch.randn_like
+    randint, randn_like, uniform_ = torch.randint, torch.randn_like, torch.Tensor.uniform_
     torch.randint = lambda *a, **k: tt.clone()
     torch.randn_like = lambda x, **k: noise.clone()
+    if 0 < null_cond_prob < 1:      # prob_mask_like (:55-61) draws zeros(B).uniform_(0, 1) < prob: replay a recorded draw
+        u = synth.null_uniform(b)
+        torch.Tensor.uniform_ = lambda self, *a, **k: self.copy_(u.to(self.device)) if tuple(self.shape) == (b,) else uniform_(self, *a, **k)
     try:
         m.set_train_input(ref_img=ref_img, real_vid=real_vid, ref_text=labels)
         m.optimize_parameters()
     finally:
-        torch.randint, torch.randn_like = randint, randn_like
+        torch.randint, torch.randn_like, torch.Tensor.uniform_ = randint, randn_like, uniform_
     rng = np.random.Generator(np.random.PCG64(77))
     names, gnorm, pnorm, gprobe = [], [], [], []
     small = {}
@@ -220,7 +226,7 @@ def c3_steps_case(name, b=16, t=40, s=32, steps=(999, 500, 0)):
 
 def train_full_case(name, b=4, t=40, hw=128):
     """BASELINE.json configs[3] per-GPU shape class at full T: one reference training step (B=4, T=40, 128x128)."""
-    labels = ["label a", "None", "label c", "label d"][:b]
+    labels = (["label a", "None", "label c", "label d"] * 2)[:b]
     train_case(name, b, t, hw, labels, compact=True)
 
 
@@ -263,16 +269,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true")
     ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
+    ap.add_argument("--variants", action="store_true", help="only the variant fixtures: static clipping, use_residual_flow (sampling and "
+                    "training), stochastic null conditioning (0 < null_cond_prob < 1)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
-    ap.add_argument("--full", choices=["c3", "c4", "c5"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
+    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.full:
         {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"), "c4": lambda: train_full_case("train_step_c4_b4_t40"),
+         "c4b8": lambda: train_full_case("train_step_c4_b8_t40", b=8),
          "c5": lambda: c5_case("sample_ddim10_c5_256")}[args.full]()
         return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])
+        return
+    if args.variants:
+        sampler_case("sample_ddim5_tiny_static", 2, 4, 8, 32, 5, 1000, static_clip=True)
+        sampler_case("sample_ddim5_tiny_resflow", 2, 4, 8, 32, 5, 1000, use_residual_flow=True)
+        train_case("train_step_128_resflow_p05", 4, 2, 128, ["label a", "None", "label c", "label d"], null_cond_prob=0.5,
+                   use_residual_flow=True)
         return
     if args.train_flops:
         train_flops()

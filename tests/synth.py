@@ -43,9 +43,14 @@ def train_inputs(batch, frames, img_hw, seed=9):
         vid.append((0.7 * torch.roll(ref, shifts=(2 * t + 1, -t), dims=(2, 3)) + 0.3 * d).clamp(0, 1))
     real_vid = torch.stack(vid, dim=2).contiguous()
     cond = torch.from_numpy(rng.standard_normal((batch, 768)).astype(np.float32))
-    tt = torch.tensor([417, 23, 801, 5][:batch])
+    tt = torch.tensor(([417, 23, 801, 5] * ((batch + 3) // 4))[:batch])
     noise = torch.from_numpy(rng.standard_normal((batch, 3, frames, img_hw // 4, img_hw // 4)).astype(np.float32))
     return ref.contiguous(), real_vid, cond, tt, noise
+
+
+def null_uniform(batch, seed=14):
+    """The uniform(0, 1) draw prob_mask_like makes for a stochastic null-condition mask (0 < null_cond_prob < 1), recorded."""
+    return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).random(batch, dtype=np.float32))
 
 
 def inputs(batch, img_hw, seed=7):

@@ -28,7 +28,7 @@ from cvpr23_lfdm_amd import FlowDiffusion, _build, _native
 if kind == "emu":
     _native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))
 dev = "cuda" if kind == "hip" else "cpu"
-B, T, HW = 2, 2, 128
+B, T, HW = int(os.environ.get("LFDM_DP_B", "2")), 2, 128
 torch.manual_seed(11)
 m = FlowDiffusion(img_size=HW // 4, num_frames=T, sampling_timesteps=5, null_cond_prob=0.5, is_train=True, lr=1e-4,
                   config_pth=synth.CONFIG, pretrained_pth="")
@@ -50,7 +50,7 @@ p0 = m.unet.get("mid_block1.block1.proj.weight").detach().clone()
 torch.manual_seed(1234)
 losses, masks = [], []
 for step in range(2):
-    m.set_train_input(ref_img=ref_img.to(dev), real_vid=torch.roll(real_vid, step, dims=2).to(dev), ref_text=["anger", "None"] if step == 0 else ["fear", "anger"])
+    m.set_train_input(ref_img=ref_img.to(dev), real_vid=torch.roll(real_vid, step, dims=2).to(dev), ref_text=(["anger", "None", "fear"] if step == 0 else ["fear", "anger", "anger"])[:B])
     m.optimize_parameters()
     losses.append(float(m.loss)); masks.append(m.unet.null_cond_mask.cpu().tolist())
 names = ["init_conv.bias", "mid_block1.block1.proj.weight", "final_conv.1.weight", "downs.0.2.fn.fn.to_qkv.weight", "ups.3.0.mlp.1.bias"]
@@ -65,12 +65,12 @@ if dist.is_initialized():
 '''
 
 
-def _launch(tmp_path, kind, world):
+def _launch(tmp_path, kind, world, batch=2):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    outdir = tmp_path / ("out_w%d" % world)
+    outdir = tmp_path / ("out_w%d_b%d" % (world, batch))
     outdir.mkdir()
-    env = dict(os.environ, LFDM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", LFDM_DP_OUT=str(outdir))
+    env = dict(os.environ, LFDM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", LFDM_DP_OUT=str(outdir), LFDM_DP_B=str(batch))
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
     if world == 1:
         cmd = [sys.executable, str(script), REPO, kind]
@@ -101,6 +101,38 @@ def _check(tmp_path, kind):
     for s in range(2):                                                                # loss of step 2 was computed with step 1's update
         mean_of_shards = 0.5 * (r0["losses"][s] + r1["losses"][s])
         assert abs(mean_of_shards - single["losses"][s]) <= 2e-4 * abs(single["losses"][s]), (s, mean_of_shards, single["losses"][s])
+
+
+def _check_uneven(tmp_path, kind, batch, shards):
+    """A batch the ranks cannot split evenly (the reference scripts use BATCH_SIZE = 5 and no drop_last; nn.DataParallel scatters
+    it unevenly): tensor_split shards, each rank's loss weighted by shard * world / batch - the update is the single process's."""
+    single = _launch(tmp_path, kind, 1, batch)[0]
+    r0, r1 = _launch(tmp_path, kind, 2, batch)
+    assert (r0["shard_batch"], r1["shard_batch"]) == shards and r0["checksum_spread"] == 0.0 and r0["params"] == r1["params"]
+    assert r0["masks"][0] + r1["masks"][0] == single["masks"][0]
+    lr = 1e-4
+    for k, v in single["params"].items():
+        d = (torch.tensor(r0["params"][k]) - torch.tensor(v)).abs()
+        assert float(d.mean()) < 0.02 * lr and float((d > 0.5 * lr).float().mean()) < 0.01, (k, float(d.mean()), float(d.max()))
+    for s in range(2):
+        weighted = (shards[0] * r0["losses"][s] + shards[1] * r1["losses"][s]) / batch
+        assert abs(weighted - single["losses"][s]) <= 2e-4 * abs(single["losses"][s]), (s, weighted, single["losses"][s])
+
+
+@pytest.mark.gpu
+def test_two_ranks_uneven_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _check_uneven(tmp_path, "hip", 3, (2, 1))
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_video(tmp_path):
+    """Batch 1 on two ranks: rank 1 has no video - it skips the model, keeps its random generator in step and contributes zero
+    gradients; both ranks still apply the single process's update."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _check_uneven(tmp_path, "hip", 1, (1, 0))
 
 
 @pytest.mark.gpu

@@ -97,3 +97,18 @@ def test_bench_timing_protocol_gloo_world2(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["world"] == 2 and out["elapsed"] >= 0.055     # max over ranks: rank 1 sleeps 3 x 20 ms
+
+
+def test_bench_self_launch_gpus2():
+    """`python bench.py --gpus 2` with no launcher in the environment re-execs itself under torch.distributed.run: two ranks
+    rendezvous (gloo here), run the barrier / max-over-ranks protocol and rank 0 prints ONE line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LFDM_BENCH_DRYRUN="1", LFDM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["elapsed"] >= 0.018      # rank 1 sleeps 2 x 10 ms

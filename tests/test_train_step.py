@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import synth
-from util import assert_close
+from util import assert_close, record_margin
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_step_128.npz")
 
@@ -53,6 +53,7 @@ def test_training_step_matches_reference(monkeypatch):
     assert_close(m.fake_warped_vid[:, :, -1], T("fake_warped_vid"), 2e-3, "fake_warped_vid")
     for k in ("loss", "rec_loss", "rec_warp_loss"):
         got, want = float(getattr(m, k)), float(g[k])
+        record_margin(k, abs(got - want), abs(want), 1e-3)
         assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (k, got, want)
 
     names = [str(n) for n in g["names"]]
@@ -72,6 +73,7 @@ def test_training_step_matches_reference(monkeypatch):
         for tag, e in (("grad norm", rel), ("grad probe", relp), ("updated weight norm", pn)):
             if e > worst[1]:
                 worst = ("%s of %s" % (tag, k), e)
+    record_margin("largest relative deviation over all parameter gradients / updated weights: " + worst[0], worst[1], 1.0, 5e-3)
     assert worst[1] < 5e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
     for key in g.files:
         if key.startswith("grad/"):

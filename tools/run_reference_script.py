@@ -15,6 +15,8 @@ What a launcher has to interpose, because the scripts hard-code their environmen
                           differently while initialising parameters that the checkpoints then overwrite)
   --record DIR            raw frames of every imageio.mimsave / Image.save call + the model's result tensors -> DIR/*.npz
   --emu                   drive the kernels through the x86 emulation build (GPU-less container; TEST infrastructure)
+Under `torchrun --nproc-per-node N` every rank runs the whole script (the wrapper shards each batch: any batch size, uneven
+shards are weighted); only rank 0 writes the script's snapshots and images (--all-ranks-write lifts that).
 On a box without a GPU `.cuda()` is a no-op (both backends).  Used by tests/test_reference_scripts.py.
 """
 import argparse
@@ -84,6 +86,8 @@ def main():
     ap.add_argument("--model-kw", action="append")
     ap.add_argument("--reseed", type=int, default=None)
     ap.add_argument("--record", default="")
+    ap.add_argument("--all-ranks-write", action="store_true", help="under torchrun: let every rank write the script's snapshots / "
+                    "images (default: rank 0 only; the others' torch.save / imageio / PIL saves are no-ops)")
     ap.add_argument("--bert", default="", help="local Hugging Face BERT directory (hidden size 768) standing in for the "
                     "torch.hub download of bert-base-cased (DM/modules/text.py:20,27): LFDM_BERT_PATH for this repository's "
                     "classes, a torch.hub.load replacement for the reference's")
@@ -140,6 +144,21 @@ def main():
     if a.backend == "ours" and a.emu:
         from cvpr23_lfdm_amd import _build, _native
         _native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))
+
+    # ---- one process per GPU (torchrun): every rank runs the whole unchanged script, but only rank 0 may write its files ----
+    # (snapshots, sample images / GIFs; N processes truncating the same checkpoint path can leave it corrupt.  misc.Logger gives
+    #  the other ranks a log file of their own, cvpr23_lfdm_amd/io_compat.py.)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) > 0 and not a.all_ranks_write:
+        import imageio as _imageio
+        torch.save = lambda *x, **k: None
+        for fn in ("mimsave", "imsave", "imwrite", "mimwrite"):
+            if hasattr(_imageio, fn):
+                setattr(_imageio, fn, lambda *x, **k: None)
+        try:
+            from PIL import Image as _Image
+            _Image.Image.save = lambda self, *x, **k: None
+        except ImportError:
+            pass
 
     # ---- recording hooks --------------------------------------------------------------------------------------------
     state = {"model": None, "saves": 0}
