@@ -114,8 +114,11 @@ def abs_quantile(x_flat, q):
     return torch.lerp(srt[:, lo_i], srt[:, hi_i], frac)
 
 
-def dynamic_threshold(x0, q=0.9):
-    """video_flow_diffusion.py:719-732 / :805-818 (use_dynamic_thres=True)."""
+def dynamic_threshold(x0, q=0.9, dynamic=True):
+    """video_flow_diffusion.py:719-732 / :805-818: s = max(1, quantile_q |x0|) per sample with use_dynamic_thres=True (what
+    FlowDiffusion passes), s = 1 otherwise (GaussianDiffusion's own default); then x0.clamp(-s, s) / s."""
+    if not dynamic:
+        return x0.clamp(-1.0, 1.0)
     s = abs_quantile(x0.reshape(x0.shape[0], -1), q).clamp_min(1.0)
     s = s.view(-1, *([1] * (x0.dim() - 1)))
     return torch.maximum(torch.minimum(x0, s), -s) / s
@@ -407,7 +410,7 @@ def predict_start_from_noise(sd, x_t, t, eps):
             - _bc(sd["sqrt_recipm1_alphas_cumprod"][t], b) * eps)
 
 
-def ddim_step(sd, img, fea_rep, cond, time, time_next, noise, eta=1.0, cond_scale=1.0):
+def ddim_step(sd, img, fea_rep, cond, time, time_next, noise, eta=1.0, cond_scale=1.0, dynamic=True):
     """One iteration of ddim_sample (:791-827). `noise` is the tensor the reference would draw
     with randn_like (ignored when time_next == 0). Returns (img_next, pred_noise, x_start)."""
     b = img.shape[0]
@@ -415,19 +418,19 @@ def ddim_step(sd, img, fea_rep, cond, time, time_next, noise, eta=1.0, cond_scal
     alpha_next = sd["alphas_cumprod_prev"][time_next]
     t = torch.full((b,), time, dtype=torch.long)
     eps = unet_forward_with_cond_scale(sd, torch.cat([img, fea_rep], dim=1), t, cond, cond_scale)
-    x0 = dynamic_threshold(predict_start_from_noise(sd, img, t, eps))
+    x0 = dynamic_threshold(predict_start_from_noise(sd, img, t, eps), dynamic=dynamic)
     sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
     c = ((1 - alpha_next) - sigma ** 2).sqrt()
     nz = noise if time_next > 0 else 0.0
     return x0 * alpha_next.sqrt() + c * eps + sigma * nz, eps, x0
 
 
-def ddpm_step(sd, img, fea_rep, cond, time, noise, cond_scale=1.0):
+def ddpm_step(sd, img, fea_rep, cond, time, noise, cond_scale=1.0, dynamic=True):
     """p_sample (:737-746) with p_mean_variance (:712-735)."""
     b = img.shape[0]
     t = torch.full((b,), time, dtype=torch.long)
     eps = unet_forward_with_cond_scale(sd, torch.cat([img, fea_rep], dim=1), t, cond, cond_scale)
-    x0 = dynamic_threshold(predict_start_from_noise(sd, img, t, eps))
+    x0 = dynamic_threshold(predict_start_from_noise(sd, img, t, eps), dynamic=dynamic)
     mean = _bc(sd["posterior_mean_coef1"][t], b) * x0 + _bc(sd["posterior_mean_coef2"][t], b) * img
     logvar = _bc(sd["posterior_log_variance_clipped"][t], b)
     nonzero = 0.0 if time == 0 else 1.0
@@ -435,7 +438,7 @@ def ddpm_step(sd, img, fea_rep, cond, time, noise, cond_scale=1.0):
 
 
 def sample(sd, fea, cond, shape, sampling_timesteps, timesteps=1000, eta=1.0, cond_scale=1.0,
-           noise_fn=None, record=None):
+           noise_fn=None, record=None, dynamic=True):
     """GaussianDiffusion.sample (:762-775): DDIM when sampling_timesteps < timesteps else DDPM.
     Noise is drawn through `noise_fn(shape)` (default torch.randn on the default generator) in
     the reference's order: one draw for x_T, then one per step (DDIM skips
@@ -454,10 +457,10 @@ def sample(sd, fea, cond, shape, sampling_timesteps, timesteps=1000, eta=1.0, co
     if sampling_timesteps < timesteps:
         for time, time_next in ddim_time_pairs(timesteps, sampling_timesteps):
             z = draw() if time_next > 0 else None
-            img, _, _ = ddim_step(sd, img, fea_rep, cond, time, time_next, z, eta, cond_scale)
+            img, _, _ = ddim_step(sd, img, fea_rep, cond, time, time_next, z, eta, cond_scale, dynamic)
     else:
         for time in reversed(range(timesteps)):
-            img, _, _ = ddpm_step(sd, img, fea_rep, cond, time, draw(), cond_scale)
+            img, _, _ = ddpm_step(sd, img, fea_rep, cond, time, draw(), cond_scale, dynamic)
     return img
 
 
@@ -526,12 +529,12 @@ def identity_grid(b, nf, h, w):
 
 def sample_one_video(dsd, gsd, img, cond, num_frames, latent_size, sampling_timesteps,
                      timesteps=1000, eta=1.0, cond_scale=1.0, noise_fn=None, record=None,
-                     use_residual_flow=False):
+                     use_residual_flow=False, dynamic=True):
     """FlowDiffusion.sample_one_video (video_flow_diffusion_model.py:190-216)."""
     fea = generator_compute_fea(gsd, img)
     b = cond.shape[0]
     pred = sample(dsd, fea, cond, (b, 3, num_frames, latent_size, latent_size),
-                  sampling_timesteps, timesteps, eta, cond_scale, noise_fn, record)
+                  sampling_timesteps, timesteps, eta, cond_scale, noise_fn, record, dynamic)
     grid = pred[:, :2]
     if use_residual_flow:
         grid = grid + identity_grid(b, num_frames, latent_size, latent_size)

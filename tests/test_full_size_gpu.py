@@ -4,7 +4,8 @@ random projections of every result, so batch-16 / 40-frame / 256x256 tensors are
 
   c3  MHAD shape class, DDPM-1000, batch 16, 40 frames: teacher-forced sampler steps at t = 999, 500, 0 through the REAL
       sampling path (fea term, step tables, stem, trunk, radix-select threshold, update; one captured hipGraph per call)
-  c4  one DM training step at B = 4, T = 40, 128x128 (pseudo ground truth of 160 frames, loss, pred_x0, every gradient norm)
+  c4  one DM training step at B = 4 and at the per-GPU B = 8, T = 40, 128x128 (pseudo ground truth of 160 / 320 frames, loss, pred_x0,
+      every gradient norm)
   c5  NATOPS variant (learned null condition, upsample + reflect), 64x64 latent, 256x256 frames, 40 frames, DDIM-10
 """
 import os
@@ -66,8 +67,10 @@ def test_c3_ddpm_steps_batch16():
         assert_close(pr.float(), torch.from_numpy(g["probes_%d" % i]).float(), 2e-3, "random projections, t=%d" % step)
 
 
-def test_c4_training_step_t40(monkeypatch):
-    g = gold("train_step_c4_b4_t40")
+@pytest.mark.parametrize("fixture", ["train_step_c4_b4_t40", "train_step_c4_b8_t40"])
+def test_c4_training_step_t40(monkeypatch, fixture):
+    """(_b8_: the per-GPU batch of BASELINE.json configs[3], 64 videos over 8 GPUs - 320 pseudo-ground-truth frames.)"""
+    g = gold(fixture)
     b, t, hw = int(g["b"]), int(g["t"]), int(g["hw"])
     from cvpr23_lfdm_amd import FlowDiffusion
     m = FlowDiffusion(img_size=hw // 4, num_frames=t, sampling_timesteps=5, timesteps=1000, null_cond_prob=0.0, is_train=True, lr=1e-3,

@@ -60,12 +60,17 @@ def test_generator(name):
     assert_close(out["prediction"].cpu(), g["prediction"], 1e-3, "prediction")
 
 
-@pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny", "sample_ddim100_c2"])
+@pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny", "sample_ddim100_c2", "sample_ddim5_tiny_static",
+                                  "sample_ddim5_tiny_resflow"])
 def test_sample_one_video(name):
+    """(_static: the reference run with use_dynamic_thres=False - x0.clamp(-1, 1) -, _resflow: with use_residual_flow=True.)"""
     g = gold(name)
     b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
+    variant = dict(use_residual_flow=True) if name.endswith("_resflow") else {}
     m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=int(g["steps"]),
-                                         timesteps=int(g["timesteps"]))
+                                         timesteps=int(g["timesteps"]), **variant)
+    if name.endswith("_static"):
+        m.diffusion.use_dynamic_thres = False
     img, cond = synth.inputs(b, hw)
     m.diffusion.noise_source = synth.NoiseTape(int(g["noise_seed"]))
     m.set_sample_input(sample_img=img.cuda(), sample_text=cond.cuda())
