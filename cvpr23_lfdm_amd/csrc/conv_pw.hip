@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   __shared__ __attribute__((aligned(16))) float scratch[4 * 32 * LD];
   __shared__ float s_ln[2][4][32];     // fused LayerNorm: [sum | sum of squares][wave][row]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index is uniform, but derived from threadIdx the compiler cannot know it: every buffer load whose descriptor or
+  // chunk offset depends on it was wrapped in a per-load "waterfall" loop (cdna_hip_programming.md T20) - readfirstlane makes it scalar
+  const int wave = lfdm_uniform(tid >> 6);
   const int wk = wave % KW, wn = wave / KW;
   // block id -> (row tile, column tile): ids round-robin over the 8 XCDs, an XCD walks the column tiles of one row tile
   const int id = blockIdx.x, slot = id >> 3;

@@ -8,6 +8,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(LFDM_EMU_BUILD)
 #include "hip_emu.h"
@@ -40,6 +41,15 @@ __device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
 #endif
 
 #define LFDM_WAVE 64
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN .. END-1 (indices usable as template / asm immediates)
+template <int BEGIN, int END, class F>
+__device__ __forceinline__ void lfdm_static_for(F&& f) {
+  if constexpr (BEGIN < END) {
+    f(std::integral_constant<int, BEGIN>{});
+    lfdm_static_for<BEGIN + 1, END>(f);
+  }
+}
 
 // Buffer-descriptor loads: an out-of-range byte offset returns zeros, which turns "is this filter tap
 // inside the image" into one v_cndmask on the offset instead of a divergent branch around the load
@@ -82,6 +92,39 @@ __device__ __forceinline__ float2 lfdm_buf_load_f2(lfdm_buf b, uint32_t off) {
 }
 #endif
 #define LFDM_BUF_OOB 0xFFFFFFF0u
+
+// Register-operand load pipelines.  hipcc (ROCm 7.2) undoes a source-level "load group g+1, multiply group g" loop whenever the loaded
+// values feed MFMAs straight from registers: the load is sunk across the back-edge to its use and every group pays the full memory
+// latency (attn_lowres.hip, first version: 18.6 us for 3 us of MFMA).  The loads of such loops are therefore issued by inline asm
+// (volatile: never moved or sunk) and retired by hand-counted s_waitcnt vmcnt(N) - loads return in order, N = the number of loads
+// issued AFTER the ones being waited for; the waited registers are "+v" operands of the wait, so no consumer can be scheduled above
+// it (cdna_hip_programming.md 5.4 rule 18, 5.7).  Only in fully unrolled straight-line code (no loop-carried asm outputs).
+#if defined(LFDM_EMU_BUILD)
+template <int OFF = 0> static inline void lfdm_gload_f4(f32x4& dst, const float* p) { memcpy(&dst, (const char*)p + OFF, 16); }
+template <int N> static inline void lfdm_vmwait() {}
+template <int N> static inline void lfdm_vmwait(f32x4&) {}
+template <int N> static inline void lfdm_vmwait(f32x4&, f32x4&) {}
+template <int N> static inline void lfdm_vmwait(f32x4&, f32x4&, f32x4&, f32x4&) {}
+static inline void lfdm_tie(f32x4&) {}
+static inline int lfdm_uniform(int v) { return v; }
+#else
+template <int OFF = 0>      // OFF: byte offset folded into the instruction (0 .. 4095)
+__device__ __forceinline__ void lfdm_gload_f4(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void lfdm_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void lfdm_vmwait(f32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void lfdm_vmwait(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void lfdm_vmwait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lfdm_tie(f32x4& a) { asm volatile("" : "+v"(a)::"memory"); }      // orders a consumer behind the preceding wait
+// a value the compiler cannot prove wave-uniform (anything derived from threadIdx) made uniform for it: keeps buffer descriptors /
+// scalar selects out of per-load "waterfall" loops (cdna_hip_programming.md T20)
+__device__ __forceinline__ int lfdm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 
 // In-launch hand-off between workgroups (split-K: the last workgroup of a tile reduces the slabs).  Protocol of
 // cdna_hip_programming.md section 6 Guideline 16 (counter form): every storing wave drains its stores, one lane issues an

@@ -471,6 +471,36 @@ def linear_attention_fused_cl(x, wqkv, n_frames, hw, *, eps=1e-5, out=None, ws=N
     return out
 
 
+def linear_attention_lowres_cl(x, wqkv, wsum, n_frames, hw, *, eps=1e-5, out=None):
+    """LayerNorm + to_qkv + linear attention core in ONE launch (low-resolution levels: hw <= 64 or 192 < hw <= 256 pixels per frame,
+    C % 64 == 0); wqkv (768, C) with gamma folded, wsum (768,) = its row sums (pack_ln_conv_weight)."""
+    lib = _lib()
+    _chk(lib, x, wqkv, wsum, out)
+    assert wqkv.shape == (768, x.shape[1]) and wqkv.is_contiguous() and wsum.numel() >= 768
+    if out is None:
+        out = torch.empty(x.shape[0], 256, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_linear_attention_lowres_cl_f32(_p(x), x.stride(0), x.shape[1], _p(wqkv), _p(wsum), _p(out), n_frames, hw, eps,
+                                                      _stream(lib)), "lfdm_linear_attention_lowres_cl_f32")
+    return out
+
+
+def linear_attention_lowres_ok(hw, channels):
+    return channels % 64 == 0 and (hw <= 64 or 192 < hw <= 256)
+
+
+def attention_lowres_cl(x, wqkv, wsum, batch, frames, hw, mode, *, bias=None, rot_cos=None, rot_sin=None, eps=1e-5, out=None):
+    """LayerNorm + to_qkv + softmax attention core in ONE launch (<= 64 tokens per sequence, C % 64 == 0): mode 0 over the frames of
+    a pixel (rotary tables + relative-position bias), mode 1 over the pixels of a frame."""
+    lib = _lib()
+    _chk(lib, x, wqkv, wsum, bias, rot_cos, rot_sin, out)
+    assert wqkv.shape == (768, x.shape[1]) and wqkv.is_contiguous() and wsum.numel() >= 768
+    if out is None:
+        out = torch.empty(x.shape[0], 256, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_attention_lowres_cl_f32(_p(x), x.stride(0), x.shape[1], _p(wqkv), _p(wsum), _p(out), batch, frames, hw, mode,
+                                               _p(bias), _p(rot_cos), _p(rot_sin), eps, _stream(lib)), "lfdm_attention_lowres_cl_f32")
+    return out
+
+
 def linear_attention_cl(qkv, n_frames, hw, *, out=None, ws=None):
     lib = _lib()
     _chk(lib, qkv, out, ws)

@@ -5,6 +5,8 @@ liblfdm_hip.so (channels-last activations, weights repacked once, skip concatena
 residual adds / GroupNorm affine fused into kernel arguments).  No torch compute op runs on the
 activation path; torch only provides device memory and the stream.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -12,6 +14,12 @@ from . import ops
 from .params import ParamTree, build_tree, unet_spec, weights_epoch
 
 BERT_MODEL_DIM = 768
+# LFDM_LOWRES_ATTN=0: the low-resolution attention blocks as separate projection / core launches (A/B switch for profiling)
+_LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"
+# measured (tools/bench_attn_lowres.py, profiles/r03_f_bench_attn_lowres.txt): the one-launch kernels win at <= 64 pixels per frame
+# (4x4: 19 vs 31 us linear, 19 vs 26 temporal; 8x8: 33 vs 35 / 23 vs 29) and lose at 16x16 (69 vs 64 / 63 vs 52: 2048 workgroups of one
+# head each re-read the frame's rows eight times and hold 78-110 KB of LDS)
+_LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
 
 
 def prob_mask_like(shape, prob, device):
@@ -155,15 +163,15 @@ class Unet3D(ParamTree):
 
         def temporal(prefix):
             wq, gam = g(prefix + "fn.fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma")
-            if wq.shape[1] == 64:      # finest level: LayerNorm + to_qkv + attention run as ONE kernel, qkv never materialised
-                pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
+            # LayerNorm + to_qkv + attention as ONE kernel (qkv never materialised): W' = W * gamma row-major, for the finest level's
+            # wave-per-sequence kernel and the low-resolution levels' workgroup-per-(sequence, head) kernel
+            pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
             pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
 
         def spatial_linear(prefix):
             wq, gam = g(prefix + "fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma")
-            if wq.shape[1] == 64:      # finest level: LayerNorm + to_qkv + linear attention without a qkv tensor
-                pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
+            pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()      # (see temporal)
             pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
             pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
@@ -192,6 +200,8 @@ class Unet3D(ParamTree):
         resblock("mid_block1.")
         pk["mid_spatial_attn.qkv.w"], pk["mid_spatial_attn.qkv.wsum"] = ops.pack_ln_conv_weight(
             g("mid_spatial_attn.fn.fn.fn.to_qkv.weight"), g("mid_spatial_attn.fn.norm.gamma"))
+        pk["mid_spatial_attn.qkv.wf"] = (g("mid_spatial_attn.fn.fn.fn.to_qkv.weight").reshape(768, -1)
+                                         * g("mid_spatial_attn.fn.norm.gamma").reshape(1, -1)).contiguous()
         pk["mid_spatial_attn.out.w"] = ops.pack_conv_weight(g("mid_spatial_attn.fn.fn.fn.to_out.weight"))
         temporal("mid_temporal_attn.")
         resblock("mid_block2.")
@@ -332,10 +342,14 @@ class Unet3D(ParamTree):
 
     def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables):
         bias, cos, sin = tables
-        if (prefix + "qkv.wf") in pk and frames <= 64:
+        if c == 64 and frames <= 64:
             att = self._buf("at.o", x.shape[0], 256)
             ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
                                             rot_sin=sin, out=att)
+        elif _LOWRES_ATTN and c % 64 == 0 and frames <= 64 and s * s <= _LOWRES_MAX_HW:      # one launch: workgroup = (pixel sequence, head)
+            att = self._buf("at.o", x.shape[0], 256)
+            ops.attention_lowres_cl(x, pk[prefix + "qkv.wf"], pk[prefix + "qkv.wsum"], batch, frames, s * s, 0, bias=bias,
+                                    rot_cos=cos, rot_sin=sin, out=att)
         else:
             qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
             ops.attention_cl(qkv, batch, frames, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=att)
@@ -343,17 +357,24 @@ class Unet3D(ParamTree):
         return self._conv(att, pk[prefix + "out.w"], c, 1, batch * frames, s, residual=x, out=out)
 
     def _spatial_attn(self, pk, prefix, x, batch, frames, s, c, outname):
-        qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
-        ops.attention_cl(qkv, batch, frames, s * s, 1, out=att)
+        if _LOWRES_ATTN and c % 64 == 0 and s * s <= 64:
+            att = self._buf("at.o", x.shape[0], 256)
+            ops.attention_lowres_cl(x, pk[prefix + "qkv.wf"], pk[prefix + "qkv.wsum"], batch, frames, s * s, 1, out=att)
+        else:
+            qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
+            ops.attention_cl(qkv, batch, frames, s * s, 1, out=att)
         out = self._buf(outname, x.shape[0], c)
         return self._conv(att, pk[prefix + "out.w"], c, 1, batch * frames, s, residual=x, out=out)
 
     def _linear_attn(self, pk, prefix, x, batch, frames, s, c, outname):
         n_img = batch * frames
-        if (prefix + "qkv.wf") in pk:
+        if c == 64:
             att = self._buf("at.o", x.shape[0], 256)
             ws = self._buf("la.wsf", 1, ops.linear_attention_fused_ws_floats(n_img, s * s))
             ops.linear_attention_fused_cl(x, pk[prefix + "qkv.wf"], n_img, s * s, out=att, ws=ws)
+        elif _LOWRES_ATTN and ops.linear_attention_lowres_ok(s * s, c) and s * s <= _LOWRES_MAX_HW:      # one launch: workgroup = (frame, head)
+            att = self._buf("at.o", x.shape[0], 256)
+            ops.linear_attention_lowres_cl(x, pk[prefix + "qkv.wf"], pk[prefix + "qkv.wsum"], n_img, s * s, out=att)
         else:
             qkv, att = self._attn_common(pk, prefix, x, n_img, s, c)
             ws = self._buf("la.ws", n_img, 8 * 32 * 32)

@@ -313,6 +313,21 @@ int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, co
                                        int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                        lfdm_stream_t stream);
 
+/* The same two blocks - PreNorm LayerNorm + to_qkv + attention core, without to_out - as ONE launch for the low-resolution levels
+ * (C % 64 == 0 channels, a few hundred to a few thousand rows), where separate projection / reduce / core launches sit at their
+ * launch latency: one workgroup per (frame, head) resp. (sequence, head) projects its rows with the head's 96 filter rows (fp32
+ * MFMA, K split over the wavefronts), keeps q | k | v in LDS and writes the head's 32 output columns.
+ * wqkv: (768, C) row-major with the LayerNorm gamma folded in; wsum[o] = sum_c wqkv[o][c] (768 floats: the algebraic LayerNorm fold
+ * y = rstd * (x.W' - mean * wsum)); out: rows of 256.
+ * lfdm_linear_attention_lowres_cl_f32: SpatialLinearAttention (video_flow_diffusion.py:240-265), hw <= 64 or 192 < hw <= 256 pixels
+ * per frame.  lfdm_attention_lowres_cl_f32: Attention (:286-363); mode 0 = over the frames of a pixel (rot_cos / rot_sin (T,16), bias
+ * (8,T,T) as in lfdm_attention_cl_f32), mode 1 = over the pixels of a frame (mid block); at most 64 tokens per sequence. */
+int lfdm_linear_attention_lowres_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wsum, float* out,
+                                        int n_frames, int hw, float ln_eps, lfdm_stream_t stream);
+int lfdm_attention_lowres_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wsum, float* out, int batch,
+                                 int frames, int hw, int mode, const float* bias, const float* rot_cos, const float* rot_sin,
+                                 float ln_eps, lfdm_stream_t stream);
+
 /* Winograd F(2x2,3x3) filter transform U = G g G^T into the operand layout of lfdm_conv_params.weight_wino:
  * out[16][cin/16][coutp][16] (zero for output channels >= cout).  w: 3x3 filters of the reference layout
  * (Cout, Cin, 3, 3) (video_flow_diffusion.py:197 Block.proj / LFAE util.py:73-76 ResBlock2d); element (o, i, a, b) at

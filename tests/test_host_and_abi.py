@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 25
     assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
     lib = _native.NativeLibrary(path, "hip")          # getattr on every symbol; raises if one is missing
-    assert lib.lfdm_abi_version() == 3          # 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2
+    assert lib.lfdm_abi_version() == 4          # 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2; 4: *_lowres_cl_f32
     nm = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True).stdout
     for sym in declared:
         assert re.search(r"\bT %s\b" % sym, nm), sym
@@ -112,3 +112,16 @@ def test_bench_self_launch_gpus2():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["elapsed"] >= 0.018      # rank 1 sleeps 2 x 10 ms
+
+
+def test_asm_load_pipelines_are_safe():
+    """Every kernel file that issues loads by inline asm (lfdm_gload_f4) is compiled to gfx950 assembly and walked by
+    tools/check_asm_pipeline.py: no instruction may touch the destination of a load that is still in flight (hipcc spills / re-uses
+    such registers under pressure - a wild-pointer fault on the GPU), nothing pending at a branch or at the end."""
+    import glob
+    files = [f for f in glob.glob(os.path.join(REPO, "cvpr23_lfdm_amd", "csrc", "*.hip")) if "lfdm_gload_f4" in open(f).read()]
+    assert files
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_asm_pipeline.py")] + files, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 problem(s)" in r.stdout

@@ -719,6 +719,64 @@ def test_linear_attention_fused(backend, hw):
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + linear attention")
 
 
+@pytest.mark.parametrize("c,hw,nf", [(512, 16, 3), (256, 64, 2), (128, 36, 2), (192, 9, 5), (128, 256, 2), (64, 200, 2), (512, 16, 40), (256, 64, 40),
+                                     (128, 256, 40)])
+def test_linear_attention_lowres(backend, c, hw, nf):
+    """LayerNorm + to_qkv + SpatialLinearAttention core in ONE launch (attn_lowres.hip: workgroup = (frame, head); channels split over
+    the wavefronts for <= 64 pixels, rows split for 256-pixel frames; ragged row tiles) vs the reference formulas."""
+    dev = backend
+    if nf == 40 and not big(dev):
+        pytest.skip("full frame count: GPU only")
+    x = rnd(nf, hw, c, seed=1) * 2 + 0.3
+    gamma = rnd(c, seed=2) * 0.3 + 1
+    wq = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
+    mean = x.mean(dim=-1, keepdim=True)
+    var = x.var(dim=-1, unbiased=False, keepdim=True)
+    normed = (x - mean) / (var + 1e-5).sqrt() * gamma
+    qkv = normed @ wq.t()
+    q, k, v = [z.reshape(nf, hw, 8, 32).permute(0, 2, 3, 1) for z in qkv.chunk(3, dim=-1)]  # b h d n
+    q = q.softmax(dim=-2) * (32 ** -0.5)
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(nf * hw, 256)
+    wf = (wq * gamma.reshape(1, -1)).contiguous()
+    wsum = wf.double().sum(dim=1).float()
+    assert ops.linear_attention_lowres_ok(hw, c)
+    out = ops.linear_attention_lowres_cl(x.reshape(-1, c).to(dev), wf.to(dev), wsum.to(dev), nf, hw)
+    assert_close(out.cpu(), ref, TOL, "low-res LN + qkv + linear attention")
+
+
+@pytest.mark.parametrize("c,frames,s,mode", [(128, 40, 2, 0), (512, 40, 1, 0), (256, 7, 2, 0), (192, 20, 1, 0), (512, 3, 4, 1), (256, 2, 6, 1),
+                                             (512, 40, 4, 0), (256, 40, 8, 0), (128, 40, 16, 0), (512, 40, 4, 1)])
+def test_attention_lowres(backend, c, frames, s, mode):
+    """LayerNorm + to_qkv + softmax attention core in ONE launch (attn_lowres.hip: workgroup = (sequence, head)): mode 0 over the
+    frames of a pixel with rotary + relative-position bias, mode 1 over the pixels of a frame (mid block); 1-4 token tiles."""
+    dev = backend
+    if s >= 4 and frames == 40 and not big(dev):
+        pytest.skip("full-size level: GPU only")
+    b, hw = 1, s * s
+    x = rnd(b, c, frames, s, s, seed=1) * 2 + 0.5
+    gamma = rnd(1, c, 1, 1, 1, seed=2) * 0.3 + 1
+    wq = rnd(768, c, seed=3, scale=1.0 / math.sqrt(c))
+    normed = O.channel_layernorm(x, gamma)
+    wf = (wq * gamma.reshape(1, -1)).contiguous()
+    wsum = wf.double().sum(dim=1).float()
+    if mode == 0:
+        emb = rnd(32, 8, seed=4)
+        bias = O.rel_pos_bias(emb, frames)
+        freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+        cos, sin = O.rotary_tables(freqs, frames)
+        tokens = normed.permute(0, 3, 4, 2, 1).reshape(b, hw, frames, c)
+        ref = _attention_ref(tokens @ wq.t(), bias, (cos, sin)).permute(0, 2, 1, 3).reshape(-1, 256)
+        kw = dict(bias=bias.contiguous().to(dev), rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
+    else:
+        tokens = normed.permute(0, 2, 3, 4, 1).reshape(b, frames, hw, c)
+        ref = _attention_ref(tokens @ wq.t(), None, None).reshape(-1, 256)
+        kw = {}
+    out = ops.attention_lowres_cl(unet_to_cl(x).to(dev), wf.to(dev), wsum.to(dev), b, frames, hw, mode, **kw)
+    assert_close(out.cpu(), ref, TOL, "low-res LN + qkv + attention, mode %d" % mode)
+
+
 @pytest.mark.parametrize("cin,k,h,w", [(16, 7, 20, 18), (64, 7, 16, 16), (32, 3, 5, 33)])
 def test_conv2d_smalln(backend, cin, k, h, w):
     """<= 4 output channels on the 4x4x1 MFMA blocks (LFAE final 7x7 RGB conv + sigmoid); ragged tiles."""

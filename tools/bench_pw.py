@@ -75,7 +75,7 @@ def main():
         os.environ["LFDM_PW"] = "0"
         pp, keep, ks, kind = make()
         t_old = timed(lambda: ops.conv_launch(pp))
-        os.environ["LFDM_PW"] = "1"
+        os.environ["LFDM_PW"] = "2"        # every eligible geometry
         os.environ.pop("LFDM_PW_TN", None)
         os.environ.pop("LFDM_PW_KW", None)
         pp, keep, _, kind_pw = make()
