@@ -388,9 +388,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) gs[j][e] = gq[j][e] = 0.f;
+  // bias / LayerNorm column sums (per column tile) and the residual float4 of EVERY pass are requested before the first pass: inside
+  // the pass loop (a barrier pair per 32x32 tile) each was a load -> wait -> store round trip, 16 of them for a 128x128 tile
+  // (the residual rows one row tile i at a time: all TM*TN*4 float4 at once spilled in the 128x128 instantiation)
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pre_b[TN], pre_w[TN], pre_r[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int colbase = n0 + wn * WN + 32 * j + 4 * c4;
+    const bool cok = vec_ok && colbase < p.cout;
+    pre_b[j] = (cok && p.bias) ? *reinterpret_cast<const float4*>(p.bias + colbase) : z4;
+    pre_w[j] = (FAST && LN && cok) ? *reinterpret_cast<const float4*>(p.ln_wsum + colbase) : z4;
+  }
 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = wm * WM + 32 * i + it * 8 + rsub;
+        const int colbase = n0 + wn * WN + 32 * j + 4 * c4;
+        pre_r[j][it] = z4;
+        if (vec_ok && p.residual && colbase < p.cout && s_img[row] >= 0) {
+          const int64_t orow = ((int64_t)s_img[row] * p.ho + s_qy[row] * p.out_scale + p.out_off_y) * p.wo + s_qx[row] * p.out_scale + p.out_off_x;
+          pre_r[j][it] = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
+        }
+      }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       __syncthreads();
@@ -411,21 +435,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(lfdm_conv_params p) {
         const int64_t orow = ((int64_t)img * p.ho + oy) * p.wo + ox;
         if (vec_ok) {
           if (FAST && LN) {      // y = rstd * (x.W' - mean * sum_c W')
-            const float4 ws = *reinterpret_cast<const float4*>(p.ln_wsum + colbase);
+            const float4 ws = pre_w[j];
             const float mu = s_lnm[row], rs = s_lnr[row];
             v.x = rs * (v.x - mu * ws.x); v.y = rs * (v.y - mu * ws.y);
             v.z = rs * (v.z - mu * ws.z); v.w = rs * (v.w - mu * ws.w);
           }
-          if (p.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + colbase);
+          {
+            const float4 bb = pre_b[j];
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
           if (p.gn_partial) {
             gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
             gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
           }
-          if (p.residual) {
-            const float4 rr = *reinterpret_cast<const float4*>(p.residual + orow * p.ldr + colbase);
+          {
+            const float4 rr = pre_r[j][it];
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
           v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);

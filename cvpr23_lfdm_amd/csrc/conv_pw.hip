@@ -122,6 +122,21 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   const int orow = m0 + trow;
   const bool vec_row = orow < M;
   float mean = 0.f, rstd = 1.f;
+  // bias / LayerNorm column sums / residual rows of EVERY pass are requested here, before the accumulators go through LDS: loaded
+  // inside the pass loop each of them was a load -> wait -> store round trip (~1 us per pass on a launch that should take 5)
+  constexpr int NP = NW * TN;
+  float4 pre_b[NP], pre_w[NP], pre_r[NP];
+#pragma unroll
+  for (int g = 0; g < NW; ++g)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (g * TN + j) * 32 + 4 * c4;
+      const bool ok = vec_row && col < p.cout;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      pre_b[g * TN + j] = (ok && p.bias) ? *reinterpret_cast<const float4*>(p.bias + col) : z;
+      pre_w[g * TN + j] = (LN && ok) ? *reinterpret_cast<const float4*>(p.ln_wsum + col) : z;
+      pre_r[g * TN + j] = (ok && p.residual) ? *reinterpret_cast<const float4*>(p.residual + (int64_t)orow * p.ldr + col) : z;
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     if (j > 0) __syncthreads();
@@ -153,17 +168,13 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
       const int col = n0 + (g * TN + j) * 32 + 4 * c4;
       if (!vec_row || col >= p.cout) continue;
       if (LN) {                          // y = rstd * (x.W' - mean * sum_c W')
-        const float4 ws = *reinterpret_cast<const float4*>(p.ln_wsum + col);
+        const float4 ws = pre_w[g * TN + j];
         v.x = rstd * (v.x - mean * ws.x); v.y = rstd * (v.y - mean * ws.y);
         v.z = rstd * (v.z - mean * ws.z); v.w = rstd * (v.w - mean * ws.w);
       }
-      if (p.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
-        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      }
-      if (p.residual) {
-        const float4 rr = *reinterpret_cast<const float4*>(p.residual + (int64_t)orow * p.ldr + col);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      {
+        const float4 bb = pre_b[g * TN + j], rr = pre_r[g * TN + j];
+        v.x += bb.x + rr.x; v.y += bb.y + rr.y; v.z += bb.z + rr.z; v.w += bb.w + rr.w;
       }
       if (p.act) {
         v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);

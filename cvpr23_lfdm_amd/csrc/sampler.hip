@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
                                                              float* __restrict__ x0_out, int64_t n,
                                                              const float* __restrict__ coef,
                                                              const int32_t* __restrict__ step_dev,
-                                                             Ranks rk, const unsigned* __restrict__ hists) {
+                                                             Ranks rk, unsigned* __restrict__ hists, int hist_samples,
+                                                             unsigned* __restrict__ ticket, int32_t* __restrict__ advance_dev) {
   __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
   float s = 1.0f;                       // rk.frac < 0: static clipping, x0.clamp(-1, 1) (use_dynamic_thres=False, :729-732)
@@ -230,6 +231,22 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
     if (k_x != 0.f) v += k_x * xb[i];
     if (k_noise != 0.f && nb) v += k_noise * nb[i];
     xb[i] = v;
+  }
+  // End-of-step housekeeping by the workgroup that finishes last (every workgroup has read the histograms and the step counter before
+  // it takes its ticket): clear the histograms for the next step and advance the step counter - two launches (zero_u32, advance_step)
+  // of every replayed step otherwise.  The ticket word is left at zero again.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    const bool last = lfdm_ticket_take(ticket) == total - 1;
+    if (last) lfdm_ticket_reset(ticket);
+    s_res[0] = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_res[0]) {
+    const int64_t nz = (int64_t)hist_samples * HIST_PER_SAMPLE;
+    for (int64_t i = threadIdx.x; i < nz; i += 256) hists[i] = 0u;
+    if (advance_dev && threadIdx.x == 0) *advance_dev += 1;
   }
 }
 
@@ -297,7 +314,21 @@ extern "C" int lfdm_cfg_combine_f32(const float* cond_eps, const float* null_eps
 }
 
 extern "C" size_t lfdm_sampler_ws_bytes(int batch, int64_t n) {
-  return (size_t)batch * HIST_PER_SAMPLE * sizeof(unsigned) + (size_t)batch * (size_t)n * sizeof(float);
+  return (size_t)batch * HIST_PER_SAMPLE * sizeof(unsigned) + (size_t)batch * (size_t)n * sizeof(float) + 64;     // + the ticket word
+}
+
+extern "C" int lfdm_sampler_ws_init(void* ws, size_t ws_bytes, int batch, int64_t n, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ws || batch <= 0 || n <= 0 || ws_bytes < lfdm_sampler_ws_bytes(batch, n)) {
+    lfdm_set_error("sampler_ws_init: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  unsigned* hists = reinterpret_cast<unsigned*>(ws);
+  const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
+  LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream, hists, nz);
+  unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(hists + (size_t)batch * HIST_PER_SAMPLE) + (size_t)batch * n);
+  LFDM_LAUNCH(zero_u32_kernel, dim3(1), dim3(256), 0, stream, ticket, (int64_t)16);
+  return lfdm_check_launch("sampler_ws_init");
 }
 
 extern "C" int lfdm_abs_quantile_f32(const float* x, int batch, int64_t n, float quantile,
@@ -323,6 +354,10 @@ extern "C" int lfdm_abs_quantile_f32(const float* x, int batch, int64_t n, float
               (const int32_t*)nullptr, hists);
   run_select(x, batch, n, rk, hists, stream);
   LFDM_LAUNCH(quantile_out_kernel, dim3(batch), dim3(256), 0, stream, rk, (const unsigned*)hists, q_out);
+  {   // leave the histograms cleared: lfdm_sampler_step_f32 relies on that when it is handed the same workspace
+    const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
+    LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream, hists, nz);
+  }
   return lfdm_check_launch("abs_quantile");
 }
 
@@ -348,17 +383,19 @@ extern "C" int lfdm_sampler_step_f32(float* x, const float* eps, const float* no
   }
   Ranks rk = make_ranks(n, dynamic ? quantile : 0.f);
   if (!dynamic) rk.frac = -1.f;
-  {
+  // the histograms are clear on entry: lfdm_sampler_ws_init, then the last workgroup of every update kernel - for one or two samples
+  // (a single workgroup clearing more would lengthen the kernel's tail: larger batches keep the clearing launch)
+  const bool fold_clear = batch <= 2;
+  if (!fold_clear) {
     const int64_t nz = (int64_t)batch * HIST_PER_SAMPLE;
-    LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream,
-                hists, nz);
+    LFDM_LAUNCH(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256 > 64 ? 64 : (nz + 255) / 256)), dim3(256), 0, stream, hists, nz);
   }
+  unsigned* ticket = reinterpret_cast<unsigned*>(x0buf + (size_t)batch * n);
   const dim3 grid(blocks_for(n), batch), block(256);
   LFDM_LAUNCH(quantile_pass0_kernel, grid, block, 0, stream, (const float*)x, eps, x0buf, n, coef,
               (const int32_t*)step_dev, hists);         // (also the x0 = c_x*x - c_eps*eps pass)
   if (dynamic) run_select(x0buf, batch, n, rk, hists, stream);
   LFDM_LAUNCH(sampler_update_kernel, grid, block, 0, stream, x, eps, noise, x0buf, x0_out, n, coef,
-              (const int32_t*)step_dev, rk, (const unsigned*)hists);
-  if (advance) LFDM_LAUNCH(advance_step_kernel, dim3(1), dim3(64), 0, stream, step_dev);
+              (const int32_t*)step_dev, rk, hists, fold_clear ? batch : 0, ticket, advance ? step_dev : (int32_t*)nullptr);
   return lfdm_check_launch("sampler_step");
 }

@@ -2,6 +2,7 @@
 // timestep embedding (timestep read from device memory for graph replay), the planar-input
 // small-C_in direct convolution (UNet init conv's step-dependent 3 channels, LFAE first conv) and
 // the two 1x1x1 output heads writing the planar (B,3,T,H,W) prediction.
+#include <stdlib.h>
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -265,6 +266,114 @@ extern "C" int lfdm_sinusoidal_f32(const int32_t* t_dev, int t_stride, const flo
   return lfdm_check_launch("sinusoidal");
 }
 
+// The same convolution on the matrix pipe: M = pixels, N = 64 output channels, K = kh*kw*cin (147 for the UNet's 7x7 stem over the
+// three step-dependent channels) on v_mfma_f32_32x32x2_f32.  One workgroup = a 4-row x 32-column patch of one frame; its input
+// window ((4 + kh - 1) x (32 + kw - 1) per channel, zeros outside the image) and the 64-column filter slice sit in LDS; wavefront
+// r owns output row r of the patch: lane (pixel l&31, k-slot l>>5) reads its A element lds[c][r + ky][pixel + kx] - consecutive
+// lanes, consecutive addresses - and the two B elements w[k][32*nt + l&31].  The k index walks (ky, kx, c) in the weight's own
+// order; the D layout has lane = channel, so a register of the accumulator is one pixel's 128-byte row segment: stores need no
+// transposition.  (The VALU form above: 42 us for the sampler's stem; it spends 64 FMAs per loaded input value on one lane.)
+constexpr int CPM_ROWS = 4, CPM_COLS = 32;
+__global__ __launch_bounds__(256) void conv_planar_in_mfma_kernel(
+    const float* __restrict__ x, int batch, int cin, int cin_total, int frames, int h, int w,
+    const float* __restrict__ wgt, int kh, int kw, int cout, const float* __restrict__ bias,
+    const float* __restrict__ add_term, float* __restrict__ out, int ldo, int act, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float ws[(CPI_MAX_K + 1) * 64];
+  __shared__ float win[8 * (CPM_ROWS + 6) * (CPM_COLS + 6)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int K = kh * kw * cin;
+  const int Kp = (K + 1) & ~1;
+  const int co0 = blockIdx.y * 64;
+  const int tile = blockIdx.x % (tiles_x * tiles_y);
+  const int bt = blockIdx.x / (tiles_x * tiles_y);
+  const int b = bt / frames, t = bt - b * frames;
+  const int oy0 = (tile / tiles_x) * CPM_ROWS, ox0 = (tile % tiles_x) * CPM_COLS;
+  const int py = kh / 2, px = kw / 2;
+  const int wr = CPM_ROWS + kh - 1, wc = CPM_COLS + kw - 1;
+  // filter slice [Kp][64] (row K of an odd K: zeros) and input window (zero outside the image): every load of the workgroup is
+  // requested before the first one is written to LDS (the first version waited for each of its ~15 round trips in turn)
+  constexpr int WMAX = ((CPI_MAX_K + 1) * 16 + 255) / 256;                       // float4 items per thread
+  constexpr int XMAX = (8 * (CPM_ROWS + 6) * (CPM_COLS + 6) + 255) / 256;
+  float4 wv[WMAX];
+  float xv[XMAX];
+#pragma unroll
+  for (int j = 0; j < WMAX; ++j) {
+    const int i = tid + 256 * j, kk = i >> 4, j4 = i & 15;
+    wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kk < K) wv[j] = *reinterpret_cast<const float4*>(wgt + (int64_t)kk * cout + co0 + 4 * j4);
+  }
+  const int hw = h * w;
+  const int nwin = cin * wr * wc;
+#pragma unroll
+  for (int j = 0; j < XMAX; ++j) {
+    const int i = tid + 256 * j;
+    const int c = i / (wr * wc), rem = i - c * (wr * wc);
+    const int ry = rem / wc, rx = rem - ry * wc;
+    const int iy = oy0 + ry - py, ix = ox0 + rx - px;
+    xv[j] = 0.f;
+    if (i < nwin && iy >= 0 && iy < h && ix >= 0 && ix < w) xv[j] = x[(((int64_t)b * cin_total + c) * frames + t) * hw + iy * w + ix];
+  }
+#pragma unroll
+  for (int j = 0; j < WMAX; ++j) {
+    const int i = tid + 256 * j;
+    if (i < Kp * 16) *reinterpret_cast<float4*>(ws + (i >> 4) * 64 + 4 * (i & 15)) = wv[j];
+  }
+#pragma unroll
+  for (int j = 0; j < XMAX; ++j) {
+    const int i = tid + 256 * j;
+    if (i < nwin) win[i] = xv[j];
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  // The contraction order is free: k-slot 0 (lanes 0-31) walks k = 0 .. Kp/2-1, k-slot 1 the upper half - each lane half then steps
+  // through (ky, kx, c) in the weight's own order by +1 with two selects (the first version interleaved the slots, k = 2*step + slot,
+  // and spent ~700 cycles per step in divergent carry loops: 32 us for this kernel, no faster than the VALU form)
+  const int half_k = Kp >> 1;
+  int k = khalf * half_k;
+  int ky = k / (kw * cin), kx = (k - ky * kw * cin) / cin, c = k - (ky * kw + kx) * cin;
+  for (int st = 0; st < half_k; ++st, ++k) {
+    const int kyc = ky < kh ? ky : kh - 1;                     // (index K of an odd K: any valid address, its filter row is zero)
+    const float a = win[(c * wr + wave + kyc) * wc + l31 + kx];
+    const float b0 = ws[k * 64 + l31], b1 = ws[k * 64 + 32 + l31];
+    acc[0] = mfma_32x32x2(a, b0, acc[0]);
+    acc[1] = mfma_32x32x2(a, b1, acc[1]);
+    const bool cw_ = c + 1 == cin;
+    c = cw_ ? 0 : c + 1;
+    const bool kw_ = cw_ && kx + 1 == kw;
+    kx = kw_ ? 0 : (cw_ ? kx + 1 : kx);
+    ky = kw_ ? ky + 1 : ky;
+  }
+  const int oy = oy0 + wave;
+  if (oy >= h) return;
+  // the 32 add-term values of this lane are requested together (one load -> wait -> store round trip per value cost more than the
+  // whole contraction), then bias / activation / 128-byte row-segment stores
+  float addv[2][16];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const int oxc = ox < w ? ox : w - 1;
+      addv[nt][r] = add_term ? add_term[((int64_t)b * hw + oy * w + oxc) * cout + co0 + 32 * nt + l31] : 0.f;
+    }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int ch = co0 + 32 * nt + l31;
+    const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (ox >= w) continue;
+      const float v = acc[nt][r] + bv + addv[nt][r];
+      out[(((int64_t)b * frames + t) * hw + oy * w + ox) * ldo + ch] = apply_act(v, act);
+    }
+  }
+}
+
 extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, int cin_total,
                                           int frames, int h, int w, const float* wgt, int kh,
                                           int kw, int cout, const float* bias,
@@ -278,6 +387,14 @@ extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, in
     return LFDM_EINVAL;
   }
   const int64_t total = (int64_t)batch * frames * h * w;
+  static const bool mfma_off = [] { const char* e = getenv("LFDM_STEM_MFMA"); return e && e[0] == '0'; }();
+  const int tiles_x = (w + CPM_COLS - 1) / CPM_COLS, tiles_y = (h + CPM_ROWS - 1) / CPM_ROWS;
+  const int64_t nblk = (int64_t)batch * frames * tiles_x * tiles_y;
+  if (!mfma_off && cin <= 8 && kh <= 7 && kw <= 7 && (cout & 3) == 0 && ((((uintptr_t)wgt) & 15) == 0) && nblk < (1ll << 31)) {
+    LFDM_LAUNCH(conv_planar_in_mfma_kernel, dim3((unsigned)nblk, cout / 64), dim3(256), 0, stream, x, batch, cin, cin_total, frames, h,
+                w, wgt, kh, kw, cout, bias, add_term, out, ldo, act, tiles_x, tiles_y);
+    return lfdm_check_launch("conv_planar_in_mfma");
+  }
   const dim3 grid((unsigned)((total + CPI_PIX - 1) / CPI_PIX), cout / 64);
   LFDM_LAUNCH(conv_planar_in_kernel, grid, dim3(256), 0, stream, x, batch, cin, cin_total, frames, h, w, wgt, kh, kw, cout, bias,
               add_term, out, ldo, act);

@@ -583,8 +583,12 @@ def heads_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, batch, frame
 
 
 def sampler_ws(batch, n, device):
+    """Workspace of sampler_step / abs_quantile, initialised (lfdm_sampler_ws_init: histograms + end-of-step ticket cleared)."""
     lib = _lib()
-    return torch.empty(lib.lfdm_sampler_ws_bytes(batch, n) // 4, dtype=torch.float32, device=device)
+    ws = torch.empty((lib.lfdm_sampler_ws_bytes(batch, n) + 3) // 4, dtype=torch.float32, device=device)
+    _chk(lib, ws)
+    lib.check(lib.lfdm_sampler_ws_init(_p(ws), ws.numel() * 4, batch, n, _stream(lib)), "lfdm_sampler_ws_init")
+    return ws
 
 
 def sampler_step(x, eps, noise, coef, step_dev, *, quantile=0.9, advance=True, x0_out=None, ws=None):

@@ -20,6 +20,8 @@ _LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"
 # (4x4: 19 vs 31 us linear, 19 vs 26 temporal; 8x8: 33 vs 35 / 23 vs 29) and lose at 16x16 (69 vs 64 / 63 vs 52: 2048 workgroups of one
 # head each re-read the frame's rows eight times and hold 78-110 KB of LDS)
 _LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
+_RES_STREAM = os.environ.get("LFDM_RES_STREAM", "0") == "1"
+_RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 
 
 def prob_mask_like(shape, prob, device):
@@ -311,8 +313,24 @@ class Unet3D(ParamTree):
             return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, groups=groups, **kw)
         return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, groups=groups, **kw)
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
         n_img, rows = batch * frames, batch * frames * s * s
+        # res_conv(x) does not depend on the block1 -> block2 chain.  LFDM_RES_STREAM=1: below the finest level, where a launch leaves
+        # most CUs idle, it runs on a second stream (a parallel branch of the captured graph) and the last GroupNorm kernel adds its
+        # result.  (Round 1 measured this slower with the projection as a staged kernel + split-K reduce pair; since round 3 it is one
+        # short pointwise launch - re-measured, see DESIGN.md.)
+        side, r = None, None
+        if _RES_STREAM and (prefix + "res.w") in pk and x.is_cuda and rows <= _RES_STREAM_MAX_ROWS:
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                r = self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"],
+                               out=self._buf("rb.res", rows, cout), scratch="splitk.side")
         h1 = self._buf("rb.h1", rows, cout)
         _, st = self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
                            bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,), ww=pk[prefix + "block1.proj.ww"])
@@ -325,6 +343,10 @@ class Unet3D(ParamTree):
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
                            out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st, residual=r)
+            return out
         self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st,
                  residual=None if has_res else x)
         if has_res:

@@ -241,6 +241,9 @@ int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int cha
  * ws: lfdm_sampler_ws_bytes(batch, n).  advance != 0 increments *step_dev at the end.
  */
 size_t lfdm_sampler_ws_bytes(int batch, int64_t n);
+/* once per workspace, before its first lfdm_sampler_step_f32: clears the histograms and the end-of-step ticket (every step leaves
+ * them cleared again: its last workgroup does the housekeeping, incl. the step-counter increment) */
+int lfdm_sampler_ws_init(void* ws, size_t ws_bytes, int batch, int64_t n, lfdm_stream_t stream);
 int lfdm_sampler_step_f32(float* x, const float* eps, const float* noise, float* x0_out,
                           int batch, int64_t n, const float* coef, int32_t* step_dev,
                           float quantile, int advance, void* ws, size_t ws_bytes,

@@ -188,3 +188,31 @@ def test_c5_shape_natops_variant(backend):
     m.sample_one_video(cond_scale=1.0)
     for k in ("sample_vid_grid", "sample_vid_conf", "sample_warped_vid", "sample_out_vid"):
         assert_close(getattr(m, k).cpu(), ref[k], 1e-3, "%s (C5 shape)" % k)
+
+
+@pytest.mark.gpu
+def test_multi_step_graphs_draw_the_same_noise(monkeypatch):
+    """Several sampler steps per graph launch with the noise draws captured inside (LFDM_GRAPH_STEPS): for the same seed the
+    videos equal the one-step-per-replay loop's bit for bit (torch's graph-safe philox state makes the captured normal_() calls draw what
+    the eager calls would), over two consecutive videos, incl. the chunk whose last step draws nothing and a ragged last chunk."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cvpr23_lfdm_amd import _native
+    _native._set_library_for_tests(None)
+    outs = {}
+    for k in ("1", "3", "4"):
+        monkeypatch.setenv("LFDM_GRAPH_STEPS", k)
+        m, _, _ = synth.build_flow_diffusion("cuda", img_size=8, num_frames=4, sampling_timesteps=7)
+        img, cond = synth.inputs(1, 32, seed=5)
+        m.set_sample_input(sample_img=img.cuda(), sample_text=cond.cuda())
+        torch.manual_seed(321)
+        vids = []
+        for _ in range(2):
+            m.sample_one_video(cond_scale=1.0)
+            vids.append(m.sample_out_vid.clone())
+        outs[k] = vids
+    for k in ("3", "4"):
+        for a, b in zip(outs["1"], outs[k]):
+            assert torch.equal(a, b), "LFDM_GRAPH_STEPS=%s draws different noise" % k
+    assert not torch.equal(outs["1"][0], outs["1"][1])

@@ -509,6 +509,17 @@ def test_conv_planar_in_and_heads(backend):
     out = ops.conv_planar_in_cl(x.to(dev), b, 3, 7, t, s, s, ops.pack_planar_in_weight(wt).to(dev), 7, 7, 64,
                                 bias=bias.to(dev), add_term=to_cl(add).to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "conv_planar_in")
+    # ragged patch grid (rows not a multiple of 4, more than 32 columns), 128 output channels, odd K (5*5*3 = 75), ReLU, no add term:
+    # the matrix-pipe form and the VALU form (LFDM_STEM_MFMA=0 is read once per process: the latter is covered by the emulator runs
+    # of earlier rounds' fixtures; here whichever the library selects)
+    n2, h2, w2 = 2, 6, 40
+    x2 = rnd(n2, 3, 1, h2, w2, seed=11)
+    wt2 = rnd(128, 3, 1, 5, 5, seed=12, scale=0.1)
+    b2 = rnd(128, seed=13)
+    ref2 = F.relu(F.conv3d(x2, wt2, b2, padding=(0, 2, 2)))
+    out2 = ops.conv_planar_in_cl(x2.to(dev), n2, 3, 3, 1, h2, w2, ops.pack_planar_in_weight(wt2).to(dev), 5, 5, 128, bias=b2.to(dev),
+                                 act=ops.ACT_RELU)
+    assert_close(out2.cpu().reshape(n2, h2, w2, 128).permute(0, 3, 1, 2).unsqueeze(2), ref2, TOL, "conv_planar_in ragged")
     # heads
     yf, yo = rnd(b, 64, t, s, s, seed=5), rnd(b, 64, t, s, s, seed=6)
     wf, bf, wo, bo = rnd(2, 64, seed=7, scale=0.2), rnd(2, seed=8), rnd(1, 64, seed=9, scale=0.2), rnd(1, seed=10)

@@ -8,6 +8,8 @@ import sys
 
 import torch
 
+os.environ.setdefault("LFDM_PW_MAXM", "1000000")      # read once by the library: the sweep includes the 40 960-row level
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvpr23_lfdm_amd import ops  # noqa: E402
 
