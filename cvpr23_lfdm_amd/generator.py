@@ -257,6 +257,11 @@ class Generator(ParamTree):
             skips = self.encode(img)
             d = 2 ** self.num_down_blocks
             fea = self.compute_fea_from_skips(skips, b, h // d, w // d).clone()
+            if not decode:
+                # the deferred decode must not read the executor's reusable arenas (skips are views of them): any other generator
+                # pass before real_out_vid / real_warped_vid is first read would silently change the video
+                skips = [t.clone() for t in skips]
+
             def run_decode():
                 with torch.no_grad():
                     return self.decode_video(img, skips, maps[:, 0], maps[:, 1], maps[:, 2], frames, fh, fw,

@@ -145,20 +145,6 @@ def antialias_down(x, weight, scale):
     return ops.depthwise_down_planar(x.float(), weight.detach().float(), int(1 / scale), ka, kb)
 
 
-def coordinate_grid(h, w, device):
-    """make_coordinate_grid (util.py:51-67): (h, w, 2) with (x, y) in [-1, 1]."""
-    x = 2 * (torch.arange(w, device=device).float() / (w - 1)) - 1
-    y = 2 * (torch.arange(h, device=device).float() / (h - 1)) - 1
-    return torch.stack((x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)), dim=2)
-
-
-def inv2x2(m):
-    """Closed-form inverse of (..., 2, 2) matrices (the reference calls torch.inverse: batched LU on a solver library)."""
-    a, b, c, d = m[..., 0, 0], m[..., 0, 1], m[..., 1, 0], m[..., 1, 1]
-    det = a * d - b * c
-    return torch.stack((torch.stack((d, -b), dim=-1), torch.stack((-c, a), dim=-1)), dim=-2) / det.unsqueeze(-1).unsqueeze(-1)
-
-
 def _sign1(x):
     """Fortran SIGN(1, x): +1 for x >= 0."""
     return torch.where(x < 0, -torch.ones_like(x), torch.ones_like(x))
@@ -241,27 +227,11 @@ def svd2x2_sym_lapack(a, b, c):
     return u, torch.stack((torch.where(sw, s2, s1), torch.where(sw, s1, s2)), dim=-1)
 
 
-def region2gaussian(center, covar, h, w):
-    """util.py:22-48 for a (N, K, 2) centre and a (N, K, 2, 2) covariance (or a float)."""
-    grid = coordinate_grid(h, w, center.device).view(1, 1, h, w, 2)
-    d = grid - center.view(*center.shape[:2], 1, 1, 2)
-    if isinstance(covar, float):
-        return torch.exp(-0.5 * (d ** 2).sum(-1) / covar)
-    # d^T C^-1 d written out for 2x2 (the reference's two broadcast matmuls became N*K*h*w tiny GEMMs: 50 ms each)
-    inv = inv2x2(covar)
-    i00, i01 = inv[..., 0, 0].unsqueeze(-1).unsqueeze(-1), inv[..., 0, 1].unsqueeze(-1).unsqueeze(-1)
-    i10, i11 = inv[..., 1, 0].unsqueeze(-1).unsqueeze(-1), inv[..., 1, 1].unsqueeze(-1).unsqueeze(-1)
-    dx, dy = d[..., 0], d[..., 1]
-    under = (dx * i00 + dy * i10) * dx + (dx * i01 + dy * i11) * dy
-    return torch.exp(-0.5 * under)
-
-
 class RegionPredictorExec:
     def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3):
         self.tree, self.temperature, self.scale_factor, self.pca_based, self.pad = tree, temperature, scale_factor, pca_based, pad
         self.hg = HourglassExec(tree, "predictor.", num_blocks, in_pad_to=32)      # 3-channel image in a 32-wide buffer (the
         #                                                     head's fast schedules want both concatenated sources in 32s)
-        self.host_svd = False
 
     @torch.no_grad()
     def __call__(self, x):
@@ -272,35 +242,15 @@ class RegionPredictorExec:
         out, skip = self.hg.forward(_image_rows(x, pad_to=32, full=True), n, h, w)
         k_regions = self.tree.get("regions.weight").shape[0]
         ho, wo = h + 2 * self.pad - 6, w + 2 * self.pad - 6                    # 7x7 head
-        if self.pca_based and not self.host_svd and ho * wo <= 4096:
-            # one launch: spatial softmax, centre, covariance, U sqrt(S) (the element-wise formulation below = ~250 tiny launches)
-            rows = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad, planar=False)
-            return ops.lfae_region_stats(rows, n, k_regions, ho, wo, self.temperature)
-        pred = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad)
-        shp = pred.shape
-        region = F.softmax(pred.view(n, shp[1], -1) / self.temperature, dim=2).view(*shp)
-        grid = coordinate_grid(shp[2], shp[3], x.device).view(1, 1, shp[2], shp[3], 2)
-        r = region.unsqueeze(-1)
-        mean = (r * grid).sum(dim=(2, 3))
-        params = {"shift": mean, "heatmap": region}
         if not self.pca_based:
             raise NotImplementedError("regression-based affine (estimate_affine and not pca_based): no LFDM config uses it")
-        ms = grid - mean.unsqueeze(-2).unsqueeze(-2)                       # (N, K, h, w, 2)
-        mx, my = ms[..., 0], ms[..., 1]
-        cxx, cxy, cyy = (mx * mx * region).sum(dim=(2, 3)), (mx * my * region).sum(dim=(2, 3)), (my * my * region).sum(dim=(2, 3))
-        covar = torch.stack((torch.stack((cxx, cxy), dim=-1), torch.stack((cxy, cyy), dim=-1)), dim=-2)
-        params["covar"] = covar
-        # the reference: torch.svd(covar.cpu()) per frame (region_predictor.py:16-25); here LAPACK's 2x2 path in closed form
-        # on the device for all frames at once (host_svd=True keeps the LAPACK call for A/B checks)
-        if self.host_svd:
-            u, s, _ = torch.svd(covar.reshape(-1, 2, 2).cpu())
-            u, s = u.to(covar.device), s.to(covar.device)
-        else:
-            u, s = svd2x2_sym_lapack(cxx.reshape(-1), cxy.reshape(-1), cyy.reshape(-1))
-        d = torch.diag_embed(s ** 0.5)
-        params["affine"] = (u * (s ** 0.5).unsqueeze(-2)).view(*covar.shape)          # U @ diag(sqrt(S))
-        params["u"], params["d"] = u, d
-        return params
+        if n > 65535 or ho * wo > 4096:
+            raise ValueError("RegionPredictor: %d frames with %dx%d heat-maps per call (the fused launch takes at most 65535 frames "
+                             "of at most 4096 pixels; split the batch)" % (n, ho, wo))
+        # one launch: spatial softmax, centre, covariance, U sqrt(S) with LAPACK's sign convention (region_predictor.py:16-25 does
+        # torch.svd(covar.cpu()) per frame; svd2x2_sym_lapack above is the same closed form in tensor ops, kept for tests/test_svd2x2.py)
+        rows = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad, planar=False)
+        return ops.lfae_region_stats(rows, n, k_regions, ho, wo, self.temperature)
 
 
 class BGMotionPredictorExec:
@@ -348,6 +298,9 @@ class PixelwiseFlowPredictorExec:
             t = 1 if frames is None else frames
             b, c, h, w = source_image.shape
             n = b * t
+            if n > 65535 or h * w > 4096:
+                raise ValueError("PixelwiseFlowPredictor: %d frames of %dx%d per call (the library launches take at most 65535 frames of "
+                                 "at most 4096 pixels; split the batch)" % (n, h, w))
             rows, sparse = ops.lfae_motion_inputs(source_image, driving, source, bg_params, t, region_var=self.region_var,
                                                   revert_axis_swap=self.revert_axis_swap, use_covar=self.use_covar_heatmap)
             out, skip = self.hg.forward(rows, n, h, w)
@@ -359,48 +312,8 @@ class PixelwiseFlowPredictorExec:
             if has_occ:
                 res["occlusion_map"] = occ
             return res
-        if frames is not None and frames != 1:                   # the general formulation below works per driving frame
-            rep = lambda v: v.unsqueeze(1).expand(v.shape[0], frames, *v.shape[1:]).reshape(v.shape[0] * frames, *v.shape[1:])
-            source_image = rep(source_image)
-            source = {kk: rep(v) for kk, v in source.items()}
-        n, c, h, w = source_image.shape
-        dev = source_image.device
-        # heat-map representation (:48-65)
-        cov_d = driving["covar"] if self.use_covar_heatmap else self.region_var
-        cov_s = source["covar"] if self.use_covar_heatmap else self.region_var
-        heat = region2gaussian(driving["shift"], cov_d, h, w) - region2gaussian(source["shift"], cov_s, h, w)
-        heat = torch.cat((torch.zeros(n, 1, h, w, device=dev), heat), dim=1).unsqueeze(2)          # (N, K+1, 1, h, w)
-        # sparse motions (:67-93)
-        ident = coordinate_grid(h, w, dev).view(1, 1, h, w, 2)
-        cg = ident - driving["shift"].view(n, k, 1, 1, 2)
-        if "affine" in driving:
-            aff = torch.matmul(source["affine"], inv2x2(driving["affine"]))                       # (N, K, 2, 2)
-            if self.revert_axis_swap:
-                aff = aff * torch.sign(aff[:, :, 0:1, 0:1])
-            a = aff.view(n, k, 1, 1, 2, 2)
-            cx, cy = cg[..., 0], cg[..., 1]                                                        # per-pixel 2x2 @ 2x1, written out
-            cg = torch.stack((a[..., 0, 0] * cx + a[..., 0, 1] * cy, a[..., 1, 0] * cx + a[..., 1, 1] * cy), dim=-1)
-        d2s = cg + source["shift"].view(n, k, 1, 1, 2)
-        bg = ident.repeat(n, 1, 1, 1, 1)
-        if bg_params is not None:
-            m3 = bg_params.view(n, 1, 1, 1, 3, 3)
-            gx, gy = bg[..., 0], bg[..., 1]
-            hx = m3[..., 0, 0] * gx + m3[..., 0, 1] * gy + m3[..., 0, 2]
-            hy = m3[..., 1, 0] * gx + m3[..., 1, 1] * gy + m3[..., 1, 2]
-            hz = m3[..., 2, 0] * gx + m3[..., 2, 1] * gy + m3[..., 2, 2]
-            bg = torch.stack((hx / hz, hy / hz), dim=-1)
-        sparse = torch.cat((bg, d2s), dim=1)                                                       # (N, K+1, h, w, 2)
-        # deformed source (:95-102)
-        rep = source_image.unsqueeze(1).expand(n, k + 1, c, h, w).reshape(n * (k + 1), c, h, w)
-        deformed = F.grid_sample(rep, sparse.reshape(n * (k + 1), h, w, 2), align_corners=False).view(n, k + 1, c, h, w)
-        inp = torch.cat((heat, deformed), dim=2) if self.use_deformed_source else heat
-        inp = inp.reshape(n, -1, h, w)
-        out, skip = self.hg.forward(_image_rows(inp, pad_to=32, full=True), n, h, w)
-        has_occ = self.tree.has(p + "occlusion.weight")
-        heads = _head_conv(self.tree, (p + "mask.", p + "occlusion.") if has_occ else (p + "mask.",), out, skip, n, h, w, 3)
-        mask = F.softmax(heads[:, :k + 1], dim=1)                                                    # (N, K+1, h, w)
-        deformation = (sparse.permute(0, 1, 4, 2, 3) * mask.unsqueeze(2)).sum(dim=1).permute(0, 2, 3, 1)
-        res = {"optical_flow": deformation.contiguous()}
-        if has_occ:
-            res["occlusion_map"] = torch.sigmoid(heads[:, k + 1:]).contiguous()
-        return res
+        # (a pure-ATen formulation of this head / tail - F.grid_sample and element-wise tensors over (N, K+1, h, w[, 2]) - used to stand
+        #  here for other configurations: a silent non-native route on the product path.  No LFDM configuration reaches it.)
+        raise NotImplementedError("PixelwiseFlowPredictor: only the LFDM configurations are built (RGB source, use_deformed_source=True, "
+                                  "num_regions <= 32); got %d channels, use_deformed_source=%s, %d regions"
+                                  % (source_image.shape[1], self.use_deformed_source, k))

@@ -44,6 +44,11 @@ class FlatAdam(torch.optim.Optimizer):
                 gviews.append(fg[o:o + k].view(p.shape))
                 st = self.state[p]
                 if "exp_avg" in st:                    # state loaded before the first step
+                    if st["exp_avg"].numel() != k or st["exp_avg_sq"].numel() != k:
+                        raise ValueError("FlatAdam.load_state_dict: the moment of parameter #%d has %d elements, the parameter %s has %d - "
+                                         "the state was saved for a different parameter ORDER (torch indexes optimizer state by "
+                                         "position: it must come from a model with the same registration order)"
+                                         % (len(offs) and list(ps).index(p), st["exp_avg"].numel(), tuple(p.shape), k))
                     fm[o:o + k].copy_(st["exp_avg"].reshape(-1))
                     fv[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
                 st.setdefault("step", torch.tensor(0.0))

@@ -90,7 +90,10 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
     hidden = heads * dim_head
     time_dim = dim * 4
     emb_dim = time_dim + cond_dim
-    spec = [("time_rel_pos_bias.relative_attention_bias.weight", (32, heads), ("normal",), False)]
+    spec = []
+    if learn_null_cond:      # a root-level nn.Parameter: named_parameters() yields it before every sub-module's (reference :438-440)
+        spec.append(("null_cond_emb", (1, cond_dim), ("normal",), False))
+    spec += [("time_rel_pos_bias.relative_attention_bias.weight", (32, heads), ("normal",), False)]
     spec += _conv_entries("init_conv.", dim, channels, 1, init_kernel_size, init_kernel_size)
 
     def temporal(prefix, c):
@@ -123,8 +126,6 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
     spec += temporal("init_temporal_attn.", dim)
     spec += _conv_entries("time_mlp.1.", time_dim, dim)
     spec += _conv_entries("time_mlp.3.", time_dim, time_dim)
-    if learn_null_cond:
-        spec.append(("null_cond_emb", (1, cond_dim), ("normal",), False))
 
     dims = [dim] + [dim * m for m in dim_mults]
     in_out = list(zip(dims[:-1], dims[1:]))

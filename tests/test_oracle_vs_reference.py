@@ -29,14 +29,17 @@ def test_unet_and_sampler_match_live_reference():
     assert mod.__file__.startswith(reference_loader.REFERENCE_ROOT)
 
 
-def test_optimizer_state_of_the_reference_loads_into_flat_adam():
+@pytest.mark.parametrize("learn_null_cond", [False, True])
+def test_optimizer_state_of_the_reference_loads_into_flat_adam(learn_null_cond):
     """torch.optim state dicts index parameters by POSITION: with the reference's registration order mirrored
     (params.unet_spec) an `optimizer_diff` saved by the reference's training script restores into FlatAdam with every
     moment on the right parameter (train_video_flow_diffusion_mug.py:181 `model.optimizer_diff.load_state_dict`)."""
     import synth
     from cvpr23_lfdm_amd import FlowDiffusion
     ref = reference_loader.load_reference()
-    kw = dict(img_size=8, num_frames=2, sampling_timesteps=5, is_train=True, config_pth=synth.CONFIG, pretrained_pth="")
+    # (learn_null_cond: the root-level null_cond_emb parameter comes FIRST in the reference's named_parameters())
+    kw = dict(img_size=8, num_frames=2, sampling_timesteps=5, is_train=True, config_pth=synth.CONFIG, pretrained_pth="",
+              learn_null_cond=learn_null_cond)
     rm, om = ref.vfdm.FlowDiffusion(**kw), FlowDiffusion(**kw)
     rnames = [k for k, _ in rm.diffusion.named_parameters()]
     assert rnames == [k for k, _ in om.diffusion.named_parameters()]
@@ -50,3 +53,12 @@ def test_optimizer_state_of_the_reference_loads_into_flat_adam():
     for i, p in enumerate(om.diffusion.parameters()):
         st = om.optimizer_diff.state[p]
         assert st["exp_avg"].shape == p.shape and float(st["exp_avg"].flatten()[0]) == float(i + 1) and float(st["step"]) == 3.0
+    # the moments are folded into the flat buffers at the first use: every one must have its parameter's size
+    om.optimizer_diff.ensure_flat()
+    # ... and a state saved for another parameter order is refused with a clear message instead of being mis-assigned
+    bad = rm.optimizer_diff.state_dict()
+    bad["state"][0], bad["state"][1] = bad["state"][1], bad["state"][0]
+    om2 = FlowDiffusion(**kw)
+    om2.optimizer_diff.load_state_dict(bad)
+    with pytest.raises(ValueError, match="parameter ORDER"):
+        om2.optimizer_diff.ensure_flat()
