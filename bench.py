@@ -193,6 +193,25 @@ def in_situ_family_us(model, is_member, ms_per_video_full, videos=3):
     return (ms_per_video_full - ms_without) * 1e3 / WORKLOAD["sampling_timesteps"], ms_without
 
 
+def evidence_files():
+    """The committed rocprofv3 evidence of the current build: profiles/LATEST holds the tag of the last tools/gpu_final.sh run
+    (<tag>_kernel_stats.txt, <tag>_step_sequence.txt) and, on its second line, the counter file of tools/prof_step_pmc.sh."""
+    out = {"kernel_stats": None, "step_sequence": None, "pmc": None}
+    latest = os.path.join(REPO_ROOT, "profiles", "LATEST")
+    if not os.path.exists(latest):
+        return out
+    lines = open(latest).read().split()
+    tag = lines[0] if lines else None
+    for key, name in (("kernel_stats", "%s_kernel_stats.txt" % tag), ("step_sequence", "%s_step_sequence.txt" % tag)):
+        if tag and os.path.exists(os.path.join(REPO_ROOT, "profiles", name)):
+            out[key] = "profiles/" + name
+    for name in lines[1:2] + ["r02_traffic.json"]:
+        if os.path.exists(os.path.join(REPO_ROOT, "profiles", name)):
+            out["pmc"] = "profiles/" + name
+            break
+    return out
+
+
 def conv_roofline(model, ms_per_sampler_step):
     """Roofline of the dominant kernel, measured live: the Winograd convolution launches (conv_wino_kernel) of one sampler
     step are re-captured as their own hipGraph - same parameter structs, same arenas, 40 different filter sets so the
@@ -231,40 +250,62 @@ def conv_roofline(model, ms_per_sampler_step):
     rows["winograd_in_situ"] = {"us_per_step": w["us_per_step"], "us_per_launch": w["us_per_launch"], "tflops": w["tflops"], "frac": w["frac"],
                                 "ms_per_video_with": round(ms_video_now, 2), "ms_per_video_without": round(ms_without, 2)}
     executed = w["gflop_per_step"] * 16.0 / 36.0
-    traffic, traffic_src = None, None
-    tf = os.path.join(REPO_ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tf):          # PMC counters cannot be read from inside the process: committed rocprofv3 passes of this build
-        with open(tf) as f:
+    prof = evidence_files()
+    # PMC counters cannot be read from inside the process: the committed rocprofv3 --pmc passes of this build (tools/prof_step_pmc.sh)
+    traffic, traffic_src, step_traffic, direct_traffic = None, None, None, None
+    if prof["pmc"]:
+        with open(os.path.join(REPO_ROOT, prof["pmc"])) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj.get("wino_bytes_per_step"), tj.get("source")
-    # cross-check: the rocprofv3 kernel table committed for this build (tools/gpu_final.sh -> profiles/), same command line
+        traffic, traffic_src = tj.get("wino_bytes_per_step"), prof["pmc"] + ": " + tj.get("source", "")
+        direct_traffic = tj.get("direct_bytes_per_step")
+        if tj.get("step_bytes"):
+            step_traffic = {"bytes": tj["step_bytes"], "fetch_bytes": tj.get("step_fetch_bytes"), "write_bytes": tj.get("step_write_bytes"),
+                            "launches": tj.get("launches_per_step"), "mfma_util": tj.get("step_mfma_util"),
+                            "unit": "HBM-side bytes of ALL launches of one sampler step (FETCH_SIZE x2 + WRITE_SIZE); mfma_util = "
+                                    "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)", "file": prof["pmc"]}
+    # cross-check against the rocprofv3 kernel table + dispatch sequence committed for this build (tools/gpu_final.sh -> profiles/<LATEST>_*)
+    n_split = sum(1 for p in fam["winograd"] if ops.conv_plan(p)[1] > 1)
     rocprof = None
-    latest = os.path.join(REPO_ROOT, "profiles", "LATEST")            # tag of the evidence run of the current build (tools/gpu_final.sh)
-    tag = open(latest).read().strip() if os.path.exists(latest) else None
-    for name in ([tag + "_kernel_stats.txt"] if tag else []):
-        if os.path.exists(os.path.join(REPO_ROOT, "profiles", name)):
-            for ln in open(os.path.join(REPO_ROOT, "profiles", name)):
-                if ln.startswith("conv_wino_kernel<false"):
-                    f = ln.split()
-                    avg = float(f[-4])
-                    rocprof = {"file": "profiles/" + name, "avg_us_per_launch": avg,
-                               "tflops_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3, 2),
-                               "frac_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}
-                    break
-            if rocprof:
+    if prof["kernel_stats"]:
+        for ln in open(os.path.join(REPO_ROOT, prof["kernel_stats"])):
+            if ln.startswith("conv_wino_kernel<false"):
+                avg = float(ln.split()[-4])
+                rocprof = {"file": prof["kernel_stats"], "avg_us_per_launch": avg,
+                           "tflops_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3, 2),
+                           "frac_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "what": "KERNEL ONLY: the conv_wino_kernel rows of the table, without the split-K reduce launches"}
                 break
+    if rocprof and prof["step_sequence"]:
+        red_us, red_n, prev = 0.0, 0, ""
+        for ln in open(os.path.join(REPO_ROOT, prof["step_sequence"])):
+            f = ln.split()
+            if len(f) < 5 or not f[0].isdigit():
+                continue
+            if f[1].startswith("conv_splitk_reduce_kernel") and prev.startswith("conv_wino_kernel"):
+                red_us, red_n = red_us + float(f[-2]), red_n + 1
+            prev = f[1]
+        with_red = avg * w["launches"] + red_us
+        rocprof.update(split_k_reduce_launches=red_n, split_k_reduce_us_per_step=round(red_us, 1), sequence_file=prof["step_sequence"],
+                       frac_with_reduce_passes=round(w["gflop_per_step"] / with_red * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4))
     try:
         sat = wino_saturated(next(model.unet.parameters()).device)
     except Exception as e:                       # an extra, never a reason to lose the bench line
         sat = {"error": repr(e)}
     all_flops = sum(rows[k]["gflop_per_step"] for k in ("winograd", "direct") if k in rows)
     all_us = sum(rows[k]["us_per_step"] for k in ("winograd", "direct") if k in rows)
+    if direct_traffic and "direct" in rows:
+        rows["direct"]["traffic"] = direct_traffic
+        rows["direct"]["traffic_over_algorithmic"] = round(direct_traffic / max(1, rows["direct"]["algorithmic_bytes_per_step"]), 2)
     return {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) - the %d launches of one "
-                                       "sampler step, incl. their split-K reduce passes" % w["launches"],
+                                       "sampler step TOGETHER WITH the %d conv_splitk_reduce_kernel passes that finish the split-K ones" % (w["launches"], n_split),
             "achieved": w["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": w["frac"],
-            "traffic": traffic, "traffic_unit": "HBM-side bytes per sampler step over the same launches (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not live)",
+            "frac_definition": "direct-form FLOPs of the family / in-situ time of (kernel + its split-K reduce passes) / peak; `rocprofv3` carries the "
+                               "kernel-only figure from the committed kernel table and the reduce passes that make up the difference",
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per sampler step over the same launches incl. their reduce passes (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes, not live)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_step": w["algorithmic_bytes_per_step"],
-            "launches": w["launches"], "us_per_launch": w["us_per_launch"], "gflop_per_step": w["gflop_per_step"],
+            "traffic_over_algorithmic": round(traffic / max(1, w["algorithmic_bytes_per_step"]), 2) if traffic else None,
+            "step_traffic": step_traffic,
+            "launches": w["launches"], "split_k_launches": n_split, "us_per_launch": w["us_per_launch"], "gflop_per_step": w["gflop_per_step"],
             "executed_mfma_tflops": round(executed / (w["us_per_step"] * 1e-6) / 1e3, 2),
             "executed_mfma_frac": round(executed / (w["us_per_step"] * 1e-6) / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
             "families": rows,
@@ -275,9 +316,11 @@ def conv_roofline(model, ms_per_sampler_step):
             "rocprofv3": rocprof,
             "kernel_at_saturating_size": sat,
             "note": "achieved / frac count the reference's direct-form FLOPs (SURVEY.md 8d); the Winograd launches execute 16/36 of theirs "
-                    "on the matrix pipe (executed_*).  us_per_launch = in situ: (video time of the captured step) - (video time of the "
-                    "same step captured without these launches), / 100 steps / launches - agrees with the rocprofv3 kernel table "
-                    "(profiles/); `isolated_replay` = the same launches replayed alone as a hipGraph (inputs cold: slower)"}
+                    "on the matrix pipe (executed_*; kernel_at_saturating_size.frac can exceed 1 for that reason - read its executed_mfma_frac).  "
+                    "us_per_launch = in situ: (video time of the captured step) - (video time of the same step captured without these launches "
+                    "and their reduce passes), / 100 steps / launches; the rocprofv3 kernel table's average is the kernel alone and is lower by the "
+                    "reduce passes (rocprofv3.split_k_reduce_us_per_step); `isolated_replay` = the same launches replayed alone as a hipGraph "
+                    "(inputs cold: slower)"}
 
 
 def wino_saturated(dev):
@@ -358,16 +401,16 @@ def warp_bench(model, img, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     gbs = nbytes / sec / 1e9
-    traffic = None
-    tf = os.path.join(REPO_ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tf):
-        with open(tf) as f:
+    traffic, pmc = None, evidence_files()["pmc"]
+    if pmc:
+        with open(os.path.join(REPO_ROOT, pmc)) as f:
             traffic = json.load(f).get("warp_bytes_per_video")
     return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 5 launches = all warps of one 40-frame decode)",
             "us_per_video": round(sec * 1e6, 1), "elements": elems,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(gbs / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": nbytes,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/warp_only.py (tools/prof_traffic.sh), not live"}}
+                         "frac_of_counter_bytes": round(traffic / sec / 1e9 / 8000.0, 4) if traffic else None,
+                         "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over the decode's warp launches, not live" % pmc}}
 
 
 def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
@@ -486,7 +529,9 @@ def cpu_baseline():
     per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t * t_dec
     return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": best, "kind": "port", "host_cpus": ncpu,
             "thread_sweep_s_per_8_frame_unet_forward": {str(k): round(v, 3) for k, v in sweep.items()},
-            "sample": "oracle/lfdm_oracle.py on host CPU, %d threads (best of the sweep): %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each "
+            "reference_figure": "SURVEY.md 6: the reference itself (its own code, torch CPU) takes 1.56 s per UNet forward of this shape on the 8 cores of "
+                                "the build container (0.0053-0.0061 videos/s); /root/reference does not travel to the GPU box, so what is timed here is the PORT (kind = 'port')",
+            "sample": "the PORT oracle/lfdm_oracle.py (a restatement of the reference, not the reference) on host CPU, %d threads (best of the sweep): %d UNet fwd @ (%d,259,%d,%d,%d) = %.2f s each "
                       "(min %.2f, max %.2f), compute_fea %.3f s, %d decode frames = %.3f s each; extrapolated to %d steps + %d frames"
                       % (best, n_unet, b, t, s, s, t_unet, min(times), max(times), t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
 
