@@ -401,16 +401,18 @@ def warp_bench(model, img, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     gbs = nbytes / sec / 1e9
-    traffic, pmc = None, evidence_files()["pmc"]
+    traffic, pmc, pmc_launches = None, evidence_files()["pmc"], None
     if pmc:
         with open(os.path.join(REPO_ROOT, pmc)) as f:
-            traffic = json.load(f).get("warp_bytes_per_video")
+            tj = json.load(f)
+        traffic, pmc_launches = tj.get("warp_bytes_per_video"), tj.get("warp_launches", 5)
     return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 5 launches = all warps of one 40-frame decode)",
             "us_per_video": round(sec * 1e6, 1), "elements": elems,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(gbs / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": nbytes,
                          "frac_of_counter_bytes": round(traffic / sec / 1e9 / 8000.0, 4) if traffic else None,
-                         "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over the decode's warp launches, not live" % pmc}}
+                         "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE over the %s warp launches of one sample_one_video decode, not live"
+                                           % (pmc, pmc_launches)}}
 
 
 def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):

@@ -95,13 +95,16 @@ def main():
         tot["gui_active_cycles"] += tc.get("GRBM_GUI_ACTIVE", 0.0)
         tot["dur_us_serialised"] += dur
     # the decode's warp launches (after the last sampler step)
-    warp = {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0, "dur_us_serialised": 0.0, "sq": {}, "tcc": {}}
+    warp = {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0, "dur_us_serialised": 0.0, "sq": {}, "tcc": {}, "list": []}
     tails = {k: [d for d in v[1] if d[1].startswith("warp_")] for k, v in steps.items()}
     for i, d in enumerate(tails["fetch"]):
         warp["launches"] += 1
         warp["fetch_bytes"] += 2.0 * 1024.0 * d[2].get("FETCH_SIZE", 0.0)
         warp["write_bytes"] += 1024.0 * tails["write"][i][2].get("WRITE_SIZE", 0.0)
         warp["dur_us_serialised"] += tails["sq"][i][3] / 1e3
+        warp["list"].append({"kernel": d[1][:60], "fetch_bytes": round(2.0 * 1024.0 * d[2].get("FETCH_SIZE", 0.0)),
+                             "write_bytes": round(1024.0 * tails["write"][i][2].get("WRITE_SIZE", 0.0)),
+                             "dur_us_serialised": round(tails["sq"][i][3] / 1e3, 1)})
         for k2, v2 in tails["sq"][i][2].items():
             warp["sq"][k2] = warp["sq"].get(k2, 0.0) + v2
         for k2, v2 in tails["tcc"][i][2].items():
@@ -122,7 +125,7 @@ def main():
            "warp_launches": warp["launches"], "warp_fetch_bytes_per_video": round(warp["fetch_bytes"]),
            "warp_write_bytes_per_video": round(warp["write_bytes"]), "warp_bytes_per_video": round(warp["fetch_bytes"] + warp["write_bytes"]),
            "warp_sq": {k: round(v) for k, v in warp["sq"].items()}, "warp_tcc": {k: round(v) for k, v in warp["tcc"].items()},
-           "warp_dur_us_serialised": round(warp["dur_us_serialised"], 1)}
+           "warp_dur_us_serialised": round(warp["dur_us_serialised"], 1), "warp_launch_list": warp["list"]}
     with open(out_json, "w") as f:
         json.dump(res, f, indent=1)
     print("# last sampler step: %d launches; HBM-side %.1f MB fetched (x2-corrected) + %.1f MB written; matrix-pipe utilisation (MFMA-busy cycles / "
@@ -136,6 +139,8 @@ def main():
         print()
     print("# warp launches of the decode: %d launches, %.1f MB fetched + %.1f MB written, %.1f us serialised"
           % (warp["launches"], warp["fetch_bytes"] / 1e6, warp["write_bytes"] / 1e6, warp["dur_us_serialised"]))
+    for w in warp["list"]:
+        print("  %-60s %8.1f MB fetched %8.1f MB written %7.1f us" % (w["kernel"], w["fetch_bytes"] / 1e6, w["write_bytes"] / 1e6, w["dur_us_serialised"]))
     for k2, v2 in sorted(warp["sq"].items()):
         print("  %-28s %16.0f" % (k2, v2))
     for k2, v2 in sorted(warp["tcc"].items()):
