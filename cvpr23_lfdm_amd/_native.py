@@ -43,6 +43,7 @@ class ConvParams(C.Structure):
         ("tile_counters", C.c_void_p), ("tile_counters_len", i32), ("weight_wino", C.c_void_p),
         ("deconv4", i32), ("groups", i32),
         ("pool2", i32),
+        ("weight_wino4", C.c_void_p),
     ]
 
 
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "lfdm_linear_attention_lowres_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, i32, i32, f32, stream_t]),
     "lfdm_attention_lowres_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32, stream_t]),
     "lfdm_pack_wino_weight_f32": (i32, [f32p, i32, i32, i32, i32, i32, f32p, stream_t]),
+    "lfdm_pack_wino4_weight_f32": (i32, [f32p, i32, i32, i32, i32, f32p, stream_t]),
     "lfdm_pack_conv_weight_f32": (i32, [f32p, i32, i32, i32, i64, i64, i32, f32p, stream_t]),
     "lfdm_lfae_motion_inputs_f32": (i32, [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, i32, i32, i32, i32, i32, i32,
                                           f32p, i32, f32p, stream_t]),

@@ -645,6 +645,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
 int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);  // conv_wino.hip
 int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
+int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream);         // conv_wino4.hip
 
 namespace {
 
@@ -655,6 +656,7 @@ struct ConvPlan {
   int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip),
                    // 2 = Winograd F(2x2,3x3), 128-pixel x 32-column tiles (conv_wino.hip),
                    // 3 = pointwise register-operand GEMM, 32-row tiles, never split-K (conv_pw.hip)
+                   // 4 = Winograd F(4x4,3x3), 512-pixel x 32-column tiles, batched shapes only (conv_wino4.hip)
   int bm, bn, ksplit;
   bool fast, simple;
 };
@@ -720,6 +722,24 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                      p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
                      p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
                      M <= pw_max_m && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
+  // F(4x4,3x3) (conv_wino4.hip): an opt-in of the caller (weight_wino4 given: its fp32 error is ~4e-6 of the output scale against
+  // ~1e-6 for F(2x2)) and only where every CU gets several of its one-per-CU workgroups - the batched shapes of training / throughput
+  // mode.  LFDM_WINO4=0 disables it, LFDM_WINO4_MIN overrides the workgroup-count threshold.
+  if (wino && p.weight_wino4 && p.c1 == 0 && p.c0 % 16 == 0 && p.hq % 4 == 0 && p.wq % 4 == 0 && !(p.groups > 1) && !p.pool2 &&
+      !p.gn_partial && user_k <= 1 && p.coutp % 32 == 0 && (((uintptr_t)p.weight_wino4) & 15) == 0 &&
+      (int64_t)36 * (cin / 8) * p.coutp * 32 < (1ll << 32) - 64) {
+    const char* em = getenv("LFDM_WINO4_MIN");      // (read per call: tests and tools toggle it at run time)
+    const long min_blocks4 = em ? atol(em) : 2048l;
+    const char* e4 = getenv("LFDM_WINO4");
+    const int64_t blocks4 = (((int64_t)p.n_img * (p.hq / 4) * (p.wq / 4) + 31) / 32) * (p.coutp / 32);
+    if (!(e4 && e4[0] == '0') && blocks4 >= min_blocks4) {
+      pl.kind = 4;
+      pl.bm = 512;
+      pl.bn = 32;
+      pl.ksplit = 1;
+      return pl;
+    }
+  }
   if (wino) {
     pl.kind = 2;
     pl.bm = 128;
@@ -891,6 +911,8 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     rc = lfdm_conv_wino_launch(p, pl.bn, stream);
   } else if (pl.kind == 3) {
     rc = lfdm_conv_pw_launch(p, stream);
+  } else if (pl.kind == 4) {
+    rc = lfdm_conv_wino4_launch(p, stream);
   } else {
     const dim3 grid((unsigned)((M + pl.bm - 1) / pl.bm), (unsigned)((p.coutp + pl.bn - 1) / pl.bn), p.ksplit * (p.deconv4 ? 4 : 1));
     if (pl.bm == 128 && pl.bn == 128) launch_conv<128, 128>(p, pl.fast, pl.simple, grid, stream);

@@ -1,0 +1,377 @@
+// Winograd F(4x4, 3x3) schedule of the 3x3 / stride-1 / zero-padded convolution on fp32 MFMA, for the BATCHED shapes (training's
+// frozen-LFAE decode, throughput mode): include/lfdm_hip.h lfdm_conv_params.weight_wino4 (schedule 4).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 6x6 input patch d / 4x4 output tile Y: 36 "frequency positions", each an ordinary GEMM
+// over c_in -> 36/144 = 1/4 of the multiplications of the direct form, 16/9 fewer than F(2x2, 3x3) (conv_wino.hip).  That kernel's K
+// loop already runs at the matrix-pipe bound on these shapes (profiles/r02_g_wino_phases.txt), so only a cheaper algorithm moves it.
+// The price: 36 accumulator tiles instead of 16, and a transform of ~12 packed operations per patch element - a workgroup that did
+// both like conv_wino.hip would need > 256 registers per lane or leave the matrix pipe idle during its transforms.  So the roles are
+// split (one workgroup per CU, 384 threads):
+//   * waves 0-3 = CONSUMERS, one per SIMD: wave w owns positions 9w .. 9w+8 of 32 tiles x 32 output channels (9 x 16 accumulator
+//     registers), A fragments = V from LDS (ds_read_b128), B fragments = the pre-transformed filters straight from global memory in
+//     operand order ([36][C_in/8][coutp][8]), refilled in place for the next chunk once their MFMAs are issued;
+//   * waves 4-5 = PRODUCERS: thread = (tile, channel pair) loads the pair's 6x6 patch (36 8-byte buffer loads, out-of-image taps =
+//     out-of-range offset = 0), applies B^T d B with packed fp32 arithmetic (both channels per instruction) and writes V[36][32][8]
+//     of the NEXT 8-channel chunk into the other LDS buffer, then requests the patch after that (two register sets, two chunks ahead);
+//   * one barrier per chunk; the matrix pipe of every SIMD sees a continuous MFMA stream while the VALU of two SIMDs transforms.
+// Output transform: all accumulators go through LDS once (36 planes x 32 tiles x 32 channels = 144 KB, aliasing the V buffers),
+// thread = (tile, 4 channels) applies A^T . A and writes the tile's 16 pixels as float4 with bias / residual / activation.
+// Error against the direct form: ~4e-6 of the output scale in fp32 (tests/test_ops_parity.py::test_conv2d_winograd4), F(2x2): ~1e-6.
+#include <cstdio>
+#include <cstdlib>
+
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W4T = 32;            // tiles per workgroup (4x4 outputs each: 512 pixels)
+constexpr int W4N = 32;            // output channels per workgroup
+constexpr int W4K = 8;             // input channels per chunk
+constexpr int LDV4 = W4K + 4;      // LDS row stride of V (floats): 48-byte rows, conflict-free b128 reads
+constexpr int V4SZ = 36 * W4T * LDV4;      // floats per V buffer (55 296 B)
+
+// B^T x for one 6-vector (Lavin & Gray, F(4x4,3x3)): 12 operations
+__device__ __forceinline__ void bt6(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
+                                    f32x2& o0, f32x2& o1, f32x2& o2, f32x2& o3, f32x2& o4, f32x2& o5) {
+  const f32x2 a = d4 - 4.0f * d2, b = d3 - 4.0f * d1, c = d4 - d2, e = d3 - d1;
+  o0 = 4.0f * d0 - 5.0f * d2 + d4;
+  o1 = a + b;
+  o2 = a - b;
+  o3 = c + 2.0f * e;
+  o4 = c - 2.0f * e;
+  o5 = 4.0f * d1 - 5.0f * d3 + d5;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int gx, int ny, int ablate) {
+  (void)ablate;      // (unused; probe builds -DLFDM_W4_PROBE=<mask> leave pipeline stages out at compile time: tools/probe_wino4_ablate.sh)
+  constexpr int SMEM4 = 2 * V4SZ > 36 * W4T * W4N ? 2 * V4SZ : 36 * W4T * W4N;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM4];      // V double buffer (108 KB); the epilogue's accumulator planes (144 KB) alias it
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = lfdm_uniform(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int up = p.upsample ? 1 : 0;
+  const int th = p.hq >> 2, tw = p.wq >> 2;
+  const unsigned ntiles = (unsigned)p.n_img * th * tw;
+  // Workgroup order (1-D grid): ids are dealt round-robin to the 8 XCDs; inside an XCD consecutive workgroups walk the COLUMN tiles of
+  // one tile block, so the workgroups that need the same input patches run at the same time behind the same L2 (each reads its
+  // 1.2 MB of patches once from HBM instead of once per column tile), and the tile blocks that are in flight together on an XCD walk
+  // the filter chunks roughly in step (the 9.4 MB of F(4x4) filters come through L2 / the Infinity Cache, not HBM).
+  // First version (grid = tile blocks x column tiles, tile blocks fastest): HBM-bound - 6 GB of input re-reads per 256 -> 256 launch.
+  const int id = blockIdx.x, slot = id >> 3;
+  const int bx = (id & 7) + 8 * (slot / ny), by = slot % ny;
+  if (bx >= gx) return;          // (whole workgroups: no barrier has been reached)
+  const unsigned t0 = (unsigned)bx * W4T;
+  const int n0 = by * W4N;
+  const int cin = p.c0;
+  const int nch = cin / W4K;
+
+  // nch is even (C_in % 16 == 0: the plan's condition): the chunk loops below run two chunks per trip as ONE basic block - with a
+  // break between the halves hipcc renamed the accumulators from trip to trip (out-of-place MFMAs: both tuples live, spills)
+  const int last = nch - 1;
+  auto clampc = [&](int c) { return c < last ? c : last; };      // re-fetching the last chunk is harmless
+  float* const V0 = smem;
+  float* const V1 = smem + V4SZ;
+
+  // The two roles live in separate branches (the wave index is scalar: a uniform branch), each with its own copy of the chunk loop
+  // and the SAME number of barriers - a common loop would keep the producers' 144 patch registers and the consumers' 144 accumulator
+  // registers alive together.
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- PRODUCERS (waves 4, 5): thread = (tile, channel pair)
+    const int pt = tid - 256;
+    const int x_tile = pt >> 2, x_pair = pt & 3;
+    const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+    const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
+    uint32_t base0 = 0;
+    uint64_t valid = 0;                             // bit (6*r + c): patch pixel inside the image
+    {
+      const unsigned t = t0 + x_tile;
+      if (t < ntiles) {
+        const int n = (int)(t / (unsigned)(th * tw));
+        const unsigned rem = t - (unsigned)n * (th * tw);
+        const int ty = (int)(rem / (unsigned)tw), tx = (int)(rem - (unsigned)ty * tw);
+        // physical pixel of the patch corner: logical (4ty-1, 4tx-1); through the upsample that is (2ty-1, 2tx-1)
+        const uint32_t pix = up ? (uint32_t)((n * p.hi + 2 * ty - 1) * p.wi + 2 * tx - 1)
+                                : (uint32_t)((n * p.hi + 4 * ty - 1) * p.wi + 4 * tx - 1);
+        base0 = (pix * (uint32_t)p.ld0 + 2u * x_pair) * 4u;
+        const unsigned rows = 0x3Fu & ~(ty == 0 ? 1u : 0u) & ~(ty == th - 1 ? 32u : 0u);
+        const unsigned cols = 0x3Fu & ~(tx == 0 ? 1u : 0u) & ~(tx == tw - 1 ? 32u : 0u);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if ((rows >> r) & 1u) valid |= (uint64_t)cols << (6 * r);
+      }
+    }
+    const uint32_t ld4 = (uint32_t)p.ld0 * 4u;
+    f32x2 pa[36], pb[36];                           // two patch register sets (two chunks in flight)
+    auto fetch_patch = [&](f32x2 (&d)[36], int chunk) {
+#ifdef LFDM_W4_PROBE
+      if constexpr ((LFDM_W4_PROBE & 1) != 0) return;
+#endif
+      const uint32_t base = base0 + (uint32_t)chunk * (W4K * 4u);
+#pragma unroll
+      for (int q = 0; q < 36; ++q) {
+        const int r = q / 6, c = q % 6;
+        // upsampled: logical rows 4ty-1 .. 4ty+4 are physical rows 2ty-1 + ((r+1)>>1)
+        const int py = up ? (r + 1) >> 1 : r, px = up ? (c + 1) >> 1 : c;
+        const uint32_t delta = (uint32_t)(py * p.wi + px) * ld4;
+        const float2 v = lfdm_buf_load_f2(buf0, ((valid >> q) & 1ull) ? base + delta : LFDM_BUF_OOB);
+        d[q].x = v.x;
+        d[q].y = v.y;
+      }
+    };
+    auto transform_store = [&](f32x2 (&d)[36], float* V) {
+#ifdef LFDM_W4_PROBE
+      if constexpr ((LFDM_W4_PROBE & 16) != 0) return;
+      if constexpr ((LFDM_W4_PROBE & 2) != 0) {
+        float* dst = V + x_tile * LDV4 + 2 * x_pair;
+#pragma unroll
+        for (int q = 0; q < 36; ++q) *reinterpret_cast<f32x2*>(dst + q * (W4T * LDV4)) = d[q];
+        return;
+      }
+#endif
+      // columns first (t = B^T d, in place), then rows (V = t B)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        bt6(d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c], d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c]);
+      float* dst = V + x_tile * LDV4 + 2 * x_pair;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        f32x2 o[6];
+        bt6(d[6 * i], d[6 * i + 1], d[6 * i + 2], d[6 * i + 3], d[6 * i + 4], d[6 * i + 5], o[0], o[1], o[2], o[3], o[4], o[5]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(dst + (6 * i + j) * (W4T * LDV4)) = o[j];
+      }
+    };
+    fetch_patch(pa, 0);
+    fetch_patch(pb, clampc(1));
+    transform_store(pa, V0);
+    fetch_patch(pa, clampc(2));
+    __syncthreads();
+    for (int kc = 0; kc < nch; kc += 2) {
+      transform_store(pb, V1);                      // chunk kc+1 while the consumers multiply chunk kc from V0
+      fetch_patch(pb, clampc(kc + 3));
+      __syncthreads();
+      transform_store(pa, V0);                      // chunk kc+2 while the consumers multiply chunk kc+1 from V1
+      fetch_patch(pa, clampc(kc + 4));
+      __syncthreads();
+    }
+    __syncthreads();                                // the consumers' epilogue: one more barrier
+    return;
+  }
+
+  // ---------------------------------------------------------------- CONSUMERS (waves 0-3, one per SIMD)
+  const lfdm_buf bufw = lfdm_make_buf(p.weight_wino4, (uint32_t)((int64_t)36 * nch * p.coutp * W4K * 4));
+  const int cw = wave;
+  const int ncol = n0 + l31;
+  // B fragments: group g (three positions) of a chunk lives in bfr[g]; while group g is multiplied the fragments of the group after
+  // next are requested into the buffer that became free one group ago (two groups = 24 MFMAs = ~1500 cycles of flight time; one group
+  // ahead - 768 cycles - left the matrix pipe waiting for L2 at every group, 4300 cycles per chunk for 2304 of MFMA)
+  float4 bfr[3][3];
+  // byte offset = position * (nch * coutp * 32) + chunk * (coutp * 32) [scalar] + this lane's column / k-half [vector]
+  const uint32_t chunk_bytes = (uint32_t)p.coutp * (W4K * 4u);
+  const uint32_t pos_bytes = (uint32_t)nch * chunk_bytes;
+  // (coutp % 32 == 0 and gridDim.y = coutp / 32 - the plan's condition - so every lane's column exists)
+  const uint32_t b_lane = ((uint32_t)ncol * W4K + 4u * kh) * 4u;
+  auto fetch_bg = [&](float4 (&dst)[3], int g, int chunk) {
+#ifdef LFDM_W4_PROBE
+    if constexpr ((LFDM_W4_PROBE & 4) != 0) { if (chunk > 0) return; }
+#endif
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const uint32_t uni = (uint32_t)(9 * cw + 3 * g + u) * pos_bytes + (uint32_t)chunk * chunk_bytes;
+      dst[u] = lfdm_buf_load_f4(bufw, uni + b_lane);
+    }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  auto load_a = [&](float4 (&a)[3], const float* V, int g) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) a[u] = *reinterpret_cast<const float4*>(V + ((9 * cw + 3 * g + u) * W4T + l31) * LDV4 + 4 * kh);
+  };
+  auto consume = [&](const float* V, int chunk, int next_chunk) {
+    float4 a[2][3];                                // A fragments of the current and of the next group (LDS latency under the MFMAs)
+    load_a(a[0], V, 0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {                 // three positions at a time: independent accumulator chains
+      if (g < 2) load_a(a[(g + 1) & 1], V, g + 1);
+      // the buffer of the PREVIOUS group is free (its MFMAs have been issued): it takes the group after next - group 2 of this chunk
+      // (g = 0) or group g - 1 of the next chunk - which then has two groups of MFMAs to arrive
+      if (g == 0) fetch_bg(bfr[2], 2, chunk);
+      else fetch_bg(bfr[g - 1], g - 1, next_chunk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const float4 bq = bfr[g][u], aq = a[g & 1][u];
+          const float av = e == 0 ? aq.x : e == 1 ? aq.y : e == 2 ? aq.z : aq.w;
+          const float bv = e == 0 ? bq.x : e == 1 ? bq.y : e == 2 ? bq.z : bq.w;
+#ifdef LFDM_W4_PROBE
+          if constexpr ((LFDM_W4_PROBE & 8) != 0) acc[3 * g + u][e] += av * bv;
+          else
+#endif
+          acc[3 * g + u] = mfma_32x32x2(av, bv, acc[3 * g + u]);
+        }
+#if !defined(LFDM_EMU_BUILD)
+      __builtin_amdgcn_sched_barrier(0);          // keep the groups apart: loads hoisted further would need fresh registers
+#endif
+    }
+  };
+  fetch_bg(bfr[0], 0, 0);
+  fetch_bg(bfr[1], 1, 0);
+  __syncthreads();
+  for (int kc = 0; kc < nch; kc += 2) {
+    consume(V0, kc, clampc(kc + 1));
+    __syncthreads();
+    consume(V1, kc + 1, clampc(kc + 2));
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- output transform A^T M A through LDS
+  // every accumulator goes to its plane first ([36 positions][32 tiles][32 channels]: 147 KB, the accumulators are dead afterwards),
+  // then thread = (tile, 4 channels) reads its 36 float4 and produces the tile's 4x4 output pixels
+  float* const Ms = smem;
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Ms[((9 * cw + q) * W4T + tile) * W4N + l31] = acc[q][r];
+    }
+  const int e_quad = tid & 7, e_tile = tid >> 3;      // the 256 consumer threads
+  int my_n = -1, my_ty = 0, my_tx = 0;
+  {
+    const unsigned t = t0 + e_tile;
+    if (t < ntiles) {
+      my_n = (int)(t / (unsigned)(th * tw));
+      const unsigned rem = t - (unsigned)my_n * (th * tw);
+      my_ty = (int)(rem / (unsigned)tw);
+      my_tx = (int)(rem - (unsigned)my_ty * tw);
+    }
+  }
+  const int co = n0 + 4 * e_quad;
+  const bool live = my_n >= 0 && co < p.cout;
+  const int64_t orow0 = ((int64_t)my_n * p.hq + 4 * my_ty) * p.wq + 4 * my_tx;
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + co);
+  // the 16 residual rows of the tile are requested before the barrier (the accumulator registers are free now); loaded inside the store
+  // loop each was a load -> wait -> store round trip, because `out` may alias `residual` (ResBlock2d: in place) and nothing can be hoisted
+  float4 res[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && p.residual) res[o] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (o >> 2) * p.wq + (o & 3)) * p.ldr + co);
+  }
+  __syncthreads();
+  if (!live) return;
+  // T[i][b] = sum_j M[i][j] A[j][b]
+  float4 T[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float4 m[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const float4*>(Ms + ((6 * i + j) * W4T + e_tile) * W4N + 4 * e_quad);
+#define LFDM_W4_COL(f)                                                                                          \
+    {                                                                                                           \
+      const float s12 = m[1].f + m[2].f, d12 = m[1].f - m[2].f, s34 = m[3].f + m[4].f, d34 = m[3].f - m[4].f;  \
+      T[i][0].f = m[0].f + s12 + s34;                                                                           \
+      T[i][1].f = d12 + 2.0f * d34;                                                                             \
+      T[i][2].f = s12 + 4.0f * s34;                                                                             \
+      T[i][3].f = d12 + 8.0f * d34 + m[5].f;                                                                    \
+    }
+    LFDM_W4_COL(x) LFDM_W4_COL(y) LFDM_W4_COL(z) LFDM_W4_COL(w)
+#undef LFDM_W4_COL
+  }
+  // Y[a][b] = sum_i A^T[a][i] T[i][b], one output column b at a time (4 pixels of 4 channels each)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float4 y[4];
+#define LFDM_W4_ROW(f)                                                                                                            \
+    {                                                                                                                             \
+      const float s12 = T[1][b].f + T[2][b].f, d12 = T[1][b].f - T[2][b].f, s34 = T[3][b].f + T[4][b].f, d34 = T[3][b].f - T[4][b].f; \
+      y[0].f = T[0][b].f + s12 + s34;                                                                                             \
+      y[1].f = d12 + 2.0f * d34;                                                                                                  \
+      y[2].f = s12 + 4.0f * s34;                                                                                                  \
+      y[3].f = d12 + 8.0f * d34 + T[5][b].f;                                                                                      \
+    }
+    LFDM_W4_ROW(x) LFDM_W4_ROW(y) LFDM_W4_ROW(z) LFDM_W4_ROW(w)
+#undef LFDM_W4_ROW
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t orow = orow0 + a * p.wq + b;
+      const float4 rr = res[4 * a + b];
+      float4 v = make_float4(y[a].x + bb.x + rr.x, y[a].y + bb.y + rr.y, y[a].z + bb.z + rr.z, y[a].w + bb.w + rr.w);
+      if (ACT) {
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+      }
+      *reinterpret_cast<float4*>(p.out + orow * p.ldo + co) = v;
+    }
+  }
+}
+
+// U = G g G^T (6x6 per filter), one thread per (input channel k, output channel n)
+__global__ __launch_bounds__(256) void pack_wino4_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
+                                                         float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)cin * coutp) return;
+  const int n = (int)(idx % coutp), k = (int)(idx / coutp);
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = n < cout ? w[(int64_t)n * ld_o + (int64_t)k * 9 + t] : 0.f;
+  // rows of G: [1/4 0 0], [-1/6 -1/6 -1/6], [-1/6 1/6 -1/6], [1/24 1/12 1/6], [1/24 -1/12 1/6], [0 0 1]
+  auto g6 = [](float a, float b, float c, float (&o)[6]) {
+    o[0] = 0.25f * a;
+    o[1] = (-1.0f / 6.0f) * (a + b + c);
+    o[2] = (-1.0f / 6.0f) * (a - b + c);
+    o[3] = (1.0f / 24.0f) * a + (1.0f / 12.0f) * b + (1.0f / 6.0f) * c;
+    o[4] = (1.0f / 24.0f) * a - (1.0f / 12.0f) * b + (1.0f / 6.0f) * c;
+    o[5] = c;
+  };
+  float r[6][3];                                        // G g
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float o[6];
+    g6(g[b], g[3 + b], g[6 + b], o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i][b] = o[i];
+  }
+  const int nch = cin / W4K;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float u[6];
+    g6(r[i][0], r[i][1], r[i][2], u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[((((int64_t)(6 * i + j)) * nch + k / W4K) * coutp + n) * W4K + (k % W4K)] = u[j];
+  }
+}
+
+}  // namespace
+
+extern "C" int lfdm_pack_wino4_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, float* out, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!w || !out || cout <= 0 || cin <= 0 || cin % W4K != 0 || coutp < cout || coutp % 32 != 0 || ld_o < cin * 9) {
+    lfdm_set_error("pack_wino4_weight: input channels must be a multiple of 8 and coutp a multiple of 32 >= the output channels");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)cin * coutp;
+  LFDM_LAUNCH(pack_wino4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, ld_o, cout, cin, coutp, out);
+  return lfdm_check_launch("pack_wino4_weight");
+}
+
+// 1-D grid of (tile blocks rounded up to 8) x column tiles workgroups.  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip) for schedule 4.
+int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream) {
+  const int64_t ntiles = (int64_t)p.n_img * (p.hq / 4) * (p.wq / 4);
+  const int gx = (int)((ntiles + W4T - 1) / W4T), ny = (p.coutp + W4N - 1) / W4N;
+  const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny));
+  const int ablate = 0;
+  if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(384), 0, stream, p, gx, ny, ablate);
+  else LFDM_LAUNCH((conv_wino4_kernel<false>), grid, dim3(384), 0, stream, p, gx, ny, ablate);
+  return lfdm_check_launch("conv_wino4");
+}

@@ -97,6 +97,7 @@ class Generator(ParamTree):
             w, b = conv_bn("up_blocks.%d.conv." % i, "up_blocks.%d.norm." % i)
             pk["up%d.w" % i], pk["up%d.b" % i] = ops.pack_conv_weight(w), b
             pk["up%d.ww" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
+            pk["up%d.w4" % i] = ops.pack_wino4_weight(w) if w.shape[1] % 16 == 0 else None      # F(4x4,3x3): batched launches only
         for i in range(self.num_bottleneck_blocks):
             p = "bottleneck.r%d." % i
             a1, b1 = bn_affine(p + "norm1.")                 # pre-activation BN + ReLU (util.py:85-86)
@@ -107,6 +108,10 @@ class Generator(ParamTree):
             # Winograd F(2x2,3x3) forms of the same filters (the library chooses the schedule)
             pk["r%d.ww1" % i] = ops.pack_wino_weight(w) if w.shape[1] % 16 == 0 else None
             pk["r%d.ww2" % i] = ops.pack_wino_weight(g(p + "conv2.weight").contiguous()) if w.shape[1] % 16 == 0 else None
+            # ... and the F(4x4,3x3) forms: the library takes them only for launches of >= 2048 workgroups (the 320-frame decode of a
+            # training step / throughput mode), never for the 40 frames of a B = 1 sample (lfdm_conv_params.weight_wino4)
+            pk["r%d.w41" % i] = ops.pack_wino4_weight(w) if w.shape[1] % 16 == 0 else None
+            pk["r%d.w42" % i] = ops.pack_wino4_weight(g(p + "conv2.weight").contiguous()) if w.shape[1] % 16 == 0 else None
             pk["r%d.b2" % i] = g(p + "conv2.bias").contiguous()
         # output channels padded to a multiple of 4 (zero filters): float4 epilogue -> the 32-column KSW tile instead of
         # a 64-column tile for 3 real channels
@@ -182,9 +187,9 @@ class Generator(ParamTree):
             t0 = ops.affine_act_cl(out, pk["r%d.a1" % i], pk["r%d.b1" % i], ops.ACT_RELU,
                                    out=self._buf("dec.t0", n * lh * lw, cb))
             t1 = ops.conv2d_cl(t0, pk["r%d.w1" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.bb1" % i], act=ops.ACT_RELU,
-                               out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i])
+                               out=self._buf("dec.t1", n * lh * lw, cb), weight_wino=pk["r%d.ww1" % i], weight_wino4=pk["r%d.w41" % i])
             out = ops.conv2d_cl(t1, pk["r%d.w2" % i], cb, 3, 3, n, lh, lw, bias=pk["r%d.b2" % i], residual=out,
-                                out=out, weight_wino=pk["r%d.ww2" % i])
+                                out=out, weight_wino=pk["r%d.ww2" % i], weight_wino4=pk["r%d.w42" % i])
         res_h, res_w = lh, lw
         for i in range(self.num_down_blocks):                # apply_optical(skip, prev) + UpBlock2d (:152-155)
             skip = skips[-(i + 1)]
@@ -193,7 +198,7 @@ class Generator(ParamTree):
                                   out=self._buf("dec.w%d" % i, n * res_h * res_w, ci), **wk)
             co = self._feat(self.num_down_blocks - i - 1)
             out = ops.conv2d_cl(blended, pk["up%d.w" % i], co, 3, 3, n, res_h, res_w, bias=pk["up%d.b" % i],
-                                upsample=True, act=ops.ACT_RELU, weight_wino=pk["up%d.ww" % i],
+                                upsample=True, act=ops.ACT_RELU, weight_wino=pk["up%d.ww" % i], weight_wino4=pk["up%d.w4" % i],
                                 out=self._buf("dec.u%d" % i, n * 4 * res_h * res_w, co))
             res_h, res_w = res_h * 2, res_w * 2
         blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,

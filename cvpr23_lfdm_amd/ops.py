@@ -219,6 +219,22 @@ def pack_wino_weight(w, coutp=None, dgrad=False):
     return out
 
 
+def pack_wino4_weight(w, coutp=None):
+    """(Cout, Cin, 3, 3) -> Winograd F(4x4,3x3) filters U = G g G^T as [36][Cin/8][coutp][8] (lfdm_conv_params.weight_wino4, the
+    batched-shape schedule of conv_wino4.hip).  lfdm_pack_wino4_weight_f32."""
+    lib = _lib()
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and w.dtype == torch.float32 and cin % 8 == 0
+    assert w.stride(3) == 1 and w.stride(2) == 3 and w.stride(1) == 9, "input-channel slices of a contiguous filter only"
+    _chk(lib, w)
+    coutp = coutp or (cout + 31) // 32 * 32
+    out = torch.empty(36, cin // 8, coutp, 8, dtype=torch.float32, device=w.device)
+    lib.check(lib.lfdm_pack_wino4_weight_f32(_p(w), w.stride(0), cout, cin, coutp, _p(out), _stream(lib)), "lfdm_pack_wino4_weight_f32")
+    return out
+
+
 def pack_planar_in_weight(w):
     """(Cout, Cin, kh, kw) -> [kh*kw*Cin][Cout] (tap-major, then channel) for conv_planar_in_cl."""
     if w.dim() == 5:
@@ -234,7 +250,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -291,8 +307,13 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         assert kh == 2 and kw == 2 and out_scale == 2 and deconv4.is_contiguous() and deconv4.shape == (4,) + tuple(weight.shape) \
             and deconv4.data_ptr() == weight.data_ptr(), "weight must be deconv4[0]"
         p.deconv4 = 1
+    p.weight_wino4 = None
+    if weight_wino4 is not None:        # F(4x4,3x3) form for batched shapes (the library decides: lfdm_conv2d_schedule == 4)
+        _chk(lib, weight_wino4)
+        assert weight_wino is not None and weight_wino4.shape == (36, cin // 8, coutp, 8) and weight_wino4.is_contiguous()
+        p.weight_wino4 = weight_wino4.data_ptr()
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4)   # keep the tensors alive with the struct
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4)   # keep the tensors alive with the struct
     return p, out
 
 
@@ -324,7 +345,7 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
     lib = _lib()
     _chk(lib, partial, gn_partial)
     p, out = conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, **kw_)
-    if (weight is None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) != 2:
+    if (weight is None or kw_.get("pool2")) and lib.lfdm_conv2d_schedule(C.byref(p)) not in ((2,) if kw_.get("pool2") else (2, 4)):
         raise WinogradUnavailable("the library would not run the Winograd schedule for this geometry: pass the direct-form pack / "
                                   "run the pooling as a launch of its own")
     if gn_partial is not None:      # before the plan is asked for: the pointwise schedule has no fused statistics

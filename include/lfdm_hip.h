@@ -121,6 +121,13 @@ typedef struct lfdm_conv_params {
      (LFAE/modules/util.py:136-150) is taken in the epilogue: out has (ho, wo) = (hq / 2, wq / 2) rows per image, one Winograd
      output tile each; needs an output activation, no residual, no fused GroupNorm statistics, no split-K. */
   int pool2;
+  /* Optional Winograd F(4x4,3x3) form of the SAME filter (lfdm_pack_wino4_weight_f32: U = G g G^T as [36 positions][C0/8][coutp][8]) -
+     an opt-in for BATCHED shapes: 1/4 of the direct form's multiplications (F(2x2): 4/9), fp32 error ~4e-6 of the output scale
+     (F(2x2): ~1e-6).  Taken (schedule 4, conv_wino4.hip) only when weight_wino is given too and would run, one source, C0 % 8 == 0,
+     H % 4 == W % 4 == 0, no groups / pool2 / fused GroupNorm statistics / forced split-K, and the launch has >= 2048 of its
+     512-pixel x 32-column workgroups (LFDM_WINO4_MIN; LFDM_WINO4=0 disables): the frozen-LFAE decode of a training step, throughput
+     mode - never the B = 1 sampler.  Bias / residual / activation / virtual x2 upsample as in the F(2x2) schedule. */
+  const float* weight_wino4;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
@@ -132,7 +139,8 @@ int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit);
  * across waves (conv_ksw), 2 = Winograd F(2x2,3x3) (conv_wino: reads weight_wino only - `weight` is then never dereferenced, so
  * a caller that re-packs filters every step, i.e. training, can skip the direct-form pack), 3 = pointwise register-operand
  * GEMM (conv_pw: 1x1 / stride 1 projections with C % 32 == 0 - to_qkv incl. the LayerNorm fold, to_out, res_conv,
- * video_flow_diffusion.py:224,246-247,300-301 - 32-row tiles, never split-K; LFDM_PW=0 in the environment disables it), < 0 = error */
+ * video_flow_diffusion.py:224,246-247,300-301 - 32-row tiles, never split-K; LFDM_PW=0 in the environment disables it), 4 = Winograd
+ * F(4x4,3x3) (conv_wino4: reads weight_wino4 only; batched shapes, see lfdm_conv_params.weight_wino4), < 0 = error */
 int lfdm_conv2d_schedule(const lfdm_conv_params* p);
 /* bytes of `partial` needed (0 when the plan does not split K) */
 size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
@@ -340,6 +348,9 @@ int lfdm_attention_lowres_cl_f32(const float* x, int ldx, int channels, const fl
  * coutp >= cin.  dgrad == 0 requires cin % 16 == 0 and coutp >= cout; coutp % 32 == 0. */
 int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
                               lfdm_stream_t stream);
+/* the F(4x4,3x3) filters of lfdm_conv_params.weight_wino4: out[36][cin/8][coutp][8] (zero for output channels >= cout), same `w`
+ * addressing as above; cin % 8 == 0, coutp % 32 == 0, coutp >= cout.  (ABI version 5.) */
+int lfdm_pack_wino4_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, float* out, lfdm_stream_t stream);
 
 /* PixelwiseFlowPredictor around its hourglass (LFAE/modules/pixelwise_flow_predictor.py:48-128) for all N = batch*frames driving
  * frames of a training step, frame n = b*frames + t using source image / source regions b:

@@ -5,6 +5,7 @@ Runs twice: backend=hip on the MI355X (`-m gpu`, the parity tests proper, at C2-
 backend=emu (the kernel sources under the x86 fiber emulator, tiny shapes - index-logic check).
 Tolerance: 1e-4 relative to the output scale per op (fp32 kernels with a different summation
 order than ATen; the north-star budget for the whole chain is 1e-3)."""
+import ctypes
 import math
 import os
 
@@ -899,6 +900,54 @@ def test_pack_wino_weight(backend):
     assert ops.conv_plan(pp)[0] == 128
     dx = ops.conv2d_cl(to_cl(dy).to(dev), wd, 32, 3, 3, n, h, w, weight_wino=ww)
     assert_close(from_cl(dx.cpu(), n, h, w), x.grad, TOL, "winograd dgrad")
+
+
+@pytest.mark.parametrize("case", [
+    dict(cin=16, cout=32, n=2, h=8, w=8),                                          # 8 tiles: a ragged workgroup
+    dict(cin=32, cout=40, n=10, h=8, w=8, residual=True, act=1),                   # 40 tiles: two workgroups, padded columns
+    dict(cin=16, cout=64, n=3, h=4, w=12, upsample=True, act=1),                   # through the virtual x2 upsample (8 x 24 image)
+    dict(cin=48, cout=32, n=1, h=16, w=4, residual=True),                          # one tile per image row; 3 chunk pairs
+    dict(cin=256, cout=256, n=40, h=32, w=32, residual=True, gpu_only=True),       # LFAE bottleneck ResBlock2d convolution
+    dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),   # UpBlock2d
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv2d_winograd4(backend, case, monkeypatch):
+    """Winograd F(4x4,3x3) schedule for batched shapes (conv_wino4.hip, lfdm_conv_params.weight_wino4, schedule 4) against F.conv2d
+    in float64: bar 2e-5 of the output scale (fp32 transforms: ~4e-6), and the F(2x2) result of the same call for comparison."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    monkeypatch.setenv("LFDM_WINO", "1")
+    monkeypatch.setenv("LFDM_WINO4", "1")
+    monkeypatch.setenv("LFDM_WINO4_MIN", "1")
+    cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
+    bias = rnd(cout, seed=3)
+    up = bool(case.get("upsample"))
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin.double(), wt.double(), bias.double(), padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    res = None
+    if case.get("residual"):
+        res = rnd(*ref.shape, seed=4)
+        ref = ref + res.double()
+    act = case.get("act", 0)
+    if act == 1:
+        ref = F.relu(ref)
+    ref = ref.float()
+    xs = to_cl(x).to(dev)
+    wtd = wt.to(dev)
+    wd, ww, w4 = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wtd), ops.pack_wino4_weight(wtd)
+    kw = dict(bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act, weight_wino=ww, upsample=up)
+    pp, _ = ops.conv_params(xs, wd, cout, 3, 3, n, h, w, weight_wino4=w4, **kw)
+    assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 4, "the F(4x4) plan was not selected"
+    out = ops.conv2d_cl(xs, wd, cout, 3, 3, n, h, w, weight_wino4=w4, **kw)
+    assert_close(from_cl(out.cpu(), n, ho, wo), ref, 2e-5, "winograd F(4x4) conv")
+    monkeypatch.setenv("LFDM_WINO4", "0")
+    pp, _ = ops.conv_params(xs, wd, cout, 3, 3, n, h, w, weight_wino4=w4, **kw)
+    assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 2
+    out2 = ops.conv2d_cl(xs, wd, cout, 3, 3, n, h, w, weight_wino4=w4, **kw)
+    assert_close(from_cl(out2.cpu(), n, ho, wo), ref, 1e-5, "winograd F(2x2) conv")
 
 
 @pytest.mark.parametrize("seed", range(4))
