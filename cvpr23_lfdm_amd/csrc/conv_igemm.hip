@@ -725,7 +725,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   // F(4x4,3x3) (conv_wino4.hip): an opt-in of the caller (weight_wino4 given: its fp32 error is ~4e-6 of the output scale against
   // ~1e-6 for F(2x2)) and only where every CU gets several of its one-per-CU workgroups - the batched shapes of training / throughput
   // mode.  LFDM_WINO4=0 disables it, LFDM_WINO4_MIN overrides the workgroup-count threshold.
-  if (wino && p.weight_wino4 && p.c1 == 0 && p.c0 % 16 == 0 && p.hq % 4 == 0 && p.wq % 4 == 0 && !(p.groups > 1) && !p.pool2 &&
+  if (wino && p.weight_wino4 && p.c1 == 0 && p.c0 % 32 == 0 && p.hq % 4 == 0 && p.wq % 4 == 0 && !(p.groups > 1) && !p.pool2 &&
       !p.gn_partial && user_k <= 1 && p.coutp % 32 == 0 && (((uintptr_t)p.weight_wino4) & 15) == 0 &&
       (int64_t)36 * (cin / 8) * p.coutp * 32 < (1ll << 32) - 64) {
     const char* em = getenv("LFDM_WINO4_MIN");      // (read per call: tests and tools toggle it at run time)

@@ -6,14 +6,17 @@
 // loop already runs at the matrix-pipe bound on these shapes (profiles/r02_g_wino_phases.txt), so only a cheaper algorithm moves it.
 // The price: 36 accumulator tiles instead of 16, and a transform of ~12 packed operations per patch element - a workgroup that did
 // both like conv_wino.hip would need > 256 registers per lane or leave the matrix pipe idle during its transforms.  So the roles are
-// split (one workgroup per CU, 384 threads):
-//   * waves 0-3 = CONSUMERS, one per SIMD: wave w owns positions 9w .. 9w+8 of 32 tiles x 32 output channels (9 x 16 accumulator
-//     registers), A fragments = V from LDS (ds_read_b128), B fragments = the pre-transformed filters straight from global memory in
-//     operand order ([36][C_in/8][coutp][8]), refilled in place for the next chunk once their MFMAs are issued;
-//   * waves 4-5 = PRODUCERS: thread = (tile, channel pair) loads the pair's 6x6 patch (36 8-byte buffer loads, out-of-image taps =
-//     out-of-range offset = 0), applies B^T d B with packed fp32 arithmetic (both channels per instruction) and writes V[36][32][8]
-//     of the NEXT 8-channel chunk into the other LDS buffer, then requests the patch after that (two register sets, two chunks ahead);
-//   * one barrier per chunk; the matrix pipe of every SIMD sees a continuous MFMA stream while the VALU of two SIMDs transforms.
+// split (one workgroup per CU, 512 threads, every SIMD holds one consumer and one producer wave):
+//   * waves 0-3 = CONSUMERS: wave w owns positions 9w .. 9w+8 of 32 tiles x 32 output channels (9 x 16 accumulator registers), A
+//     fragments = V from LDS (ds_read_b128), B fragments = the pre-transformed filters straight from global memory in operand order
+//     ([36][C_in/8][coutp][8]), three positions at a time, requested two groups ahead;
+//   * waves 4-7 = PRODUCERS: thread = (tile, channel pair of a 16-channel period) loads the pair's 6x6 patch (36 8-byte buffer loads;
+//     the 8 pairs of a pixel are 8 adjacent lanes = one 64-byte segment, out-of-image taps = out-of-range offset = 0), applies B^T d B
+//     with packed fp32 arithmetic (both channels per instruction) and writes V[36][32][16] of the NEXT period into the other LDS
+//     buffer, then requests the patch after that (two register sets, two periods ahead);
+//   * one barrier per 16-channel period; the matrix pipe of every SIMD sees a continuous MFMA stream while the VALU transforms.
+//   (First version: 8-channel periods produced by two waves from 32-byte segments: the ablation builds of tools/probe_wino4_ablate.sh
+//   showed the consumers alone at 803 us and the patch loads costing 520 us of a 1527 us launch - half-used 64-byte L2 requests.)
 // Output transform: all accumulators go through LDS once (36 planes x 32 tiles x 32 channels = 144 KB, aliasing the V buffers),
 // thread = (tile, 4 channels) applies A^T . A and writes the tile's 16 pixels as float4 with bias / residual / activation.
 // Error against the direct form: ~4e-6 of the output scale in fp32 (tests/test_ops_parity.py::test_conv2d_winograd4), F(2x2): ~1e-6.
@@ -30,8 +33,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int W4T = 32;            // tiles per workgroup (4x4 outputs each: 512 pixels)
 constexpr int W4N = 32;            // output channels per workgroup
 constexpr int W4K = 8;             // input channels per chunk
-constexpr int LDV4 = W4K + 4;      // LDS row stride of V (floats): 48-byte rows, conflict-free b128 reads
-constexpr int V4SZ = 36 * W4T * LDV4;      // floats per V buffer (55 296 B)
+constexpr int W4C = 16;            // input channels per barrier period (two 8-channel chunks of the filter layout)
+constexpr int LDV4 = W4C;          // LDS row of V: 16 floats = four 16-byte slots, slot s of row r stored at s ^ ((r >> 2) & 3) (no padding:
+                                   // the swizzle makes the b128 fragment reads of 16 consecutive rows conflict-free)
+constexpr int V4SZ = 36 * W4T * LDV4;      // floats per V buffer (73 728 B)
 
 // B^T x for one 6-vector (Lavin & Gray, F(4x4,3x3)): 12 operations
 __device__ __forceinline__ void bt6(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
@@ -46,10 +51,10 @@ __device__ __forceinline__ void bt6(const f32x2 d0, const f32x2 d1, const f32x2 
 }
 
 template <bool ACT>
-__global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int gx, int ny, int ablate) {
+__global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int gx, int ny, int ablate) {
   (void)ablate;      // (unused; probe builds -DLFDM_W4_PROBE=<mask> leave pipeline stages out at compile time: tools/probe_wino4_ablate.sh)
   constexpr int SMEM4 = 2 * V4SZ > 36 * W4T * W4N ? 2 * V4SZ : 36 * W4T * W4N;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM4];      // V double buffer (108 KB); the epilogue's accumulator planes (144 KB) alias it
+  __shared__ __attribute__((aligned(16))) float smem[SMEM4];      // V double buffer (144 KB); the epilogue's accumulator planes (144 KB) alias it
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = lfdm_uniform(tid >> 6);
@@ -68,12 +73,14 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
   const unsigned t0 = (unsigned)bx * W4T;
   const int n0 = by * W4N;
   const int cin = p.c0;
-  const int nch = cin / W4K;
+  const int nch = cin / W4K;           // 8-channel chunks of the filter layout
+  const int nper = cin / W4C;          // 16-channel periods (even: C_in % 32 == 0 is the plan's condition)
 
-  // nch is even (C_in % 16 == 0: the plan's condition): the chunk loops below run two chunks per trip as ONE basic block - with a
-  // break between the halves hipcc renamed the accumulators from trip to trip (out-of-place MFMAs: both tuples live, spills)
-  const int last = nch - 1;
-  auto clampc = [&](int c) { return c < last ? c : last; };      // re-fetching the last chunk is harmless
+  // nper is even: the period loops below run two periods per trip as ONE basic block - with a break between the halves hipcc renamed
+  // the accumulators from trip to trip (out-of-place MFMAs: both tuples live, spills)
+  const int last = nch - 1, lastp = nper - 1;
+  auto clampc = [&](int c) { return c < last ? c : last; };      // re-fetching the last chunk / period is harmless
+  auto clampp = [&](int c) { return c < lastp ? c : lastp; };
   float* const V0 = smem;
   float* const V1 = smem + V4SZ;
 
@@ -81,9 +88,9 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
   // and the SAME number of barriers - a common loop would keep the producers' 144 patch registers and the consumers' 144 accumulator
   // registers alive together.
   if (wave >= 4) {
-    // ---------------------------------------------------------------- PRODUCERS (waves 4, 5): thread = (tile, channel pair)
+    // ---------------------------------------------------------------- PRODUCERS (waves 4-7): thread = (tile, channel pair of 8)
     const int pt = tid - 256;
-    const int x_tile = pt >> 2, x_pair = pt & 3;
+    const int x_tile = pt >> 3, x_pair = pt & 7;
     const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
     const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
     uint32_t base0 = 0;
@@ -111,10 +118,14 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
 #ifdef LFDM_W4_PROBE
       if constexpr ((LFDM_W4_PROBE & 1) != 0) return;
 #endif
-      const uint32_t base = base0 + (uint32_t)chunk * (W4K * 4u);
+      const uint32_t base = base0 + (uint32_t)chunk * (W4C * 4u);
+      // issue order inside a patch row: columns 0, 4, 1, 5, 2, 3 - a wave's 8 lanes-of-8 are 8 horizontally adjacent tiles, and column
+      // c + 4 of tile i is column c of tile i + 1: requested back to back, 7/8 of the second load's 64-byte segments hit L1
+      // (the launch is bound by L2 -> L1 bandwidth: profiles/r03_p_wino4_ablation.txt)
 #pragma unroll
-      for (int q = 0; q < 36; ++q) {
-        const int r = q / 6, c = q % 6;
+      for (int qq = 0; qq < 36; ++qq) {
+        constexpr int corder[6] = {0, 4, 1, 5, 2, 3};
+        const int r = qq / 6, c = corder[qq % 6], q = 6 * r + c;
         // upsampled: logical rows 4ty-1 .. 4ty+4 are physical rows 2ty-1 + ((r+1)>>1)
         const int py = up ? (r + 1) >> 1 : r, px = up ? (c + 1) >> 1 : c;
         const uint32_t delta = (uint32_t)(py * p.wi + px) * ld4;
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
 #ifdef LFDM_W4_PROBE
       if constexpr ((LFDM_W4_PROBE & 16) != 0) return;
       if constexpr ((LFDM_W4_PROBE & 2) != 0) {
-        float* dst = V + x_tile * LDV4 + 2 * x_pair;
+        float* dst = V + x_tile * LDV4 + 4 * ((x_pair >> 1) ^ ((x_tile >> 2) & 3)) + 2 * (x_pair & 1);
 #pragma unroll
         for (int q = 0; q < 36; ++q) *reinterpret_cast<f32x2*>(dst + q * (W4T * LDV4)) = d[q];
         return;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
 #pragma unroll
       for (int c = 0; c < 6; ++c)
         bt6(d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c], d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c]);
-      float* dst = V + x_tile * LDV4 + 2 * x_pair;
+      float* dst = V + x_tile * LDV4 + 4 * ((x_pair >> 1) ^ ((x_tile >> 2) & 3)) + 2 * (x_pair & 1);      // swizzled 16-byte slot
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         f32x2 o[6];
@@ -147,16 +158,16 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
       }
     };
     fetch_patch(pa, 0);
-    fetch_patch(pb, clampc(1));
+    fetch_patch(pb, clampp(1));
     transform_store(pa, V0);
-    fetch_patch(pa, clampc(2));
+    fetch_patch(pa, clampp(2));
     __syncthreads();
-    for (int kc = 0; kc < nch; kc += 2) {
-      transform_store(pb, V1);                      // chunk kc+1 while the consumers multiply chunk kc from V0
-      fetch_patch(pb, clampc(kc + 3));
+    for (int kp = 0; kp < nper; kp += 2) {
+      transform_store(pb, V1);                      // period kp+1 while the consumers multiply period kp from V0
+      fetch_patch(pb, clampp(kp + 3));
       __syncthreads();
-      transform_store(pa, V0);                      // chunk kc+2 while the consumers multiply chunk kc+1 from V1
-      fetch_patch(pa, clampc(kc + 4));
+      transform_store(pa, V0);                      // period kp+2 while the consumers multiply period kp+1 from V1
+      fetch_patch(pa, clampp(kp + 4));
       __syncthreads();
     }
     __syncthreads();                                // the consumers' epilogue: one more barrier
@@ -191,16 +202,19 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
   for (int q = 0; q < 9; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  auto load_a = [&](float4 (&a)[3], const float* V, int g) {
+  const int a_swz = (l31 >> 2) & 3;
+  auto load_a = [&](float4 (&a)[3], const float* V, int half, int g) {      // channels [8*half + 4*kh, +4) = 16-byte slot 2*half + kh
 #pragma unroll
-    for (int u = 0; u < 3; ++u) a[u] = *reinterpret_cast<const float4*>(V + ((9 * cw + 3 * g + u) * W4T + l31) * LDV4 + 4 * kh);
+    for (int u = 0; u < 3; ++u)
+      a[u] = *reinterpret_cast<const float4*>(V + ((9 * cw + 3 * g + u) * W4T + l31) * LDV4 + 4 * ((2 * half + kh) ^ a_swz));
   };
-  auto consume = [&](const float* V, int chunk, int next_chunk) {
+  // one 8-channel chunk (half `half` of the period in V) against filter chunk `chunk`
+  auto consume = [&](const float* V, int half, int chunk, int next_chunk) {
     float4 a[2][3];                                // A fragments of the current and of the next group (LDS latency under the MFMAs)
-    load_a(a[0], V, 0);
+    load_a(a[0], V, half, 0);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {                 // three positions at a time: independent accumulator chains
-      if (g < 2) load_a(a[(g + 1) & 1], V, g + 1);
+      if (g < 2) load_a(a[(g + 1) & 1], V, half, g + 1);
       // the buffer of the PREVIOUS group is free (its MFMAs have been issued): it takes the group after next - group 2 of this chunk
       // (g = 0) or group g - 1 of the next chunk - which then has two groups of MFMAs to arrive
       if (g == 0) fetch_bg(bfr[2], 2, chunk);
@@ -226,10 +240,12 @@ __global__ __launch_bounds__(384) void conv_wino4_kernel(lfdm_conv_params p, int
   fetch_bg(bfr[0], 0, 0);
   fetch_bg(bfr[1], 1, 0);
   __syncthreads();
-  for (int kc = 0; kc < nch; kc += 2) {
-    consume(V0, kc, clampc(kc + 1));
+  for (int kp = 0; kp < nper; kp += 2) {
+    consume(V0, 0, 2 * kp, 2 * kp + 1);
+    consume(V0, 1, 2 * kp + 1, 2 * kp + 2);
     __syncthreads();
-    consume(V1, kc + 1, clampc(kc + 2));
+    consume(V1, 0, 2 * kp + 2, 2 * kp + 3);
+    consume(V1, 1, 2 * kp + 3, clampc(2 * kp + 4));
     __syncthreads();
   }
 
@@ -371,7 +387,7 @@ int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream) {
   const int gx = (int)((ntiles + W4T - 1) / W4T), ny = (p.coutp + W4N - 1) / W4N;
   const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny));
   const int ablate = 0;
-  if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(384), 0, stream, p, gx, ny, ablate);
-  else LFDM_LAUNCH((conv_wino4_kernel<false>), grid, dim3(384), 0, stream, p, gx, ny, ablate);
+  if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+  else LFDM_LAUNCH((conv_wino4_kernel<false>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
   return lfdm_check_launch("conv_wino4");
 }

@@ -903,10 +903,10 @@ def test_pack_wino_weight(backend):
 
 
 @pytest.mark.parametrize("case", [
-    dict(cin=16, cout=32, n=2, h=8, w=8),                                          # 8 tiles: a ragged workgroup
+    dict(cin=32, cout=32, n=2, h=8, w=8),                                          # 8 tiles: a ragged workgroup
     dict(cin=32, cout=40, n=10, h=8, w=8, residual=True, act=1),                   # 40 tiles: two workgroups, padded columns
-    dict(cin=16, cout=64, n=3, h=4, w=12, upsample=True, act=1),                   # through the virtual x2 upsample (8 x 24 image)
-    dict(cin=48, cout=32, n=1, h=16, w=4, residual=True),                          # one tile per image row; 3 chunk pairs
+    dict(cin=64, cout=64, n=3, h=4, w=12, upsample=True, act=1),                   # through the virtual x2 upsample (8 x 24 image)
+    dict(cin=96, cout=32, n=1, h=16, w=4, residual=True),                          # one tile per image row; 6 periods
     dict(cin=256, cout=256, n=40, h=32, w=32, residual=True, gpu_only=True),       # LFAE bottleneck ResBlock2d convolution
     dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),   # UpBlock2d
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
