@@ -1,12 +1,18 @@
-# end-of-round evidence: the whole -m gpu suite, smoke(), the default bench, a profiled step (kernel table + dispatch sequence),
-# the training kernel table.  Outputs under gpurun_out/$TAG (copy what should be judged into profiles/ as ${TAG}_*, and put the tag into profiles/LATEST:
-# bench.py quotes that run's rocprofv3 average beside its live figure).
+# end-of-round evidence: the whole -m gpu suite (with the achieved error of every comparison logged), smoke(), the default bench, bench.py --gpus 2
+# self-launched on the one GPU, a profiled step (kernel table + dispatch sequence), whole-step counters, the training kernel table.  Every
+# command under its own timeout.  Outputs under gpurun_out/$TAG (copy what should be judged into profiles/ as ${TAG}_*, and put the tag + the
+# counter file into profiles/LATEST: bench.py quotes them beside its live figures).
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -n 4 $O/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
-timeout 600 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
-# the N = 2 code path of bench.py on ONE GPU (both ranks on cuda:0, gloo instead of RCCL): barrier / max-over-ranks protocol, rank-0-only extras,
-# the training step with the gradient all-reduce across two ranks
-LFDM_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 600 $O/bench_n2_one_gpu.json; echo
-bash tools/prof_sequence.sh $TAG > $O/prof.txt 2>&1; tail -n 1 $O/step_sequence.txt
-bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt gpurun_out/p3/train_top_launches.txt $O/; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
+rm -f $O/parity.jsonl
+LFDM_PARITY_LOG=$O/parity.jsonl timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -n 4 $O/pytest_gpu.txt
+timeout 60 python tools/parity_margins.py $O/parity.jsonl $O/parity_margins.json | tail -n 3
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
+# (the CPU baseline leg is left to the driver's own bench run: ~2 minutes of host time that the evidence run does not need)
+timeout 500 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
+timeout 300 bash tools/prof_sequence.sh $TAG > $O/prof.txt 2>&1; tail -n 1 $O/step_sequence.txt
+timeout 400 bash tools/prof_step_pmc.sh $TAG > $O/pmc.txt 2>&1; head -n 3 $O/step_pmc.txt
+# the N = 2 code path of bench.py on ONE GPU: plain `python bench.py --gpus 2` re-executes itself under torch.distributed.run (both ranks on
+# cuda:0, gloo because fewer GPUs than ranks): barrier / max-over-ranks protocol, rank-0-only extras, the training step with the gradient
+# all-reduce across two ranks and its exposed-communication figure
+timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline --no-roofline > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 700 $O/bench_n2_one_gpu.json; echo
+timeout 300 bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt gpurun_out/p3/train_top_launches.txt $O/; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
