@@ -374,14 +374,15 @@ def warp_bench(model, img, iters=20):
     n = b * t
     h = img.shape[2]
     prevs = {k: torch.rand(n * r * r, c, device=img.device) for k, (r, c) in
-             {"u0": (h // 2, skips[1].shape[1]), "u1": (h, skips[0].shape[1]), "rgb": (h, 4)}.items()}
-    outs = {"lat": torch.empty(n * s * s, skips[2].shape[1], device=img.device),
+             {"l1": (s, skips[2].shape[1]), "u0": (h // 2, skips[1].shape[1]), "u1": (h, skips[0].shape[1]), "rgb": (h, 4)}.items()}
+    outs = {"lat": torch.empty(n * s * s, skips[2].shape[1], device=img.device), "l1": torch.empty_like(prevs["l1"]),
             "u0": torch.empty_like(prevs["u0"]), "u1": torch.empty_like(prevs["u1"]),
             "def": torch.empty(b, 3, t, h, h, device=img.device), "pred": torch.empty(b, 3, t, h, h, device=img.device)}
 
     def one_decode_warps():
         ops.warp_planar(img, t, fx, fy, None, s, s, wk["fsb"], wk["fst"], out=outs["def"])
         ops.warp_cl(skips[2], b, t, s, s, fx, fy, occ, out=outs["lat"], **wk)
+        ops.warp_cl(skips[2], b, t, s, s, fx, fy, occ, prev=prevs["l1"], out=outs["l1"], **wk)     # (a34: the latent-resolution skip again, blended)
         ops.warp_cl(skips[1], b, t, h // 2, h // 2, fx, fy, occ, prev=prevs["u0"], out=outs["u0"], **wk)
         ops.warp_cl(skips[0], b, t, h, h, fx, fy, occ, prev=prevs["u1"], out=outs["u1"], **wk)
         ops.warp_planar(img, t, fx, fy, occ, s, s, wk["fsb"], wk["fst"], prev=prevs["rgb"][:, :3], prev_is_cl=True,
@@ -389,7 +390,7 @@ def warp_bench(model, img, iters=20):
 
     # reference frame count: deform_input x6 per frame (the (3,128,128) source warp appears twice in a34)
     pure = n * (3 * h * h + skips[2].shape[1] * s * s)
-    blend = n * (skips[1].shape[1] * (h // 2) ** 2 + skips[0].shape[1] * h * h + 3 * h * h)
+    blend = n * (skips[2].shape[1] * s * s + skips[1].shape[1] * (h // 2) ** 2 + skips[0].shape[1] * h * h + 3 * h * h)
     elems, nbytes = pure + blend, 8 * pure + 12 * blend
     one_decode_warps()
     torch.cuda.synchronize()
@@ -406,7 +407,7 @@ def warp_bench(model, img, iters=20):
         with open(os.path.join(REPO_ROOT, pmc)) as f:
             tj = json.load(f)
         traffic, pmc_launches = tj.get("warp_bytes_per_video"), tj.get("warp_launches", 5)
-    return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 5 launches = all warps of one 40-frame decode)",
+    return {"value": round(elems / sec / 1e9, 2), "unit": "Gpix/s (channel-pixels, 6 launches = all warps of one 40-frame decode)",
             "us_per_video": round(sec * 1e6, 1), "elements": elems,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(gbs / 8000.0, 4), "traffic": traffic, "algorithmic_bytes": nbytes,
@@ -613,13 +614,19 @@ def main():
             "gflop_per_video_reference_dataflow": GFLOP_PER_VIDEO_REFERENCE,
             "whole_job_tflops_reference_dataflow": round(value * GFLOP_PER_VIDEO_REFERENCE / 1e3, 2),
         }
+        def guarded(fn, *a):                 # the secondary measurements must never cost the headline line
+            try:
+                return fn(*a)
+            except Exception as e:
+                return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
         if not args.no_roofline:
-            line["roofline"] = conv_roofline(model, 1e3 * elapsed / args.steps / WORKLOAD["sampling_timesteps"])
+            line["roofline"] = guarded(conv_roofline, model, 1e3 * elapsed / args.steps / WORKLOAD["sampling_timesteps"])
             log("roofline done")
-            line["warp"] = warp_bench(model, img)
+            line["warp"] = guarded(warp_bench, model, img)
             log("warp done")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = guarded(cpu_baseline)
             log("cpu baseline done")
     train = None
     if args.train_steps > 0:                 # every rank takes part (gradient all-reduce); after the headline measurement
