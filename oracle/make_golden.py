@@ -272,13 +272,14 @@ def main():
     ap.add_argument("--variants", action="store_true", help="only the variant fixtures: static clipping, use_residual_flow (sampling and "
                     "training), stochastic null conditioning (0 < null_cond_prob < 1)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
-    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
+    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.full:
         {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"), "c4": lambda: train_full_case("train_step_c4_b4_t40"),
          "c4b8": lambda: train_full_case("train_step_c4_b8_t40", b=8),
-         "c5": lambda: c5_case("sample_ddim10_c5_256")}[args.full]()
+         "c5": lambda: c5_case("sample_ddim10_c5_256"),
+         "c5d50": lambda: c5_case("sample_ddim50_c5_256", steps=50)}[args.full]()      # the configuration's real step count (~8 min here)
         return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])

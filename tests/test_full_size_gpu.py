@@ -126,8 +126,9 @@ def test_c4_training_step_t40(monkeypatch, fixture):
     assert worst[1] < 5e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
 
 
-def test_c5_natops_256_t40():
-    g = gold("sample_ddim10_c5_256")
+@pytest.mark.parametrize("fixture", ["sample_ddim10_c5_256", "sample_ddim50_c5_256"])      # 10 steps, and the configuration's own 50
+def test_c5_natops_256_t40(fixture):
+    g = gold(fixture)
     b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
     m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=int(g["steps"]), timesteps=int(g["timesteps"]),
                                          learn_null_cond=True, use_deconv=False, padding_mode="reflect")

@@ -21,7 +21,12 @@ SHAPES = [
     ("UNet 128->128 @16 x320 (B=8)", 320, 128, 128, 16, 16, False, False, 0),
     ("UNet 256->256 @8 x640 (B=16)", 640, 256, 256, 8, 8, False, False, 0),
     ("LFAE bottleneck 256->256 @32 x40 (B=1)", 40, 256, 256, 32, 32, False, True, 0),
+    ("UNet 64->64 @32 x40 (B=1)", 40, 64, 64, 32, 32, False, False, 0),
+    ("UNet 128->64 @32 x40 (B=1)", 40, 128, 64, 32, 32, False, False, 0),
+    ("UNet 128->128 @16 x40 (B=1)", 40, 128, 128, 16, 16, False, False, 0),
 ]
+if os.environ.get("W4_FROM"):
+    SHAPES = SHAPES[int(os.environ["W4_FROM"]):]
 
 
 def timed(fn, iters):
@@ -35,6 +40,25 @@ def timed(fn, iters):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def timed_graph(fn, n=20, reps=10):
+    """small launches: inside a replayed hipGraph (what the sampler does), us per launch"""
+    for _ in range(3):
+        fn()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (n * reps)
 
 
 def main():
@@ -68,7 +92,7 @@ def main():
             ops.conv_launch(pp)
             torch.cuda.synchronize()
             outs.append(out.clone())
-            us.append(timed(lambda: ops.conv_launch(pp), 10 if n >= 320 else 30))
+            us.append(timed_graph(lambda: ops.conv_launch(pp)) if n < 320 else timed(lambda: ops.conv_launch(pp), 10))
         gf = 2.0 * n * ho * wo * cout * cin * 9 / 1e9
         diff = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
         print("%-44s %8.1f | %9.1f %6.1f | %9.1f %6.1f | %5.2f | %9.2e" % (name, gf, us[0], gf / us[0] * 1e3, us[1], gf / us[1] * 1e3,
