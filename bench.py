@@ -252,12 +252,16 @@ def conv_roofline(model, ms_per_sampler_step):
     executed = w["gflop_per_step"] * 16.0 / 36.0
     prof = evidence_files()
     # PMC counters cannot be read from inside the process: the committed rocprofv3 --pmc passes of this build (tools/prof_step_pmc.sh)
-    traffic, traffic_src, step_traffic, direct_traffic = None, None, None, None
+    traffic, traffic_src, step_traffic, direct_traffic, traffic_lower = None, None, None, None, None
     if prof["pmc"]:
         with open(os.path.join(REPO_ROOT, prof["pmc"])) as f:
             tj = json.load(f)
         traffic, traffic_src = tj.get("wino_bytes_per_step"), prof["pmc"] + ": " + tj.get("source", "")
         direct_traffic = tj.get("direct_bytes_per_step")
+        wf = tj.get("families", {}).get("winograd", {})
+        # FETCH_SIZE counts 64 B per request: whole-line (128 B) requests need the guide's x2, isolated 64-byte segments (the patch gathers)
+        # are counted exactly (profiles/r03_x_fetch_calib.txt) - the x2 figure above is an UPPER bound for a kernel that mixes both
+        traffic_lower = round(wf["fetch_bytes"] / 2 + wf["write_bytes"]) if wf.get("fetch_bytes") else None
         if tj.get("step_bytes"):
             step_traffic = {"bytes": tj["step_bytes"], "fetch_bytes": tj.get("step_fetch_bytes"), "write_bytes": tj.get("step_write_bytes"),
                             "launches": tj.get("launches_per_step"), "mfma_util": tj.get("step_mfma_util"),
@@ -304,6 +308,9 @@ def conv_roofline(model, ms_per_sampler_step):
             "traffic": traffic, "traffic_unit": "HBM-side bytes per sampler step over the same launches incl. their reduce passes (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes, not live)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_step": w["algorithmic_bytes_per_step"],
             "traffic_over_algorithmic": round(traffic / max(1, w["algorithmic_bytes_per_step"]), 2) if traffic else None,
+            "traffic_lower_bound": traffic_lower,
+            "traffic_bounds_note": "traffic = FETCH_SIZE x2 + WRITE_SIZE (the guide's correction, exact for whole-line requests); traffic_lower_bound = FETCH_SIZE x1 "
+                                   "+ WRITE_SIZE (exact for isolated 64-byte segments such as the patch gathers); calibration: profiles/r03_x_fetch_calib.txt",
             "step_traffic": step_traffic,
             "launches": w["launches"], "split_k_launches": n_split, "us_per_launch": w["us_per_launch"], "gflop_per_step": w["gflop_per_step"],
             "executed_mfma_tflops": round(executed / (w["us_per_step"] * 1e-6) / 1e3, 2),

@@ -111,7 +111,8 @@ def main():
             warp["tcc"][k2] = warp["tcc"].get(k2, 0.0) + v2
     res = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, one pass each) over tools/pmc_video.py "
                      "(tools/prof_step_pmc.sh); last of 3 eager sampler steps, B = 1, 40 frames",
-           "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads, MI355X_MICROARCH.md); WRITE_SIZE as reported",
+           "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane streaming reads, MI355X_MICROARCH.md); WRITE_SIZE as reported.  "
+                         "Upper bound: isolated 64-byte segments are counted exactly (profiles/r03_x_fetch_calib.txt) - halve a family's fetch_bytes for the lower bound",
            "launches_per_step": n,
            "step_fetch_bytes": round(tot["fetch_bytes"]), "step_write_bytes": round(tot["write_bytes"]),
            "step_bytes": round(tot["fetch_bytes"] + tot["write_bytes"]),
