@@ -950,6 +950,47 @@ def test_conv2d_winograd4(backend, case, monkeypatch):
     assert_close(from_cl(out2.cpu(), n, ho, wo), ref, 1e-5, "winograd F(2x2) conv")
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_conv2d_winograd4_random_geometries(backend, seed, monkeypatch):
+    """Seeded random geometries through the F(4x4,3x3) schedule (ragged tile blocks, odd image counts, padded output columns, the virtual
+    upsample, residual in place, ReLU) against fp64 F.conv2d."""
+    import random
+    dev = backend
+    rnd_ = random.Random(4000 + seed)
+    monkeypatch.setenv("LFDM_WINO", "1")
+    monkeypatch.setenv("LFDM_WINO4", "1")
+    monkeypatch.setenv("LFDM_WINO4_MIN", "1")
+    for trial in range(4 if dev == "cpu" else 10):
+        cin = 32 * rnd_.randint(1, 3)
+        cout = rnd_.choice([24, 32, 40, 64, 96])
+        n = rnd_.randint(1, 5)
+        up = rnd_.random() < 0.3
+        h, w = rnd_.choice([1, 2, 3]) * (2 if up else 4), rnd_.choice([1, 2, 3, 5]) * (2 if up else 4)
+        x = rnd(n, cin, h, w, seed=10 * seed + trial)
+        wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
+        bias = rnd(cout, seed=5)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+        ref = F.conv2d(xin.double(), wt.double(), bias.double(), padding=1)
+        ho, wo = ref.shape[2], ref.shape[3]
+        inplace = rnd_.random() < 0.5
+        res = rnd(*ref.shape, seed=4 + trial) if inplace or rnd_.random() < 0.3 else None
+        if res is not None:
+            ref = ref + res.double()
+        act = rnd_.choice([0, 1])
+        if act:
+            ref = F.relu(ref)
+        wtd = wt.to(dev)
+        wd, ww, w4 = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wtd), ops.pack_wino4_weight(wtd)
+        resd = None if res is None else to_cl(res).to(dev)
+        kw = dict(bias=bias.to(dev), residual=resd, act=act, weight_wino=ww, weight_wino4=w4, upsample=up)
+        if inplace:
+            kw["out"] = resd                     # ResBlock2d: out aliases residual
+        pp, _ = ops.conv_params(to_cl(x).to(dev), wd, cout, 3, 3, n, h, w, **kw)
+        assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 4, (cin, cout, n, h, w, up)
+        out = ops.conv2d_cl(to_cl(x).to(dev), wd, cout, 3, 3, n, h, w, **kw)
+        assert_close(from_cl(out.cpu(), n, ho, wo), ref.float(), 2e-5, "winograd F(4x4) conv, random geometry %s" % ((cin, cout, n, h, w, up, inplace, act),))
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
     """Seeded random geometries through the Winograd schedule (tile raggedness, odd image counts, two-source splits,
