@@ -340,14 +340,21 @@ class GaussianDiffusion(nn.Module):
         unet = self.denoise_fn
         if torch.is_grad_enabled() and unet.training and any(p.requires_grad for p in unet.parameters()):
             from .unet_train import unet_train_forward
+            fkw = {}                            # forward(x, *args, **kwargs) -> denoise_fn(...) (:897-903, :870): the focus-present arguments
+            if "focus_present_mask" in kwargs and kwargs["focus_present_mask"] is not None:
+                fkw["focus"] = torch.as_tensor(kwargs.pop("focus_present_mask")).reshape(-1).tolist()
+            else:
+                kwargs.pop("focus_present_mask", None)
+            if "prob_focus_present" in kwargs:
+                fkw["prob_focus_present"] = float(kwargs.pop("prob_focus_present"))
             if kwargs:
-                raise NotImplementedError("p_losses(**%s): focus_present_mask is never enabled by the LFDM scripts" % list(kwargs))
+                raise TypeError("p_losses: unexpected keyword arguments %s" % list(kwargs))
             if fea.dim() == 5 and fea.stride(2) != 0 and fea.shape[2] > 1:
                 raise NotImplementedError("training with per-frame `fea`: the LFDM pipeline conditions on ONE reference "
                                           "frame (video_flow_diffusion.py:901); pass the (B,256,S,S) feature map")
             fea2d = fea[:, :, 0] if fea.dim() == 5 else fea
             pred_noise = unet_train_forward(unet, x_noisy, fea2d, t, cond, null_cond_prob=self.null_cond_prob,
-                                            none_cond_mask=none_cond_mask, rank_shard=self.rank_shard)
+                                            none_cond_mask=none_cond_mask, rank_shard=self.rank_shard, **fkw)
         else:
             was_training = unet.training
             unet.eval()

@@ -362,8 +362,22 @@ class Unet3D(ParamTree):
         self._conv(x, pk[prefix + "qkv.w"], 768, 1, n_img, s, out=qkv, ln_wsum=pk[prefix + "qkv.wsum"])
         return qkv, self._buf("at.o", rows, 256)
 
-    def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables):
+    def _temporal_attn(self, pk, prefix, x, batch, frames, s, c, outname, tables, focus=None):
         bias, cos, sin = tables
+        if focus is not None and any(focus):
+            # focus_present_mask (Attention.forward :313-317 / :342-352): a focused sample attends only to itself - its softmax row is
+            # exactly one-hot, so its attention output IS its value rows: to_out runs on the V columns of the LayerNorm-folded
+            # projection for those samples, on the attention output for the others (library launches on row ranges; never captured)
+            qkv, att = self._attn_common(pk, prefix, x, batch * frames, s, c)
+            if not all(focus):
+                ops.attention_cl(qkv, batch, frames, s * s, 0, bias=bias, rot_cos=cos, rot_sin=sin, out=att)
+            out = self._buf(outname, x.shape[0], c)
+            rows = frames * s * s
+            for b in range(batch):
+                sl = slice(b * rows, (b + 1) * rows)
+                src = qkv[sl, 512:768] if focus[b] else att[sl]
+                self._conv(src, pk[prefix + "out.w"], c, 1, frames, s, residual=x[sl], out=out[sl])
+            return out
         if c == 64 and frames <= 64:
             att = self._buf("at.o", x.shape[0], 256)
             ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
@@ -419,9 +433,10 @@ class Unet3D(ParamTree):
                                      7, 7, self.dim, bias=None if add_term is not None else pk["init.b"],
                                      add_term=add_term, out=r)
 
-    def run_trunk(self, pk, r, ss, batch, frames, s, out):
+    def run_trunk(self, pk, r, ss, batch, frames, s, out, focus=None):
         """r: init_conv output (B*T*S*S, dim) CL; ss: (B, sum 2C) scale/shift rows;
-        out: planar (B, 3, T, S, S)."""
+        out: planar (B, 3, T, S, S); focus: None or one bool per sample (focus_present_mask: every temporal attention of the
+        down / mid / up path, not init_temporal_attn - :547 vs :570, :575, :584)."""
         n_img = batch * frames
         tables = self._tables(pk, frames)
         dim = self.dim
@@ -434,7 +449,7 @@ class Unet3D(ParamTree):
             x = self._resblock(pk, p + "0.", x, None, batch, frames, res, ss, co, "d%d.a" % lvl)
             x = self._resblock(pk, p + "1.", x, None, batch, frames, res, ss, co, "d%d.b" % lvl)
             x = self._linear_attn(pk, p + "2.", x, batch, frames, res, co, "d%d.c" % lvl)
-            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, co, "d%d.skip" % lvl, tables)
+            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, co, "d%d.skip" % lvl, tables, focus)
             skips.append(x)
             if lvl < nl - 1:
                 out_d = self._buf("d%d.down" % lvl, n_img * (res // 2) ** 2, co)
@@ -443,14 +458,14 @@ class Unet3D(ParamTree):
         mid = self.levels[-1][1]
         x = self._resblock(pk, "mid_block1.", x, None, batch, frames, res, ss, mid, "m.a")
         x = self._spatial_attn(pk, "mid_spatial_attn.", x, batch, frames, res, mid, "m.b")
-        x = self._temporal_attn(pk, "mid_temporal_attn.", x, batch, frames, res, mid, "m.c", tables)
+        x = self._temporal_attn(pk, "mid_temporal_attn.", x, batch, frames, res, mid, "m.c", tables, focus)
         x = self._resblock(pk, "mid_block2.", x, None, batch, frames, res, ss, mid, "m.d")
         for lvl, (ci, co) in enumerate(reversed(self.levels)):
             p = "ups.%d." % lvl
             x = self._resblock(pk, p + "0.", x, skips.pop(), batch, frames, res, ss, ci, "u%d.a" % lvl)
             x = self._resblock(pk, p + "1.", x, None, batch, frames, res, ss, ci, "u%d.b" % lvl)
             x = self._linear_attn(pk, p + "2.", x, batch, frames, res, ci, "u%d.c" % lvl)
-            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, ci, "u%d.d" % lvl, tables)
+            x = self._temporal_attn(pk, p + "3.", x, batch, frames, res, ci, "u%d.d" % lvl, tables, focus)
             if lvl < nl - 1:
                 out_u = self._buf("u%d.up" % lvl, n_img * (res * 2) ** 2, ci)
                 if self.use_deconv:      # ConvTranspose (1,4,4) s2 p1 = four 2x2 parity convolutions, ONE launch
@@ -501,8 +516,13 @@ class Unet3D(ParamTree):
         (fea may differ per frame here; the samplers use the cheaper split path where it is constant)."""
         if self.has_cond and cond is None:
             raise AssertionError("cond must be passed in if cond_dim specified")
-        if prob_focus_present != 0 or (focus_present_mask is not None and bool(focus_present_mask.any())):
-            raise NotImplementedError("focus_present_mask: the LFDM scripts never enable it")
+        # :542-543: drawn BEFORE the null-condition mask (it consumes the RNG for 0 < prob < 1)
+        if focus_present_mask is None:
+            focus_present_mask = prob_mask_like((x.shape[0],), prob_focus_present, device=x.device)
+        focus = [bool(v) for v in torch.as_tensor(focus_present_mask).reshape(-1).tolist()]
+        if len(focus) != x.shape[0]:
+            raise ValueError("focus_present_mask: one entry per sample expected")
+        focus = focus if any(focus) else None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             # training mode under autograd: the differentiable executor (native forward AND backward kernels).  It takes
             # the reference image features as ONE (B,256,S,S) map - which is what the LFDM pipeline feeds (:901 repeats
@@ -516,7 +536,7 @@ class Unet3D(ParamTree):
                 raise NotImplementedError("Unet3D.forward under autograd: `fea` must be constant over the frame axis "
                                           "(video_flow_diffusion.py:901)")
             return unet_train_forward(self, x[:, :n_dyn].float(), fea[:, :, 0].contiguous().float(), time, cond,
-                                      null_cond_prob=null_cond_prob, none_cond_mask=none_cond_mask)
+                                      null_cond_prob=null_cond_prob, none_cond_mask=none_cond_mask, focus=focus)
         pk = self.packed()
         x = x.contiguous().float()
         batch, _, frames, s, _ = x.shape
@@ -543,4 +563,4 @@ class Unet3D(ParamTree):
             r = self.stem(pk, xd, term, batch * frames, 1, s)
         else:
             r = self.stem(pk, x, None, batch, frames, s)
-        return self.run_trunk(pk, r, ss, batch, frames, s, out)
+        return self.run_trunk(pk, r, ss, batch, frames, s, out, focus)

@@ -50,12 +50,18 @@ def _resblock(unet, c, prefix, x, skip, res, cout, temb_cond):
     return A.GroupNormSiLU.apply(h, g(prefix + "block2.norm.weight"), g(prefix + "block2.norm.bias"), None, x, c.batch, True)
 
 
-def _temporal_attn(unet, c, prefix, x, res):
+def _temporal_attn(unet, c, prefix, x, res, focus=None):
     g = unet.get
     n_img = c.batch * c.frames
     normed = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"))
     qkv = A.conv_cl(normed, g(prefix + "fn.fn.fn.to_qkv.weight"), None, n_img=n_img, hi=res, wi=res)
-    att = A.AttentionCL.apply(qkv, c.bias, c.cos, c.sin, c.batch, c.frames, res * res, 0)
+    if focus is not None and all(focus):          # Attention.forward :313-317: the values pass straight through to_out
+        att = qkv[:, 512:768].contiguous()
+    else:
+        att = A.AttentionCL.apply(qkv, c.bias, c.cos, c.sin, c.batch, c.frames, res * res, 0)
+        if focus is not None and any(focus):      # :342-352: a focused sample's softmax rows are exactly one-hot -> its value rows
+            rowmask = torch.tensor(focus, device=x.device).repeat_interleave(c.frames * res * res).view(-1, 1)
+            att = torch.where(rowmask, qkv[:, 512:768], att)
     return A.conv_cl(att, g(prefix + "fn.fn.fn.to_out.weight"), None, residual=x, n_img=n_img, hi=res, wi=res)
 
 
@@ -78,7 +84,8 @@ def _linear_attn(unet, c, prefix, x, res):
                      n_img=n_img, hi=res, wi=res)
 
 
-def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_cond_mask=None, rank_shard=None):
+def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_cond_mask=None, rank_shard=None, focus=None,
+                       prob_focus_present=0.):
     """x_dyn (B, 3, T, S, S) noisy flow/occlusion, fea (B, 256, S, S) reference-image features (constant over T),
     time (B,) long, cond (B, 768)  ->  eps_hat (B, 3, T, S, S) with grad to every UNet parameter."""
     g = unet.get
@@ -88,6 +95,18 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     dev = x_dyn.device
     n_img = b * t
     dim = unet.dim
+
+    # --- focus_present_mask (:542-543; drawn before the null-condition mask, like the reference): a list of bools or None
+    if focus is None and prob_focus_present != 0:
+        if rank_shard is not None:
+            from .diffusion import shard_bounds
+            lo, hi, total = shard_bounds(rank_shard, b)
+            focus = prob_mask_like((total,), prob_focus_present, device=dev)[lo:hi].tolist()
+        else:
+            focus = prob_mask_like((b,), prob_focus_present, device=dev).tolist()
+    if focus is not None:
+        focus = [bool(v) for v in focus]
+        focus = focus if any(focus) else None
 
     # --- conditioning (B x 1024 vectors: torch) (:549-562)
     if rank_shard is not None:       # sharded data parallelism: the draw of the global batch, this rank's slice
@@ -142,7 +161,7 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
         x = _resblock(unet, c, p + "0.", x, None, res, co, tc)
         x = _resblock(unet, c, p + "1.", x, None, res, co, tc)
         x = _linear_attn(unet, c, p + "2.", x, res)
-        x = _temporal_attn(unet, c, p + "3.", x, res)
+        x = _temporal_attn(unet, c, p + "3.", x, res, focus)
         skips.append(x)
         if lvl < nl - 1:
             x = A.conv_cl(x, g(p + "4.weight"), g(p + "4.bias"), n_img=n_img, hi=res, wi=res, stride=2, pad=(1, 1))
@@ -150,14 +169,14 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     mid = levels[-1][1]
     x = _resblock(unet, c, "mid_block1.", x, None, res, mid, tc)
     x = _mid_spatial_attn(unet, c, "mid_spatial_attn.", x, res)
-    x = _temporal_attn(unet, c, "mid_temporal_attn.", x, res)
+    x = _temporal_attn(unet, c, "mid_temporal_attn.", x, res, focus)
     x = _resblock(unet, c, "mid_block2.", x, None, res, mid, tc)
     for lvl, (ci, co) in enumerate(reversed(levels)):
         p = "ups.%d." % lvl
         x = _resblock(unet, c, p + "0.", x, skips.pop(), res, ci, tc)
         x = _resblock(unet, c, p + "1.", x, None, res, ci, tc)
         x = _linear_attn(unet, c, p + "2.", x, res)
-        x = _temporal_attn(unet, c, p + "3.", x, res)
+        x = _temporal_attn(unet, c, p + "3.", x, res, focus)
         if lvl < nl - 1:
             if unet.use_deconv:
                 x = A.conv_cl(x, g(p + "4.weight"), g(p + "4.bias"), n_img=n_img, hi=res, wi=res, kind="deconv")

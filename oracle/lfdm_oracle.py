@@ -221,11 +221,13 @@ def channel_layernorm(x, gamma, eps=1e-5):
     return (x - mean) / (var + eps).sqrt() * gamma
 
 
-def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None):
-    """Attention.forward (:303-363) with focus_present_mask all-False.
-    tokens (..., n, C); w_qkv (768, C); w_out (C, 256)."""
+def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None, focus=None):
+    """Attention.forward (:303-363).  tokens (..., n, C) - for the temporal form (b, h*w, f, C); w_qkv (768, C); w_out (C, 256);
+    focus: None or the (b,) bool focus_present_mask (:313-317, :342-352: a focused sample attends only to itself)."""
     qkv = tokens @ w_qkv.t()
     q, k, v = qkv.chunk(3, dim=-1)
+    if focus is not None and bool(focus.all()):          # :313-317: the values pass straight through to_out
+        return v @ w_out.t()
 
     def heads(z):
         return z.reshape(*z.shape[:-1], HEADS, DIM_HEAD).transpose(-2, -3)  # (..., h, n, d)
@@ -238,6 +240,11 @@ def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None):
     sim = q @ k.transpose(-1, -2)
     if pos_bias is not None:
         sim = sim + pos_bias
+    if focus is not None and not bool((~focus).all()):  # :342-352
+        n = sim.shape[-1]
+        mask = torch.where(focus.view(-1, 1, 1, 1, 1), torch.eye(n, dtype=torch.bool).view(1, 1, 1, n, n),
+                           torch.ones(n, n, dtype=torch.bool).view(1, 1, 1, n, n))
+        sim = sim.masked_fill(~mask, -torch.finfo(sim.dtype).max)
     sim = sim - sim.amax(dim=-1, keepdim=True)
     attn = sim.softmax(dim=-1)
     out = attn @ v                                   # (..., h, n, d)
@@ -245,13 +252,13 @@ def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None):
     return out @ w_out.t()
 
 
-def temporal_attention(x, sd, prefix, pos_bias, rotary):
+def temporal_attention(x, sd, prefix, pos_bias, rotary, focus=None):
     """Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention))) (:397-399,413)."""
     b, c, f, h, w = x.shape
     normed = channel_layernorm(x, sd[prefix + "fn.norm.gamma"])
     tokens = normed.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
     out = softmax_attention(tokens, sd[prefix + "fn.fn.fn.to_qkv.weight"],
-                            sd[prefix + "fn.fn.fn.to_out.weight"], pos_bias, rotary)
+                            sd[prefix + "fn.fn.fn.to_out.weight"], pos_bias, rotary, focus)
     out = out.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2)
     return out + x
 
@@ -321,8 +328,9 @@ def time_embedding(time, sd, prefix, dim=64):
     return F.linear(e, sd[prefix + "time_mlp.3.weight"], sd[prefix + "time_mlp.3.bias"])
 
 
-def unet_forward(sd, x, time, cond, null_mask=None, prefix="denoise_fn."):
-    """Unet3D.forward (:528-588) for prob_focus_present=0.
+def unet_forward(sd, x, time, cond, null_mask=None, prefix="denoise_fn.", focus_mask=None):
+    """Unet3D.forward (:528-588); focus_mask = the (B,) bool focus_present_mask (None = all False; it reaches every temporal attention
+    of the down / mid / up path, not init_temporal_attn: :547, :570, :575, :584).
     x (B,259,T,S,S) = [3 noisy channels | 256 fea channels]; time (B,) long; cond (B,768);
     null_mask (B,) bool (True -> use the null condition embedding).
     The variant (deconv/zeros vs upconv/reflect, learned null cond) is inferred from the keys."""
@@ -349,14 +357,14 @@ def unet_forward(sd, x, time, cond, null_mask=None, prefix="denoise_fn."):
         x = resnet_block(x, sd, q + "0.", t)
         x = resnet_block(x, sd, q + "1.", t)
         x = spatial_linear_attention(x, sd, q + "2.")
-        x = temporal_attention(x, sd, q + "3.", bias, rotary)
+        x = temporal_attention(x, sd, q + "3.", bias, rotary, focus_mask)
         skips.append(x)
         if (q + "4.weight") in sd:
             x = F.conv3d(x, sd[q + "4.weight"], sd[q + "4.bias"], stride=(1, 2, 2), padding=(0, 1, 1))
 
     x = resnet_block(x, sd, p + "mid_block1.", t)
     x = mid_spatial_attention(x, sd, p + "mid_spatial_attn.")
-    x = temporal_attention(x, sd, p + "mid_temporal_attn.", bias, rotary)
+    x = temporal_attention(x, sd, p + "mid_temporal_attn.", bias, rotary, focus_mask)
     x = resnet_block(x, sd, p + "mid_block2.", t)
 
     for lvl in range(n_levels):
@@ -365,7 +373,7 @@ def unet_forward(sd, x, time, cond, null_mask=None, prefix="denoise_fn."):
         x = resnet_block(x, sd, q + "0.", t)
         x = resnet_block(x, sd, q + "1.", t)
         x = spatial_linear_attention(x, sd, q + "2.")
-        x = temporal_attention(x, sd, q + "3.", bias, rotary)
+        x = temporal_attention(x, sd, q + "3.", bias, rotary, focus_mask)
         if (q + "4.weight") in sd:                      # ConvTranspose3d (:158)
             x = F.conv_transpose3d(x, sd[q + "4.weight"], sd[q + "4.bias"],
                                    stride=(1, 2, 2), padding=(0, 1, 1))

@@ -75,6 +75,18 @@ def unet_case(name, b, t, s, **variant):
     save(name, b=b, t=t, s=s, **outs)
 
 
+def unet_focus_case(name, b=3, t=4, s=8):
+    """Unet3D.forward with focus_present_mask (:542-543, Attention.forward :313-317 / :342-352): a mixed mask and the all-True shortcut."""
+    m = reference_model(s, t, 5)
+    x, time, cond = synth.unet_inputs(b, t, s)
+    mixed = torch.tensor([True, False, True][:b])
+    with torch.no_grad():
+        out_mixed = m.unet(x, time, cond=cond, null_cond_prob=0.0, focus_present_mask=mixed)
+        out_all = m.unet(x, time, cond=cond, null_cond_prob=0.0, focus_present_mask=torch.ones(b, dtype=torch.bool))
+        out_p1 = m.unet(x, time, cond=cond, null_cond_prob=0.0, prob_focus_present=1.0)
+    save(name, b=b, t=t, s=s, mask_mixed=mixed, focus_mixed=out_mixed, focus_all=out_all, focus_p1=out_p1)
+
+
 def sampler_case(name, b, t, s, hw, steps, timesteps, video_frames=None, static_clip=False, **variant):
     """video_frames: keep only these frame indices of the image-resolution outputs (fixture size).  static_clip: the
     GaussianDiffusion default use_dynamic_thres=False (x0.clamp(-1, 1), :729-732) instead of the wrapper's dynamic threshold."""
@@ -271,6 +283,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
     ap.add_argument("--variants", action="store_true", help="only the variant fixtures: static clipping, use_residual_flow (sampling and "
                     "training), stochastic null conditioning (0 < null_cond_prob < 1)")
+    ap.add_argument("--focus", action="store_true", help="only the focus_present_mask fixture (unet_tiny_focus)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
     ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
@@ -281,10 +294,14 @@ def main():
          "c5": lambda: c5_case("sample_ddim10_c5_256"),
          "c5d50": lambda: c5_case("sample_ddim50_c5_256", steps=50)}[args.full]()      # the configuration's real step count (~8 min here)
         return
+    if args.focus:
+        unet_focus_case("unet_tiny_focus")
+        return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])
         return
     if args.variants:
+        unet_focus_case("unet_tiny_focus")
         sampler_case("sample_ddim5_tiny_static", 2, 4, 8, 32, 5, 1000, static_clip=True)
         sampler_case("sample_ddim5_tiny_resflow", 2, 4, 8, 32, 5, 1000, use_residual_flow=True)
         train_case("train_step_128_resflow_p05", 4, 2, 128, ["label a", "None", "label c", "label d"], null_cond_prob=0.5,

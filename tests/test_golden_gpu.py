@@ -47,6 +47,19 @@ def test_unet_forward(name, variant):
         assert_close(m.unet.forward_with_cond_scale(x, time, cond=cond, cond_scale=2.0).cpu(), g["scale2"], 1e-3, "scale2")
 
 
+def test_unet_forward_focus_present_mask():
+    """focus_present_mask / prob_focus_present (Unet3D.forward :542-543, Attention.forward :313-317, :342-352) against the reference."""
+    g = gold("unet_tiny_focus")
+    b, t, s = int(g["b"]), int(g["t"]), int(g["s"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=5)
+    x, time, cond = synth.unet_inputs(b, t, s)
+    x, time, cond = x.cuda(), time.cuda(), cond.cuda()
+    with torch.no_grad():
+        assert_close(m.unet(x, time, cond=cond, focus_present_mask=g["mask_mixed"].cuda()).cpu(), g["focus_mixed"], 1e-3, "mixed focus mask")
+        assert_close(m.unet(x, time, cond=cond, focus_present_mask=torch.ones(b, dtype=torch.bool)).cpu(), g["focus_all"], 1e-3, "all focused")
+        assert_close(m.unet(x, time, cond=cond, prob_focus_present=1.0).cpu(), g["focus_p1"], 1e-3, "prob_focus_present = 1")
+
+
 @pytest.mark.parametrize("name", ["generator_32", "generator_128"])
 def test_generator(name):
     g = gold(name)

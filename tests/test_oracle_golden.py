@@ -47,6 +47,18 @@ def test_unet_forward(name, variant):
     assert_close(O.unet_forward_with_cond_scale(dsd, x, time, cond, 2.0), g["scale2"], 1e-5, "scale2")
 
 
+def test_unet_forward_focus_present_mask():
+    """Attention.forward's focus_present_mask branches (:313-317 all focused, :342-352 mixed) through Unet3D.forward, pinned by the reference."""
+    g = gold("unet_tiny_focus")
+    b, t, s = int(g["b"]), int(g["t"]), int(g["s"])
+    dsd = {"denoise_fn." + k: v for k, v in synth.unet_state().items()}
+    x, time, cond = synth.unet_inputs(b, t, s)
+    zeros = torch.zeros(b, dtype=torch.bool)
+    assert_close(O.unet_forward(dsd, x, time, cond, zeros, focus_mask=g["mask_mixed"]), g["focus_mixed"], 1e-5, "mixed focus mask")
+    assert_close(O.unet_forward(dsd, x, time, cond, zeros, focus_mask=~zeros), g["focus_all"], 1e-5, "all focused")
+    assert torch.equal(g["focus_all"], g["focus_p1"])          # prob_focus_present = 1 is the all-True mask
+
+
 def test_generator():
     g = gold("generator_32")
     b, hw = int(g["b"]), int(g["hw"])
