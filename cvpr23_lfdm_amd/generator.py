@@ -29,8 +29,6 @@ class Generator(ParamTree):
             num_regions=num_regions, with_flow_predictor=pixelwise_flow_predictor_params is not None,
             fp_block_expansion=fp.get("block_expansion", 64), fp_max_features=fp.get("max_features", 1024),
             fp_num_blocks=fp.get("num_blocks", 5)))
-        if not skips:
-            raise NotImplementedError("Generator(skips=False): every LFDM config sets skips: True")
         self.num_channels = num_channels
         self.num_down_blocks = num_down_blocks
         self.num_bottleneck_blocks = num_bottleneck_blocks
@@ -194,15 +192,19 @@ class Generator(ParamTree):
         for i in range(self.num_down_blocks):                # apply_optical(skip, prev) + UpBlock2d (:152-155)
             skip = skips[-(i + 1)]
             ci = skip.shape[1]
-            blended = ops.warp_cl(skip, b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
-                                  out=self._buf("dec.w%d" % i, n * res_h * res_w, ci), **wk)
+            blended = out                                    # Generator(skips=False): no skip blending (:152-153)
+            if self.skips:
+                blended = ops.warp_cl(skip, b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
+                                      out=self._buf("dec.w%d" % i, n * res_h * res_w, ci), **wk)
             co = self._feat(self.num_down_blocks - i - 1)
             out = ops.conv2d_cl(blended, pk["up%d.w" % i], co, 3, 3, n, res_h, res_w, bias=pk["up%d.b" % i],
                                 upsample=True, act=ops.ACT_RELU, weight_wino=pk["up%d.ww" % i], weight_wino4=pk["up%d.w4" % i],
                                 out=self._buf("dec.u%d" % i, n * 4 * res_h * res_w, co))
             res_h, res_w = res_h * 2, res_w * 2
-        blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
-                              out=self._buf("dec.wf", n * res_h * res_w, skips[0].shape[1]), **wk)
+        blended = out
+        if self.skips:
+            blended = ops.warp_cl(skips[0], b, frames, res_h, res_w, flow_x, flow_y, occ, prev=out,
+                                  out=self._buf("dec.wf", n * res_h * res_w, skips[0].shape[1]), **wk)
         rgb_buf = self._buf("dec.rgb", n * res_h * res_w, pk["final.cout"])
         if pk["final.small"] is not None:
             wsm, bsm = pk["final.small"]
@@ -211,6 +213,8 @@ class Generator(ParamTree):
         else:
             rgb = ops.conv2d_cl(blended, pk["final.w"], pk["final.cout"], 7, 7, n, res_h, res_w, bias=pk["final.b"],
                                 act=ops.ACT_SIGMOID, out=rgb_buf)[:, :c]
+        if not self.skips:          # (:160-161: no final blend with the warped source - only the layout change remains; no LFDM config)
+            return rgb.reshape(b, frames, res_h, res_w, c).permute(0, 4, 1, 2, 3).contiguous(), deformed
         prediction = ops.warp_planar(img, frames, flow_x, flow_y, occ, fh, fw, fsb, fst, prev=rgb, prev_is_cl=True,
                                      occ_scale=occ_scale, occ_bias=occ_bias)
         return prediction, deformed

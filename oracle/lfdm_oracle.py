@@ -505,8 +505,8 @@ def generator_compute_fea(gsd, img, n_down=2):
     return generator_encode(gsd, img, n_down)[-1]
 
 
-def generator_forward_with_flow(gsd, img, flow, occ, n_down=2, n_bottleneck=6):
-    """Generator.forward_with_flow (generator.py:136-166) with skips=True.
+def generator_forward_with_flow(gsd, img, flow, occ, n_down=2, n_bottleneck=6, use_skips=True):
+    """Generator.forward_with_flow (generator.py:136-166); use_skips = the constructor's `skips` (:153, :156, :161).
     img (B,3,H,W); flow (B,h,w,2); occ (B,1,h,w) -> dict(prediction, deformed)."""
     skips = generator_encode(gsd, img, n_down)
     deformed = deform_input(img, flow)
@@ -517,13 +517,16 @@ def generator_forward_with_flow(gsd, img, flow, occ, n_down=2, n_bottleneck=6):
         y = _conv(F.relu(_bn_eval(y, gsd, q + "norm2.")), gsd, q + "conv2.", 1)
         out = y + out
     for i in range(n_down):                            # UpBlock2d (util.py:107-112)
-        out = apply_optical(out, skips[-(i + 1)], flow, occ)
+        if use_skips:
+            out = apply_optical(out, skips[-(i + 1)], flow, occ)
         q = "up_blocks.%d." % i
         out = F.interpolate(out, scale_factor=2)
         out = F.relu(_bn_eval(_conv(out, gsd, q + "conv.", 1), gsd, q + "norm."))
-    out = apply_optical(out, skips[0], flow, occ)
+    if use_skips:
+        out = apply_optical(out, skips[0], flow, occ)
     out = torch.sigmoid(F.conv2d(out, gsd["final.weight"], gsd["final.bias"], padding=3))
-    out = apply_optical(out, img, flow, occ)
+    if use_skips:
+        out = apply_optical(out, img, flow, occ)
     return {"prediction": out, "deformed": deformed}
 
 

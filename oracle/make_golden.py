@@ -113,6 +113,17 @@ def generator_case(name, b, hw):
     save(name, b=b, hw=hw, fea=fea, prediction=out["prediction"], deformed=out["deformed"])
 
 
+def generator_noskips_case(name, b=2, hw=32):
+    """Generator(skips=False) (generator.py:24,57,153-161): the reference class itself with the constructor flag cleared."""
+    m = reference_model(hw // 4, 2, 5)
+    m.generator.skips = False
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    with torch.no_grad():
+        out = m.generator.forward_with_flow(img, flow, occ)
+    save(name, b=b, hw=hw, prediction=out["prediction"], deformed=out["deformed"])
+
+
 def train_case(name, b, t, hw, labels, compact=False, null_cond_prob=0.0, **variant):
     """One full DM training step of the reference (FlowDiffusion.optimize_parameters, single-GPU class) on synthetic
     frozen-LFAE + UNet checkpoints: pseudo ground truth, losses, per-parameter gradient / updated-weight statistics.
@@ -283,7 +294,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="only the DM training-step fixture")
     ap.add_argument("--variants", action="store_true", help="only the variant fixtures: static clipping, use_residual_flow (sampling and "
                     "training), stochastic null conditioning (0 < null_cond_prob < 1)")
-    ap.add_argument("--focus", action="store_true", help="only the focus_present_mask fixture (unet_tiny_focus)")
+    ap.add_argument("--focus", action="store_true", help="only the fixtures of the branches no LFDM script takes: focus_present_mask (unet_tiny_focus), Generator(skips=False)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
     ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
@@ -296,6 +307,7 @@ def main():
         return
     if args.focus:
         unet_focus_case("unet_tiny_focus")
+        generator_noskips_case("generator_32_noskips")
         return
     if args.train:
         train_case("train_step_128", 2, 2, 128, ["label a", "None"])

@@ -73,6 +73,19 @@ def test_generator(name):
     assert_close(out["prediction"].cpu(), g["prediction"], 1e-3, "prediction")
 
 
+def test_generator_without_skips():
+    """Generator(skips=False): no skip blending, no final blend with the warped source (generator.py:153-161)."""
+    g = gold("generator_32_noskips")
+    b, hw = int(g["b"]), int(g["hw"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=hw // 4, num_frames=2, sampling_timesteps=5)
+    m.generator.skips = False
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    out = m.generator.forward_with_flow(img.cuda(), flow.cuda(), occ.cuda())
+    assert_close(out["deformed"].cpu(), g["deformed"], 1e-3, "deformed")
+    assert_close(out["prediction"].cpu(), g["prediction"], 1e-3, "prediction")
+
+
 @pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny", "sample_ddim100_c2", "sample_ddim5_tiny_static",
                                   "sample_ddim5_tiny_resflow"])
 def test_sample_one_video(name):

@@ -71,6 +71,17 @@ def test_generator():
     assert_close(out["prediction"], g["prediction"], 1e-5, "prediction")
 
 
+def test_generator_without_skips():
+    """Generator(skips=False) (generator.py:153-161), minted from the reference class with the flag cleared."""
+    g = gold("generator_32_noskips")
+    b, hw = int(g["b"]), int(g["hw"])
+    img, _ = synth.inputs(b, hw)
+    flow, occ = synth.flow_inputs(b, hw // 4)
+    out = O.generator_forward_with_flow(synth.generator_state(), img, flow, occ, use_skips=False)
+    assert_close(out["deformed"], g["deformed"], 1e-5, "deformed")
+    assert_close(out["prediction"], g["prediction"], 1e-5, "prediction")
+
+
 @pytest.mark.parametrize("name", ["sample_ddim5_tiny", "sample_ddpm8_tiny", "sample_ddim5_tiny_static", "sample_ddim5_tiny_resflow"])
 def test_sample_one_video(name):
     """(_static: use_dynamic_thres=False, _resflow: use_residual_flow=True - both minted from the unmodified reference.)"""
