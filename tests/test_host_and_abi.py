@@ -125,3 +125,48 @@ def test_asm_load_pipelines_are_safe():
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "0 problem(s)" in r.stdout
+
+
+def test_pmc_video_report_on_a_synthetic_rocpd_database(tmp_path):
+    """tools/pmc_video_report.py (whole-step counters behind bench.py's roofline.step_traffic): the last sampler step is cut out between
+    the last two sampler_update_kernel dispatches, split-K reduce launches go to the family of the convolution before them, FETCH_SIZE is
+    doubled and both sizes are KB."""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+    seq = ["void (anonymous namespace)::step_cond_kernel(int)", "void conv_wino_kernel<false, 1, false>(lfdm_conv_params)",
+           "void conv_splitk_reduce_kernel(lfdm_conv_params)", "void conv_pw_kernel<1, 4, true>(lfdm_conv_params, int, int)",
+           "void gn_apply_kernel<512>(float const*)", "void sampler_update_kernel(p)"]
+    dbs = []
+    for tag, ctrs in (("f", {"FETCH_SIZE": 100.0}), ("w", {"WRITE_SIZE": 10.0}),
+                      ("s", {"SQ_VALU_MFMA_BUSY_CYCLES": 512.0, "SQ_BUSY_CU_CYCLES": 1.0, "SQ_WAVE_CYCLES": 4.0, "SQ_WAIT_ANY": 1.0}),
+                      ("t", {"TCC_HIT_sum": 3.0, "TCC_REQ_sum": 4.0, "GRBM_GUI_ACTIVE": 1.0})):
+        path = str(tmp_path / ("p_%s.db" % tag))
+        db = sqlite3.connect(path)
+        db.execute("create table pmc_events(dispatch_id int, name text, counter_name text, counter_value real, duration int)")
+        did = 0
+        for _ in range(3):
+            for k in seq:
+                did += 1
+                for cn, v in ctrs.items():
+                    for _inst in range(2):                      # two counter instances per dispatch
+                        db.execute("insert into pmc_events values(?,?,?,?,?)", (did, k, cn, v, 5000))
+        for k in ("void warp_cl_kernel<4>(p)", "void warp_planar_pixel_kernel(p)"):
+            did += 1
+            for cn, v in ctrs.items():
+                db.execute("insert into pmc_events values(?,?,?,?,?)", (did, k, cn, v, 30000))
+        db.commit()
+        db.close()
+        dbs.append(path)
+    out = str(tmp_path / "step.json")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_video_report.py")] + dbs + [out], check=True, stdout=subprocess.DEVNULL)
+    r = json.load(open(out))
+    assert r["launches_per_step"] == len(seq)
+    assert r["step_fetch_bytes"] == len(seq) * 2 * 100 * 2 * 1024          # 2 instances x 100 KB, doubled
+    assert r["step_write_bytes"] == len(seq) * 2 * 10 * 1024
+    assert r["families"]["winograd"]["launches"] == 2                       # the convolution and its reduce pass
+    assert r["families"]["direct"]["launches"] == 1 and r["families"]["norm"]["launches"] == 1
+    assert r["warp_launches"] == 2 and [w["kernel"][:7] for w in r["warp_launch_list"]] == ["warp_cl", "warp_pl"]
+    assert abs(r["step_mfma_util"] - (len(seq) * 2 * 512.0) / (1024.0 * len(seq) * 1.0)) < 1e-3   # GUI_ACTIVE: mean over instances
