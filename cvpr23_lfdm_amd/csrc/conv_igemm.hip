@@ -880,6 +880,11 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
                    "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
   }
+  if (p.defer_reduce && (p.ln_wsum || p.deconv4 || p.residual || p.act != LFDM_ACT_NONE || p.gn_partial || p.tile_counters)) {
+    lfdm_set_error("conv2d: defer_reduce leaves the raw split-K slabs for lfdm_groupnorm_splitk_apply_cl_f32: no LayerNorm fold, deconv4, "
+                   "residual, activation, fused statistics or in-launch reduction");
+    return LFDM_EINVAL;
+  }
   p.ksplit = pl.ksplit;
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
@@ -921,7 +926,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     rc = lfdm_check_launch("conv_igemm");
   }
   if (rc) return rc;
-  if (p.ksplit > 1 && !splitk_fused(pl, p)) {
+  if (p.ksplit > 1 && !splitk_fused(pl, p) && !p.defer_reduce) {
     LFDM_LAUNCH(conv_splitk_reduce_kernel,
                 dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M), p.deconv4 ? 4 : 1), dim3(256), 0,
                 stream, p);

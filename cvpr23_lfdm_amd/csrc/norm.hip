@@ -347,6 +347,135 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
                 scale_shift, ss_ld, eps, silu, residual);
 }
 
+
+// GroupNorm straight from split-K slabs: one workgroup per (group, sample) sums the slabs of its rows x channels into registers, reduces the
+// statistics (double), and writes y = silu(x * A[c] + B[c]) (+ residual).  1024 threads, GSK_MAX float4 per thread.
+constexpr int GSK_MAX = 20;
+__global__ __launch_bounds__(1024) void gn_splitk_apply_kernel(const float* __restrict__ partial, int ksplit, int64_t slab_stride, int coutp,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int pixels,
+                                                               int channels, int groups, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                               int ss_ld, const float* __restrict__ residual, float eps, int silu) {
+  __shared__ double red_s[16], red_q[16];
+  __shared__ float s_stat[2];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cg = channels / groups, cg4 = cg >> 2;              // 1024 % cg4 == 0: a thread keeps its channel quad
+  const int items = pixels * cg4;
+  const int q = tid % cg4, c0 = g * cg + 4 * q;
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bb = *reinterpret_cast<const float4*>(bias + c0);
+  float4 v[GSK_MAX];
+  float ls = 0.f, lq = 0.f;
+#pragma unroll
+  for (int it = 0; it < GSK_MAX; ++it) {
+    const int i = tid + it * 1024;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < items) {
+      const int64_t row = (int64_t)b * pixels + i / cg4;
+      const float* src = partial + row * coutp + c0;
+      float4 a = bb;
+      for (int z = 0; z < ksplit; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)z * slab_stride);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      v[it] = a;
+      ls += (a.x + a.y) + (a.z + a.w);
+      lq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+  }
+  double ds = (double)ls, dq = (double)lq;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    ds += __shfl_xor(ds, m);
+    dq += __shfl_xor(dq, m);
+  }
+  if ((tid & 63) == 0) {
+    red_s[tid >> 6] = ds;
+    red_q[tid >> 6] = dq;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      ts += red_s[w];
+      tq += red_q[w];
+    }
+    const double n = (double)pixels * (double)cg;
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_stat[0] = (float)mean;
+    s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = s_stat[0], rstd = s_stat[1];
+  float aa[4], ab[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    const float a = rstd * gamma[c];
+    float bsh = beta[c] - mean * a, asc = a;
+    if (scale_shift) {
+      const float sc = scale_shift[(int64_t)b * ss_ld + c] + 1.0f;
+      const float sh = scale_shift[(int64_t)b * ss_ld + channels + c];
+      asc = a * sc;
+      bsh = bsh * sc + sh;
+    }
+    aa[e] = asc;
+    ab[e] = bsh;
+  }
+#pragma unroll
+  for (int it = 0; it < GSK_MAX; ++it) {
+    const int i = tid + it * 1024;
+    if (i < items) {
+      const int64_t row = (int64_t)b * pixels + i / cg4;
+      float4 y;
+      y.x = fmaf(v[it].x, aa[0], ab[0]);
+      y.y = fmaf(v[it].y, aa[1], ab[1]);
+      y.z = fmaf(v[it].z, aa[2], ab[2]);
+      y.w = fmaf(v[it].w, aa[3], ab[3]);
+      if (silu) {
+        y.x = siluf_(y.x);
+        y.y = siluf_(y.y);
+        y.z = siluf_(y.z);
+        y.w = siluf_(y.w);
+      }
+      if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + row * channels + c0);
+        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+      }
+      *reinterpret_cast<float4*>(out + row * channels + c0) = y;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lfdm_groupnorm_splitk_ok(int pixels, int channels, int groups) {
+  if (pixels <= 0 || channels <= 0 || groups <= 0 || groups > 64 || channels % groups != 0) return 0;
+  const int cg = channels / groups;
+  if (cg % 4 != 0 || 1024 % (cg / 4) != 0) return 0;
+  return (int64_t)pixels * (cg / 4) <= (int64_t)GSK_MAX * 1024 ? 1 : 0;
+}
+
+extern "C" int lfdm_groupnorm_splitk_apply_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias,
+                                                  float* out, int batch, int pixels, int channels, int groups, const float* gamma,
+                                                  const float* beta, const float* scale_shift, int ss_ld, const float* residual,
+                                                  float eps, int apply_silu, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!partial || !out || !gamma || !beta || ksplit < 1 || batch <= 0 || coutp < channels || coutp % 4 != 0 ||
+      slab_stride < (long long)batch * pixels * coutp || (scale_shift && ss_ld < 2 * channels) ||
+      !lfdm_groupnorm_splitk_ok(pixels, channels, groups) || (((uintptr_t)partial | (uintptr_t)out) & 15) != 0 ||
+      (bias && ((uintptr_t)bias & 15) != 0) || (residual && ((uintptr_t)residual & 15) != 0)) {
+    lfdm_set_error("groupnorm_splitk_apply: bad arguments (see lfdm_groupnorm_splitk_ok)");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(gn_splitk_apply_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(1024), 0, stream, partial, ksplit, (int64_t)slab_stride,
+              coutp, bias, out, pixels, channels, groups, gamma, beta, scale_shift, ss_ld, residual, eps, apply_silu);
+  return lfdm_check_launch("groupnorm_splitk_apply");
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels) {

@@ -250,7 +250,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, defer_reduce=False):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -312,6 +312,7 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         _chk(lib, weight_wino4)
         assert weight_wino is not None and weight_wino4.shape == (36, cin // 8, coutp, 8) and weight_wino4.is_contiguous()
         p.weight_wino4 = weight_wino4.data_ptr()
+    p.defer_reduce = int(bool(defer_reduce))     # split-K slabs stay raw for groupnorm_splitk_apply_cl (no reduce launch)
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
     p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4)   # keep the tensors alive with the struct
     return p, out
@@ -432,6 +433,26 @@ def groupnorm_apply_cl(x, batch, gamma, beta, partial, nchunk, *, groups=8, scal
                                               scale_shift.stride(0) if scale_shift is not None else 0,
                                               _p(residual), eps, int(silu), _p(partial), nchunk, _p(ws),
                                               ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_apply_cl_f32")
+    return out
+
+
+def groupnorm_splitk_ok(pixels, channels, groups=8):
+    """Can groupnorm_splitk_apply_cl take this (sample, group) size in one workgroup (lfdm_groupnorm_splitk_ok)?"""
+    return bool(_lib().lfdm_groupnorm_splitk_ok(pixels, channels, groups))
+
+
+def groupnorm_splitk_apply_cl(partial, ksplit, slab_stride, coutp, bias, out, batch, gamma, beta, *, groups=8, scale_shift=None,
+                              residual=None, eps=1e-5, silu=True):
+    """GroupNorm (+ scale/shift, SiLU, residual) straight from the raw split-K slabs of the preceding convolution
+    (conv_params(defer_reduce=True)): bias + slab sum + statistics + apply in ONE launch.  lfdm_groupnorm_splitk_apply_cl_f32."""
+    lib = _lib()
+    rows, ch = out.shape
+    _chk(lib, partial, bias, out, gamma, beta, scale_shift, residual)
+    assert out.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == out.shape))
+    lib.check(lib.lfdm_groupnorm_splitk_apply_cl_f32(_p(partial), ksplit, slab_stride, coutp, _p(bias), _p(out), batch, rows // batch, ch,
+                                                     groups, _p(gamma), _p(beta), _p(scale_shift),
+                                                     scale_shift.stride(0) if scale_shift is not None else 0, _p(residual), eps,
+                                                     int(silu), _stream(lib)), "lfdm_groupnorm_splitk_apply_cl_f32")
     return out
 
 

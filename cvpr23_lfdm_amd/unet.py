@@ -21,6 +21,7 @@ _LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"
 # head each re-read the frame's rows eight times and hold 78-110 KB of LDS)
 _LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
 _RES_STREAM = os.environ.get("LFDM_RES_STREAM", "0") == "1"
+_GN_SPLITK = os.environ.get("LFDM_GN_SPLITK", "0") == "1"      # conv (split-K) -> GroupNorm without the reduce launch (ops.groupnorm_splitk_apply_cl)
 _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 
 
@@ -293,6 +294,12 @@ class Unet3D(ParamTree):
             part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
+        if (gn is not None and _GN_SPLITK and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
+                ops.groupnorm_splitk_ok(m // gn[0], cout, gn[1] if len(gn) > 1 else 8)):
+            # the slabs stay raw: the GroupNorm launch sums them, adds the bias and normalises (one workgroup per (sample, group))
+            p.defer_reduce = 1
+            ops.conv_launch(p)
+            return y, ("slabs", part, ksplit, m * coutp, coutp, bias)
         if gn is not None:
             batch, groups = gn[0], (gn[1] if len(gn) > 1 else 8)
             pixels = m // batch
@@ -308,6 +315,9 @@ class Unet3D(ParamTree):
         return (y, stats) if gn is not None else y
 
     def _gn(self, x, batch, gamma, beta, stats, groups=8, **kw):
+        if stats is not None and stats[0] == "slabs":
+            _, part, ksplit, slab_stride, coutp, bias = stats
+            return ops.groupnorm_splitk_apply_cl(part, ksplit, slab_stride, coutp, bias, x, batch, gamma, beta, groups=groups, **kw)
         gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
         if stats is not None:
             return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, groups=groups, **kw)

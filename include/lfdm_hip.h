@@ -128,6 +128,11 @@ typedef struct lfdm_conv_params {
      512-pixel x 32-column workgroups (LFDM_WINO4_MIN; LFDM_WINO4=0 disables): the frozen-LFAE decode of a training step, throughput
      mode - never the B = 1 sampler.  Bias / residual / activation / virtual x2 upsample as in the F(2x2) schedule. */
   const float* weight_wino4;
+  /* Optional (ABI version 6): defer_reduce = 1 and a plan that splits K -> the reduce pass is NOT launched: `partial` keeps the raw slabs
+     [ksplit][M][coutp] (no bias) for lfdm_groupnorm_splitk_apply_cl_f32, which sums them, adds the bias and applies the GroupNorm in one
+     launch (the low-resolution ResnetBlocks of a B = 1 step: conv + reduce + apply -> conv + apply).  `out` is not written.  Needs no
+     residual / activation / fused statistics / LayerNorm fold / deconv4.  Ignored when the plan does not split K. */
+  int defer_reduce;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
@@ -169,6 +174,16 @@ int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch, int pixel
                                 const float* scale_shift, int ss_ld, const float* residual,
                                 float eps, int apply_silu, const float* partial, int nchunk,
                                 void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* GroupNorm (+ scale/shift, SiLU, residual as above) straight from the split-K slabs of the preceding convolution
+ * (lfdm_conv_params.defer_reduce): x[row][c] = bias[c] + sum_z partial[z * slab_stride + row * coutp + c] is formed in registers, the
+ * statistics of a (sample, group) are reduced inside ONE workgroup (grid = groups x batch, 1024 threads, <= 20 float4 per thread:
+ * lfdm_groupnorm_splitk_ok), so neither the reduce launch nor a statistics pass exists.  out: (batch*pixels, channels) rows, ldo = channels. */
+int lfdm_groupnorm_splitk_ok(int pixels, int channels, int groups);
+int lfdm_groupnorm_splitk_apply_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias, float* out,
+                                       int batch, int pixels, int channels, int groups, const float* gamma, const float* beta,
+                                       const float* scale_shift, int ss_ld, const float* residual, float eps, int apply_silu,
+                                       lfdm_stream_t stream);
 
 /* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
 int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,

@@ -313,6 +313,43 @@ def test_conv2d_winograd_grouped(backend, case):
         assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")
 
 
+@pytest.mark.parametrize("case", [dict(b=2, pixels=40, c=128, ksplit=3, ss=True, res=False), dict(b=1, pixels=640, c=512, ksplit=6, ss=True, res=True),
+                                  dict(b=3, pixels=96, c=64, ksplit=1, ss=False, res=True, silu=False),
+                                  dict(b=1, pixels=2560, c=256, ksplit=3, ss=False, res=False, gpu_only=True)],
+                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
+def test_groupnorm_from_splitk_slabs(backend, case):
+    """lfdm_groupnorm_splitk_apply_cl_f32: bias + sum of the raw split-K slabs + GroupNorm(8) + scale/shift + SiLU + residual in one launch
+    (the conv -> reduce -> apply triple of the low-resolution ResnetBlocks without its middle launch) against F.group_norm."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    b, pixels, c, ks = case["b"], case["pixels"], case["c"], case["ksplit"]
+    coutp = (c + 31) // 32 * 32
+    rows = b * pixels
+    slabs = rnd(ks, rows, coutp, seed=1)
+    bias = rnd(c, seed=2)
+    gamma, beta = rnd(c, seed=3) + 1.0, rnd(c, seed=4)
+    ss = rnd(b, 2 * c, seed=5) * 0.5 if case["ss"] else None
+    res = rnd(rows, c, seed=6) if case["res"] else None
+    x = slabs[:, :, :c].double().sum(0).float() + bias                       # (rows, c) CL
+    xr = x.view(b, pixels, c).permute(0, 2, 1)                               # (b, c, pixels)
+    ref = F.group_norm(xr, 8, gamma, beta, eps=1e-5)
+    if ss is not None:
+        ref = ref * (ss[:, :c].unsqueeze(-1) + 1) + ss[:, c:].unsqueeze(-1)
+    if case.get("silu", True):
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(rows, c)
+    if res is not None:
+        ref = ref + res
+    assert ops.groupnorm_splitk_ok(pixels, c, 8)
+    out = torch.full((rows, c), float("nan"), device=dev)
+    ops.groupnorm_splitk_apply_cl(slabs.to(dev), ks, rows * coutp, coutp, bias.to(dev), out, b, gamma.to(dev), beta.to(dev),
+                                  scale_shift=None if ss is None else ss.to(dev), residual=None if res is None else res.to(dev),
+                                  silu=case.get("silu", True))
+    assert_close(out.cpu(), ref, TOL, "groupnorm from split-K slabs")
+    assert not ops.groupnorm_splitk_ok(10240, 128, 8)                         # 16x16 x 40 frames: too many elements for one workgroup
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,with_ss", [(64, True), (128, False), (512, True)])
 def test_groupnorm_silu(backend, c, with_ss):
