@@ -527,12 +527,15 @@ class Unet3D(ParamTree):
         if self.has_cond and cond is None:
             raise AssertionError("cond must be passed in if cond_dim specified")
         # :542-543: drawn BEFORE the null-condition mask (it consumes the RNG for 0 < prob < 1)
-        if focus_present_mask is None:
-            focus_present_mask = prob_mask_like((x.shape[0],), prob_focus_present, device=x.device)
-        focus = [bool(v) for v in torch.as_tensor(focus_present_mask).reshape(-1).tolist()]
-        if len(focus) != x.shape[0]:
-            raise ValueError("focus_present_mask: one entry per sample expected")
-        focus = focus if any(focus) else None
+        if focus_present_mask is None and prob_focus_present in (0, 1):      # (no random draw, no device round trip)
+            focus = [True] * x.shape[0] if prob_focus_present == 1 else None
+        else:
+            if focus_present_mask is None:
+                focus_present_mask = prob_mask_like((x.shape[0],), prob_focus_present, device=x.device)
+            focus = [bool(v) for v in torch.as_tensor(focus_present_mask).reshape(-1).tolist()]
+            if len(focus) != x.shape[0]:
+                raise ValueError("focus_present_mask: one entry per sample expected")
+            focus = focus if any(focus) else None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             # training mode under autograd: the differentiable executor (native forward AND backward kernels).  It takes
             # the reference image features as ONE (B,256,S,S) map - which is what the LFDM pipeline feeds (:901 repeats

@@ -97,7 +97,9 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     dim = unet.dim
 
     # --- focus_present_mask (:542-543; drawn before the null-condition mask, like the reference): a list of bools or None
-    if focus is None and prob_focus_present != 0:
+    if focus is None and prob_focus_present == 1:
+        focus = [True] * b
+    elif focus is None and prob_focus_present != 0:
         if rank_shard is not None:
             from .diffusion import shard_bounds
             lo, hi, total = shard_bounds(rank_shard, b)
