@@ -25,6 +25,19 @@ def _deps():
     return _sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(REPO_ROOT, "include", "lfdm_hip.h")]
 
 
+def source_fingerprint():
+    """12 hex digits over the kernel sources, the C ABI header and the package's Python files: identifies the BUILD a measurement
+    was taken on (bench.py prints it live; the rocprofv3 evidence files under profiles/ record the one they were taken on)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = _deps() + sorted(glob.glob(os.path.join(PKG_DIR, "*.py")))
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

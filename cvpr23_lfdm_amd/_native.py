@@ -75,6 +75,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "lfdm_last_error": (C.c_char_p, []),
     "lfdm_abi_version": (i32, []),
+    "lfdm_calib_mfma_f32": (i32, [f32p, i32, i32, stream_t]),
     "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
     "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
     "lfdm_conv2d_plan": (i32, [C.POINTER(ConvParams), C.POINTER(i32), C.POINTER(i32)]),

@@ -643,7 +643,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);  // conv_wino.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStream_t stream);  // conv_wino.hip
 int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
 int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream);         // conv_wino4.hip
 
@@ -659,6 +659,7 @@ struct ConvPlan {
                    // 4 = Winograd F(4x4,3x3), 512-pixel x 32-column tiles, batched shapes only (conv_wino4.hip)
   int bm, bn, ksplit;
   bool fast, simple;
+  int kgroups = 1;      // kind 2: K groups inside a workgroup (conv_wino.hip, template parameter G)
 };
 
 int conv_force() {   // debugging aid for tools/bench_conv.py: LFDM_CONV_FORCE=igemm|ksw
@@ -770,6 +771,31 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       if (k > 8) k = 8;
       if (k < 1) k = 1;
     }
+    // K groups (round 4, conv_wino.hip): where the whole launch fits the chip in one round of ONE workgroup per CU, run G = 3 wave
+    // groups per workgroup on interleaved chunks (latency hidden by the other groups' MFMAs, accumulators merged through LDS) and split K
+    // across workgroups only as far as 256 CUs allow: a third to a half of the slabs, no reduce launch at all at 8x8.
+    // LFDM_WINO_KG = 0 disables, 2 / 3 force that G for every launch whose geometry allows it (tools / tests; read per call).
+    int kg = 1;
+    {
+      const char* e = getenv("LFDM_WINO_KG");
+      const int force = e ? atoi(e) : -1;
+      const bool can = pl.bn == 32 && !p.pool2;
+      static const int min_ch = [] { const char* m = getenv("LFDM_WINO_KG_MINCH"); return m ? atoi(m) : 3; }();
+      static const int max_ch = [] { const char* m = getenv("LFDM_WINO_KG_MAXCH"); return m ? atoi(m) : 8; }();
+      if (can && force >= 2 && force <= 3) {
+        kg = force;
+      } else if (can && force != 0 && blocks <= 256) {
+        const int g = 3;
+        int kk = nch / (min_ch * g);
+        if (kk > 256 / blocks) kk = (int)(256 / blocks);
+        if (kk < 1) kk = 1;
+        if ((nch + kk * g - 1) / (kk * g) <= max_ch) {      // else: too long a slice per group for one workgroup per CU - the old plan
+          kg = g;
+          k = kk;
+        }
+      }
+    }
+    pl.kgroups = kg;
     pl.ksplit = user_k >= 1 ? user_k : k;
     if (pl.ksplit > nch) pl.ksplit = nch;
     if (p.pool2) pl.ksplit = 1;                     // the pooled epilogue needs the finished sums
@@ -913,7 +939,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
-    rc = lfdm_conv_wino_launch(p, pl.bn, stream);
+    rc = lfdm_conv_wino_launch(p, pl.bn, pl.kgroups, stream);
   } else if (pl.kind == 3) {
     rc = lfdm_conv_pw_launch(p, stream);
   } else if (pl.kind == 4) {

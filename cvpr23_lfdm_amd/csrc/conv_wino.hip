@@ -49,16 +49,25 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).  The same activation
 // written as a SECOND OUTPUT of the producing convolution's epilogue (one more float4 store per pixel) cost 103 us per launch
 // for the same 112 us pass: no gain either, removed (profiles/r02_ac_*).
-template <bool ACT, int NT, bool POOL = false>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+// G = K groups per workgroup (round 4).  A launch with fewer workgroups than the chip has slots (the 16x16 / 8x8 / 4x4 levels of a
+// B = 1 step) leaves every workgroup ALONE on its CU: one wave per SIMD, nothing to run while a chunk's patches and filter fragments are
+// in flight - 2.8 us per chunk against 0.85 us of matrix-pipe time (profiles/r02_g_wino_phases.txt); more split-K slices buy that
+// overlap only through HBM slabs and a reduce launch.  With G > 1 the workgroup has G x 4 waves: group g runs chunks g, g + G, ... of the
+// workgroup's K slice on its own V buffer - G waves per SIMD, so one group's loads fly under the other groups' MFMAs - and the groups'
+// accumulators meet in LDS on the way into the output transform (the epilogue reads G x 8 planes instead of 8).  All groups run the same
+// trip count (one barrier pair per round); a group whose last chunk does not exist multiplies zero patches.
+template <bool ACT, int NT, bool POOL = false, int G = 1>
+__global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
-  __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
+  __shared__ __attribute__((aligned(16))) float smem[G * VSZ];   // V during the loop (one buffer per K group); >= 8*WT*LDM each for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ float s_gn[2][4][WNB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kgrp = G > 1 ? lfdm_uniform((int)(threadIdx.x >> 8)) : 0;      // K group of this wave (wave-uniform)
+  const int tid = G > 1 ? (int)(threadIdx.x & 255u) : (int)threadIdx.x;     // thread inside the group: every index below is per group
+  const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
 #ifdef LFDM_WINO_TIMING
   // probe build only (tools/probe_wino_phases.py): cycle stamps of every workgroup go to p.tile_counters (unused by this schedule)
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
   float2 patch[16];
-  auto fetch_patch = [&](float2 (&patch)[16], int chunk) {
+  auto fetch_patch = [&](float2 (&patch)[16], int chunk, unsigned vmask) {
     int cc = chunk * WKC + cbase;
     const bool second = cc >= p.c0;
     if (second) cc -= p.c0;
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       // uniform (scalar registers); upsampled: logical rows 2ty-1..2ty+2 are physical rows ty-1, ty, ty, ty+1
       const int py = up ? ((q >> 2) + 1) >> 1 : (q >> 2), px = up ? ((q & 3) + 1) >> 1 : (q & 3);
       const uint32_t delta = (uint32_t)(py * p.wi + px) * ld4;
-      patch[q] = lfdm_buf_load_f2(buf, ((valid_mask >> q) & 1u) ? base + delta : LFDM_BUF_OOB);
+      patch[q] = lfdm_buf_load_f2(buf, ((vmask >> q) & 1u) ? base + delta : LFDM_BUF_OOB);
     }
   };
   // ---- weight fragments: lane (co = n0 + l31, k-slot kh) holds U[pos][16*chunk + 8*kh + s][co], s = 0..7 ----
@@ -211,29 +220,34 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const int kc_last = kc_end - 1;
   auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
 
-  float* const Vs = smem;           // [16 pos][WT tiles][LD]
+  float* const Vs = smem + kgrp * VSZ;           // [16 pos][WT tiles][LD] of this K group
 #ifdef LFDM_WINO_TIMING
   tstamp[1] = __builtin_readcyclecounter();
 #endif
+  // group g owns chunks kc_begin + g, + G, ...; every group runs `rounds` iterations (the barriers are workgroup wide): a chunk index
+  // past the slice reads zero patches (mask 0 -> out-of-range offsets) against the slice's last filter fragments
+  const int rounds = (kc_end - kc_begin + G - 1) / G;
+  const int kc0 = kc_begin + kgrp;
 #pragma unroll
-  for (int pi = 0; pi < 4; ++pi) fetch_b(pi, kc_begin);
+  for (int pi = 0; pi < 4; ++pi) fetch_b(pi, clampc(kc0));
   {
-    fetch_patch(patch, kc_begin);
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-      const int nxt = clampc(kc + 1);
+    fetch_patch(patch, clampc(kc0), (G == 1 || kc0 < kc_end) ? valid_mask : 0u);
+    for (int r = 0; r < rounds; ++r) {
+      const int nxt_raw = kc0 + (r + 1) * G;
+      const int nxt = clampc(nxt_raw);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
 #ifdef LFDM_WINO_TIMING
-      if (kc == kc_begin) tstamp[2] = __builtin_readcyclecounter();     // first patch arrived + transformed
+      if (r == 0) tstamp[2] = __builtin_readcyclecounter();     // first patch arrived + transformed
 #endif
       __syncthreads();
-      fetch_patch(patch, nxt);                                   // in flight under this chunk's MFMAs
+      fetch_patch(patch, nxt, (G == 1 || nxt_raw < kc_end) ? valid_mask : 0u);     // in flight under this round's MFMAs
 #pragma unroll
       for (int pi = 0; pi < 4; ++pi) {
         float4 a0, a1;
         load_a(Vs, pi, a0, a1);
         mfma_pos(a0, a1, pi);
-        fetch_b(pi, nxt);                                        // refilled in place for the next chunk
+        fetch_b(pi, nxt);                                        // refilled in place for the next round
       }
       __syncthreads();
     }
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   // Read side: thread = (tile, 4 consecutive output channels): 8 ds_read_b128, then the 2x2 output pixels as float4 stores
   // (8 lanes cover a pixel's 128-byte row segment) - 4x fewer LDS / global instructions than one channel per lane
   // (epilogue 4.7 -> measured in profiles/r02_*).  The plan only selects this schedule when float4 accesses are legal.
-  float* const Ms = smem;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
+  // K groups: every group parks its planes in its own buffer; group 0 sums them while it reads and runs the epilogue alone
+  float* const Ms = smem + kgrp * VSZ;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
   const int e_tile = tid >> 3, e_c4 = tid & 7;
   float gs[NT][4], gq[NT][4];
 #pragma unroll
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     if (p.bias && ksplit == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
     const int n = my_n;                                 // e_tile == x_tile == tid >> 3
     const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
-    const bool live = n >= 0 && co < p.coutp;
+    const bool live = n >= 0 && co < p.coutp && kgrp == 0;
     float4 res[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                        // residual rows requested before the barrier
@@ -278,6 +293,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       float4 m[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) m[q] = *reinterpret_cast<const float4*>(Ms + (q * WT + e_tile) * LDM + 4 * e_c4);
+#pragma unroll
+      for (int g = 1; g < G; ++g)       // (kgrp == 0 here: Ms is buffer 0, the other groups' planes follow at VSZ strides)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(Ms + g * VSZ + (q * WT + e_tile) * LDM + 4 * e_c4);
+          m[q].x += t.x; m[q].y += t.y; m[q].z += t.z; m[q].w += t.w;
+        }
       float4 y[4];                   // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
       y[0] = make_float4(m[0].x + m[2].x + m[4].x, m[0].y + m[2].y + m[4].y, m[0].z + m[2].z + m[4].z, m[0].w + m[2].w + m[4].w);
       y[1] = make_float4(m[1].x + m[3].x + m[5].x, m[1].y + m[3].y + m[5].y, m[1].z + m[3].z + m[5].z, m[1].w + m[3].w + m[5].w);
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #ifdef LFDM_WINO_TIMING
   tstamp[4] = __builtin_readcyclecounter();
   tstamp[5] = wall_clock64() - wall0;
-  if (tid == 0 && p.tile_counters) {
+  if (threadIdx.x == 0 && p.tile_counters) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.tile_counters) +
                               ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
     for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
           sv += __shfl_xor(sv, msk);
           qv += __shfl_xor(qv, msk);
         }
-        if (lane < 8) {
+        if (lane < 8 && kgrp == 0) {
           s_gn[0][wave][WN * ct + 4 * e_c4 + e] = sv;
           s_gn[1][wave][WN * ct + 4 * e_c4 + e] = qv;
         }
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     __syncthreads();
     const int cg = p.cout / p.gn_groups;
     const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32: host check)
-    if (tid < gpt && n0 + tid * cg < p.cout) {
+    if (kgrp == 0 && tid < gpt && n0 + tid * cg < p.cout) {
       float sv = 0.f, qv = 0.f;
       for (int c = 0; c < cg; ++c)
         for (int w4 = 0; w4 < 4; ++w4) {
@@ -414,12 +436,22 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
   return lfdm_check_launch("pack_wino_weight");
 }
 
-// grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, hipStream_t stream) {
-  if (getenv("LFDM_WINO_TRACE") != nullptr) fprintf(stderr, "conv_wino: bn=%d ksplit=%d groups=%d\n", bn, p.ksplit, p.groups);   // which schedule ran: sweeps and tests
+// grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).  kgroups = G (1, 2, 3; 32-column tiles only).
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStream_t stream) {
+  if (getenv("LFDM_WINO_TRACE") != nullptr) fprintf(stderr, "conv_wino: bn=%d ksplit=%d groups=%d kgroups=%d\n", bn, p.ksplit, p.groups, kgroups);   // which schedule ran: sweeps and tests
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
+  if (kgroups > 1 && bn == 32 && !p.pool2) {
+    if (kgroups == 2) {
+      if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, 2>), grid, dim3(512), 0, stream, p);
+      else LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 2>), grid, dim3(512), 0, stream, p);
+    } else {
+      if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, 3>), grid, dim3(768), 0, stream, p);
+      else LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 3>), grid, dim3(768), 0, stream, p);
+    }
+    return lfdm_check_launch("conv_wino");
+  }
   if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)
     if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
     else LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);

@@ -580,6 +580,39 @@ def step_cond(step_table, batch_base, step_dev, out):
     return out
 
 
+def calib_mfma(device, blocks=256, iters=4000, reps=3):
+    """Box calibration (lfdm_calib_mfma_f32; never on the product path): the fp32 matrix rate and the shader clock this GPU holds
+    under a pure v_mfma_f32_32x32x2_f32 load RIGHT NOW.  Returns {"tflops", "mhz", "mhz_min", "mhz_max", "us"} (best of `reps`)."""
+    lib = _lib()
+    out = torch.zeros(2 * blocks + 256, dtype=torch.float32, device=device)
+    _chk(lib, out)
+    launch = lambda n: lib.check(lib.lfdm_calib_mfma_f32(_p(out), blocks, n, _stream(lib)), "lfdm_calib_mfma_f32")
+    launch(64)
+    # an idle chip sits at ~500 MHz and needs some milliseconds of load to ramp: 30 ms of the same kernel first (round 4, call A: the
+    # un-warmed figure read 134 TFLOP/s at 2115 MHz on a box that holds 2390 MHz)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(60):
+        launch(iters)
+    e1.record()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch(iters)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3
+        v = out[:2 * blocks].view(blocks, 2).double().cpu()
+        mhz = 100.0 * v[:, 0] / v[:, 1].clamp(min=1.0)
+        row = {"tflops": round(blocks * 4 * iters * 4 * 4096.0 / us / 1e6, 1), "mhz": round(float(mhz.median()), 0),
+               "mhz_min": round(float(mhz.min()), 0), "mhz_max": round(float(mhz.max()), 0), "us": round(us, 1)}
+        if best is None or row["tflops"] > best["tflops"]:
+            best = row
+    return best
+
+
 def sinusoidal_freqs(dim, device):
     """fp32 frequency table, computed with the reference's expression (video_flow_diffusion.py:148-150)."""
     import math

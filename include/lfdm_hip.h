@@ -508,6 +508,12 @@ int lfdm_depthwise_down_planar_f32(const float* x, const float* wgt, float* out,
 int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int pad,
                               int reflect, int backward, lfdm_stream_t stream);
 
+/* Box calibration, not on the product path (bench.py prints it beside every timing; ABI version 7): `blocks` workgroups of four
+ * wavefronts run `iters` x 4 independent v_mfma_f32_32x32x2_f32 (2 * 32 * 32 * 2 FLOP each, pseudo-random operands) and
+ * record, per workgroup b, out[2b] = shader cycles and out[2b+1] = 100 MHz real-time ticks of the loop: effective clock (MHz) =
+ * 100 * out[2b] / out[2b+1]; the caller times the launch for the TFLOP/s.  out holds 2 * blocks + 256 floats. */
+int lfdm_calib_mfma_f32(float* out, int blocks, int iters, lfdm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -863,14 +863,21 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn", ["32", "64"], ids=["n32", "n64"])
+@pytest.mark.parametrize("bn", ["32", "64", "32-kg2", "32-kg3", "32-auto"], ids=["n32", "n64", "n32kg2", "n32kg3", "n32auto"])
 def test_conv2d_winograd(backend, case, bn, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
-    tile order of the low-resolution levels."""
+    tile order of the low-resolution levels and the K-group workgroups (G = 2 / 3 wave groups on interleaved chunks, merged in LDS;
+    `auto` = the plan's own choice of G and split-K)."""
     dev = backend
     if case.get("gpu_only") and not big(dev):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
+    bn, _, kg = bn.partition("-")
+    monkeypatch.setenv("LFDM_WINO_KG", {"": "0", "kg2": "2", "kg3": "3"}.get(kg, ""))
+    if kg == "auto":
+        monkeypatch.delenv("LFDM_WINO_KG")
+        case = dict(case)
+        case.pop("ksplit", None)                    # the plan chooses split-K as well
     monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
@@ -893,12 +900,12 @@ def test_conv2d_winograd(backend, case, bn, monkeypatch):
         src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
     wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
     kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act,
-              ksplit=case.get("ksplit", 1), weight_wino=ww, upsample=up)
+              ksplit=case.get("ksplit", 0 if kg == "auto" else 1), weight_wino=ww, upsample=up)
     pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
     rows, ks = ops.conv_plan(pp)
     assert rows == (128 if ks == 1 else 16), "the Winograd plan was not selected"
     partial = None
-    if case.get("gn"):
+    if case.get("gn") and ks == 1:
         pixels = h * w * n // 2                    # two samples
         partial = torch.zeros(2 * (pixels // rows), 16, device=dev)
         kw.update(gn_partial=partial, gn_groups=8, gn_pixels=pixels)
@@ -1046,6 +1053,7 @@ def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
         split = rnd_.choice([0, 16]) if cin > 16 else 0
         monkeypatch.setenv("LFDM_WINO", "1")
         monkeypatch.setenv("LFDM_WINO_BN", rnd_.choice(["32", "64"]))
+        monkeypatch.setenv("LFDM_WINO_KG", rnd_.choice(["0", "2", "3", "3"]))       # K groups per workgroup (0 = one group)
         x = rnd(n, cin, h, w, seed=10 * seed + trial)
         wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
         bias = rnd(cout, seed=5)

@@ -127,6 +127,13 @@ def main():
            "warp_write_bytes_per_video": round(warp["write_bytes"]), "warp_bytes_per_video": round(warp["fetch_bytes"] + warp["write_bytes"]),
            "warp_sq": {k: round(v) for k, v in warp["sq"].items()}, "warp_tcc": {k: round(v) for k, v in warp["tcc"].items()},
            "warp_dur_us_serialised": round(warp["dur_us_serialised"], 1), "warp_launch_list": warp["list"]}
+    try:        # the build these counters were taken on (bench.py prints it beside its own live fingerprint)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from cvpr23_lfdm_amd._build import source_fingerprint
+        res["build"] = source_fingerprint()
+    except Exception:
+        res["build"] = None
     with open(out_json, "w") as f:
         json.dump(res, f, indent=1)
     print("# last sampler step: %d launches; HBM-side %.1f MB fetched (x2-corrected) + %.1f MB written; matrix-pipe utilisation (MFMA-busy cycles / "
