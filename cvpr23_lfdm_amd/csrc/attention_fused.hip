@@ -30,6 +30,12 @@ constexpr int HEADS = 8;
 constexpr int DH = 32;
 constexpr int OUT_LD = HEADS * DH;      // 256
 
+#if defined(LFDM_EMU_BUILD)
+static inline float fast_exp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }      // v_exp_f32(x * log2 e)
+#endif
+
 // Attention of one (sequence, head) from operand-layout fragments (see the header comment): scores transposed,
 // softmax in registers, P V, store.  qf/kf[ti][4*fi + r] = feature 16*fi + 4*lq + r of token 16*ti + l15 (q scaled and
 // rotated, k rotated); vf[half][4*ti + r] = v[token 16*ti + 4*lq + r][16*half + l15].
@@ -50,6 +56,9 @@ __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const flo
       for (int s = 0; s < 8; ++s) acc = mfma_16x16x4(kf[tj][s], qf[ti][s], acc);
       st[ti][tj] = acc;
     }
+  // VALU diet (round 4; the head loop spends as many issue cycles outside the matrix pipe as inside it: 39 IEEE divisions, 36 expf
+  // expansions per head): exp is the hardware exponential (v_exp_f32 on x * log2 e: the arguments are <= 0, the
+  // result within 2 ulp of expf), and the normalisation multiplies by ONE reciprocal per query instead of dividing every probability.
 #pragma unroll
   for (int ti = 0; ti < NT; ++ti) {
     const int qt = ti * 16 + l15;                     // this lane's query token
@@ -58,7 +67,7 @@ __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const flo
     for (int tj = 0; tj < NT; ++tj) {
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
       const int key0 = tj * 16 + lq * 4;
-      if (bias && qt < L && key0 < L) {
+      if (bias && qt < L && key0 < L) {                 // (guarded: unconditional loads of all nine fragments spill 84 registers)
         const float* bp = bias + ((int64_t)head * L + qt) * L + key0;
         if (bias_vec) {                                 // four consecutive keys of one query row: one 16-byte load
           const float4 b4 = *reinterpret_cast<const float4*>(bp);
@@ -70,9 +79,7 @@ __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const flo
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = st[ti][tj][r];
-        if (key0 + r >= L) v = -3.0e38f;
-        else v += bv[r];
+        const float v = (key0 + r >= L) ? -3.0e38f : st[ti][tj][r] + bv[r];
         st[ti][tj][r] = v;
         m = fmaxf(m, v);
       }
@@ -85,16 +92,17 @@ __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const flo
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = tj * 16 + lq * 4 + r;
-        const float e = key < L ? expf(st[ti][tj][r] - m) : 0.f;
+        const float e = key < L ? fast_exp(st[ti][tj][r] - m) : 0.f;
         st[ti][tj][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] / sum;
+      for (int r = 0; r < 4; ++r) st[ti][tj][r] = st[ti][tj][r] * inv;
   }
 
   // ---- O = P V ----

@@ -771,25 +771,26 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       if (k > 8) k = 8;
       if (k < 1) k = 1;
     }
-    // K groups (round 4, conv_wino.hip): where the whole launch fits the chip in one round of ONE workgroup per CU, run G = 3 wave
-    // groups per workgroup on interleaved chunks (latency hidden by the other groups' MFMAs, accumulators merged through LDS) and split K
-    // across workgroups only as far as 256 CUs allow: a third to a half of the slabs, no reduce launch at all at 8x8.
-    // LFDM_WINO_KG = 0 disables, 2 / 3 force that G for every launch whose geometry allows it (tools / tests; read per call).
+    // K groups (round 4, conv_wino.hip: G wave groups per workgroup on interleaved chunks, accumulators merged through LDS).  Built against
+    // the per-chunk latency of workgroups that are alone on their CUs and MEASURED NEUTRAL (tools/bench_wino_kg.py with cold filters,
+    // profiles/r04_b_bench_wino_kg.txt: 512 -> 512 @4x4 G3 k3 35.6 us vs the plan's k6 34.9, 256 -> 256 @8x8 G3 k1 35.3 vs k3 31.6; end
+    // to end 306.3 vs 300.7 ms per video): two co-resident split-K workgroups already keep a CU's matrix pipe 2/3 busy in the K loop, what
+    // those launches lose is fixed cost (set-up, first patch, epilogue, reduce pass), which K groups do not remove.  Opt-in only:
+    // LFDM_WINO_KG = 2 / 3 forces that G, "auto" = G 3 with as little split-K as fills 256 CUs (read per call: tools / tests).
     int kg = 1;
     {
       const char* e = getenv("LFDM_WINO_KG");
-      const int force = e ? atoi(e) : -1;
-      const bool can = pl.bn == 32 && !p.pool2;
-      static const int min_ch = [] { const char* m = getenv("LFDM_WINO_KG_MINCH"); return m ? atoi(m) : 3; }();
-      static const int max_ch = [] { const char* m = getenv("LFDM_WINO_KG_MAXCH"); return m ? atoi(m) : 8; }();
-      if (can && force >= 2 && force <= 3) {
+      const int force = (e && e[0] >= '2' && e[0] <= '3') ? e[0] - '0' : 0;
+      const bool autok = e && e[0] == 'a';
+      const bool can = (pl.bn == 32 || force == 2) && !p.pool2;      // (64-column workgroups: two groups at most - registers)
+      if (can && force) {
         kg = force;
-      } else if (can && force != 0 && blocks <= 256) {
-        const int g = 3;
+      } else if (can && autok && blocks <= 256) {
+        const int g = 3, min_ch = 3, max_ch = 8;
         int kk = nch / (min_ch * g);
         if (kk > 256 / blocks) kk = (int)(256 / blocks);
         if (kk < 1) kk = 1;
-        if ((nch + kk * g - 1) / (kk * g) <= max_ch) {      // else: too long a slice per group for one workgroup per CU - the old plan
+        if ((nch + kk * g - 1) / (kk * g) <= max_ch) {      // else: too long a slice per group for one workgroup per CU - the plain plan
           kg = g;
           k = kk;
         }

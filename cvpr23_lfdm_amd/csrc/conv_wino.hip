@@ -442,6 +442,11 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStr
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
+  if (kgroups == 2 && bn == 64 && !p.pool2) {      // 64 columns x two K groups: 250 VGPRs x two waves per SIMD
+    if (act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, 2>), grid, dim3(512), 0, stream, p);
+    else LFDM_LAUNCH((conv_wino_kernel<false, 2, false, 2>), grid, dim3(512), 0, stream, p);
+    return lfdm_check_launch("conv_wino");
+  }
   if (kgroups > 1 && bn == 32 && !p.pool2) {
     if (kgroups == 2) {
       if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, 2>), grid, dim3(512), 0, stream, p);

@@ -89,11 +89,14 @@ class GaussianDiffusion(nn.Module):
         # draws are made for the GLOBAL batch on every rank (identical generators) and sliced
         self.rank_shard = None
 
-    def skip_step_draws(self, total, sample_shape, device):
-        """Advance the default generator exactly as one training step over `total` videos does (t :899, noise :858, the null
-        condition mask :55-61) without running the model - a data-parallel rank whose shard is empty this step."""
+    def skip_step_draws(self, total, sample_shape, device, prob_focus_present=0.):
+        """Advance the default generator exactly as one training step over `total` videos does (t :899, noise :858, the
+        focus-present mask :542-543 - drawn before - and the null condition mask :55-61) without running the model - a
+        data-parallel rank whose shard is empty this step."""
         torch.randint(0, self.num_timesteps, (total,), device=device)
         torch.randn_like(torch.empty((total,) + tuple(sample_shape), device=device))
+        if 0 < prob_focus_present < 1:
+            torch.zeros((total,), device=device).float().uniform_(0, 1)
         if 0 < self.null_cond_prob < 1:
             torch.zeros((total,), device=device).float().uniform_(0, 1)
 

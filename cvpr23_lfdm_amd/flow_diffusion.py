@@ -302,6 +302,15 @@ class FlowDiffusion(nn.Module):
             self.unet.null_cond_mask = torch.zeros(0, dtype=torch.bool, device=dev)
             self.loss = torch.zeros((), device=dev)
             self.rec_loss, self.rec_warp_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)
+            # what the training scripts read after a step (sample images, logs): zero-video tensors of the right rank, so an empty
+            # rank's first step does not meet attributes that only forward() would have created
+            nf, hw = self.diffusion.num_frames, self.real_vid.shape[-1] if getattr(self, "real_vid", None) is not None else 4 * s
+            vid = torch.zeros(0, 3, nf, hw, hw, device=dev)
+            self.real_vid_grid = self.fake_vid_grid = torch.zeros(0, 2, nf, s, s, device=dev)
+            self.real_vid_conf = self.fake_vid_conf = torch.zeros(0, 1, nf, s, s, device=dev)
+            self.ref_img_fea = torch.zeros(0, 256, s, s, device=dev)
+            self.fake_out_vid = self.fake_warped_vid = vid
+            self._real_decode, self._real_out_vid, self._real_warped_vid = None, vid, vid
             self.optimizer_diff.zero_grad()
             self._dp.prepare()
             self._dp.finish()

@@ -37,7 +37,7 @@ class FlatAdam(torch.optim.Optimizer):
             fm = torch.zeros_like(fp)
             fv = torch.zeros_like(fp)
             gviews = []
-            for p, o in zip(ps, offs):
+            for pi, (p, o) in enumerate(zip(ps, offs)):
                 k = p.numel()
                 fp[o:o + k].copy_(p.data.reshape(-1))
                 p.data = fp[o:o + k].view(p.shape)
@@ -48,7 +48,7 @@ class FlatAdam(torch.optim.Optimizer):
                         raise ValueError("FlatAdam.load_state_dict: the moment of parameter #%d has %d elements, the parameter %s has %d - "
                                          "the state was saved for a different parameter ORDER (torch indexes optimizer state by "
                                          "position: it must come from a model with the same registration order)"
-                                         % (len(offs) and list(ps).index(p), st["exp_avg"].numel(), tuple(p.shape), k))
+                                         % (pi, st["exp_avg"].numel(), tuple(p.shape), k))
                     fm[o:o + k].copy_(st["exp_avg"].reshape(-1))
                     fv[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
                 st.setdefault("step", torch.tensor(0.0))
@@ -147,9 +147,12 @@ class FlatAdam(torch.optim.Optimizer):
 class GradAllReduce:
     """Sum all-reduce of FlatAdam's gradient buffer across ranks (torch.distributed; backend "nccl" = RCCL over xGMI
     on the GPU box, "gloo" in CPU tests).  Buckets are contiguous slices of the flat buffer, walked from the END
-    (the last layers finish their gradients first); a bucket is launched asynchronously by the autograd hook of the
-    last of its parameters to become ready, so the exchange overlaps the remaining backward.  `finish()` waits for
-    all buckets (and launches any that never fired, e.g. parameters without gradient this step)."""
+    (the last layers finish their gradients first); a bucket becomes READY in the autograd hook of the last of its
+    parameters, so the exchange overlaps the remaining backward.  Collectives are issued STRICTLY IN BUCKET-LIST ORDER on
+    every rank: a ready bucket is launched only once all buckets before it have been launched (RCCL / gloo match
+    collectives by issue order and the buckets differ in size - a rank whose hooks fire in another order, or a rank with
+    an empty shard that launches everything from `finish()`, must not permute them).  `finish()` launches what is left
+    (parameters without gradient this step, an empty shard) in the same order and waits for all buckets."""
 
     def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
         import torch.distributed as dist
@@ -162,6 +165,8 @@ class GradAllReduce:
         self._hooks = []
         self._buckets = None
         self._flat_id = None
+        self._next = 0
+        self.launch_order = []
         # profile = True: finish() brackets its waits with events on the compute stream; exposed_ms() then reports how long the
         # compute stream stood still for the exchange per step (the part of the all-reduce NOT hidden under backward)
         self.profile = False
@@ -224,15 +229,27 @@ class GradAllReduce:
             b = self._buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
-                self._launch(b)
+                self._stage(b)                    # copy now (overlaps backward) ...
+                b["ready"] = True
+                self._launch_ready()              # ... launch as soon as every earlier bucket has been launched
         return hook
 
-    def _launch(self, b):
+    def _stage(self, b):
         if not b["staged"]:                       # the bucket's gradients -> its slice of the flat buffer (one multi-tensor copy)
             self.opt.stage_grads(b["fl"], b["idxs"])
             b["staged"] = True
-        if self.world > 1 and b["handle"] is None:
-            b["handle"] = self.dist.all_reduce(b["view"], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch_ready(self, force=False):
+        """Issue the all-reduces of the leading run of ready buckets (all remaining ones with force=True), in list order."""
+        while self._next < len(self._buckets):
+            b = self._buckets[self._next]
+            if not (b["ready"] or force):
+                return
+            self._stage(b)
+            if self.world > 1 and b["handle"] is None:
+                b["handle"] = self.dist.all_reduce(b["view"], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.launch_order.append(self._next)
+            self._next += 1
 
     def prepare(self):
         """Call before backward (after zero_grad)."""
@@ -241,12 +258,13 @@ class GradAllReduce:
             b["pending"] = len(b["params"])
             b["handle"] = None
             b["staged"] = False
+            b["ready"] = False
+        self._next = 0
+        self.launch_order = []                    # bucket indices in the order their collectives were issued (tests)
 
     def finish(self):
         """Call after backward, before optimizer.step()."""
-        for b in self._buckets:
-            if b["handle"] is None:
-                self._launch(b)
+        self._launch_ready(force=True)
         timed = self.profile and self.world > 1 and torch.cuda.is_available() and self._buckets and self._buckets[0]["view"].is_cuda
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -253,7 +253,7 @@ def train_full_case(name, b=4, t=40, hw=128):
     train_case(name, b, t, hw, labels, compact=True)
 
 
-def c5_case(name, b=1, t=40, s=64, hw=256, steps=10):
+def c5_case(name, b=1, t=40, s=64, hw=256, steps=10, stride=2):
     """BASELINE.json configs[4] geometry at FULL frame count: NATOPS variant (learned null condition, nearest-upsample +
     reflect-padded Upsample), 64x64 latent, 256x256 frames, 40 frames, DDIM (10 of the 50 steps: minutes on this CPU)."""
     variant = dict(learn_null_cond=True, use_deconv=False, padding_mode="reflect")
@@ -264,9 +264,10 @@ def c5_case(name, b=1, t=40, s=64, hw=256, steps=10):
         m.sample_one_video(cond_scale=1.0)
     vf = np.array([0, 20, 39])
     st, pr = probes(m.sample_out_vid)
-    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=1000, noise_seed=11, video_frames=vf,
-         sample_vid_grid=m.sample_vid_grid[:, :, :, ::2, ::2], sample_vid_conf=m.sample_vid_conf[:, :, :, ::2, ::2],
-         sample_out_vid=m.sample_out_vid[:, :, vf][..., ::2, ::2], sample_warped_vid=m.sample_warped_vid[:, :, vf][..., ::2, ::2],
+    q = stride          # sub-sampling of the stored tensors (the statistics / projections cover every element)
+    save(name, b=b, t=t, s=s, hw=hw, steps=steps, timesteps=1000, noise_seed=11, video_frames=vf, stride=q,
+         sample_vid_grid=m.sample_vid_grid[:, :, :, ::q, ::q], sample_vid_conf=m.sample_vid_conf[:, :, :, ::q, ::q],
+         sample_out_vid=m.sample_out_vid[:, :, vf][..., ::q, ::q], sample_warped_vid=m.sample_warped_vid[:, :, vf][..., ::q, ::q],
          out_stats=st, out_probes=pr)
 
 
@@ -296,13 +297,14 @@ def main():
                     "training), stochastic null conditioning (0 < null_cond_prob < 1)")
     ap.add_argument("--focus", action="store_true", help="only the fixtures of the branches no LFDM script takes: focus_present_mask (unet_tiny_focus), Generator(skips=False)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
-    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
+    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50", "c5b4"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.full:
         {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"), "c4": lambda: train_full_case("train_step_c4_b4_t40"),
          "c4b8": lambda: train_full_case("train_step_c4_b8_t40", b=8),
          "c5": lambda: c5_case("sample_ddim10_c5_256"),
+         "c5b4": lambda: c5_case("sample_ddim50_c5_256_b4", b=4, steps=50, stride=4),      # configs[4] at its per-GPU batch (32 videos over 8 GPUs), ~35 min here
          "c5d50": lambda: c5_case("sample_ddim50_c5_256", steps=50)}[args.full]()      # the configuration's real step count (~8 min here)
         return
     if args.focus:

@@ -126,9 +126,10 @@ def test_c4_training_step_t40(monkeypatch, fixture):
     assert worst[1] < 5e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
 
 
-@pytest.mark.parametrize("fixture", ["sample_ddim10_c5_256", "sample_ddim50_c5_256"])      # 10 steps, and the configuration's own 50
-def test_c5_natops_256_t40(fixture):
+@pytest.mark.parametrize("fixture", ["sample_ddim10_c5_256", "sample_ddim50_c5_256", "sample_ddim50_c5_256_b4"])      # 10 steps, the configuration's own 50, and
+def test_c5_natops_256_t40(fixture):                                                                                   # its per-GPU batch (32 videos / 8 GPUs = B 4)
     g = gold(fixture)
+    q = int(g["stride"]) if "stride" in g else 2
     b, t, s, hw = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"])
     m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=int(g["steps"]), timesteps=int(g["timesteps"]),
                                          learn_null_cond=True, use_deconv=False, padding_mode="reflect")
@@ -139,10 +140,10 @@ def test_c5_natops_256_t40(fixture):
     vf = torch.from_numpy(g["video_frames"]).long()
     T = lambda k: torch.from_numpy(g[k])
     assert m.sample_out_vid.shape == (b, 3, t, hw, hw)
-    assert_close(m.sample_vid_grid[:, :, :, ::2, ::2].cpu(), T("sample_vid_grid"), 1e-3, "flow")
-    assert_close(m.sample_vid_conf[:, :, :, ::2, ::2].cpu(), T("sample_vid_conf"), 1e-3, "occlusion")
-    assert_close(m.sample_out_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_out_vid"), 1e-3, "frames")
-    assert_close(m.sample_warped_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_warped_vid"), 1e-3, "warped frames")
+    assert_close(m.sample_vid_grid[:, :, :, ::q, ::q].cpu(), T("sample_vid_grid"), 1e-3, "flow")
+    assert_close(m.sample_vid_conf[:, :, :, ::q, ::q].cpu(), T("sample_vid_conf"), 1e-3, "occlusion")
+    assert_close(m.sample_out_vid.cpu()[:, :, vf][..., ::q, ::q], T("sample_out_vid"), 1e-3, "frames")
+    assert_close(m.sample_warped_vid.cpu()[:, :, vf][..., ::q, ::q], T("sample_warped_vid"), 1e-3, "warped frames")
     st, pr = probes(m.sample_out_vid)
     assert_close(st.float(), T("out_stats").float(), 1e-3, "video statistics")
     assert_close(pr.float(), T("out_probes").float(), 2e-3, "video projections")

@@ -863,7 +863,7 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn", ["32", "64", "32-kg2", "32-kg3", "32-auto"], ids=["n32", "n64", "n32kg2", "n32kg3", "n32auto"])
+@pytest.mark.parametrize("bn", ["32", "64", "32-kg2", "32-kg3", "32-auto", "64-kg2"], ids=["n32", "n64", "n32kg2", "n32kg3", "n32auto", "n64kg2"])
 def test_conv2d_winograd(backend, case, bn, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
     tile order of the low-resolution levels and the K-group workgroups (G = 2 / 3 wave groups on interleaved chunks, merged in LDS;
@@ -875,7 +875,7 @@ def test_conv2d_winograd(backend, case, bn, monkeypatch):
     bn, _, kg = bn.partition("-")
     monkeypatch.setenv("LFDM_WINO_KG", {"": "0", "kg2": "2", "kg3": "3"}.get(kg, ""))
     if kg == "auto":
-        monkeypatch.delenv("LFDM_WINO_KG")
+        monkeypatch.setenv("LFDM_WINO_KG", "auto")
         case = dict(case)
         case.pop("ksplit", None)                    # the plan chooses split-K as well
     monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
