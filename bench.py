@@ -671,9 +671,20 @@ def main():
                                                     "batch=%d per GPU (throughput mode, NOT configs[1])" % args.batch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
-    local = local % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    rccl_ranks = None
+    if world > 1:       # who sits where: with enough devices every rank must own its own GPU (RCCL refuses duplicates anyway)
+        import torch.distributed as dist
+        mine = torch.tensor([local, ndev], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        devices = [int(v[0]) for v in every]
+        rccl_ranks = {"backend": dist.get_backend(), "devices": devices, "visible_gpus": ndev,
+                      "one_rank_per_gpu": len(set(devices)) == world}
+        assert ndev < world or len(set(devices)) == world, "ranks share a GPU although %d are visible: %s" % (ndev, devices)
 
     import contextlib
     import synth
@@ -743,7 +754,7 @@ def main():
                        "sampler": "DDIM-100 eta=1, cond_scale=1", "parallelism": "replicas x%d (videos sharded, no collective)" % world},
             "gflop_per_video_reference_dataflow": GFLOP_PER_VIDEO_REFERENCE,
             "whole_job_tflops_reference_dataflow": round(value * GFLOP_PER_VIDEO_REFERENCE / 1e3, 2),
-            "blocks": blocks, "box": box, "build": source_fingerprint(),
+            "blocks": blocks, "box": box, "build": source_fingerprint(), "rccl_ranks": rccl_ranks,
         }
         def guarded(fn, *a):                 # the secondary measurements must never cost the headline line
             try:

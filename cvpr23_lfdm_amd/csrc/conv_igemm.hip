@@ -611,6 +611,64 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(lfdm_conv_param
   }
 }
 
+// The same pass for the shapes the sampler produces (round 4): KS slabs known at compile time, all KS 16-byte loads of an item in flight
+// together (one memory round trip instead of two), bias / residual / result as float4, no per-element index arithmetic.  Needs what the
+// launch site checks: cout == coutp, 16-byte aligned rows, no LayerNorm fold, output pixel = row (no out_scale / offsets), not deconv4.
+// Summation order z = 0, 1, ... (fixed: bit reproducible).  Same grid, same GroupNorm partial layout as the generic kernel.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_vec_kernel(lfdm_conv_params p) {
+  __shared__ float red_s[256], red_q[256];
+  const int tid = threadIdx.x;
+  const int M = p.n_img * p.hq * p.wq;
+  const int c4n = p.coutp / 4;
+  const int cw = c4n / gridDim.y;
+  const int cq0 = blockIdx.y * cw;
+  const int m0 = blockIdx.x * SPLITK_ROWS;
+  const int items = SPLITK_ROWS * cw;
+  const int64_t zs = (int64_t)M * p.coutp;
+  float gs = 0.f, gq = 0.f;
+  for (int it = tid; it < items; it += 256) {
+    const int r = it / cw;
+    const int col = (cq0 + it - r * cw) * 4;
+    const int m = m0 + r;
+    if (m >= M) continue;
+    const float* pp = p.partial + (int64_t)m * p.coutp + col;
+    float4 v[KS];
+#pragma unroll
+    for (int z = 0; z < KS; ++z) v[z] = *reinterpret_cast<const float4*>(pp + z * zs);
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), rr = bb;
+    if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + col);
+    if (p.residual) rr = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + col);
+    float4 s = v[0];
+#pragma unroll
+    for (int z = 1; z < KS; ++z) { s.x += v[z].x; s.y += v[z].y; s.z += v[z].z; s.w += v[z].w; }
+    s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
+    gs += (s.x + s.y) + (s.z + s.w);
+    gq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+    s.x = apply_act(s.x + rr.x, p.act); s.y = apply_act(s.y + rr.y, p.act);
+    s.z = apply_act(s.z + rr.z, p.act); s.w = apply_act(s.w + rr.w, p.act);
+    *reinterpret_cast<float4*>(p.out + (int64_t)m * p.ldo + col) = s;
+  }
+  if (p.gn_partial) {
+    red_s[tid] = gs;
+    red_q[tid] = gq;
+    __syncthreads();
+    const int cg4 = (p.cout / p.gn_groups) / 4;
+    const int gpb = cw / cg4;
+    if (tid < gpb) {
+      float ts = 0.f, tq = 0.f;
+      for (int rep = 0; rep < 256; rep += cw)
+        for (int k = 0; k < cg4; ++k) {
+          ts += red_s[rep + tid * cg4 + k];
+          tq += red_q[rep + tid * cg4 + k];
+        }
+      float* dst = p.gn_partial + ((int64_t)blockIdx.x * p.gn_groups + cq0 / cg4 + tid) * 2;
+      dst[0] = ts;
+      dst[1] = tq;
+    }
+  }
+}
+
 // column chunks for the reduce grid: enough workgroups to cover the chip, chunks of >= 16 float4 that
 // divide the row and (with fused GroupNorm statistics) hold whole groups and divide 256
 int splitk_col_chunks(const lfdm_conv_params& p, int64_t M) {
@@ -756,6 +814,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       static const long min_blocks64 = [] { const char* e = getenv("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1536l; }();
       if (min_blocks64 > 0 && p.coutp % 64 == 0 && !(p.groups > 1) && ((ntiles + 31) / 32) * (p.coutp / 64) >= min_blocks64) pl.bn = 64;
     }
+    if (p.gn_in_partial) pl.bn = 32;                 // the fused input GroupNorm exists on the 32-column workgroup only
     const int64_t blocks = ((ntiles + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
     const int nch = cin / 16 / (p.groups > 1 ? p.groups : 1);      // chunks of one output channel's reduction
     // (16-tile workgroups on v_mfma_f32_16x16x4 - twice the workgroups at half the matrix work, half the split-K factor - were built
@@ -782,7 +841,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       const char* e = getenv("LFDM_WINO_KG");
       const int force = (e && e[0] >= '2' && e[0] <= '3') ? e[0] - '0' : 0;
       const bool autok = e && e[0] == 'a';
-      const bool can = (pl.bn == 32 || force == 2) && !p.pool2;      // (64-column workgroups: two groups at most - registers)
+      const bool can = (pl.bn == 32 || force == 2) && !p.pool2 && !p.gn_in_partial;      // (64-column workgroups: two groups at most - registers)
       if (can && force) {
         kg = force;
       } else if (can && autok && blocks <= 256) {
@@ -817,7 +876,10 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.ksplit = user_k >= 1 ? user_k : k;
   } else {
     pl.kind = 0;
-    const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= 256;
+    // 128x128 tiles only from two workgroups per CU up (round 4: the 320 / 480-workgroup launches of a B = 1 step - the merged output heads'
+    // res_conv, the LayerNorm-fused qkv projections at 16x16 - run 128x64 tiles instead: 295.7 -> 293.0 ms per video, profiles/r04_f_*)
+    static const long wide_min = [] { const char* e = getenv("LFDM_IGEMM_WIDE_MIN"); return e ? atol(e) : 512l; }();
+    const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= wide_min;
     const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
     pl.bm = wide ? 128 : (small_m ? 64 : 128);
     pl.bn = wide ? 128 : 64;
@@ -912,6 +974,16 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
                    "residual, activation, fused statistics or in-launch reduction");
     return LFDM_EINVAL;
   }
+  if (p.gn_in_partial) {
+    const int g = p.gn_in_groups;
+    if (pl.kind != 2 || p.c1 != 0 || p.upsample || p.pool2 || p.act != LFDM_ACT_NONE || g <= 0 || g > 64 || p.c0 % g != 0 || p.c0 > 1024 ||
+        p.gn_in_pixels <= 0 || p.gn_in_pixels % 128 != 0 || ((int64_t)p.n_img * p.hq * p.wq) % p.gn_in_pixels != 0 || p.gn_in_nchunk <= 0 ||
+        !p.gn_in_gamma || !p.gn_in_beta || (p.gn_in_ss && p.gn_in_ss_ld < 2 * p.c0)) {
+      lfdm_set_error("conv2d: gn_in_* (GroupNorm + SiLU of the input inside the convolution) needs the Winograd schedule (see lfdm_conv2d_schedule), one "
+                     "source, no upsample / pool / output activation, c0 <= 1024, c0 % groups == 0, pixels per sample % 128 == 0");
+      return LFDM_EINVAL;
+    }
+  }
   p.ksplit = pl.ksplit;
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
@@ -954,9 +1026,25 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   }
   if (rc) return rc;
   if (p.ksplit > 1 && !splitk_fused(pl, p) && !p.defer_reduce) {
-    LFDM_LAUNCH(conv_splitk_reduce_kernel,
-                dim3((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M), p.deconv4 ? 4 : 1), dim3(256), 0,
-                stream, p);
+    const dim3 rgrid((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M), p.deconv4 ? 4 : 1);
+    static const bool vec_on = [] { const char* e = getenv("LFDM_REDUCE_VEC"); return !(e && e[0] == '0'); }();      // (A/B knob)
+    const bool vec = vec_on && p.ksplit <= 8 && !p.deconv4 && !p.ln_wsum && p.cout == p.coutp && p.ldo % 4 == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                     p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq &&
+                     (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (!p.residual || (p.ldr % 4 == 0 && (((uintptr_t)p.residual) & 15) == 0)) &&
+                     (((uintptr_t)p.partial) & 15) == 0;
+    if (vec) {
+      switch (p.ksplit) {
+        case 2: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<2>, rgrid, dim3(256), 0, stream, p); break;
+        case 3: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<3>, rgrid, dim3(256), 0, stream, p); break;
+        case 4: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<4>, rgrid, dim3(256), 0, stream, p); break;
+        case 5: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<5>, rgrid, dim3(256), 0, stream, p); break;
+        case 6: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<6>, rgrid, dim3(256), 0, stream, p); break;
+        case 7: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<7>, rgrid, dim3(256), 0, stream, p); break;
+        default: LFDM_LAUNCH(conv_splitk_reduce_vec_kernel<8>, rgrid, dim3(256), 0, stream, p); break;
+      }
+    } else {
+      LFDM_LAUNCH(conv_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, p);
+    }
     rc = lfdm_check_launch("conv_splitk_reduce");
   }
   return rc;

@@ -56,7 +56,11 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // workgroup's K slice on its own V buffer - G waves per SIMD, so one group's loads fly under the other groups' MFMAs - and the groups'
 // accumulators meet in LDS on the way into the output transform (the epilogue reads G x 8 planes instead of 8).  All groups run the same
 // trip count (one barrier pair per round); a group whose last chunk does not exist multiplies zero patches.
-template <bool ACT, int NT, bool POOL = false, int G = 1>
+// GNIN (round 4, lfdm_conv_params.gn_in_*): the input is the previous convolution's raw output; its GroupNorm + scale/shift + SiLU is applied to
+// the patches on their way into the transform (block1's norm inside block2's convolution: one launch less per ResnetBlock).  The
+// workgroup merges the statistics partials of its sample (double, fixed order - the arithmetic of gn_apply_kernel) while its first
+// patch / filter loads are in flight and keeps A[c], B[c] of its K slice in LDS.
+template <bool ACT, int NT, bool POOL = false, int G = 1, bool GNIN = false>
 __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_wino_kernel(lfdm_conv_params p) {
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
@@ -64,6 +68,9 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   __shared__ __attribute__((aligned(16))) float smem[G * VSZ];   // V during the loop (one buffer per K group); >= 8*WT*LDM each for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ float s_gn[2][4][WNB];
+  constexpr int GIN_MAXC = 1024;
+  __shared__ __attribute__((aligned(16))) float s_gin[GNIN ? 2 * GIN_MAXC : 4];      // A[c] | B[c] of this workgroup's K slice
+  __shared__ float s_gstat[GNIN ? 128 : 4];                                          // mean | rstd per group
 
   const int kgrp = G > 1 ? lfdm_uniform((int)(threadIdx.x >> 8)) : 0;      // K group of this wave (wave-uniform)
   const int tid = G > 1 ? (int)(threadIdx.x & 255u) : (int)threadIdx.x;     // thread inside the group: every index below is per group
@@ -232,9 +239,66 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   for (int pi = 0; pi < 4; ++pi) fetch_b(pi, clampc(kc0));
   {
     fetch_patch(patch, clampc(kc0), (G == 1 || kc0 < kc_end) ? valid_mask : 0u);
+    if (GNIN) {
+      // (the loads above are in flight)  statistics of this tile block's sample: 32 lanes walk one group's chunks, as gn_apply_kernel does
+      const int groups = p.gn_in_groups, nchunk = p.gn_in_nchunk;
+      const int b = (int)((t0 < ntiles ? t0 : ntiles - 1) / (unsigned)(p.gn_in_pixels >> 2));      // (a tile = four pixels; host: pixels % 128 == 0)
+      const int sub = tid & 31;
+      for (int g0 = 0; g0 < groups; g0 += 8) {
+        const int g = g0 + (tid >> 5);
+        double sm = 0.0, sq = 0.0;
+        if (g < groups) {
+          for (int k = sub; k < nchunk; k += 32) {
+            const float* src = p.gn_in_partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
+            sm += (double)src[0];
+            sq += (double)src[1];
+          }
+        }
+        for (int msk = 16; msk >= 1; msk >>= 1) {
+          sm += __shfl_xor(sm, msk);
+          sq += __shfl_xor(sq, msk);
+        }
+        if (g < groups && sub == 0) {
+          const double n = (double)p.gn_in_pixels * (double)(p.c0 / groups);
+          const double mean = sm / n;
+          double var = sq / n - mean * mean;
+          if (var < 0.0) var = 0.0;
+          s_gstat[g] = (float)mean;
+          s_gstat[64 + g] = (float)(1.0 / sqrt(var + (double)p.gn_in_eps));
+        }
+      }
+      __syncthreads();
+      const int cg = p.c0 / groups;
+      const int c_lo = cbase + kc_begin * WKC, nslice = (kc_end - kc_begin) * WKC;
+      for (int lc = tid; lc < nslice; lc += 256) {
+        const int c = c_lo + lc, g = c / cg;
+        const float a = s_gstat[64 + g] * p.gn_in_gamma[c];
+        float bb = p.gn_in_beta[c] - s_gstat[g] * a;
+        float aa = a;
+        if (p.gn_in_ss) {
+          const float sc = p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + c] + 1.0f;
+          const float sh = p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + p.c0 + c];
+          aa = a * sc;
+          bb = bb * sc + sh;
+        }
+        s_gin[lc] = aa;
+        s_gin[GIN_MAXC + lc] = bb;
+      }
+      __syncthreads();
+    }
     for (int r = 0; r < rounds; ++r) {
       const int nxt_raw = kc0 + (r + 1) * G;
       const int nxt = clampc(nxt_raw);
+      if (GNIN) {      // norm -> scale/shift -> SiLU of the in-image patch pixels (padding stays zero)
+        const int lc = (kc0 + r * G - kc_begin) * WKC + 2 * x_c2;
+        const float2 ga = *reinterpret_cast<const float2*>(s_gin + lc), gb = *reinterpret_cast<const float2*>(s_gin + GIN_MAXC + lc);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const bool in = (valid_mask >> q) & 1u;
+          patch[q].x = in ? silu_fast_(fmaf(patch[q].x, ga.x, gb.x)) : 0.f;
+          patch[q].y = in ? silu_fast_(fmaf(patch[q].y, ga.y, gb.y)) : 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
 #ifdef LFDM_WINO_TIMING
@@ -442,6 +506,10 @@ int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStr
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
+  if (p.gn_in_partial) {                  // (lfdm_conv2d_cl_f32 has checked: 32-column tiles, one K group, no output activation, no pool)
+    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 1, true>), grid, dim3(256), 0, stream, p);
+    return lfdm_check_launch("conv_wino");
+  }
   if (kgroups == 2 && bn == 64 && !p.pool2) {      // 64 columns x two K groups: 250 VGPRs x two waves per SIMD
     if (act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, 2>), grid, dim3(512), 0, stream, p);
     else LFDM_LAUNCH((conv_wino_kernel<false, 2, false, 2>), grid, dim3(512), 0, stream, p);

@@ -161,6 +161,14 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
 
+// SiLU on the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): for activations recomputed inside a consumer's
+// load path (lfdm_conv_params.gn_in_*), where the IEEE division + expf expansion of siluf_ would cost more than the launch it saves
+#if defined(LFDM_EMU_BUILD)
+static inline float silu_fast_(float x) { return x / (1.0f + expf(-x)); }
+#else
+__device__ __forceinline__ float silu_fast_(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
+
 // activation codes shared by the C ABI (include/lfdm_hip.h)
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.f ? v : 0.f;

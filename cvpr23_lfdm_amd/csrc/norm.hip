@@ -76,10 +76,20 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
     const float* __restrict__ x, float* __restrict__ out, int pixels, int channels, int groups,
     const float* __restrict__ partial, int nchunk, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ scale_shift, int ss_ld, float eps, int silu,
-    const float* __restrict__ residual) {
+    const float* __restrict__ residual, int xcd_r) {
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ __attribute__((aligned(16))) float s_a[GN_MAX_C], s_b[GN_MAX_C];
   const int b = blockIdx.y, tid = threadIdx.x;
+  // XCD affinity (round 4).  Workgroups are dealt round-robin to the 8 XCDs in linear-id order, and the convolution that produced x
+  // (and the one that will read the result) runs the workgroup of 128-pixel tile block t on XCD t % 8 - its output is still in THAT L2
+  // (written back at the kernel boundary, not invalidated).  With xcd_r = R > 0 (R runs of NT float4 per tile block, a power of two,
+  // gridDim.x % 8R == 0 - launch_gn_apply checks) the runs are re-dealt so that the workgroup on XCD v walks runs of tile blocks = v
+  // (mod 8): same-XCD reads instead of cross-XCD ones (MI355X_MICROARCH.md "handoff-payload": 1.7x).  Speed only.
+  unsigned jb = blockIdx.x;
+  if (xcd_r > 0) {
+    const unsigned r8 = 8u * (unsigned)xcd_r, q = jb / r8, rem = jb - q * r8;
+    jb = q * r8 + (rem & 7u) * (unsigned)xcd_r + (rem >> 3);
+  }
   // the first two float4 of this thread are requested BEFORE the statistics are merged: their HBM latency runs under the
   // prologue instead of after it
   const int c4n = channels >> 2;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
   float4* ob = reinterpret_cast<float4*>(out) + (int64_t)b * per_b;
   const float4* rb = residual ? reinterpret_cast<const float4*>(residual) + (int64_t)b * per_b : nullptr;
   const int64_t stride = (int64_t)gridDim.x * NT;
-  const int64_t i0 = (int64_t)blockIdx.x * NT + tid;
+  const int64_t i0 = (int64_t)jb * NT + tid;
   float4 pre_v[2], pre_r[2];        // (four in flight measured 1.6x SLOWER: the selects below stop being register renames)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -336,15 +346,25 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
   if (nb < 1) nb = 1;
   if (nb > 8192) nb = 8192;        // per sample (grid y = batch); the 2C-channel output heads need 5120 at 32x32 x 40 frames
   const dim3 grid((unsigned)nb, batch);
+  // XCD-affine run order (see the kernel): R = runs of nt float4 per 128-pixel tile block, a power of two; whole groups of 8R runs only
+  int xcd_r = 0;
+  {
+    const char* e = getenv("LFDM_GN_XCD");      // (read per call: A/B in tools)
+    const int64_t blk_f4 = 128ll * (channels / 4);
+    if (!(e && e[0] == '0') && blk_f4 % nt == 0) {
+      const int64_t r = blk_f4 / nt;
+      if (r >= 1 && r <= 64 && (r & (r - 1)) == 0 && nb % (8 * r) == 0 && (per_b % ((int64_t)nt)) == 0) xcd_r = (int)r;
+    }
+  }
   if (nt == 1024)
     LFDM_LAUNCH(gn_apply_kernel<1024>, grid, dim3(1024), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
-                scale_shift, ss_ld, eps, silu, residual);
+                scale_shift, ss_ld, eps, silu, residual, xcd_r);
   else if (nt == 512)
     LFDM_LAUNCH(gn_apply_kernel<512>, grid, dim3(512), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
-                scale_shift, ss_ld, eps, silu, residual);
+                scale_shift, ss_ld, eps, silu, residual, xcd_r);
   else
     LFDM_LAUNCH(gn_apply_kernel<256>, grid, dim3(256), 0, stream, x, out, pixels, channels, groups, partial, nchunk, gamma, beta,
-                scale_shift, ss_ld, eps, silu, residual);
+                scale_shift, ss_ld, eps, silu, residual, xcd_r);
 }
 
 

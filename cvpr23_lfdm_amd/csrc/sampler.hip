@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
                                                              float* __restrict__ x0buf,
                                                              float* __restrict__ x0_out, int64_t n,
                                                              const float* __restrict__ coef,
-                                                             const int32_t* __restrict__ step_dev,
+                                                             const int32_t* step_dev,      // (no __restrict__: advance_dev is the same word)
                                                              Ranks rk, unsigned* __restrict__ hists, int hist_samples,
-                                                             unsigned* __restrict__ ticket, int32_t* __restrict__ advance_dev) {
+                                                             unsigned* __restrict__ ticket, int32_t* advance_dev) {
   __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
   float s = 1.0f;                       // rk.frac < 0: static clipping, x0.clamp(-1, 1) (use_dynamic_thres=False, :729-732)

@@ -250,7 +250,8 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, defer_reduce=False):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, defer_reduce=False,
+                gn_in=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -312,9 +313,22 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         _chk(lib, weight_wino4)
         assert weight_wino is not None and weight_wino4.shape == (36, cin // 8, coutp, 8) and weight_wino4.is_contiguous()
         p.weight_wino4 = weight_wino4.data_ptr()
+    # gn_in = dict(partial, nchunk, pixels, gamma, beta, groups=8, scale_shift=None, eps=1e-5): src0 is the previous convolution's raw output;
+    # its GroupNorm + scale/shift + SiLU is applied inside this convolution's patch load (Winograd schedule only; lfdm_conv_params.gn_in_*)
+    p.gn_in_partial = None
+    keep_gn = ()
+    if gn_in is not None:
+        gp, gg, gb, gss = gn_in["partial"], gn_in["gamma"], gn_in["beta"], gn_in.get("scale_shift")
+        _chk(lib, gp, gg, gb, gss)
+        assert src1 is None and gg.numel() == src0.shape[1] == gb.numel() and gp.is_contiguous()
+        p.gn_in_partial, p.gn_in_nchunk, p.gn_in_groups, p.gn_in_pixels = _p(gp), int(gn_in["nchunk"]), int(gn_in.get("groups", 8)), int(gn_in["pixels"])
+        p.gn_in_gamma, p.gn_in_beta, p.gn_in_ss = _p(gg), _p(gb), _p(gss)
+        p.gn_in_ss_ld = gss.stride(0) if gss is not None else 0
+        p.gn_in_eps = float(gn_in.get("eps", 1e-5))
+        keep_gn = (gp, gg, gb, gss)
     p.defer_reduce = int(bool(defer_reduce))     # split-K slabs stay raw for groupnorm_splitk_apply_cl (no reduce launch)
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
-    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4)   # keep the tensors alive with the struct
+    p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4) + keep_gn   # keep the tensors alive with the struct
     return p, out
 
 

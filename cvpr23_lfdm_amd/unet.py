@@ -23,6 +23,13 @@ _LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
 _RES_STREAM = os.environ.get("LFDM_RES_STREAM", "0") == "1"
 _GN_SPLITK = os.environ.get("LFDM_GN_SPLITK", "0") == "1"      # conv (split-K) -> GroupNorm without the reduce launch (ops.groupnorm_splitk_apply_cl)
 _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
+# block1's GroupNorm + scale/shift + SiLU inside block2's Winograd convolution (lfdm_conv_params.gn_in_*): one launch less per ResnetBlock.
+# MEASURED SLOWER (round 4, profiles/r04_d_*): 146 instead of 165 launches per step, but every fused convolution takes ~10 us longer (the
+# statistics merge + A/B table sit in its prologue, the activation is recomputed for each of the 4 overlapping patches x column tiles) for
+# a 5-12 us launch saved: 304.2 vs 298.4 ms per video.  Off by default.  LFDM_GN_FUSE = 1 turns it on wherever the geometry allows;
+# LFDM_GN_FUSE_MAX_ROWS bounds the activation rows (B*T*S*S) it is used at.
+_GN_FUSE = os.environ.get("LFDM_GN_FUSE", "0") == "1"
+_GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
 
 
 def prob_mask_like(shape, prob, device):
@@ -288,7 +295,10 @@ class Unet3D(ParamTree):
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         coutp = p.coutp
+        if gn is not None:
+            p.gn_partial = 1      # (placeholder: "fused statistics wanted" changes the plan - schedules 3 / 4 have none; include/lfdm_hip.h)
         tile_rows, ksplit = ops.conv_plan(p)
+        p.gn_partial = None
         m = n_img * p.hq * p.wq
         if ksplit > 1:
             part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
@@ -309,7 +319,9 @@ class Unet3D(ParamTree):
             in_reduce = ksplit > 1 and not fused and 256 % (coutp // 4) == 0 and coutp == cout    # ... from the split-K reduce pass (any group width)
             if pixels % tile_rows == 0 and cg % 4 == 0 and (in_tile or in_reduce):
                 nchunk = pixels // tile_rows
-                stats = (self._buf("gn.partial", batch * nchunk, 2 * groups), nchunk)
+                # (a convolution that READS the previous statistics through gn_in writes its own into the other arena: its workgroups finish
+                #  - and store their partial sums - while others are still merging the input's)
+                stats = (self._buf("gn.partial2" if kw.get("gn_in") is not None else "gn.partial", batch * nchunk, 2 * groups), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), groups, pixels
         ops.conv_launch(p)
         return (y, stats) if gn is not None else y
@@ -322,6 +334,16 @@ class Unet3D(ParamTree):
         if stats is not None:
             return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, groups=groups, **kw)
         return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, groups=groups, **kw)
+
+    def _gn_in(self, stats, batch, rows, channels, gamma, beta, sshift, ww, groups=8):
+        """Parameters of the fused input GroupNorm of the NEXT convolution (ops.conv_params gn_in=...), or None when the separate
+        GroupNorm launch has to run: statistics not available as partial sums, no Winograd form, a geometry the kernel refuses."""
+        if not _GN_FUSE or stats is None or stats[0] == "slabs" or ww is None or rows > _GN_FUSE_MAX_ROWS:
+            return None
+        pixels = rows // batch
+        if pixels % 128 != 0 or channels > 1024 or channels % groups != 0 or channels % 16 != 0:
+            return None
+        return dict(partial=stats[0], nchunk=stats[1], pixels=pixels, gamma=gamma, beta=beta, groups=groups, scale_shift=sshift)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -348,10 +370,12 @@ class Unet3D(ParamTree):
         if ss is not None and (prefix + "ss_off") in pk:
             o = pk[prefix + "ss_off"]
             sshift = ss[:, o:o + 2 * cout]
-        self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
+        gn_in = self._gn_in(st, batch, rows, cout, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], sshift, pk[prefix + "block2.proj.ww"])
+        if gn_in is None:
+            self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
         out = self._buf(outname, rows, cout)
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
-                           out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
+                           out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"], gn_in=gn_in)
         has_res = (prefix + "res.w") in pk
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -495,10 +519,12 @@ class Unet3D(ParamTree):
             h1 = self._buf("h.h1", rows, c2)
             _, st = self._conv(x, pk["heads.block1.w"], c2, 3, n_img, res, src1=r, bias=pk["heads.block1.b"], out=h1,
                                gn=(batch, 16), ww=pk["heads.block1.ww"])
-            self._gn(h1, batch, pk["heads.norm1.w"], pk["heads.norm1.b"], st, groups=16)
+            gn_in = self._gn_in(st, batch, rows, c2, pk["heads.norm1.w"], pk["heads.norm1.b"], None, pk["heads.block2.ww"], groups=16)
+            if gn_in is None:
+                self._gn(h1, batch, pk["heads.norm1.w"], pk["heads.norm1.b"], st, groups=16)
             y = self._buf("h.y", rows, c2)
             _, st = self._conv(h1, pk["heads.block2.ww"], c2, 3, n_img, res, bias=pk["heads.block2.b"], out=y,
-                               gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2)
+                               gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2, gn_in=gn_in)
             self._gn(y, batch, pk["heads.norm2.w"], pk["heads.norm2.b"], st, groups=16)
             self._conv(x, pk["heads.res.w"], c2, 1, n_img, res, src1=r, bias=pk["heads.res.b"], residual=y, out=y)
             yf, yo = y[:, :dim], y[:, dim:]

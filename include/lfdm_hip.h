@@ -133,6 +133,24 @@ typedef struct lfdm_conv_params {
      launch (the low-resolution ResnetBlocks of a B = 1 step: conv + reduce + apply -> conv + apply).  `out` is not written.  Needs no
      residual / activation / fused statistics / LayerNorm fold / deconv4.  Ignored when the plan does not split K. */
   int defer_reduce;
+  /* Optional (ABI version 8; Winograd schedule only - lfdm_conv2d_cl_f32 refuses it on a geometry that would run another schedule,
+     ask lfdm_conv2d_schedule first): the INPUT src0 is the raw output of the previous convolution, whose GroupNorm (+ per-sample
+     scale / shift) + SiLU has not been applied: gn_in_partial != NULL -> every patch element x[pixel][c] is read as
+     silu(x * A[c] + B[c]) with A, B folded from the (sum, sum of squares) partials of that tensor exactly like
+     lfdm_groupnorm_apply_cl_f32 does (gn_in_partial [batch * gn_in_nchunk][2 * gn_in_groups], merged in double in a fixed order by
+     every workgroup), gn_in_gamma / gn_in_beta [c0], optional gn_in_ss rows (scale | shift, 2 * c0 floats per sample, row stride
+     gn_in_ss_ld).  This is Block.forward's norm -> scale/shift -> act (video_flow_diffusion.py:199-212) of ResnetBlock.block1 moved
+     into block2's convolution: the sampler's block1 GroupNorm launches disappear.  Zero padding stays zero (the activation is
+     applied to in-image pixels only).  Needs one source (c1 == 0), no upsample, gn_in_pixels (pixels per sample) % 128 == 0,
+     c0 <= 1024, c0 % gn_in_groups == 0.  SiLU here is x * rcp(1 + exp2(-x log2 e)) on the hardware exponential / reciprocal
+     (within 3 ulp of the library's GroupNorm kernels). */
+  const float* gn_in_partial;
+  int gn_in_nchunk, gn_in_groups, gn_in_pixels;
+  const float* gn_in_gamma;
+  const float* gn_in_beta;
+  const float* gn_in_ss;
+  int gn_in_ss_ld;
+  float gn_in_eps;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);
@@ -261,7 +279,10 @@ int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int cha
  *                  k_x0, k_eps, k_x, k_noise }:  x <- k_x0*x0 + k_eps*eps + k_x*x + k_noise*noise
  * quantile < 0 selects the static branch of the reference instead (use_dynamic_thres=False: x0.clamp(-1, 1), :729-732).
  * x (in/out), eps, noise: planar (B, n) with n = 3*T*S*S. x0_out optional (B, n).
- * ws: lfdm_sampler_ws_bytes(batch, n).  advance != 0 increments *step_dev at the end.
+ * ws: lfdm_sampler_ws_bytes(batch, n), and it MUST have been cleared once by lfdm_sampler_ws_init (ABI >= 4): the step relies on
+ * histograms and an end-of-step ticket word that every step leaves zeroed for the next one.  A workspace that was never initialised
+ * (e.g. fresh uninitialised memory) gives wrong dynamic thresholds and a step counter that never advances - and no error code: the
+ * library cannot look into device memory without a synchronisation.  advance != 0 increments *step_dev at the end.
  */
 size_t lfdm_sampler_ws_bytes(int batch, int64_t n);
 /* once per workspace, before its first lfdm_sampler_step_f32: clears the histograms and the end-of-step ticket (every step leaves

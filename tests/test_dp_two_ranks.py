@@ -28,6 +28,8 @@ from cvpr23_lfdm_amd import FlowDiffusion, _build, _native
 if kind == "emu":
     _native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))
 dev = "cuda" if kind == "hip" else "cpu"
+if kind == "hip" and os.environ.get("LFDM_DP_ONE_RANK_PER_DEVICE") == "1":      # the RCCL flavour: rank r owns GPU r (RCCL refuses duplicate devices)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 B, T, HW = int(os.environ.get("LFDM_DP_B", "2")), 2, 128
 torch.manual_seed(11)
 m = FlowDiffusion(img_size=HW // 4, num_frames=T, sampling_timesteps=5, null_cond_prob=0.5, is_train=True, lr=1e-4,
@@ -65,12 +67,14 @@ if dist.is_initialized():
 '''
 
 
-def _launch(tmp_path, kind, world, batch=2):
+def _launch(tmp_path, kind, world, batch=2, backend="gloo"):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    outdir = tmp_path / ("out_w%d_b%d" % (world, batch))
+    outdir = tmp_path / ("out_w%d_b%d_%s" % (world, batch, backend))
     outdir.mkdir()
-    env = dict(os.environ, LFDM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", LFDM_DP_OUT=str(outdir), LFDM_DP_B=str(batch))
+    env = dict(os.environ, LFDM_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", LFDM_DP_OUT=str(outdir), LFDM_DP_B=str(batch))
+    if backend == "nccl":      # RCCL: one rank per GPU; the host driver only supports dmabuf IPC
+        env.update(LFDM_DP_ONE_RANK_PER_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
     if world == 1:
         cmd = [sys.executable, str(script), REPO, kind]
@@ -84,9 +88,9 @@ def _launch(tmp_path, kind, world, batch=2):
     return sorted(outs, key=lambda o: o["rank"])
 
 
-def _check(tmp_path, kind):
+def _check(tmp_path, kind, backend="gloo"):
     single = _launch(tmp_path, kind, 1)[0]
-    r0, r1 = _launch(tmp_path, kind, 2)
+    r0, r1 = _launch(tmp_path, kind, 2, backend=backend)
     assert single["shard_batch"] == 2 and r0["shard_batch"] == r1["shard_batch"] == 1 and r0["world"] == 2
     assert r0["checksum_spread"] == 0.0 and r1["checksum_spread"] == 0.0          # replicas bit-identical after two steps
     assert r0["params"] == r1["params"]
@@ -140,6 +144,18 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _check(tmp_path, "hip")
+
+
+@pytest.mark.gpu
+def test_two_ranks_rccl_one_rank_per_gpu(tmp_path):
+    """The same two-rank step over RCCL (backend "nccl" on ROCm), one rank per device - the path `bench.py --gpus N` and an unchanged
+    training script under torchrun take on a multi-GPU node (reference: nn.DataParallel over the node's GPUs,
+    DM/train_video_flow_diffusion_mhad_multiGPU.py:207,249-254).  Needs two GPUs: on the one-GPU box of this pool it SKIPS, so the
+    first box with two devices exercises RCCL without anybody having to remember to."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < 2:
+        pytest.skip("RCCL needs one device per rank: %d GPU(s) visible (the gloo flavour above covers the one-GPU box)" % n)
+    _check(tmp_path, "hip", backend="nccl")
 
 
 @pytest.mark.skipif(os.environ.get("LFDM_DP_EMU", "0") != "1", reason="the same check on the emulation build: opt-in (LFDM_DP_EMU=1, ~4 min)")

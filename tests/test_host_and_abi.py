@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 25
     assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
     lib = _native.NativeLibrary(path, "hip")          # getattr on every symbol; raises if one is missing
-    assert lib.lfdm_abi_version() == 7          # 7: lfdm_calib_mfma_f32; 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2; 4: *_lowres_cl_f32; 5: .weight_wino4; 6: .defer_reduce
+    assert lib.lfdm_abi_version() == 8          # 8: lfdm_conv_params.gn_in_*; 7: lfdm_calib_mfma_f32; 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2; 4: *_lowres_cl_f32; 5: .weight_wino4; 6: .defer_reduce
     nm = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True).stdout
     for sym in declared:
         assert re.search(r"\bT %s\b" % sym, nm), sym
@@ -112,6 +112,27 @@ def test_bench_self_launch_gpus2():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["elapsed"] >= 0.018      # rank 1 sleeps 2 x 10 ms
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_over_rccl():
+    """`python bench.py --gpus 2` on a box with two GPUs: the ranks must sit on DIFFERENT devices and rendezvous over RCCL (backend
+    nccl) - bench.py asserts it and reports `rccl_ranks`.  Skips on the one-GPU box (there `profiles/*_bench_n2_one_gpu.json` is the
+    gloo flavour with both ranks on cuda:0)."""
+    import json
+    import torch
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n < 2:
+        pytest.skip("needs two GPUs for RCCL: %d visible" % n)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LFDM_DIST_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "1",
+                        "--no-cpu-baseline", "--no-roofline", "--train-steps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"]["backend"] == "nccl" and len(set(out["rccl_ranks"]["devices"])) == 2, out.get("rccl_ranks")
+    assert out["train"]["allreduce"]["buckets"] >= 1 and "error" not in out["train"]
 
 
 def test_asm_load_pipelines_are_safe():

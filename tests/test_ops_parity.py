@@ -423,6 +423,60 @@ def test_conv_fused_groupnorm_stats(backend, ksplit):
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
 
 
+@pytest.mark.parametrize("case", [
+    dict(b=2, n=8, h=8, w=8, cin=32, cout=64, nchunk=2),                          # two samples x 256 pixels, scale/shift rows
+    dict(b=1, n=4, h=8, w=8, cin=64, cout=40, nchunk=1, ksplit=2, ss=False),      # split-K slices build only their part of the A / B table
+    dict(b=2, n=16, h=4, w=4, cin=48, cout=32, nchunk=4, residual=True),          # 4x4 images: half of every patch is zero padding
+    dict(b=1, n=2, h=16, w=8, cin=64, cout=64, nchunk=2, groups=2, gn_groups=16),  # the merged output heads: grouped convolution, 16 norm groups
+    dict(b=1, n=40, h=32, w=32, cin=64, cout=64, nchunk=320, gpu_only=True),
+    dict(b=1, n=40, h=4, w=4, cin=512, cout=512, nchunk=40, ksplit=6, gpu_only=True),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_winograd_gn_in(backend, case, monkeypatch):
+    """lfdm_conv_params.gn_in_*: GroupNorm + (scale+1, shift) + SiLU of the INPUT applied inside the Winograd convolution's patch load
+    (ResnetBlock.block1's norm / act inside block2's convolution, video_flow_diffusion.py:199-212, 226-234) against
+    conv2d(silu(group_norm(x) * (scale + 1) + shift)); the statistics arrive as (sum, sum of squares) partials like the producing
+    convolution writes them."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    monkeypatch.setenv("LFDM_WINO", "1")
+    b, n, h, w, cin, cout, nchunk = (case[k] for k in ("b", "n", "h", "w", "cin", "cout", "nchunk"))
+    cgroups, gg = case.get("groups", 1), case.get("gn_groups", 8)
+    x = rnd(n, cin, h, w, seed=1) * 1.5 + 0.3
+    wt = rnd(cout, cin // cgroups, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9 / cgroups))
+    bias, gamma, beta = rnd(cout, seed=3), rnd(cin, seed=4) * 0.3 + 1, rnd(cin, seed=5) * 0.3
+    ss = rnd(b, 2 * cin, seed=6) * 0.3 if case.get("ss", True) else None
+    pixels = n // b * h * w
+    xcl = to_cl(x)                                                # (n*h*w, cin), frames of one sample contiguous
+    xs = xcl.view(b, pixels, cin)
+    xn = F.group_norm(xs.permute(0, 2, 1), gg, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    if ss is not None:
+        xn = xn * (ss[:, None, :cin] + 1) + ss[:, None, cin:]
+    act = from_cl(F.silu(xn).reshape(n * h * w, cin), n, h, w)
+    ref = F.conv2d(act, wt, bias, padding=1, groups=cgroups)
+    res = rnd(*ref.shape, seed=8) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res
+    xg = xs.view(b, nchunk, pixels // nchunk, gg, cin // gg)
+    partial = torch.stack([xg.sum(dim=(2, 4)), (xg * xg).sum(dim=(2, 4))], dim=-1).contiguous().view(b * nchunk, 2 * gg).to(dev)
+    gn_in = dict(partial=partial, nchunk=nchunk, pixels=pixels, gamma=gamma.to(dev), beta=beta.to(dev), groups=gg,
+                 scale_shift=None if ss is None else ss.to(dev))
+    if cgroups > 1:
+        ww = ops.pack_wino_weight_grouped([wt[g * (cout // cgroups):(g + 1) * (cout // cgroups)].to(dev) for g in range(cgroups)])
+        wd = ww
+    else:
+        wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
+    kw = dict(bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), ksplit=case.get("ksplit", 1), weight_wino=ww,
+              groups=cgroups, gn_in=gn_in)
+    pp, _ = ops.conv_params(xcl.to(dev), wd, cout, 3, 3, n, h, w, **kw)
+    assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 2
+    out = ops.conv2d_cl(xcl.to(dev), wd, cout, 3, 3, n, h, w, **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "Winograd convolution with the input GroupNorm + SiLU fused")
+    # the geometry checks: two sources / an upsampled input / an output activation are refused, not mis-computed
+    with pytest.raises(RuntimeError):
+        ops.conv2d_cl(xcl.to(dev), wd, cout, 3, 3, n, h, w, **dict(kw, act=1))
+
+
 @pytest.mark.parametrize("c", [64, 128, 512])
 def test_conv_fused_layernorm(backend, c):
     """PreNorm (channel LayerNorm) folded into the 1x1 qkv projection (c <= 128: row-panel schedule, ragged last
