@@ -96,6 +96,8 @@ _SIGNATURES = {
     "lfdm_attention_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, stream_t]),
     "lfdm_temporal_attention_fused_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, i32, i32, i32, f32p, f32p, f32p, f32,
                                                   stream_t]),
+    "lfdm_temporal_attention_fused_out_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32,
+                                                      stream_t]),
     "lfdm_linear_attention_lowres_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, i32, i32, f32, stream_t]),
     "lfdm_attention_lowres_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, f32, stream_t]),
     "lfdm_pack_wino_weight_f32": (i32, [f32p, i32, i32, i32, i32, i32, f32p, stream_t]),

@@ -39,10 +39,12 @@ __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }      //
 // Attention of one (sequence, head) from operand-layout fragments (see the header comment): scores transposed,
 // softmax in registers, P V, store.  qf/kf[ti][4*fi + r] = feature 16*fi + 4*lq + r of token 16*ti + l15 (q scaled and
 // rotated, k rotated); vf[half][4*ti + r] = v[token 16*ti + 4*lq + r][16*half + l15].
+// o_lds != nullptr: the attention output goes to the workgroup's LDS tile [token][256] (16-byte quads XOR-swizzled by the token, see
+// temporal_attn_fused_out_kernel) instead of global memory.
 template <int NT>
 __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const float (&kf)[NT][8], const float (&vf)[2][4 * NT],
                                              int head, int L, int l15, int lq, const float* __restrict__ bias, bool bias_vec,
-                                             float* __restrict__ out, int64_t row0, int hw) {
+                                             float* __restrict__ out, int64_t row0, int hw, float* o_lds = nullptr) {
   // ---- S^T = K Q^T: lane = query token 16*ti + l15, registers = key tokens 16*tj + 4*lq + r.  In this orientation the
   // softmax over the keys of a query is a reduction over the lane's registers plus two shuffles (the four k-slots),
   // and the result is ALREADY the A operand of P V for the token order t(lq, s) = 16*(s>>2) + 4*lq + (s&3): no LDS. ----
@@ -122,28 +124,39 @@ __device__ __forceinline__ void attend_store(const float (&qf)[NT][8], const flo
     for (int r = 0; r < 4; ++r) {
       const int t = ti * 16 + lq * 4 + r;
       if (t < L) {
-        float* dst = out + (row0 + (int64_t)t * hw) * OUT_LD + head * DH;
-        dst[l15] = o[0][r];
-        dst[16 + l15] = o[1][r];
+        if (o_lds) {      // column c = head*32 + 16*half + l15 -> quad c >> 2, swizzled by the row
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int c = head * DH + 16 * half + l15;
+            o_lds[t * OUT_LD + ((((c >> 2) ^ (t & 15)) << 2) | (c & 3))] = o[half][r];
+          }
+        } else {
+          float* dst = out + (row0 + (int64_t)t * hw) * OUT_LD + head * DH;
+          dst[l15] = o[0][r];
+          dst[16 + l15] = o[1][r];
+        }
       }
     }
   }
 }
 
-template <int LP, int C>
-__global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float* __restrict__ x, int ldx, int heads_per_block,
-                                                                 const float* __restrict__ wqkv,   // (768, C), gamma folded
-                                                                 float* __restrict__ out, int batch, int frames, int hw,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ rot_cos,
-                                                                 const float* __restrict__ rot_sin, float eps) {
+// The body of one wavefront: heads [head_begin, head_begin + heads_per_block) of sequence `seq`; results to global `out` or to `o_lds`.
+// ROT_RELOAD: the rotary factors are re-read from their (L1-resident, 2.5 KB) tables per head instead of living in 24 registers across the
+// head loop - the one-launch block needs the registers (27 spills otherwise).
+// WPACK: wqkv is in MFMA-operand order [q|k|v][head][feature half][quad q][lane][4] (lane (l15, lq) <- W[row 16*half + l15][C/4*lq + 4q ..]):
+// every fragment load instruction then reads ONE contiguous 1 KB instead of a 16-byte piece of each of its 64 lanes' 64-byte segments
+// (four times the L1 line look-ups per byte in the row-major layout).
+template <int LP, int C, bool ROT_RELOAD = false, bool WPACK = false>
+__device__ __forceinline__ void tattn_heads(const float* __restrict__ x, int ldx, int head_begin, int heads_per_block,
+                                            const float* __restrict__ wqkv, float* __restrict__ out, int frames, int hw, int64_t seq,
+                                            const float* __restrict__ bias, const float* __restrict__ rot_cos,
+                                            const float* __restrict__ rot_sin, float eps, float* o_lds) {
   constexpr int NT = LP / 16;
   constexpr int CQ = C / 4;                        // channels per k-slot
 
   const int lane = threadIdx.x & 63;
   const int l15 = lane & 15, lq = lane >> 4;
   const int L = frames;
-  const int64_t seq = blockIdx.x;
   const int64_t b = seq / hw, pix = seq - b * hw;
   const int64_t row0 = b * frames * hw + pix;
   const float scale = 0.17677669529663687f;  // 32^-0.5
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
 
   // rotary factors of this lane's tokens / feature pairs (head independent)
   float rc[NT][4], rs[NT][4];
-  if (rot_cos) {
+  if (rot_cos && !ROT_RELOAD) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
       const int t = ti * 16 + l15;
@@ -197,8 +210,6 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
   }
   const bool bias_vec = bias && (L % 4 == 0) && ((((uintptr_t)bias) & 15) == 0);
 
-  // grid.y splits the 8 heads over workgroups when there are few sequences (x is re-read per workgroup: 10-20 KB)
-  const int head_begin = blockIdx.y * heads_per_block;
 #pragma unroll 1
   for (int head = head_begin; head < head_begin + heads_per_block; ++head) {
     // ---- Q^T, K^T: rows = features (2 tiles of 16), cols = tokens (NT tiles) ----
@@ -209,10 +220,11 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
       float wa[4][CQ];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float* wsrc = wqkv + ((int64_t)((g >> 1) * OUT_LD + head * DH + 16 * (g & 1) + l15)) * C + CQ * lq;
+        const float* wsrc = WPACK ? wqkv + ((int64_t)(((g >> 1) * HEADS + head) * 2 + (g & 1)) * (CQ / 4) * 64 + lane) * 4
+                                  : wqkv + ((int64_t)((g >> 1) * OUT_LD + head * DH + 16 * (g & 1) + l15)) * C + CQ * lq;
 #pragma unroll
         for (int q = 0; q < CQ / 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(wsrc + 4 * q);
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + (WPACK ? 256 * q : 4 * q));
           wa[g][4 * q] = v.x; wa[g][4 * q + 1] = v.y; wa[g][4 * q + 2] = v.z; wa[g][4 * q + 3] = v.w;
         }
       }
@@ -242,7 +254,15 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            const float c = rc[ti][2 * fi + pr], sn = rs[ti][2 * fi + pr];   // pair of features 16*fi + 4*lq + 2*pr (+1)
+            float c, sn;                                                    // pair of features 16*fi + 4*lq + 2*pr (+1)
+            if (ROT_RELOAD) {
+              const int t = ti * 16 + l15, tt = t < L ? t : 0;
+              c = rot_cos[tt * 16 + 8 * fi + 2 * lq + pr];
+              sn = rot_sin[tt * 16 + 8 * fi + 2 * lq + pr];
+            } else {
+              c = rc[ti][2 * fi + pr];
+              sn = rs[ti][2 * fi + pr];
+            }
             const float qx = qf[ti][4 * fi + 2 * pr], qy = qf[ti][4 * fi + 2 * pr + 1];
             const float kx = kf[ti][4 * fi + 2 * pr], ky = kf[ti][4 * fi + 2 * pr + 1];
             qf[ti][4 * fi + 2 * pr] = qx * c - qy * sn;
@@ -258,10 +278,11 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
       float wb[2][CQ];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const float* wsrc = wqkv + ((int64_t)(2 * OUT_LD + head * DH + 16 * half + l15)) * C + CQ * lq;
+        const float* wsrc = WPACK ? wqkv + ((int64_t)((2 * HEADS + head) * 2 + half) * (CQ / 4) * 64 + lane) * 4
+                                  : wqkv + ((int64_t)(2 * OUT_LD + head * DH + 16 * half + l15)) * C + CQ * lq;
 #pragma unroll
         for (int q = 0; q < CQ / 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(wsrc + 4 * q);
+          const float4 v = *reinterpret_cast<const float4*>(wsrc + (WPACK ? 256 * q : 4 * q));
           wb[half][4 * q] = v.x; wb[half][4 * q + 1] = v.y; wb[half][4 * q + 2] = v.z; wb[half][4 * q + 3] = v.w;
         }
       }
@@ -281,7 +302,81 @@ __global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float*
       }
     }
 
-    attend_store<NT>(qf, kf, vf, head, L, l15, lq, bias, bias_vec, out, row0, hw);
+    attend_store<NT>(qf, kf, vf, head, L, l15, lq, bias, bias_vec, out, row0, hw, o_lds);
+  }
+}
+
+template <int LP, int C>
+__global__ __launch_bounds__(64, 2) void temporal_attn_fused_kernel(const float* __restrict__ x, int ldx, int heads_per_block,
+                                                                 const float* __restrict__ wqkv,   // (768, C), gamma folded
+                                                                 float* __restrict__ out, int batch, int frames, int hw,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ rot_cos,
+                                                                 const float* __restrict__ rot_sin, float eps) {
+  // grid.y splits the 8 heads over workgroups when there are few sequences (x is re-read per workgroup: 10-20 KB)
+  tattn_heads<LP, C>(x, ldx, blockIdx.y * heads_per_block, heads_per_block, wqkv, out, frames, hw, blockIdx.x, bias, rot_cos, rot_sin, eps, nullptr);
+}
+
+// ... + to_out + residual in the same launch (round 4; lfdm_temporal_attention_fused_out_cl_f32): Residual(PreNorm(Attention)) complete,
+// video_flow_diffusion.py:170-189, 286-363.  The separate to_out projection was a 25 us launch at 32x32 (0.67 GFLOP, 8 K chunks: all fixed
+// cost) that re-read the 42 MB attention output the kernel above had just written in 64-byte pieces.  Here a workgroup of NW waves owns one
+// pixel sequence: wave w runs heads [w * 8/NW, ...) exactly as above but parks its head outputs in the workgroup's LDS tile
+// O[token][256] (row = 1 KB, the 16-byte quads XOR-swizzled by the token so that the unpadded tile reads conflict-free as MFMA A
+// fragments), and after one barrier the waves share the projection out[t][c] = x[t][c] + sum_k O[t][k] Wout[c][k] on
+// v_mfma_f32_16x16x4_f32: output tiles (16 tokens x 16 channels) dealt round-robin to the waves, A = O from LDS (one ds_read_b128 feeds
+// four k-steps: k-slot lq of step (S, j) takes k = 16 S + 4 lq + j for BOTH operands), B = Wout straight from L2 in the same order.
+// Both weight tensors arrive PACKED in operand order (ops.pack_tattn_weights): wqkv [3][8][2][4][64 lanes][4], wout [4 ct][16 S][64 lanes][4].
+// LROWS = rows of the LDS tile (>= frames): 40 for the 40-frame videos (40 KB: four workgroups per CU), LP otherwise.
+template <int LP, int LROWS, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void temporal_attn_fused_out_kernel(const float* __restrict__ x, int ldx,
+                                                                          const float* __restrict__ wqkv, const float* __restrict__ wout,
+                                                                          float* __restrict__ out, int ldo, int frames, int hw,
+                                                                          const float* __restrict__ bias, const float* __restrict__ rot_cos,
+                                                                          const float* __restrict__ rot_sin, float eps) {
+  constexpr int C = 64, NT = LP / 16, CT = C / 16;
+  __shared__ __attribute__((aligned(16))) float o_lds[LROWS * OUT_LD];
+  const int wave = lfdm_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+  const int L = frames;
+  const int64_t seq = blockIdx.x;
+  tattn_heads<LP, C, (NW < 8), true>(x, ldx, wave * (HEADS / NW), HEADS / NW, wqkv, nullptr, frames, hw, seq, bias, rot_cos, rot_sin, eps, o_lds);
+  __syncthreads();
+  const int64_t b = seq / hw, pix = seq - b * hw;
+  const int64_t row0 = b * frames * hw + pix;
+  // output tiles (ti, ct), ti-major, dealt to the waves
+  for (int tile = wave; tile < NT * CT; tile += NW) {
+    const int ti = tile / CT, ct = tile - ti * CT;
+    const int t = ti * 16 + l15;                        // A rows: this lane's token
+    const int tr = t < L ? t : L - 1;                   // (padded tokens read a valid row; their results are never stored)
+    const float* arow = o_lds + tr * OUT_LD;
+    const float* brow = wout + ((int64_t)ct * (OUT_LD / 16) * 64 + lane) * 4;      // packed [ct][S][lane][4]: one contiguous 1 KB per load
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc;      // two chains: the 40-cycle dependent latency of 16x16x4 exceeds its 32-cycle issue
+#pragma unroll 4
+    for (int S = 0; S < OUT_LD / 16; S += 2) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + (((4 * S + lq) ^ (tr & 15)) << 2));
+      const float4 a1 = *reinterpret_cast<const float4*>(arow + (((4 * S + 4 + lq) ^ (tr & 15)) << 2));
+      const float4 w = *reinterpret_cast<const float4*>(brow + 256 * S);
+      const float4 w1 = *reinterpret_cast<const float4*>(brow + 256 * S + 256);
+      acc = mfma_16x16x4(a.x, w.x, acc);
+      acc1 = mfma_16x16x4(a1.x, w1.x, acc1);
+      acc = mfma_16x16x4(a.y, w.y, acc);
+      acc1 = mfma_16x16x4(a1.y, w1.y, acc1);
+      acc = mfma_16x16x4(a.z, w.z, acc);
+      acc1 = mfma_16x16x4(a1.z, w1.z, acc1);
+      acc = mfma_16x16x4(a.w, w.w, acc);
+      acc1 = mfma_16x16x4(a1.w, w1.w, acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+    // D: lane = channel ct*16 + l15, register r = token ti*16 + 4*lq + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = ti * 16 + 4 * lq + r;
+      if (tok < L) {
+        const int64_t row = row0 + (int64_t)tok * hw;
+        out[row * ldo + ct * 16 + l15] = acc[r] + x[row * ldx + ct * 16 + l15];
+      }
+    }
   }
 }
 
@@ -443,7 +538,41 @@ int launch_fused(const float* x, int ldx, const float* wqkv, float* out, int bat
   return lfdm_check_launch("temporal_attention_fused");
 }
 
+template <int LP, int LROWS>
+int launch_fused_out_lp(const float* x, int ldx, const float* wqkv, const float* wout, float* out, int ldo, int batch, int frames, int hw,
+                        const float* bias, const float* rot_cos, const float* rot_sin, float eps, hipStream_t stream) {
+  const int64_t nseq = (int64_t)batch * hw;
+  int nw = 1;                                        // waves per sequence: aim at >= 2048 wavefronts (like the kernel above)
+  while (nw < 8 && nseq * nw < 2048) nw <<= 1;
+  if (const char* e = getenv("LFDM_TATTN_OUT_NW")) {      // experiment knob
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) nw = v;
+  }
+  const dim3 grid((unsigned)nseq);
+  if (nw == 1) LFDM_LAUNCH((temporal_attn_fused_out_kernel<LP, LROWS, 1>), grid, dim3(64), 0, stream, x, ldx, wqkv, wout, out, ldo, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (nw == 2) LFDM_LAUNCH((temporal_attn_fused_out_kernel<LP, LROWS, 2>), grid, dim3(128), 0, stream, x, ldx, wqkv, wout, out, ldo, frames, hw, bias, rot_cos, rot_sin, eps);
+  else if (nw == 4) LFDM_LAUNCH((temporal_attn_fused_out_kernel<LP, LROWS, 4>), grid, dim3(256), 0, stream, x, ldx, wqkv, wout, out, ldo, frames, hw, bias, rot_cos, rot_sin, eps);
+  else LFDM_LAUNCH((temporal_attn_fused_out_kernel<LP, LROWS, 8>), grid, dim3(512), 0, stream, x, ldx, wqkv, wout, out, ldo, frames, hw, bias, rot_cos, rot_sin, eps);
+  return lfdm_check_launch("temporal_attention_fused_out");
+}
+
 }  // namespace
+
+extern "C" int lfdm_temporal_attention_fused_out_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wout,
+                                                        float* out, int ldo, int batch, int frames, int hw, const float* bias,
+                                                        const float* rot_cos, const float* rot_sin, float ln_eps, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wqkv || !wout || !out || batch <= 0 || frames <= 0 || frames > 64 || hw <= 0 || channels != 64 || ldx < 64 || ldx % 4 != 0 ||
+      ldo < 64 || (((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)wout) & 15) || ((rot_cos == nullptr) != (rot_sin == nullptr)) || out == x) {
+    lfdm_set_error("temporal_attention_fused_out: needs C == 64, frames <= 64, 16-byte aligned rows, out != x");
+    return LFDM_EINVAL;
+  }
+  if (frames <= 16) return launch_fused_out_lp<16, 16>(x, ldx, wqkv, wout, out, ldo, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  if (frames <= 32) return launch_fused_out_lp<32, 32>(x, ldx, wqkv, wout, out, ldo, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  if (frames <= 40) return launch_fused_out_lp<48, 40>(x, ldx, wqkv, wout, out, ldo, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  if (frames <= 48) return launch_fused_out_lp<48, 48>(x, ldx, wqkv, wout, out, ldo, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+  return launch_fused_out_lp<64, 64>(x, ldx, wqkv, wout, out, ldo, batch, frames, hw, bias, rot_cos, rot_sin, ln_eps, stream);
+}
 
 extern "C" int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
                                                     int batch, int frames, int hw, const float* bias,

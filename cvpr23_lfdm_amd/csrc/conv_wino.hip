@@ -175,11 +175,14 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
       const int n = n0 + WN * ct + l31 - grp * wcoutp;          // column inside the (group's) filter pack
+      // pack [pos][chunk][j = 0, 1][column][kh][4] (round 4): the lanes of ONE load instruction (32 columns x 2 k-slots x 16 bytes) read a
+      // contiguous 1 KB - the previous [pos][chunk][column][16] order made each instruction touch half of every lane's 32-byte piece,
+      // twice the L1 line look-ups per byte on the kernel's dominant stream
       const uint32_t off = (n < wcoutp)
-                               ? (uint32_t)(((((int64_t)pos * nchunks_all + chunk) * wcoutp + n) * WKC + 8 * kh) * 4)
+                               ? (uint32_t)((((((int64_t)pos * nchunks_all + chunk) * 2) * wcoutp + n) * 2 + kh) * 16)
                                : LFDM_BUF_OOB;
       bfrag[pi][ct][0] = lfdm_buf_load_f4(bufw, off);
-      bfrag[pi][ct][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + 16);
+      bfrag[pi][ct][1] = lfdm_buf_load_f4(bufw, off == LFDM_BUF_OOB ? LFDM_BUF_OOB : off + (uint32_t)wcoutp * 32u);
     }
   };
 
@@ -481,7 +484,10 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
     const float u[4] = {r[i][0], 0.5f * (r[i][0] + r[i][1] + r[i][2]), 0.5f * (r[i][0] - r[i][1] + r[i][2]), r[i][2]};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      out[((((int64_t)(4 * i + j)) * nch + k / WKC) * coutp + n) * WKC + (k % WKC)] = u[j];
+      {      // k % 16 = 8 * kh + 4 * half + e  ->  [pos][chunk][half][n][kh][e]
+        const int kk = k % WKC, kh2 = kk >> 3, half = (kk >> 2) & 1, e = kk & 3;
+        out[((((((int64_t)(4 * i + j)) * nch + k / WKC) * 2 + half) * coutp + n) * 2 + kh2) * 4 + e] = u[j];
+      }
   }
 }
 

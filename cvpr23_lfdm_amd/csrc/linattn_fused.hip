@@ -50,11 +50,14 @@ __device__ __forceinline__ void load_xhat(const float* __restrict__ xrow, bool o
   for (int s = 0; s < CH; ++s) xf[s] = ok ? (xf[s] - mean) * rstd : 0.f;
 }
 
-__device__ __forceinline__ void load_wrow(const float* __restrict__ w, int row, int kh, float (&wf)[CH]) {
-  const float* src = w + (int64_t)row * C + CH * kh;
+// Weight fragment of one (q | k | v, head): lane (feature l31, k-slot kh) holds W[which*256 + head*32 + l31][CH*kh .. CH*kh + CH-1].
+// The weights arrive PACKED in that order (round 4, ops.pack_linattn_weights): [3][8 heads][8 quads][64 lanes][4], so each of the eight load
+// instructions reads one contiguous 1 KB - in the row-major layout every instruction touched a 16-byte piece of 64 different 128-byte lines.
+__device__ __forceinline__ void load_wfrag(const float* __restrict__ wp, int which, int head, int lane, float (&wf)[CH]) {
+  const float* src = wp + ((int64_t)(which * HEADS + head) * (CH / 4) * 64 + lane) * 4;
 #pragma unroll
   for (int q = 0; q < CH / 4; ++q) {
-    const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+    const float4 v = *reinterpret_cast<const float4*>(src + 256 * q);
     wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w;
   }
 }
@@ -70,8 +73,8 @@ __global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* _
   const int n0 = split * SPLIT_TOK;
 
   float wk[CH], wv[CH];
-  load_wrow(wqkv, OUT_LD + h * DH + l31, kh, wk);          // B operands: lane = feature l31, k-slot = channel half
-  load_wrow(wqkv, 2 * OUT_LD + h * DH + l31, kh, wv);
+  load_wfrag(wqkv, 1, h, lane, wk);                        // B operands: lane = feature l31, k-slot = channel half
+  load_wfrag(wqkv, 2, h, lane, wv);
 
   f32x16 kacc[NTILE], vacc[NTILE];
 #pragma unroll
@@ -130,10 +133,14 @@ __global__ __launch_bounds__(256) void linattn_fused_merge_kernel(const float* _
   __shared__ float s_w[MAXS][DH];                  // weight of split p for feature d: e^{m_p - M} / denominator
   const int tid = threadIdx.x;
   const float* base = part + (int64_t)blockIdx.x * nsplit * PART;
+  // (round 4: every loop over the splits is unrolled by four - a load per trip paid one L2 round trip per split, 16 of them in a row at
+  //  32x32: 12.6 us for a kernel that moves 22 MB)
   if (tid < DH) {
     float mm = -3.0e38f;
+#pragma unroll 4
     for (int p = 0; p < nsplit; ++p) mm = fmaxf(mm, base[(int64_t)p * PART + DH * DH + tid]);
     float den = 0.f;
+#pragma unroll 4
     for (int p = 0; p < nsplit; ++p) {
       const float w = expf(base[(int64_t)p * PART + DH * DH + tid] - mm);
       s_w[p][tid] = w;
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(256) void linattn_fused_merge_kernel(const float* _
   for (int i = tid; i < DH * DH; i += 256) {
     const int d = i >> 5;
     float acc = 0.f;
+#pragma unroll 4
     for (int p = 0; p < nsplit; ++p) acc += s_w[p][d] * base[(int64_t)p * PART + i];
     ctx_out[(int64_t)blockIdx.x * DH * DH + i] = acc;
   }
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64, 2) void linattn_fused_out_kernel(const float* _
 #pragma unroll 1
   for (int h = blockIdx.z * hpb; h < (blockIdx.z + 1) * hpb; ++h) {
     float wq[CH];
-    load_wrow(wqkv, h * DH + l31, kh, wq);                 // A operand: lane = feature d
+    load_wfrag(wqkv, 0, h, lane, wq);                      // A operand: lane = feature d
     f32x16 q;
 #pragma unroll
     for (int r = 0; r < 16; ++r) q[r] = 0.f;

@@ -120,10 +120,22 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
     const int g = g0 + tid / lpg;
     double s = 0.0, q = 0.0;
     if (g < groups) {
-      for (int k = sub; k < nchunk; k += lpg) {
-        const float* src = partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
-        s += (double)src[0];
-        q += (double)src[1];
+      // four chunk loads in flight per lane (round 4: the one-load-per-trip walk paid an L2 round trip per chunk - 2.4 us of the launch
+      // at 320 chunks, tools/ubench/launch_floor.py); same summation order as before: k ascending per lane
+      const float2* src = reinterpret_cast<const float2*>(partial) + ((int64_t)b * nchunk) * groups + g;
+      int k = sub;
+      for (; k + 3 * lpg < nchunk; k += 4 * lpg) {
+        const float2 v0 = src[(int64_t)k * groups], v1 = src[(int64_t)(k + lpg) * groups];
+        const float2 v2 = src[(int64_t)(k + 2 * lpg) * groups], v3 = src[(int64_t)(k + 3 * lpg) * groups];
+        s += (double)v0.x; q += (double)v0.y;
+        s += (double)v1.x; q += (double)v1.y;
+        s += (double)v2.x; q += (double)v2.y;
+        s += (double)v3.x; q += (double)v3.y;
+      }
+      for (; k < nchunk; k += lpg) {
+        const float2 v = src[(int64_t)k * groups];
+        s += (double)v.x;
+        q += (double)v.y;
       }
     }
     for (int m = lpg >> 1; m >= 1; m >>= 1) {

@@ -505,15 +505,50 @@ def temporal_attention_fused_cl(x, wqkv, batch, frames, hw, *, bias=None, rot_co
     return out
 
 
+def pack_tattn_weights(wqkv_folded, wout):
+    """(768, 64) LayerNorm-folded to_qkv weight and (64, 256) to_out weight -> the MFMA-operand order of
+    lfdm_temporal_attention_fused_out_cl_f32 (every fragment load = one contiguous 1 KB): ([3][8][2][4][64][4], [4][16][64][4])."""
+    assert wqkv_folded.shape == (768, 64) and wout.shape == (64, 256)
+    # rows: which(3) head(8) half(2) l15(16); columns: lq(4) quad(4) e(4)  ->  which head half quad (lq l15) e
+    wq = wqkv_folded.float().reshape(3, 8, 2, 16, 4, 4, 4).permute(0, 1, 2, 5, 4, 3, 6).contiguous().view(3, 8, 2, 4, 64, 4)
+    # rows: ct(4) l15(16); columns: S(16) lq(4) e(4)  ->  ct S (lq l15) e
+    wo = wout.float().reshape(4, 16, 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(4, 16, 64, 4)
+    return wq, wo
+
+
+def temporal_attention_fused_out_cl(x, wqkv, wout, batch, frames, hw, *, bias=None, rot_cos=None, rot_sin=None, eps=1e-5, out=None):
+    """The whole temporal-attention block in one launch (C == 64): out = x + to_out(attention(LayerNorm(x))); wqkv, wout =
+    pack_tattn_weights(W_qkv * gamma, W_out)."""
+    lib = _lib()
+    _chk(lib, x, wqkv, wout, bias, rot_cos, rot_sin, out)
+    c = x.shape[1]
+    assert c == 64 and wqkv.shape == (3, 8, 2, 4, 64, 4) and wqkv.is_contiguous() and wout.shape == (4, 16, 64, 4) and wout.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape[0], c, dtype=torch.float32, device=x.device)
+    assert out.data_ptr() != x.data_ptr()
+    lib.check(lib.lfdm_temporal_attention_fused_out_cl_f32(_p(x), x.stride(0), c, _p(wqkv), _p(wout), _p(out), out.stride(0), batch, frames, hw,
+                                                           _p(bias), _p(rot_cos), _p(rot_sin), eps, _stream(lib)),
+              "lfdm_temporal_attention_fused_out_cl_f32")
+    return out
+
+
+def pack_linattn_weights(wqkv_folded):
+    """(768, 64) LayerNorm-folded to_qkv weight of SpatialLinearAttention -> the MFMA-operand order of lfdm_linear_attention_fused_cl_f32:
+    [3 = q|k|v][8 heads][8 quads][64 lanes = 32*kh + l31][4]  <-  W[which*256 + head*32 + l31][32*kh + 4*quad + e]."""
+    assert wqkv_folded.shape == (768, 64)
+    # rows: which(3) head(8) l31(32); columns: kh(2) quad(8) e(4)  ->  which head quad (kh l31) e
+    return wqkv_folded.float().reshape(3, 8, 32, 2, 8, 4).permute(0, 1, 4, 3, 2, 5).contiguous().view(3, 8, 8, 64, 4)
+
+
 def linear_attention_fused_ws_floats(n_frames, hw):
     return (int(_lib().lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) + 3) // 4
 
 
 def linear_attention_fused_cl(x, wqkv, n_frames, hw, *, eps=1e-5, out=None, ws=None):
-    """LayerNorm + to_qkv + linear attention core without materialising qkv (C == 64); wqkv (768, 64) with gamma folded."""
+    """LayerNorm + to_qkv + linear attention core without materialising qkv (C == 64); wqkv = pack_linattn_weights(W_qkv * gamma)."""
     lib = _lib()
     _chk(lib, x, wqkv, out, ws)
-    assert wqkv.shape == (768, x.shape[1]) and wqkv.is_contiguous()
+    assert x.shape[1] == 64 and wqkv.shape == (3, 8, 8, 64, 4) and wqkv.is_contiguous()
     if out is None:
         out = torch.empty(x.shape[0], 256, dtype=torch.float32, device=x.device)
     need = lib.lfdm_linear_attention_fused_ws_bytes(n_frames, hw)

@@ -30,6 +30,8 @@ _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 # LFDM_GN_FUSE_MAX_ROWS bounds the activation rows (B*T*S*S) it is used at.
 _GN_FUSE = os.environ.get("LFDM_GN_FUSE", "0") == "1"
 _GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
+# to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
+_TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 
 
 def prob_mask_like(shape, prob, device):
@@ -178,10 +180,14 @@ class Unet3D(ParamTree):
             pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()
             pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.fn.to_out.weight"))
+            if wq.shape[1] == 64:      # the one-launch block at C = 64: both weights in MFMA-operand order
+                pk[prefix + "qkv.wp"], pk[prefix + "out.wp"] = ops.pack_tattn_weights(pk[prefix + "qkv.wf"], g(prefix + "fn.fn.fn.to_out.weight").reshape(-1, 256))
 
         def spatial_linear(prefix):
             wq, gam = g(prefix + "fn.fn.to_qkv.weight"), g(prefix + "fn.norm.gamma")
             pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()      # (see temporal)
+            if wq.shape[1] == 64:      # the fused three-launch form at C = 64: weight fragments in MFMA-operand order
+                pk[prefix + "qkv.wp"] = ops.pack_linattn_weights(pk[prefix + "qkv.wf"])
             pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
             pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
@@ -412,6 +418,9 @@ class Unet3D(ParamTree):
                 src = qkv[sl, 512:768] if focus[b] else att[sl]
                 self._conv(src, pk[prefix + "out.w"], c, 1, frames, s, residual=x[sl], out=out[sl])
             return out
+        if c == 64 and frames <= 64 and _TATTN_OUT:      # the whole block (LayerNorm, to_qkv, attention, to_out, residual) in one launch
+            return ops.temporal_attention_fused_out_cl(x, pk[prefix + "qkv.wp"], pk[prefix + "out.wp"], batch, frames, s * s, bias=bias,
+                                                       rot_cos=cos, rot_sin=sin, out=self._buf(outname, x.shape[0], c))
         if c == 64 and frames <= 64:
             att = self._buf("at.o", x.shape[0], 256)
             ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
@@ -441,7 +450,7 @@ class Unet3D(ParamTree):
         if c == 64:
             att = self._buf("at.o", x.shape[0], 256)
             ws = self._buf("la.wsf", 1, ops.linear_attention_fused_ws_floats(n_img, s * s))
-            ops.linear_attention_fused_cl(x, pk[prefix + "qkv.wf"], n_img, s * s, out=att, ws=ws)
+            ops.linear_attention_fused_cl(x, pk[prefix + "qkv.wp"], n_img, s * s, out=att, ws=ws)
         elif _LOWRES_ATTN and ops.linear_attention_lowres_ok(s * s, c) and s * s <= _LOWRES_MAX_HW:      # one launch: workgroup = (frame, head)
             att = self._buf("at.o", x.shape[0], 256)
             ops.linear_attention_lowres_cl(x, pk[prefix + "qkv.wf"], pk[prefix + "qkv.wsum"], n_img, s * s, out=att)

@@ -101,7 +101,9 @@ typedef struct lfdm_conv_params {
   int tile_counters_len;
   /* Optional Winograd F(2x2,3x3) form of the SAME filter (3x3, stride 1, zero pad 1, even H and W, C0 % 16 == C1 % 16 == 0;
      also through the virtual nearest x2 upsample):
-     U = G g G^T laid out [16 positions][Cin/16][coutp][16] (cvpr23_lfdm_amd.ops.pack_wino_weight).  When given and the
+     U = G g G^T laid out [16 positions][Cin/16][2 halves j][coutp][2 k-slots kh][4] with reduction channel % 16 = 8 kh + 4 j + e - the
+     order of the kernel's two fragment loads, each a contiguous 1 KB per 32 columns (ABI version 8; lfdm_pack_wino_weight_f32 /
+     cvpr23_lfdm_amd.ops.pack_wino_weight write it; as a tensor it keeps the shape [16][Cin/16][coutp][16]).  When given and the
      geometry qualifies the library may run the 16/36-multiplication schedule (conv_wino.hip); results differ from the
      direct form by fp32 rounding only (~1e-6 relative).  LFDM_WINO=0 in the environment forces the direct form. */
   const float* weight_wino;
@@ -351,10 +353,21 @@ int lfdm_temporal_attention_fused_cl_f32(const float* x, int ldx, int channels, 
                                          int batch, int frames, int hw, const float* bias,
                                          const float* rot_cos, const float* rot_sin, float ln_eps,
                                          lfdm_stream_t stream);
+/* The same block COMPLETE in one launch (ABI version 8): out = x + to_out(attention(LayerNorm(x))) - Residual(PreNorm(EinopsToAndFrom(
+ * Attention))), video_flow_diffusion.py:170-189, 270-283, 286-363 incl. to_out (:301, no bias) and the residual add (:165).  Both weights
+ * in MFMA-operand order, lane = 16 * lq + l15 (cvpr23_lfdm_amd.ops.pack_tattn_weights):
+ *   wqkv [3 = q|k|v][8 heads][2 feature halves][4 quads][64 lanes][4]  <-  (W_qkv * gamma)[which*256 + head*32 + 16*half + l15][16*lq + 4*quad + e]
+ *   wout [4 column tiles][16 steps S][64 lanes][4]                      <-  W_out[16*ct + l15][16*S + 4*lq + e]
+ * out (rows, C) with row stride ldo, out != x.  C == 64 only (the finest UNet levels). */
+int lfdm_temporal_attention_fused_out_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wout, float* out,
+                                             int ldo, int batch, int frames, int hw, const float* bias, const float* rot_cos,
+                                             const float* rot_sin, float ln_eps, lfdm_stream_t stream);
 
 /* PreNorm LayerNorm + to_qkv (1x1 conv, no bias) + SpatialLinearAttention core (without to_out) for C == 64:
  * video_flow_diffusion.py:170-189, :249-263.  x: CL rows (n_frames*hw, C) stride ldx; wqkv (768, C) row-major with the
- * LayerNorm gamma folded in; out rows of 256.  qkv is never materialised (every pass recomputes its projection). */
+ * LayerNorm gamma folded in; out rows of 256.  qkv is never materialised (every pass recomputes its projection). 
+ * wqkv (ABI version 8): the LayerNorm-folded (768, 64) weight in MFMA-operand order [3 = q|k|v][8 heads][8 quads][64 lanes = 32*kh + l31][4]
+ * <- W[which*256 + head*32 + l31][32*kh + 4*quad + e] (cvpr23_lfdm_amd.ops.pack_linattn_weights): every fragment load = one contiguous 1 KB. */
 size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw);
 int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
                                        int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,

@@ -794,6 +794,24 @@ def test_temporal_attention_fused(backend, c, frames):
     out = ops.temporal_attention_fused_cl(unet_to_cl(x).to(dev), wf.to(dev), b, frames, hw, bias=bias.contiguous().to(dev),
                                           rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + temporal attention")
+    if c == 64:
+        # ... and the whole block in one launch: + to_out (no bias) + residual (lfdm_temporal_attention_fused_out_cl_f32), every
+        # waves-per-sequence split the launcher can pick
+        wo = rnd(c, 256, seed=9, scale=1.0 / 16)
+        xcl = unet_to_cl(x)
+        ref_out = xcl + ref @ wo.t()
+        for nw in ("1", "2", "4", "8", None):
+            if nw is None:
+                os.environ.pop("LFDM_TATTN_OUT_NW", None)
+            else:
+                os.environ["LFDM_TATTN_OUT_NW"] = nw
+            try:
+                wqp, wop = ops.pack_tattn_weights(wf, wo)
+                got = ops.temporal_attention_fused_out_cl(xcl.to(dev), wqp.to(dev), wop.to(dev), b, frames, hw, bias=bias.contiguous().to(dev),
+                                                          rot_cos=cos[:, 0::2].contiguous().to(dev), rot_sin=sin[:, 0::2].contiguous().to(dev))
+            finally:
+                os.environ.pop("LFDM_TATTN_OUT_NW", None)
+            assert_close(got.cpu(), ref_out, TOL, "temporal attention block in one launch, %s waves per sequence" % nw)
 
 
 @pytest.mark.parametrize("hw", [16, 144, 1024])
@@ -818,7 +836,7 @@ def test_linear_attention_fused(backend, hw):
     ctx = torch.einsum("bhdn,bhen->bhde", k, v)
     ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(nf * hw, 256)
     wf = (wq * gamma.reshape(1, -1)).contiguous()
-    out = ops.linear_attention_fused_cl(x.reshape(-1, c).to(dev), wf.to(dev), nf, hw)
+    out = ops.linear_attention_fused_cl(x.reshape(-1, c).to(dev), ops.pack_linattn_weights(wf).to(dev), nf, hw)
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + linear attention")
 
 
@@ -981,6 +999,8 @@ def test_pack_wino_weight(backend):
     u = torch.einsum("ia,ocab,jb->ijoc", G, wt.double(), G).reshape(16, cout, cin)
     ref = torch.zeros(16, cin // 16, 64, 16, dtype=torch.float64)
     ref[:, :, :cout] = u.view(16, cout, cin // 16, 16).permute(0, 2, 1, 3)
+    # operand order of the kernel's two fragment loads: [pos][chunk][half j][column][k-slot kh][4], k % 16 = 8 kh + 4 j + e
+    ref = ref.view(16, cin // 16, 64, 2, 2, 4).permute(0, 1, 4, 2, 3, 5).reshape(16, cin // 16, 64, 16)
     got = ops.pack_wino_weight(wt.to(dev))
     assert got.shape == ref.shape
     assert_close(got.cpu(), ref.float(), 1e-6, "pack_wino")

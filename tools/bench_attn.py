@@ -57,7 +57,7 @@ x = torch.randn(rows, c, device="cuda")
 wq = torch.randn(768, c, device="cuda") * 0.1
 out = torch.empty(rows, 256, device="cuda")
 ws = torch.empty(16 << 20, device="cuda")
-us = timeit(lambda: ops.linear_attention_fused_cl(x, wq, t, s * s, out=out, ws=ws))
+us = timeit(lambda: ops.linear_attention_fused_cl(x, ops.pack_linattn_weights(wq), t, s * s, out=out, ws=ws))
 print("res %2d C=%3d: fused %7.1f us" % (s, c, us))
 
 print("wide fused temporal attention (C = 128 @16, 256 @8) vs separate:")
