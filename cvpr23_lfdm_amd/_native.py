@@ -45,6 +45,7 @@ class ConvParams(C.Structure):
         ("pool2", i32),
         ("weight_wino4", C.c_void_p),
         ("defer_reduce", i32),
+        ("weight_pw", f32p),
         ("gn_in_partial", f32p),
         ("gn_in_nchunk", i32), ("gn_in_groups", i32), ("gn_in_pixels", i32),
         ("gn_in_gamma", f32p), ("gn_in_beta", f32p), ("gn_in_ss", f32p),

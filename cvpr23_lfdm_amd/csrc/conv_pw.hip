@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
 
   const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((int64_t)(M - 1) * p.ld0 + p.c0) * 4));
   const lfdm_buf buf1 = p.c1 > 0 ? lfdm_make_buf(p.src1, (uint32_t)(((int64_t)(M - 1) * p.ld1 + p.c1) * 4)) : buf0;
-  const lfdm_buf bufw = lfdm_make_buf(p.weight, (uint32_t)((int64_t)(K >> 5) * p.coutp * 128));
+  // weight_pw (round 4): the same filter in MFMA-operand order [K/32][coutp/32][4 u][64 lanes = 32*kh + column][4] - one contiguous 1 KB
+  // per fragment load instead of a 16-byte piece of each of 32 columns' 128-byte rows (four times the L1 line look-ups per byte)
+  const bool wpk = p.weight_pw != nullptr;
+  const lfdm_buf bufw = lfdm_make_buf(wpk ? p.weight_pw : p.weight, (uint32_t)((int64_t)(K >> 5) * p.coutp * 128));
+  const uint32_t ustride = wpk ? 1024u : 32u;
   const int row = m0 + l31;
   const bool row_ok = row < M;
   const uint32_t a_off0 = row_ok ? ((uint32_t)row * (uint32_t)p.ld0 + 4u * kh) * 4u : LFDM_BUF_OOB;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + l31;
-    b_off[j] = n < p.coutp ? ((uint32_t)n * 32u + 4u * kh) * 4u : LFDM_BUF_OOB;
+    b_off[j] = n >= p.coutp ? LFDM_BUF_OOB : wpk ? (uint32_t)(n >> 5) * 4096u + (uint32_t)lane * 16u : ((uint32_t)n * 32u + 4u * kh) * 4u;
   }
   const uint32_t wgroup_bytes = (uint32_t)p.coutp * 128u;
 
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
       ra[u] = lfdm_buf_load_f4(buf, row_ok ? abase + 32u * u : LFDM_BUF_OOB);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        rb[u][j] = lfdm_buf_load_f4(bufw, b_off[j] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[j] + 32u * u);
+        rb[u][j] = lfdm_buf_load_f4(bufw, b_off[j] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[j] + ustride * u);
     }
   };
 

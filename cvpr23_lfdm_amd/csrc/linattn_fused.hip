@@ -15,6 +15,8 @@
 //     features = register reduction + one shuffle.
 // LayerNorm: a lane holds half of its token's channels; mean / variance = local sums + one shuffle; gamma is folded
 // into the weights by the host.
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -25,7 +27,7 @@ constexpr int DH = 32;
 constexpr int OUT_LD = HEADS * DH;      // 256
 constexpr int C = 64;                   // input channels (finest level)
 constexpr int CH = C / 2;               // channels per k-slot
-constexpr int SPLIT_TOK = 64;           // tokens per context partial
+constexpr int SPLIT_TOK = 32;           // smallest context split (one token tile): sizes the workspace
 constexpr int PART = DH * DH + 2 * DH;  // floats per partial: ctx[32][32] | m[32] | s[32]
 constexpr float LA_SCALE = 0.17677669529663687f;
 
@@ -63,25 +65,31 @@ __device__ __forceinline__ void load_wfrag(const float* __restrict__ wp, int whi
 }
 
 // ---- A: grid (n_frames*8, nsplit), 64 threads ----
+// Round 4: a wave walks its split's 32-token tiles ONE AT A TIME with a running k-softmax (max m, sum s, context rescaled by e^{m_old - m_new}
+// per feature row), so the split length no longer costs registers: the launcher sizes the splits for ONE round of waves on the chip (the
+// fixed 64-token splits gave 5120 waves for 3072 slots at 32x32 - a second, two-thirds-empty round - and 16 partials per (frame, head)
+// for the merge pass).  The rescale factor lives per LANE (feature d = l31) while the context rows live per REGISTER: 16 shuffles per tile.
 __global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* __restrict__ x, int ldx,
                                                                   const float* __restrict__ wqkv, int hw, float eps,
-                                                                  float* __restrict__ part) {
-  constexpr int NTILE = SPLIT_TOK / 32;
+                                                                  float* __restrict__ part, int split_tok) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
   const int f = blockIdx.x >> 3, h = blockIdx.x & 7;
   const int split = blockIdx.y, nsplit = gridDim.y;
-  const int n0 = split * SPLIT_TOK;
+  const int n0 = split * split_tok;
+  const int n1 = (n0 + split_tok < hw) ? n0 + split_tok : hw;
 
   float wk[CH], wv[CH];
   load_wfrag(wqkv, 1, h, lane, wk);                        // B operands: lane = feature l31, k-slot = channel half
   load_wfrag(wqkv, 2, h, lane, wv);
 
-  f32x16 kacc[NTILE], vacc[NTILE];
+  float m_run = -3.0e38f, s_run = 0.f;                     // per lane = feature d = l31 (both halves hold the same value)
+  f32x16 ctx;
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) {
-    const int n = n0 + 32 * t + l31;
+  for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+  for (int t0 = n0; t0 < n1; t0 += 32) {
+    const int n = t0 + l31;
     float xf[CH];
-    load_xhat(x + ((int64_t)f * hw + (n < hw ? n : 0)) * ldx, n < hw, kh, eps, xf);
+    load_xhat(x + ((int64_t)f * hw + (n < n1 ? n : n1 - 1)) * ldx, n < n1, kh, eps, xf);
     f32x16 ka, va;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ka[r] = va[r] = 0.f;
@@ -90,39 +98,39 @@ __global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* _
       ka = mfma_32x32x2(xf[s], wk[s], ka);                 // rows = tokens, cols = features d
       va = mfma_32x32x2(xf[s], wv[s], va);                 // rows = tokens, cols = features e
     }
-    kacc[t] = ka;
-    vacc[t] = va;
+    // lane: feature l31; register r = token t0 + (r&3) + 8*(r>>2) + 4*kh
+    float m = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tok = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (tok < n1) m = fmaxf(m, ka[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float m_new = fmaxf(m_run, m);
+    const float alpha = expf(m_run - m_new);               // 0 for the first tile (m_run = -3e38)
+    float ssum = 0.f;
+    float e[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tok = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      e[r] = tok < n1 ? expf(ka[r] - m_new) : 0.f;
+      ssum += e[r];
+    }
+    ssum += __shfl_xor(ssum, 32);
+    s_run = s_run * alpha + ssum;
+    m_run = m_new;
+    // context rows d = (r&3) + 8*(r>>2) + 4*kh are scaled by the factor of feature d, which lane d holds
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] *= __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * kh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx = mfma_32x32x2(e[r], va[r], ctx);      // A: lane = d, k-slot half = token; B: lane = e, same token
   }
-  // lane: feature l31; register r of tile t = token n0 + 32*t + (r&3) + 8*(r>>2) + 4*kh
-  float m = -3.0e38f;
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (n < hw) m = fmaxf(m, kacc[t][r]);
-    }
-  m = fmaxf(m, __shfl_xor(m, 32));
-  float ssum = 0.f;
-  f32x16 ctx;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      const float e = n < hw ? expf(kacc[t][r] - m) : 0.f;
-      ssum += e;
-      ctx = mfma_32x32x2(e, vacc[t][r], ctx);              // A: lane = d, k-slot half = token; B: lane = e, same token
-    }
-  ssum += __shfl_xor(ssum, 32);
   float* dst = part + ((int64_t)blockIdx.x * nsplit + split) * PART;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * kh) * DH + l31] = ctx[r];   // ctx[d][e], lane = e
   if (kh == 0) {
-    dst[DH * DH + l31] = m;
-    dst[DH * DH + DH + l31] = ssum;
+    dst[DH * DH + l31] = m_run;
+    dst[DH * DH + DH + l31] = s_run;
   }
 }
 
@@ -221,7 +229,7 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
                                                   int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                                   lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || hw > 64 * SPLIT_TOK || channels != C || ldx < C || ldx % 4 != 0 ||
+  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || hw > 64 * 64 || channels != C || ldx < C || ldx % 4 != 0 ||
       (((uintptr_t)x | (uintptr_t)wqkv) & 15) || (int64_t)n_frames * HEADS > 0x7fffffff) {
     lfdm_set_error("linear_attention_fused: needs C == 64 and 16-byte aligned rows");
     return LFDM_EINVAL;
@@ -230,13 +238,21 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
     lfdm_set_error("linear_attention_fused: workspace too small");
     return LFDM_EWORKSPACE;
   }
-  const int nsplit = (hw + SPLIT_TOK - 1) / SPLIT_TOK;
+  // splits of whole 32-token tiles, as many as fit ONE round of waves (3 per SIMD: 3072), at most 64 (the merge kernel's table)
+  const int tiles = (hw + 31) / 32;
+  int want = (int)(3072 / ((int64_t)n_frames * HEADS));
+  if (const char* e = getenv("LFDM_LINATTN_SPLITS")) want = atoi(e);      // experiment knob
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  if (want > tiles) want = tiles;
+  const int split_tok = ((tiles + want - 1) / want) * 32;
+  const int nsplit = (hw + split_tok - 1) / split_tok;
   float* part = (float*)ws;
-  float* ctx = part + (size_t)n_frames * HEADS * nsplit * PART;
-  LFDM_LAUNCH(linattn_fused_ctx_kernel, dim3(n_frames * HEADS, nsplit), dim3(64), 0, stream, x, ldx, wqkv, hw, ln_eps, part);
+  float* ctx = part + (size_t)n_frames * HEADS * ((hw + SPLIT_TOK - 1) / SPLIT_TOK) * PART;
+  LFDM_LAUNCH(linattn_fused_ctx_kernel, dim3(n_frames * HEADS, nsplit), dim3(64), 0, stream, x, ldx, wqkv, hw, ln_eps, part, split_tok);
   LFDM_LAUNCH(linattn_fused_merge_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, (const float*)part, nsplit, ctx);
-  const int64_t tiles = (int64_t)((hw + 31) / 32) * n_frames;
-  const int hgroups = tiles >= 4096 ? 1 : (tiles >= 2048 ? 2 : 4);
+  const int64_t otiles = (int64_t)((hw + 31) / 32) * n_frames;
+  const int hgroups = otiles >= 4096 ? 1 : (otiles >= 2048 ? 2 : 4);
   LFDM_LAUNCH(linattn_fused_out_kernel, dim3((hw + 31) / 32, n_frames, hgroups), dim3(64), 0, stream, x, ldx, wqkv,
               (const float*)ctx, hw, ln_eps, out);
   return lfdm_check_launch("linear_attention_fused");

@@ -251,7 +251,7 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
                 tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, defer_reduce=False,
-                gn_in=None):
+                gn_in=None, weight_pw=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -315,8 +315,13 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         p.weight_wino4 = weight_wino4.data_ptr()
     # gn_in = dict(partial, nchunk, pixels, gamma, beta, groups=8, scale_shift=None, eps=1e-5): src0 is the previous convolution's raw output;
     # its GroupNorm + scale/shift + SiLU is applied inside this convolution's patch load (Winograd schedule only; lfdm_conv_params.gn_in_*)
+    p.weight_pw = None
+    if weight_pw is not None:          # the same 1x1 filter in operand order for the pointwise schedule (pack_pw_weight)
+        _chk(lib, weight_pw)
+        assert kh == 1 and kw == 1 and weight_pw.numel() == weight.numel() and weight_pw.is_contiguous()
+        p.weight_pw = weight_pw.data_ptr()
     p.gn_in_partial = None
-    keep_gn = ()
+    keep_gn = (weight_pw,)
     if gn_in is not None:
         gp, gg, gb, gss = gn_in["partial"], gn_in["gamma"], gn_in["beta"], gn_in.get("scale_shift")
         _chk(lib, gp, gg, gb, gss)
@@ -503,6 +508,15 @@ def temporal_attention_fused_cl(x, wqkv, batch, frames, hw, *, bias=None, rot_co
                                                        _p(rot_cos), _p(rot_sin), eps, _stream(lib)),
               "lfdm_temporal_attention_fused_cl_f32")
     return out
+
+
+def pack_pw_weight(packed):
+    """Direct-form pack of a 1x1 filter ([K/32][coutp][32], pack_conv_weight) -> the MFMA-operand order of the pointwise schedule
+    (lfdm_conv_params.weight_pw): [K/32][coutp/32][4 u][64 lanes = 32*kh + column][4 e], k % 32 = 8u + 4kh + e."""
+    g, coutp, k32 = packed.shape
+    assert k32 == 32 and coutp % 32 == 0
+    # (g, ct, column, u, kh, e) -> (g, ct, u, kh, column, e)
+    return packed.reshape(g, coutp // 32, 32, 4, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous().view(g, coutp // 32, 4, 64, 4)
 
 
 def pack_tattn_weights(wqkv_folded, wout):

@@ -298,6 +298,13 @@ class Unet3D(ParamTree):
         #  and res_conv on a second stream - slower; DESIGN.md "negative results")
         """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
+        if k == 1 and self._pk is not None and w.dim() == 3 and w.shape[1] % 32 == 0 and not kw.get("deconv4"):
+            # 1x1 projections: the operand-order pack for the pointwise schedule, built once per weight pack
+            cache = self._pk.setdefault("_pw", {})
+            wpw = cache.get(w.data_ptr())
+            if wpw is None:
+                wpw = cache[w.data_ptr()] = ops.pack_pw_weight(w)
+            kw["weight_pw"] = wpw
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         coutp = p.coutp

@@ -146,6 +146,11 @@ typedef struct lfdm_conv_params {
      applied to in-image pixels only).  Needs one source (c1 == 0), no upsample, gn_in_pixels (pixels per sample) % 128 == 0,
      c0 <= 1024, c0 % gn_in_groups == 0.  SiLU here is x * rcp(1 + exp2(-x log2 e)) on the hardware exponential / reciprocal
      (within 3 ulp of the library's GroupNorm kernels). */
+  /* Optional (ABI version 8): the SAME 1x1 filter as `weight`, for the pointwise schedule (3) only, in MFMA-operand order
+     [ceil(K/32)][coutp/32][4 u][64 lanes = 32*kh + column][4 e] <- W[k = 32g + 8u + 4kh + e][32*ct + column]
+     (cvpr23_lfdm_amd.ops.pack_pw_weight): every fragment load of conv_pw_kernel then reads one contiguous 1 KB.  Ignored by the other
+     schedules (they read `weight`); NULL = the pointwise kernel reads `weight` as before. */
+  const float* weight_pw;
   const float* gn_in_partial;
   int gn_in_nchunk, gn_in_groups, gn_in_pixels;
   const float* gn_in_gamma;

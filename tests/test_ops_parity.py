@@ -151,6 +151,10 @@ def test_conv_pointwise(backend, case, monkeypatch):
     out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
                         residual=None if res is None else to_cl(res).to(dev), act=act, **kw)
     assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv")
+    # the same filter in MFMA-operand order (lfdm_conv_params.weight_pw): identical arithmetic, contiguous fragment loads
+    out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
+                        residual=None if res is None else to_cl(res).to(dev), act=act, weight_pw=ops.pack_pw_weight(packed).to(dev), **kw)
+    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv, operand-order weights")
     monkeypatch.setenv("LFDM_PW", "0")          # the LDS-staged schedules still serve the same call
     assert ops._lib().lfdm_conv2d_schedule(__import__("ctypes").byref(pp)) in (0, 1)
     out = ops.conv2d_cl(src0, packed.to(dev), cout, 1, 1, n, h, w, src1=src1, bias=None if bias is None else bias.to(dev),
