@@ -32,6 +32,7 @@ _GN_FUSE = os.environ.get("LFDM_GN_FUSE", "0") == "1"
 _GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
+_TATTN_WIDE = os.environ.get("LFDM_TATTN_WIDE", "0") == "1"      # A/B: the channel-streaming fused kernel at C >= 128 where no one-launch form applies
 
 
 def prob_mask_like(shape, prob, device):
@@ -428,7 +429,7 @@ class Unet3D(ParamTree):
         if c == 64 and frames <= 64 and _TATTN_OUT:      # the whole block (LayerNorm, to_qkv, attention, to_out, residual) in one launch
             return ops.temporal_attention_fused_out_cl(x, pk[prefix + "qkv.wp"], pk[prefix + "out.wp"], batch, frames, s * s, bias=bias,
                                                        rot_cos=cos, rot_sin=sin, out=self._buf(outname, x.shape[0], c))
-        if c == 64 and frames <= 64:
+        if (c == 64 or (_TATTN_WIDE and c % 64 == 0 and s * s > _LOWRES_MAX_HW)) and frames <= 64:
             att = self._buf("at.o", x.shape[0], 256)
             ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
                                             rot_sin=sin, out=att)

@@ -8,7 +8,7 @@ LFDM_PARITY_LOG=$O/parity.jsonl timeout 900 python -m pytest tests -m gpu -x -q 
 timeout 60 python tools/parity_margins.py $O/parity.jsonl $O/parity_margins.json | tail -n 3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
 # (the CPU baseline leg is left to the driver's own bench run: ~2 minutes of host time that the evidence run does not need)
-timeout 500 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err      # the driver's own command line (minus the CPU baseline leg); echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
 timeout 300 bash tools/prof_sequence.sh $TAG > $O/prof.txt 2>&1; tail -n 1 $O/step_sequence.txt
 timeout 400 bash tools/prof_step_pmc.sh $TAG > $O/pmc.txt 2>&1; head -n 3 $O/step_pmc.txt
 # the N = 2 code path of bench.py on ONE GPU: plain `python bench.py --gpus 2` re-executes itself under torch.distributed.run (both ranks on
