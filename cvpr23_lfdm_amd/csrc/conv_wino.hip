@@ -243,18 +243,41 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   {
     fetch_patch(patch, clampc(kc0), (G == 1 || kc0 < kc_end) ? valid_mask : 0u);
     if (GNIN) {
-      // (the loads above are in flight)  statistics of this tile block's sample: 32 lanes walk one group's chunks, as gn_apply_kernel does
+      // (the loads above are in flight)  statistics of this tile block's sample: 32 lanes walk one group's chunks, as gn_apply_kernel does.
+      // ONE memory round trip for the whole prologue: gamma / beta / scale / shift of this thread's table entries are requested before the
+      // partial sums are walked (four chunk loads in flight), so only arithmetic and two barriers separate the loads from the first transform
       const int groups = p.gn_in_groups, nchunk = p.gn_in_nchunk;
       const int b = (int)((t0 < ntiles ? t0 : ntiles - 1) / (unsigned)(p.gn_in_pixels >> 2));      // (a tile = four pixels; host: pixels % 128 == 0)
+      const int c_lo = cbase + kc_begin * WKC, nslice = (kc_end - kc_begin) * WKC;
+      float t_g[4], t_b[4], t_sc[4], t_sh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lc = tid + 256 * j;
+        const int c = c_lo + (lc < nslice ? lc : 0);
+        t_g[j] = p.gn_in_gamma[c];
+        t_b[j] = p.gn_in_beta[c];
+        t_sc[j] = p.gn_in_ss ? p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + c] + 1.0f : 1.0f;
+        t_sh[j] = p.gn_in_ss ? p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + p.c0 + c] : 0.f;
+      }
       const int sub = tid & 31;
       for (int g0 = 0; g0 < groups; g0 += 8) {
         const int g = g0 + (tid >> 5);
         double sm = 0.0, sq = 0.0;
         if (g < groups) {
-          for (int k = sub; k < nchunk; k += 32) {
-            const float* src = p.gn_in_partial + (((int64_t)b * nchunk + k) * groups + g) * 2;
-            sm += (double)src[0];
-            sq += (double)src[1];
+          const float2* src = reinterpret_cast<const float2*>(p.gn_in_partial) + ((int64_t)b * nchunk) * groups + g;
+          int k = sub;
+          for (; k + 96 < nchunk; k += 128) {
+            const float2 v0 = src[(int64_t)k * groups], v1 = src[(int64_t)(k + 32) * groups];
+            const float2 v2 = src[(int64_t)(k + 64) * groups], v3 = src[(int64_t)(k + 96) * groups];
+            sm += (double)v0.x; sq += (double)v0.y;
+            sm += (double)v1.x; sq += (double)v1.y;
+            sm += (double)v2.x; sq += (double)v2.y;
+            sm += (double)v3.x; sq += (double)v3.y;
+          }
+          for (; k < nchunk; k += 32) {
+            const float2 v = src[(int64_t)k * groups];
+            sm += (double)v.x;
+            sq += (double)v.y;
           }
         }
         for (int msk = 16; msk >= 1; msk >>= 1) {
@@ -272,20 +295,15 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       }
       __syncthreads();
       const int cg = p.c0 / groups;
-      const int c_lo = cbase + kc_begin * WKC, nslice = (kc_end - kc_begin) * WKC;
-      for (int lc = tid; lc < nslice; lc += 256) {
-        const int c = c_lo + lc, g = c / cg;
-        const float a = s_gstat[64 + g] * p.gn_in_gamma[c];
-        float bb = p.gn_in_beta[c] - s_gstat[g] * a;
-        float aa = a;
-        if (p.gn_in_ss) {
-          const float sc = p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + c] + 1.0f;
-          const float sh = p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + p.c0 + c];
-          aa = a * sc;
-          bb = bb * sc + sh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lc = tid + 256 * j;
+        if (lc < nslice) {
+          const int g = (c_lo + lc) / cg;
+          const float a = s_gstat[64 + g] * t_g[j];
+          s_gin[lc] = a * t_sc[j];
+          s_gin[GIN_MAXC + lc] = (t_b[j] - s_gstat[g] * a) * t_sc[j] + t_sh[j];
         }
-        s_gin[lc] = aa;
-        s_gin[GIN_MAXC + lc] = bb;
       }
       __syncthreads();
     }

@@ -148,6 +148,25 @@ __device__ __forceinline__ void lfdm_ticket_reset(unsigned* c) {
 }
 #endif
 
+// Agent-scope words shared by the workgroups of ONE launch without a fence (cdna_hip_programming.md section 6 Guideline 16, the "8-byte agent
+// atomics on both sides" form: write-through sc1 stores, L1-bypassing loads): payload granules and arrival counters of the cooperative
+// split-K reduce + GroupNorm kernel (norm.hip).
+#if defined(LFDM_EMU_BUILD)
+static inline void lfdm_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long lfdm_agent_load_u64(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+static inline unsigned lfdm_agent_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+static inline void lfdm_sleep() {}
+#else
+__device__ __forceinline__ void lfdm_agent_store_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lfdm_agent_load_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned lfdm_agent_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lfdm_sleep() { __builtin_amdgcn_s_sleep(2); }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

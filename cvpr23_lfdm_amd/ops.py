@@ -460,6 +460,31 @@ def groupnorm_splitk_ok(pixels, channels, groups=8):
     return bool(_lib().lfdm_groupnorm_splitk_ok(pixels, channels, groups))
 
 
+def groupnorm_splitk_coop_ok(batch, pixels, channels, groups, ksplit):
+    return bool(_lib().lfdm_groupnorm_splitk_coop_ok(batch, pixels, channels, groups, ksplit))
+
+
+def groupnorm_splitk_coop_ws(batch, pixels, channels, groups, device):
+    """Sync workspace of groupnorm_splitk_coop_cl: zeroed here ONCE; every launch leaves it zeroed."""
+    n = int(_lib().lfdm_groupnorm_splitk_coop_ws_bytes(batch, pixels, channels, groups))
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def groupnorm_splitk_coop_cl(partial, ksplit, slab_stride, coutp, bias, out, batch, gamma, beta, sync_ws, *, groups=8, scale_shift=None,
+                             residual=None, eps=1e-5, silu=True):
+    """GroupNorm (+ scale/shift, SiLU, residual) from the raw split-K slabs of the preceding convolution (conv_params(defer_reduce=True)),
+    chip wide: slab sum + bias + statistics + apply in ONE launch (lfdm_groupnorm_splitk_coop_cl_f32)."""
+    lib = _lib()
+    rows, ch = out.shape
+    _chk(lib, partial, bias, out, gamma, beta, scale_shift, residual, sync_ws)
+    assert out.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == out.shape))
+    lib.check(lib.lfdm_groupnorm_splitk_coop_cl_f32(_p(partial), ksplit, slab_stride, coutp, _p(bias), _p(out), batch, rows // batch, ch, groups,
+                                                    _p(gamma), _p(beta), _p(scale_shift), scale_shift.stride(0) if scale_shift is not None else 0,
+                                                    _p(residual), eps, int(silu), _p(sync_ws), sync_ws.numel() * 4, _stream(lib)),
+              "lfdm_groupnorm_splitk_coop_cl_f32")
+    return out
+
+
 def groupnorm_splitk_apply_cl(partial, ksplit, slab_stride, coutp, bias, out, batch, gamma, beta, *, groups=8, scale_shift=None,
                               residual=None, eps=1e-5, silu=True):
     """GroupNorm (+ scale/shift, SiLU, residual) straight from the raw split-K slabs of the preceding convolution

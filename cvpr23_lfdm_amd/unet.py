@@ -22,6 +22,12 @@ _LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"
 _LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
 _RES_STREAM = os.environ.get("LFDM_RES_STREAM", "0") == "1"
 _GN_SPLITK = os.environ.get("LFDM_GN_SPLITK", "0") == "1"      # conv (split-K) -> GroupNorm without the reduce launch (ops.groupnorm_splitk_apply_cl)
+# ... the chip-wide form of it (ops.groupnorm_splitk_coop_cl, round 4): the reduce pass's grid keeps its values in registers and the
+# workgroups of a (sample, group) exchange their statistics through agent-scope granules.  Parity-green, bit reproducible - and SLOWER:
+# 298.3 vs 285.8 ms per video (profiles/r04_p_gn_coop_ab.json): the in-launch gather (publish, count in, poll, read 40-160 granules) costs
+# ~19 us where the reduce launch + apply launch cost 12.6 - a counter barrier is 7 us on this chip (MI355X_MICROARCH.md "barrier-counter"),
+# a kernel boundary 2.  Off by default; LFDM_GN_COOP=1 turns it on.
+_GN_COOP = os.environ.get("LFDM_GN_COOP", "0") == "1"
 _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 # block1's GroupNorm + scale/shift + SiLU inside block2's Winograd convolution (lfdm_conv_params.gn_in_*): one launch less per ResnetBlock.
 # MEASURED SLOWER (round 4, profiles/r04_d_*): 146 instead of 165 launches per step, but every fused convolution takes ~10 us longer (the
@@ -33,6 +39,10 @@ _GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 _TATTN_WIDE = os.environ.get("LFDM_TATTN_WIDE", "0") == "1"      # A/B: the channel-streaming fused kernel at C >= 128 where no one-launch form applies
+
+
+def x_is_cuda(t):
+    return t.is_cuda
 
 
 def prob_mask_like(shape, prob, device):
@@ -318,6 +328,11 @@ class Unet3D(ParamTree):
             part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
+        if (gn is not None and _GN_COOP and x_is_cuda(src0) and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
+                coutp == cout and ops.groupnorm_splitk_coop_ok(gn[0], m // gn[0], cout, gn[1] if len(gn) > 1 else 8, ksplit)):
+            p.defer_reduce = 1
+            ops.conv_launch(p)
+            return y, ("coop", part, ksplit, m * coutp, coutp, bias)
         if (gn is not None and _GN_SPLITK and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
                 ops.groupnorm_splitk_ok(m // gn[0], cout, gn[1] if len(gn) > 1 else 8)):
             # the slabs stay raw: the GroupNorm launch sums them, adds the bias and normalises (one workgroup per (sample, group))
@@ -341,6 +356,15 @@ class Unet3D(ParamTree):
         return (y, stats) if gn is not None else y
 
     def _gn(self, x, batch, gamma, beta, stats, groups=8, **kw):
+        if stats is not None and stats[0] == "coop":
+            _, part, ksplit, slab_stride, coutp, bias = stats
+            key = (batch, x.shape[0] // batch, x.shape[1], groups)
+            ws = self._coop_ws.get(key) if getattr(self, "_coop_ws", None) else None
+            if ws is None or ws.device != x.device:
+                self._coop_ws = getattr(self, "_coop_ws", None) or {}
+                ws = self._coop_ws[key] = ops.groupnorm_splitk_coop_ws(batch, x.shape[0] // batch, x.shape[1], groups, x.device)
+                self._buf_gen += 1          # (a captured graph holds this pointer)
+            return ops.groupnorm_splitk_coop_cl(part, ksplit, slab_stride, coutp, bias, x, batch, gamma, beta, ws, groups=groups, **kw)
         if stats is not None and stats[0] == "slabs":
             _, part, ksplit, slab_stride, coutp, bias = stats
             return ops.groupnorm_splitk_apply_cl(part, ksplit, slab_stride, coutp, bias, x, batch, gamma, beta, groups=groups, **kw)
@@ -352,7 +376,7 @@ class Unet3D(ParamTree):
     def _gn_in(self, stats, batch, rows, channels, gamma, beta, sshift, ww, groups=8):
         """Parameters of the fused input GroupNorm of the NEXT convolution (ops.conv_params gn_in=...), or None when the separate
         GroupNorm launch has to run: statistics not available as partial sums, no Winograd form, a geometry the kernel refuses."""
-        if not _GN_FUSE or stats is None or stats[0] == "slabs" or ww is None or rows > _GN_FUSE_MAX_ROWS:
+        if not _GN_FUSE or stats is None or stats[0] in ("slabs", "coop") or ww is None or rows > _GN_FUSE_MAX_ROWS:
             return None
         pixels = rows // batch
         if pixels % 128 != 0 or channels > 1024 or channels % groups != 0 or channels % 16 != 0:

@@ -209,6 +209,19 @@ int lfdm_groupnorm_splitk_apply_cl_f32(const float* partial, int ksplit, long lo
                                        int batch, int pixels, int channels, int groups, const float* gamma, const float* beta,
                                        const float* scale_shift, int ss_ld, const float* residual, float eps, int apply_silu,
                                        lfdm_stream_t stream);
+/* The same operation spread over the CHIP (ABI version 8): the split-K reduce pass's own grid (one workgroup per 16 rows x 64 channels) keeps the
+ * reduced values in registers, exchanges (sum, sum of squares) granules and arrival counts through `sync_ws` with agent-scope atomics (no
+ * fences, any workgroup placement) and applies the normalisation - conv + reduce + apply becomes conv + ONE launch.  lfdm_groupnorm_splitk_coop_ok:
+ * pixels % 16 == 0, channels % 64 == 0, group width dividing 64 (at most 8 groups per 64 channels) or a multiple of 64, 2 <= ksplit <= 8 and at
+ * most 1024 workgroups (all must be co-resident while a group's cohort gathers).  sync_ws: lfdm_groupnorm_splitk_coop_ws_bytes, ZEROED ONCE by
+ * the caller before its first use; every launch leaves it zeroed for the next.  ((unsigned*)sync_ws)[0] != 0 afterwards = a workgroup gave up
+ * waiting (2^20 polls) - the result is then invalid. */
+int lfdm_groupnorm_splitk_coop_ok(int batch, int pixels, int channels, int groups, int ksplit);
+size_t lfdm_groupnorm_splitk_coop_ws_bytes(int batch, int pixels, int channels, int groups);
+int lfdm_groupnorm_splitk_coop_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias, float* out,
+                                      int batch, int pixels, int channels, int groups, const float* gamma, const float* beta,
+                                      const float* scale_shift, int ss_ld, const float* residual, float eps, int apply_silu,
+                                      void* sync_ws, size_t sync_ws_bytes, lfdm_stream_t stream);
 
 /* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
 int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,

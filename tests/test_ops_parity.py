@@ -354,6 +354,51 @@ def test_groupnorm_from_splitk_slabs(backend, case):
     assert not ops.groupnorm_splitk_ok(10240, 128, 8)                         # 16x16 x 40 frames: too many elements for one workgroup
 
 
+@pytest.mark.parametrize("case", [dict(b=2, pixels=48, c=128, ksplit=3, ss=True, res=False), dict(b=1, pixels=640, c=512, ksplit=6, ss=True, res=True),
+                                  dict(b=3, pixels=96, c=64, ksplit=2, ss=False, res=True, silu=False),          # eight groups inside one 64-channel block
+                                  dict(b=1, pixels=2560, c=256, ksplit=3, ss=False, res=False, gpu_only=True),   # the 8x8 level: 640 workgroups
+                                  dict(b=2, pixels=160, c=1024, ksplit=8, ss=True, res=True, gpu_only=True)],    # groups wider than a column block
+                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
+def test_groupnorm_splitk_coop(backend, case):
+    """lfdm_groupnorm_splitk_coop_cl_f32: the same conv -> GroupNorm seam as above, chip wide: the reduce grid keeps its values in registers, the
+    workgroups of a (sample, group) exchange statistics through agent-scope granules + arrival counters (on the emulation build the entry
+    point runs the one-workgroup-per-group kernel: the cooperative kernel needs co-resident workgroups).  Launched three times on ONE
+    workspace that is zeroed once: every launch must leave it re-armed; results must be bit-identical from launch to launch."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    b, pixels, c, ks = case["b"], case["pixels"], case["c"], case["ksplit"]
+    coutp, rows = c, b * pixels
+    slabs = rnd(ks, rows, coutp, seed=1)
+    bias = rnd(c, seed=2)
+    gamma, beta = rnd(c, seed=3) + 1.0, rnd(c, seed=4)
+    ss = rnd(b, 2 * c, seed=5) * 0.5 if case["ss"] else None
+    res = rnd(rows, c, seed=6) if case["res"] else None
+    x = slabs.double().sum(0).float() + bias
+    ref = F.group_norm(x.view(b, pixels, c).permute(0, 2, 1), 8, gamma, beta, eps=1e-5)
+    if ss is not None:
+        ref = ref * (ss[:, :c].unsqueeze(-1) + 1) + ss[:, c:].unsqueeze(-1)
+    if case.get("silu", True):
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(rows, c)
+    if res is not None:
+        ref = ref + res
+    assert ops.groupnorm_splitk_coop_ok(b, pixels, c, 8, ks)
+    assert not ops.groupnorm_splitk_coop_ok(1, 40960, 64, 8, 2)               # 32x32 x 40 frames: 2560 workgroups cannot all be resident
+    ws = ops.groupnorm_splitk_coop_ws(b, pixels, c, 8, dev)
+    outs = []
+    for _ in range(3):
+        out = torch.full((rows, c), float("nan"), device=dev)
+        ops.groupnorm_splitk_coop_cl(slabs.to(dev), ks, rows * coutp, coutp, bias.to(dev), out, b, gamma.to(dev), beta.to(dev), ws,
+                                     scale_shift=None if ss is None else ss.to(dev), residual=None if res is None else res.to(dev),
+                                     silu=case.get("silu", True))
+        outs.append(out.cpu())
+    assert_close(outs[0], ref, TOL, "cooperative groupnorm from split-K slabs")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "not reproducible from launch to launch"
+    if dev != "cpu":
+        assert int(ws[:4 + 2 * b * 8].cpu().abs().sum()) == 0, "a launch left its counters dirty or a workgroup timed out (ws[0])"
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,with_ss", [(64, True), (128, False), (512, True)])
 def test_groupnorm_silu(backend, c, with_ss):
