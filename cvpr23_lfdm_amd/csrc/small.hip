@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void conv_planar_in_kernel(
   }
 }
 
-// one thread per pixel row; weights (3 x C) in LDS
+// one thread per pixel row; weights (3 x C) in LDS.
+// EXTRA (round 4, lfdm_heads_res_cl_to_planar_f32): the heads' ResnetBlocks end in h + res_conv(cat(x, r)) and the heads are linear, so
+// W1 (h + Wres [x|r] + bres) + b1 = W1 h + (W1 Wres) [x|r] + (W1 bres + b1): the 1x1 res_conv launch (27 us at 32x32: a 40 960 x 128 x 128
+// GEMM) becomes three more dot products per pixel against the composed 3 x (c0 + c1) matrix `w_extra` (rows: flow x, flow y, occlusion).
+template <bool EXTRA>
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_flow,
                                                     const float* __restrict__ y_occ, int channels, int ld,
                                                     const float* __restrict__ w_flow,
@@ -151,11 +155,16 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_
                                                     const float* __restrict__ w_occ,
                                                     const float* __restrict__ b_occ,
                                                     float* __restrict__ out, int batch, int frames,
-                                                    int hw) {
+                                                    int hw, const float* __restrict__ x0, int ld0, int c0,
+                                                    const float* __restrict__ x1, int ld1, int c1,
+                                                    const float* __restrict__ w_extra) {
   __shared__ __attribute__((aligned(16))) float wl[3 * 256];
+  __shared__ __attribute__((aligned(16))) float we[EXTRA ? 3 * 512 : 4];
   const int tid = threadIdx.x;
   for (int i = tid; i < 2 * channels; i += 256) wl[i] = w_flow[i];
   for (int i = tid; i < channels; i += 256) wl[2 * channels + i] = w_occ[i];
+  if (EXTRA)
+    for (int i = tid; i < 3 * (c0 + c1); i += 256) we[i] = w_extra[i];
   __syncthreads();
   const int64_t total = (int64_t)batch * frames * hw;
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
@@ -172,6 +181,22 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_
     s0 += (a.x * w0.x + a.y * w0.y) + (a.z * w0.z + a.w * w0.w);
     s1 += (a.x * w1.x + a.y * w1.y) + (a.z * w1.z + a.w * w1.w);
     s2 += (o.x * w2.x + o.y * w2.y) + (o.z * w2.z + o.w * w2.w);
+  }
+  if (EXTRA) {
+    const int ce = c0 + c1;
+    for (int src = 0; src < 2; ++src) {
+      const int cs = src == 0 ? c0 : c1, base = src == 0 ? 0 : c0;
+      const float4* xr = reinterpret_cast<const float4*>(src == 0 ? x0 + row * ld0 : x1 + row * ld1);
+      for (int i = 0; i < cs / 4; ++i) {
+        const float4 a = xr[i];
+        const float4 w0 = *reinterpret_cast<const float4*>(we + base + 4 * i);
+        const float4 w1 = *reinterpret_cast<const float4*>(we + ce + base + 4 * i);
+        const float4 w2 = *reinterpret_cast<const float4*>(we + 2 * ce + base + 4 * i);
+        s0 += (a.x * w0.x + a.y * w0.y) + (a.z * w0.z + a.w * w0.w);
+        s1 += (a.x * w1.x + a.y * w1.y) + (a.z * w1.z + a.w * w1.w);
+        s2 += (a.x * w2.x + a.y * w2.y) + (a.z * w2.z + a.w * w2.w);
+      }
+    }
   }
   const int64_t bt = row / hw;
   const int pix = (int)(row - bt * hw);
@@ -412,9 +437,28 @@ extern "C" int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_o
     return LFDM_EINVAL;
   }
   const int64_t total = (int64_t)batch * frames * hw;
-  LFDM_LAUNCH(heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow,
-              y_occ, channels, ld, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw);
+  LFDM_LAUNCH(heads_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow,
+              y_occ, channels, ld, w_flow, b_flow, w_occ, b_occ, out, batch, frames, hw, (const float*)nullptr, 0, 0, (const float*)nullptr, 0, 0,
+              (const float*)nullptr);
   return lfdm_check_launch("heads");
+}
+
+extern "C" int lfdm_heads_res_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels, int ld, const float* w_flow,
+                                               const float* b_flow, const float* w_occ, const float* b_occ, const float* x0, int ld0, int c0,
+                                               const float* x1, int ld1, int c1, const float* w_extra, float* out, int batch, int frames,
+                                               int hw, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!y_flow || !y_occ || !w_flow || !b_flow || !w_occ || !b_occ || !out || !x0 || !w_extra || channels <= 0 || channels > 256 ||
+      channels % 4 != 0 || ld < channels || ld % 4 != 0 || batch <= 0 || frames <= 0 || hw <= 0 || c0 <= 0 || c0 % 4 != 0 || ld0 < c0 ||
+      ld0 % 4 != 0 || c1 < 0 || c1 % 4 != 0 || (c1 > 0 && (!x1 || ld1 < c1 || ld1 % 4 != 0)) || c0 + c1 > 512 ||
+      (((uintptr_t)y_flow | (uintptr_t)y_occ | (uintptr_t)x0 | (uintptr_t)x1) & 15) != 0) {
+    lfdm_set_error("heads_res: bad arguments (C % 4 == 0, c0 + c1 <= 512, 16-byte aligned rows)");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)batch * frames * hw;
+  LFDM_LAUNCH(heads_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow, y_occ, channels, ld, w_flow, b_flow,
+              w_occ, b_occ, out, batch, frames, hw, x0, ld0, c0, x1 ? x1 : x0, ld1, c1, w_extra);
+  return lfdm_check_launch("heads_res");
 }
 
 extern "C" int lfdm_pack_conv_weight_f32(const float* w, int n_o, int n_i, int taps, int64_t stride_o, int64_t stride_i,

@@ -745,6 +745,23 @@ def heads_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, batch, frame
     return out
 
 
+def heads_res_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, x0, x1, w_extra, batch, frames, hw, *, out=None):
+    """heads_cl_to_planar with the ResnetBlocks' res_conv(cat(x0, x1)) folded in: w_extra (3, c0 + c1) = [W_flow Wres_flow ; W_occ Wres_occ],
+    b_flow / b_occ include W1 bres (lfdm_heads_res_cl_to_planar_f32)."""
+    lib = _lib()
+    _chk(lib, y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, x0, x1, w_extra, out)
+    ch = y_flow.shape[1]
+    c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
+    assert y_flow.stride(0) == y_occ.stride(0) and y_flow.stride(1) == 1 and y_occ.stride(1) == 1
+    assert w_extra.shape == (3, c0 + c1) and w_extra.is_contiguous() and x0.stride(1) == 1
+    if out is None:
+        out = torch.empty(batch, 3, frames, hw, dtype=torch.float32, device=y_flow.device)
+    lib.check(lib.lfdm_heads_res_cl_to_planar_f32(_p(y_flow), _p(y_occ), ch, y_flow.stride(0), _p(w_flow), _p(b_flow), _p(w_occ), _p(b_occ),
+                                                  _p(x0), x0.stride(0), c0, _p(x1), x1.stride(0) if x1 is not None else 0, c1, _p(w_extra),
+                                                  _p(out), batch, frames, hw, _stream(lib)), "lfdm_heads_res_cl_to_planar_f32")
+    return out
+
+
 def sampler_ws(batch, n, device):
     """Workspace of sampler_step / abs_quantile, initialised (lfdm_sampler_ws_init: histograms + end-of-step ticket cleared)."""
     lib = _lib()

@@ -38,6 +38,7 @@ _GN_FUSE = os.environ.get("LFDM_GN_FUSE", "0") == "1"
 _GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
+_HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
 _TATTN_WIDE = os.environ.get("LFDM_TATTN_WIDE", "0") == "1"      # A/B: the channel-streaming fused kernel at C >= 128 where no one-launch form applies
 
 
@@ -260,6 +261,12 @@ class Unet3D(ParamTree):
             pk["heads.res.w"], pk["heads.res.b"] = ops.pack_conv_weight(cat("res_conv.weight")), cat("res_conv.bias")
             for i in (1, 2):
                 pk["heads.norm%d.w" % i], pk["heads.norm%d.b" % i] = cat("block%d.norm.weight" % i), cat("block%d.norm.bias" % i)
+            # res_conv folded into the (linear) 1x1 heads: W1 (h + Wres u + bres) + b1 = W1 h + (W1 Wres) u + (W1 bres + b1), u = cat(x, r)
+            wf, wo = pk["final_conv.1.w"].double(), pk["occlusion_map.1.w"].double()                    # (2, dim), (1, dim)
+            rf, ro = g(hp[0] + "res_conv.weight").reshape(self.dim, -1).double(), g(hp[1] + "res_conv.weight").reshape(self.dim, -1).double()
+            pk["heads.fold.w"] = torch.cat((wf @ rf, wo @ ro), dim=0).float().contiguous()                # (3, 2 * dim)
+            pk["heads.fold.bf"] = (pk["final_conv.1.b"].double() + wf @ g(hp[0] + "res_conv.bias").double()).float().contiguous()
+            pk["heads.fold.bo"] = (pk["occlusion_map.1.b"].double() + wo @ g(hp[1] + "res_conv.bias").double()).float().contiguous()
         pk["cond.w"] = torch.cat(cond_w, dim=0).contiguous()     # (sum 2C, time_dim + cond_dim)
         pk["cond.b"] = torch.cat(cond_b, dim=0).contiguous()
         pk["cond.n"] = off
@@ -567,6 +574,10 @@ class Unet3D(ParamTree):
             _, st = self._conv(h1, pk["heads.block2.ww"], c2, 3, n_img, res, bias=pk["heads.block2.b"], out=y,
                                gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2, gn_in=gn_in)
             self._gn(y, batch, pk["heads.norm2.w"], pk["heads.norm2.b"], st, groups=16)
+            if _HEADS_FOLD and x.shape[1] % 4 == 0 and r.shape[1] % 4 == 0 and x.shape[1] + r.shape[1] == pk["heads.fold.w"].shape[1]:
+                # the blocks' res_conv(cat(x, r)) folded into the linear heads: one 1x1 convolution launch less
+                return ops.heads_res_cl_to_planar(y[:, :dim], y[:, dim:], pk["final_conv.1.w"], pk["heads.fold.bf"], pk["occlusion_map.1.w"],
+                                                  pk["heads.fold.bo"], x, r, pk["heads.fold.w"], batch, frames, res * res, out=out)
             self._conv(x, pk["heads.res.w"], c2, 1, n_img, res, src1=r, bias=pk["heads.res.b"], residual=y, out=y)
             yf, yo = y[:, :dim], y[:, dim:]
         else:

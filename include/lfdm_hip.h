@@ -289,6 +289,14 @@ int lfdm_heads_cl_to_planar_f32(const float* y_flow, const float* y_occ, int cha
                                 const float* w_flow, const float* b_flow, const float* w_occ,
                                 const float* b_occ, float* out, int batch, int frames, int hw,
                                 lfdm_stream_t stream);
+/* The same heads with the ResnetBlocks' res_conv folded in (ABI version 8): the blocks end in h + res_conv(cat(x0, x1))
+ * (video_flow_diffusion.py:224,236) and the heads are linear, so W1 (h + Wres [x0|x1] + bres) + b1 = W1 h + (W1 Wres)[x0|x1] + (W1 bres + b1):
+ * y_flow / y_occ are the blocks' outputs WITHOUT the res_conv term, w_extra (3, c0 + c1) the composed matrices (rows: flow x, flow y,
+ * occlusion), b_flow / b_occ already include W1 bres.  Replaces a 1x1 convolution launch by three more dot products per pixel. */
+int lfdm_heads_res_cl_to_planar_f32(const float* y_flow, const float* y_occ, int channels, int ld, const float* w_flow,
+                                    const float* b_flow, const float* w_occ, const float* b_occ, const float* x0, int ld0, int c0,
+                                    const float* x1, int ld1, int c1, const float* w_extra, float* out, int batch, int frames,
+                                    int hw, lfdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampler step (GaussianDiffusion.ddim_sample :791-827 / p_sample :737-746): predict x0
