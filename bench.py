@@ -376,7 +376,7 @@ def conv_roofline(model, ms_per_sampler_step):
             f = ln.split()
             if len(f) < 5 or not f[0].isdigit():
                 continue
-            if f[1].startswith("conv_splitk_reduce_kernel") and prev.startswith("conv_wino_kernel"):
+            if f[1].startswith("conv_splitk_reduce") and prev.startswith("conv_wino_kernel"):      # (incl. conv_splitk_reduce_vec_kernel<KS>)
                 red_us, red_n = red_us + float(f[-2]), red_n + 1
             prev = f[1]
         with_red = avg * w["launches"] + red_us
