@@ -542,7 +542,9 @@ template <int LP, int LROWS>
 int launch_fused_out_lp(const float* x, int ldx, const float* wqkv, const float* wout, float* out, int ldo, int batch, int frames, int hw,
                         const float* bias, const float* rot_cos, const float* rot_sin, float eps, hipStream_t stream) {
   const int64_t nseq = (int64_t)batch * hw;
-  int nw = 1;                                        // waves per sequence: aim at >= 2048 wavefronts (like the kernel above)
+  // waves per sequence: aim at >= 2048 wavefronts (like the kernel above), but never ONE wave per workgroup: the 40 KB tile admits four
+  // workgroups per CU, i.e. one wave per SIMD (batched shapes lost 4 % to that before this floor, profiles/r04_t_other_configs.json)
+  int nw = 2;
   while (nw < 8 && nseq * nw < 2048) nw <<= 1;
   if (const char* e = getenv("LFDM_TATTN_OUT_NW")) {      // experiment knob
     const int v = atoi(e);

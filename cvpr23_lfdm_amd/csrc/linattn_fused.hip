@@ -240,7 +240,10 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
   }
   // splits of whole 32-token tiles, as many as fit ONE round of waves (3 per SIMD: 3072), at most 64 (the merge kernel's table)
   const int tiles = (hw + 31) / 32;
-  int want = (int)(3072 / ((int64_t)n_frames * HEADS));
+  // (batched shapes - more (frame, head) pairs than half a round - get at least four rounds of waves instead of one long wave per pair:
+  //  a single split left 5120 waves of 32 serial tiles for 3072 slots at B = 16, profiles/r04_t_other_configs.json)
+  const int64_t pairs = (int64_t)n_frames * HEADS;
+  int want = (int)((pairs <= 1536 ? 3072 : 4 * 3072 + pairs - 1) / pairs);
   if (const char* e = getenv("LFDM_LINATTN_SPLITS")) want = atoi(e);      // experiment knob
   if (want < 1) want = 1;
   if (want > 64) want = 64;

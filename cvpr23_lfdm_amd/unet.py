@@ -42,10 +42,6 @@ _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output he
 _TATTN_WIDE = os.environ.get("LFDM_TATTN_WIDE", "0") == "1"      # A/B: the channel-streaming fused kernel at C >= 128 where no one-launch form applies
 
 
-def x_is_cuda(t):
-    return t.is_cuda
-
-
 def prob_mask_like(shape, prob, device):
     """Reference prob_mask_like (:55-61): consumes the RNG only for 0 < prob < 1."""
     if prob == 1:
@@ -335,7 +331,7 @@ class Unet3D(ParamTree):
             part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
-        if (gn is not None and _GN_COOP and x_is_cuda(src0) and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
+        if (gn is not None and _GN_COOP and src0.is_cuda and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
                 coutp == cout and ops.groupnorm_splitk_coop_ok(gn[0], m // gn[0], cout, gn[1] if len(gn) > 1 else 8, ksplit)):
             p.defer_reduce = 1
             ops.conv_launch(p)
