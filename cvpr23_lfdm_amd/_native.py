@@ -72,7 +72,20 @@ class WgradParams(C.Structure):
         ("n_img", i32), ("hi", i32), ("wi", i32), ("hq", i32), ("wq", i32),
         ("stride", i32), ("kh", i32), ("kw", i32), ("pad_y", i32), ("pad_x", i32),
         ("dy", f32p), ("cout", i32), ("lddy", i32),
-        ("dw", f32p),
+        ("dw", f32p), ("dw_layout", i32), ("dw_cin_total", i32), ("dw_ci_off", i32), ("dbias", f32p),
+    ]
+
+
+ML_MAX = 32
+
+
+class MultiLinearParams(C.Structure):
+    _fields_ = [
+        ("n_blocks", i32), ("rows", i32), ("k", i32), ("act", i32),
+        ("x", f32p),
+        ("w", f32p * ML_MAX), ("bias", f32p * ML_MAX), ("n", i32 * ML_MAX), ("y", f32p * ML_MAX),
+        ("dy", f32p * ML_MAX), ("dw", f32p * ML_MAX), ("dbias", f32p * ML_MAX),
+        ("dx", f32p),
     ]
 
 
@@ -140,6 +153,9 @@ _SIGNATURES = {
     "lfdm_planar_to_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
     "lfdm_cl_to_planar_f32": (i32, [f32p, f32p, i32, i32, i32, i32, stream_t]),
     # ---- training (backward) kernels
+    "lfdm_multi_linear_f32": (i32, [C.POINTER(MultiLinearParams), stream_t]),
+    "lfdm_multi_linear_bwd_ws_bytes": (sz, [C.POINTER(MultiLinearParams)]),
+    "lfdm_multi_linear_bwd_f32": (i32, [C.POINTER(MultiLinearParams), C.c_void_p, sz, stream_t]),
     "lfdm_conv2d_wgrad_ws_bytes": (sz, [C.POINTER(WgradParams)]),
     "lfdm_conv2d_wgrad_cl_f32": (i32, [C.POINTER(WgradParams), C.c_void_p, sz, stream_t]),
     "lfdm_sum_leading_f32": (i32, [f32p, f32p, i64, i32, stream_t]),

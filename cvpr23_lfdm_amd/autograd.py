@@ -19,6 +19,35 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def grad_out(param, like=None):
+    """The tensor a native backward kernel writes the gradient of `param` into.  When `param` lives in optim.Adam's flat storage and
+    this is its first gradient of the step (param.grad is None, i.e. zero_grad(set_to_none=True) - what the training scripts do), that
+    is the parameter's slot of the flat gradient buffer: autograd adopts the returned tensor as param.grad without a copy and
+    Adam.stage_grads / GradAllReduce find the gradient already in place (before: one staging copy per parameter per step).
+    Otherwise (second use of a shared parameter, accumulation over several backward passes, any other optimizer) a new tensor."""
+    slot = getattr(param, "_lfdm_grad_slot", None)
+    if (slot is None or param.grad is not None or param._lfdm_grad_slot_busy or slot.shape != param.shape or
+            slot.device != param.device):
+        return torch.empty(param.shape, dtype=torch.float32, device=param.device if like is None else like.device)
+    param._lfdm_grad_slot_busy = True
+    return slot.view(param.shape)
+
+
+def grad_out_pair(pa, pb):
+    """(2, C) tensor for kernels that write [d pa | d pb] as one block (GroupNorm: [dgamma | dbeta]): the two slots when they are free and
+    adjacent in the flat buffer (norm.weight / norm.bias are registered back to back), else a new tensor.  -> (block, grad_a, grad_b)."""
+    sa, sb = getattr(pa, "_lfdm_grad_slot", None), getattr(pb, "_lfdm_grad_slot", None)
+    c = pa.numel()
+    if (sa is not None and sb is not None and pa.grad is None and pb.grad is None and not pa._lfdm_grad_slot_busy and
+            not pb._lfdm_grad_slot_busy and pb.numel() == c and sa._base is not None and sa._base is sb._base and
+            sb.storage_offset() == sa.storage_offset() + c and sa.device == pa.device):
+        pa._lfdm_grad_slot_busy = pb._lfdm_grad_slot_busy = True
+        blk = sa._base[sa.storage_offset():sa.storage_offset() + 2 * c].view(2, c)
+        return blk, sa.view(pa.shape), sb.view(pb.shape)
+    blk = torch.empty(2, c, dtype=torch.float32, device=pa.device)
+    return blk, blk[0].view(pa.shape), blk[1].view(pb.shape)
+
+
 def _conv(x0, w4_direct, cout, kh, kw, n_img, hi, wi, *, weight_wino=None, **kw_):
     """ops.conv2d_cl that skips the direct-form filter pack (a handful of torch kernels per call, every step) whenever the
     library confirms the Winograd schedule; w4_direct: ((O, I, kh, kw) weight, pack mode of ops.pack_conv_weight_dev) for the
@@ -66,6 +95,7 @@ class ConvCL(Function):
             y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_conv_weight_dev(w4, 2), w4.shape[1], n_img, hi, wi, bias=b)
             stride, pad, hq, wq = 2, (1, 1), 2 * hi, 2 * wi
         ctx.save_for_backward(x0, x1, weight)
+        ctx.bias_param = bias
         ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
         return y
 
@@ -77,12 +107,22 @@ class ConvCL(Function):
         w4 = _c(weight.detach().reshape(weight.shape[0], weight.shape[1], kh, kw))
         need = ctx.needs_input_grad
         dx0 = dx1 = dw = db = None
+        bias_p = ctx.bias_param
+        taps_ok = kh * kw <= 16         # lfdm_wgrad_params.dw_layout = 1: the gradient in the weight's own layout, bias sums from the same pass
+        fused_bias = kind == "conv" and need[2] and taps_ok
         if has_bias and need[3]:
-            db = train_ops.colsum(dy)
+            db = grad_out(bias_p)
+            if not fused_bias:
+                train_ops.colsum(dy, out=db)
         if kind == "conv":
             cout = w4.shape[0]
             c0 = x0.shape[1]
-            if need[2]:
+            if need[2] and taps_ok:
+                dw = grad_out(weight)
+                train_ops.conv_wgrad(_c(x0), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad, out=dw, ci_off=0, dbias=db)
+                if x1 is not None:
+                    train_ops.conv_wgrad(_c(x1), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad, out=dw, ci_off=c0)
+            elif need[2]:
                 parts = [train_ops.conv_wgrad(_c(x0), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad)]
                 if x1 is not None:
                     parts.append(train_ops.conv_wgrad(_c(x1), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad))
@@ -108,9 +148,9 @@ class ConvCL(Function):
         else:
             cin, cout = w4.shape[0], w4.shape[1]
             if need[2]:
-                # roles exchanged: "input" = dy at (2h, 2w), "grad" = x at (h, w), stride 2, pad 1
-                dwt = train_ops.conv_wgrad(dy, _c(x0), n_img, hq, wq, hi, wi, 4, 4, stride=2, pad=(1, 1))   # (16, cout, cin)
-                dw = dwt.view(4, 4, cout, cin).permute(3, 2, 0, 1).reshape(weight.shape)
+                # roles exchanged: "input" = dy at (2h, 2w), "grad" = x at (h, w), stride 2, pad 1 -> layout 1 = (cin, cout, 4, 4)
+                dw = grad_out(weight)
+                train_ops.conv_wgrad(dy, _c(x0), n_img, hq, wq, hi, wi, 4, 4, stride=2, pad=(1, 1), out=dw)
             if need[0]:
                 dx0 = ops.conv2d_cl(dy, ops.pack_conv_weight_dev(w4, 0), cin, 4, 4, n_img, hq, wq, stride=2, pad=(1, 1))
         dres = dy if (has_res and need[4]) else None
@@ -136,8 +176,9 @@ class GroupNormSiLU(Function):
         x, gamma, beta, ss, partial = ctx.saved_tensors
         batch, nchunk, silu, has_res = ctx.meta
         dy = _c(dy)
-        dx, dg, db, dss = train_ops.groupnorm_silu_bwd(x, dy, batch, _c(gamma.detach()), _c(beta.detach()), partial, nchunk,
-                                                       scale_shift=ss, silu=silu)
+        dgb, dg, db = grad_out_pair(gamma, beta)
+        dx, _, _, dss = train_ops.groupnorm_silu_bwd(x, dy, batch, _c(gamma.detach()), _c(beta.detach()), partial, nchunk,
+                                                     scale_shift=ss, silu=silu, dgb=dgb)
         return dx, dg, db, dss, (dy if has_res else None), None, None
 
 
@@ -149,14 +190,15 @@ class LayerNormCL(Function):
         xs = _c(x.detach())
         g = _c(gamma.detach().reshape(-1))
         ctx.save_for_backward(xs, g)
-        ctx.gshape = gamma.shape
+        ctx.gamma_param = gamma
         return ops.layernorm_cl(xs, g)
 
     @staticmethod
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
-        dx, dg = train_ops.layernorm_bwd(x, _c(dy), g)
-        return dx, dg.reshape(ctx.gshape)
+        dg = grad_out(ctx.gamma_param)
+        dx, _ = train_ops.layernorm_bwd(x, _c(dy), g, dgamma=dg)
+        return dx, dg
 
 
 class AttentionCL(Function):
@@ -193,6 +235,39 @@ class LinearAttentionCL(Function):
         (q,) = ctx.saved_tensors
         n_frames, hw = ctx.meta
         return train_ops.linear_attention_bwd(q, _c(dout), n_frames, hw), None, None
+
+
+class MultiLinear(Function):
+    """(y_0, ..., y_{n-1}) with y_j = act(x) @ w_j.T + b_j: Linear layers that share their input - every ResnetBlock.mlp of a UNet
+    forward (SiLU -> Linear on cat(time_emb, cond), :230-233,240-245,562) or one layer of time_mlp (:441-447) - one native launch forward,
+    three backward (weight / bias gradients into the optimizer's slots, the input gradient summed over all blocks in a fixed order).
+    apply(x, act, n, w_0..w_{n-1}, b_0..b_{n-1}); a bias may be None."""
+
+    @staticmethod
+    def forward(ctx, x, act, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        xs = _c(x.detach())
+        ys = train_ops.multi_linear(xs, [_c(w.detach()) for w in ws], [None if b is None else _c(b.detach()) for b in bs], act)
+        ctx.save_for_backward(xs, *ws)
+        ctx.bias_params = bs
+        ctx.meta = (act, n)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        xs, *ws = ctx.saved_tensors
+        act, n = ctx.meta
+        bs = ctx.bias_params
+        need = ctx.needs_input_grad
+        dws = [grad_out(w) if need[3 + j] else None for j, w in enumerate(ws)]
+        dbs = [grad_out(b) if (b is not None and need[3 + n + j]) else None for j, b in enumerate(bs)]
+        dx = train_ops.multi_linear_bwd(xs, [_c(w.detach()) for w in ws], [None if d is None else _c(d) for d in dys], act, dws, dbs,
+                                        want_dx=need[0])
+        return (dx, None, None, *dws, *dbs)
+
+
+def multi_linear(x, weights, biases, act=train_ops.ACT_NONE):
+    return MultiLinear.apply(x, act, len(weights), *weights, *biases)
 
 
 class PlanarToCL(Function):

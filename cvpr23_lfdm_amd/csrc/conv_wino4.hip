@@ -55,7 +55,7 @@ __device__ __forceinline__ void bt6(const f32x2 d0, const f32x2 d1, const f32x2 
 
 template <bool ACT>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int gx, int ny, int ablate) {
-  (void)ablate;      // (unused; probe builds -DLFDM_W4_PROBE=<mask> leave pipeline stages out at compile time: tools/probe_wino4_ablate.sh)
+  // ablate: bit 0 = raised instruction-issue priority for the producer waves (LFDM_W4_PRIO; probe builds -DLFDM_W4_PROBE=<mask> leave pipeline stages out at compile time: tools/probe_wino4_ablate.sh)
   constexpr int SMEM4 = 2 * V4SZ > 36 * W4T * W4N ? 2 * V4SZ : 36 * W4T * W4N;
   __shared__ __attribute__((aligned(16))) float smem[SMEM4];      // V double buffer (144 KB); the epilogue's accumulator planes (144 KB) alias it
 
@@ -92,6 +92,14 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
   // registers alive together.
   if (wave >= 4) {
     // ---------------------------------------------------------------- PRODUCERS (waves 4-7): thread = (tile, channel pair of 8)
+    // Instruction-issue priority for the producers (round 4).  Cycle stamps (-DLFDM_W4_STAMP, tools/probe_wino4_stamp.py) showed the
+    // CONSUMERS waiting 3 900 of every 9 000 cycles at the period barrier while each producer instruction took ~38 cycles: a SIMD's matrix
+    // pipe and vector ALU do not run side by side here, and at equal priority the consumer wave's next MFMA (64 cycles) wins the
+    // issue slot whenever the producer wave's dependent transform chain is not ready in that very cycle.  With priority the producers
+    // finish a period in ~6 600 cycles instead of 9 000: 1 411 -> 1 263 us on 256 -> 256 @32x32 x 320 frames.
+#if !defined(LFDM_EMU_BUILD)
+    if (ablate & 1) __builtin_amdgcn_s_setprio(1);
+#endif
     const int pt = tid - 256;
     const int x_tile = pt >> 3, x_pair = pt & 7;
     const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
@@ -117,6 +125,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
     }
     const uint32_t ld4 = (uint32_t)p.ld0 * 4u;
     f32x2 pa[36], pb[36];                           // two patch register sets (two chunks in flight)
+    // (Round 4, measured and dropped: per-lane byte offsets of the 36 patch pixels kept in registers + the period as the SGPR offset of
+    // the load - no vector arithmetic per fetch - and the same for the consumers' filter loads: 3-7 % SLOWER; the loads then leave in
+    // one burst and the launch sits on L2 -> L1 delivery instead, profiles/r04_w_wino4_stamps.txt.)
     auto fetch_patch = [&](f32x2 (&d)[36], int chunk) {
 #ifdef LFDM_W4_PROBE
       if constexpr ((LFDM_W4_PROBE & 1) != 0) return;
@@ -124,7 +135,6 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
       const uint32_t base = base0 + (uint32_t)chunk * (W4C * 4u);
       // issue order inside a patch row: columns 0, 4, 1, 5, 2, 3 - a wave's 8 lanes-of-8 are 8 horizontally adjacent tiles, and column
       // c + 4 of tile i is column c of tile i + 1: requested back to back, 7/8 of the second load's 64-byte segments hit L1
-      // (the launch is bound by L2 -> L1 bandwidth: profiles/r03_p_wino4_ablation.txt)
 #pragma unroll
       for (int qq = 0; qq < 36; ++qq) {
         constexpr int corder[6] = {0, 4, 1, 5, 2, 3};
@@ -165,14 +175,42 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
     transform_store(pa, V0);
     fetch_patch(pa, clampp(2));
     __syncthreads();
+#ifdef LFDM_W4_STAMP
+    long long st_work = 0, st_bar = 0, st_t = clock64();
+#define LFDM_W4_LAP(acc) { const long long now_ = clock64(); acc += now_ - st_t; st_t = now_; }
+#else
+#define LFDM_W4_LAP(acc)
+#endif
+#ifdef LFDM_W4_STAMP
+    long long st_wait = 0, st_xf = 0;
+#define LFDM_W4_WAITSET() { asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); LFDM_W4_LAP(st_wait) }
+#else
+#define LFDM_W4_WAITSET()
+#endif
     for (int kp = 0; kp < nper; kp += 2) {
+      LFDM_W4_WAITSET()
       transform_store(pb, V1);                      // period kp+1 while the consumers multiply period kp from V0
+      LFDM_W4_LAP(st_xf)
       fetch_patch(pb, clampp(kp + 3));
+      LFDM_W4_LAP(st_work)
       __syncthreads();
+      LFDM_W4_LAP(st_bar)
+      LFDM_W4_WAITSET()
       transform_store(pa, V0);                      // period kp+2 while the consumers multiply period kp+1 from V1
+      LFDM_W4_LAP(st_xf)
       fetch_patch(pa, clampp(kp + 4));
+      LFDM_W4_LAP(st_work)
       __syncthreads();
+      LFDM_W4_LAP(st_bar)
     }
+#ifdef LFDM_W4_STAMP
+    if (lane == 0 && blockIdx.x < 256) {
+      long long* st = (long long*)p.gn_in_gamma + ((int64_t)blockIdx.x * 8 + wave) * 2;
+      st[0] = st_work; st[1] = st_bar;
+      long long* st2 = (long long*)p.gn_in_gamma + 256 * 8 * 2 + ((int64_t)blockIdx.x * 8 + wave) * 2;
+      st2[0] = st_wait; st2[1] = st_xf;
+    }
+#endif
     __syncthreads();                                // the consumers' epilogue: one more barrier
     return;
   }
@@ -243,14 +281,27 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
   fetch_bg(bfr[0], 0, 0);
   fetch_bg(bfr[1], 1, 0);
   __syncthreads();
+#ifdef LFDM_W4_STAMP
+  long long st_work = 0, st_bar = 0, st_t = clock64();
+#endif
   for (int kp = 0; kp < nper; kp += 2) {
     consume(V0, 0, 2 * kp, 2 * kp + 1);
     consume(V0, 1, 2 * kp + 1, 2 * kp + 2);
+    LFDM_W4_LAP(st_work)
     __syncthreads();
+    LFDM_W4_LAP(st_bar)
     consume(V1, 0, 2 * kp + 2, 2 * kp + 3);
     consume(V1, 1, 2 * kp + 3, clampc(2 * kp + 4));
+    LFDM_W4_LAP(st_work)
     __syncthreads();
+    LFDM_W4_LAP(st_bar)
   }
+#ifdef LFDM_W4_STAMP
+  if (lane == 0 && blockIdx.x < 256) {
+    long long* st = (long long*)p.gn_in_gamma + ((int64_t)blockIdx.x * 8 + wave) * 2;
+    st[0] = st_work; st[1] = st_bar;
+  }
+#endif
 
   // ---------------------------------------------------------------- output transform A^T M A through LDS
   // every accumulator goes to its plane first ([36 positions][32 tiles][32 channels]: 147 KB, the accumulators are dead afterwards),
@@ -389,7 +440,8 @@ int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream) {
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 4) * (p.wq / 4);
   const int gx = (int)((ntiles + W4T - 1) / W4T), ny = (p.coutp + W4N - 1) / W4N;
   const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny));
-  const int ablate = 0;
+  // producer-wave priority (kernel argument `ablate`, bit 0): on by default, LFDM_W4_PRIO=0 switches it off (A/B: profiles/r04_w_wino4_stamps.txt)
+  static const int ablate = []() { const char* e = getenv("LFDM_W4_PRIO"); return e ? atoi(e) : 1; }();
   if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
   else LFDM_LAUNCH((conv_wino4_kernel<false>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
   return lfdm_check_launch("conv_wino4");

@@ -22,7 +22,7 @@
 namespace {
 
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, int splits, float* dst_base) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, int splits, float* dst_base, float* bias_partial) {
   constexpr int TCI = 64 * WM, TCO = 64 * WN, BR = 32;
   constexpr int A_F4 = BR * TCI / 4 / 256, B_F4 = BR * TCO / 4 / 256;
   constexpr int STAGE = BR * (TCI + TCO);
@@ -47,6 +47,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
   const lfdm_buf bufx = lfdm_make_buf(p.x, (uint32_t)(((in_rows - 1) * p.ldx + p.cin) * 4));
   const lfdm_buf bufy = lfdm_make_buf(p.dy, (uint32_t)((((int64_t)M - 1) * p.lddy + p.cout) * 4));
 
+  // Bias gradient from the same pass (bias_partial != NULL): the workgroups of tap 0 / input-channel tile 0 see every dy row of their
+  // slice exactly once on its way into LDS - each thread's float4 column position is the same for all its loads (256 % (TCO/4) == 0).
+  const bool do_bias = bias_partial != nullptr && blockIdx.x == 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ra[A_F4], rb[B_F4];
   auto fetch = [&](int chunk) {
     const int r0 = chunk * BR;
@@ -76,13 +80,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
       rb[i] = lfdm_buf_load_f4(bufy, off);
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, bool fresh) {      // fresh: the registers hold a chunk that has not been staged before (the tail re-fetches the last one)
     float* const As = smem + buf * STAGE;
     float* const Bs = As + BR * TCI;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(As + 4 * (tid + 256 * i)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(Bs + 4 * (tid + 256 * i)) = rb[i];
+    if (do_bias && fresh) {
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i) { bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w; }
+    }
   };
 
   f32x16 acc[WM][WN];
@@ -95,12 +103,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
 
   if (nk > 0) {
     fetch(c_begin);
-    stage(0);
+    stage(0, true);
     __syncthreads();
     fetch(c_begin + (nk > 1 ? 1 : 0));
     for (int c = 0; c < nk; ++c) {
       const int cur = c & 1;
-      stage(cur ^ 1);
+      stage(cur ^ 1, c + 1 < nk);
       {
         const int nxt = c + 2 < nk ? c + 2 : nk - 1;
         fetch(c_begin + nxt);
@@ -136,6 +144,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
         if (ci < p.cin && co < p.cout) dst[((int64_t)tap * p.cin + ci) * p.cout + co] = acc[i][j][r];
       }
     }
+  if (do_bias) {      // (uniform per workgroup; the K loop ended with a barrier, the staging buffers are free)
+    constexpr int C4 = TCO / 4, RL = 256 / C4;
+    *reinterpret_cast<float4*>(smem + (tid / C4) * TCO + 4 * (tid % C4)) = bsum;
+    __syncthreads();
+    if (tid < TCO && co0 + tid < p.cout) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < RL; ++k) sum += smem[k * TCO + tid];
+      bias_partial[(int64_t)blockIdx.z * p.cout + co0 + tid] = sum;
+    }
+  }
+}
+
+// Second stage of a split weight gradient in the REFERENCE layout (lfdm_wgrad_params.dw_layout = 1):
+//   out[(co * cin_total + ci_off + ci) * taps + tap] = sum_s slab[s][tap][ci][co]   (s in fixed order, like sum_leading4_kernel)
+// i.e. the (cout, cin, [1,] kh, kw) tensor autograd wants for Conv3d.weight (video_flow_diffusion.py:199,224,...) without the
+// permute-copy, written straight into the optimizer's flat gradient slot.  Workgroup = CI_T input channels x 64 output channels x all
+// taps: float4 loads along co (one item = one float4 of one (ci, tap), all slabs), a transposition through LDS, then per output
+// channel one contiguous run of CI_T * taps floats.  The trailing workgroups sum the bias partials (256 columns each).
+template <int CI_T>
+__global__ __launch_bounds__(256) void wgrad_reduce_ref_kernel(const float* __restrict__ slabs, int s, int64_t slab_stride, int taps, int cin,
+                                                               int cout, float* __restrict__ out, int cin_total, int ci_off,
+                                                               const float* __restrict__ bias_partial, float* __restrict__ dbias,
+                                                               int n_dw_blocks) {
+  constexpr int TMAX = CI_T == 16 ? 1 : 16;
+  __shared__ float T[64 * CI_T * TMAX];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= n_dw_blocks) {
+    const int co = ((int)blockIdx.x - n_dw_blocks) * 256 + tid;
+    if (co < cout) {
+      float sum = 0.f;
+      for (int k = 0; k < s; ++k) sum += bias_partial[(int64_t)k * cout + co];
+      dbias[co] = sum;
+    }
+    return;
+  }
+  const int co_tiles = (cout + 63) / 64;
+  const int ci0 = ((int)blockIdx.x / co_tiles) * CI_T, co0 = ((int)blockIdx.x % co_tiles) * 64;
+  const int row = CI_T * taps;
+  for (int it = tid; it < row * 16; it += 256) {
+    const int c4 = it & 15, rest = it >> 4;
+    const int ci_l = rest / taps, tap = rest - ci_l * taps;
+    const int ci = ci0 + ci_l, co = co0 + 4 * c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ci < cin && co < cout) {
+      const float* src = slabs + ((int64_t)tap * cin + ci) * cout + co;
+#pragma unroll 8
+      for (int k = 0; k < s; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)k * slab_stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    float* t = T + (4 * c4) * row + ci_l * taps + tap;
+    t[0] = acc.x; t[row] = acc.y; t[2 * row] = acc.z; t[3 * row] = acc.w;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * row; idx += 256) {
+    const int co_l = idx / row, j = idx - co_l * row;
+    if (co0 + co_l < cout && ci0 + j / taps < cin) out[((int64_t)(co0 + co_l) * cin_total + ci_off + ci0) * taps + j] = T[idx];
+  }
 }
 
 // out[i] = sum_s in[s*n + i]  (fixed order)
@@ -284,10 +352,17 @@ WgradPlan wgrad_plan(const lfdm_wgrad_params& p) {
 
 }  // namespace
 
+// Workspace = [splits slabs of kh*kw*cin*cout floats, when the result does not come straight out of the GEMM kernel: splits > 1 or
+// dw_layout = 1] followed by [splits rows of cout bias partials, when dbias is wanted].
+static bool wgrad_needs_slabs(const lfdm_wgrad_params& p, const WgradPlan& pl) { return pl.splits > 1 || p.dw_layout == 1; }
+
 extern "C" size_t lfdm_conv2d_wgrad_ws_bytes(const lfdm_wgrad_params* p) {
   if (!p) return 0;
   const WgradPlan pl = wgrad_plan(*p);
-  return pl.splits > 1 ? (size_t)pl.splits * p->kh * p->kw * p->cin * p->cout * sizeof(float) : 0;
+  size_t floats = 0;
+  if (wgrad_needs_slabs(*p, pl)) floats += (size_t)pl.splits * p->kh * p->kw * p->cin * p->cout;
+  if (p->dbias) floats += (size_t)pl.splits * p->cout;
+  return floats * sizeof(float);
 }
 
 extern "C" int lfdm_sum_leading_f32(const float* in, float* out, int64_t n, int s, lfdm_stream_t stream_) {
@@ -323,19 +398,52 @@ extern "C" int lfdm_conv2d_wgrad_cl_f32(const lfdm_wgrad_params* pp, void* ws, s
     lfdm_set_error("wgrad: channels and row strides must be multiples of 4, buffers 16-byte aligned and < 4 GiB");
     return LFDM_EINVAL;
   }
+  const int taps = p.kh * p.kw;
+  if (p.dw_layout != 0 && p.dw_layout != 1) { lfdm_set_error("wgrad: dw_layout must be 0 (tap-major) or 1 (reference layout)"); return LFDM_EINVAL; }
+  if (p.dw_layout == 1 && (taps > 16 || p.dw_cin_total < p.dw_ci_off + p.cin || p.dw_ci_off < 0)) {
+    lfdm_set_error("wgrad: the reference layout covers filters of up to 16 taps; dw_ci_off + cin must fit dw_cin_total");
+    return LFDM_EINVAL;
+  }
   const WgradPlan pl = wgrad_plan(p);
   const size_t need = lfdm_conv2d_wgrad_ws_bytes(&p);
-  if (need > 0 && (!ws || ws_bytes < need)) { lfdm_set_error("wgrad: workspace too small (lfdm_conv2d_wgrad_ws_bytes)"); return LFDM_EWORKSPACE; }
-  float* dst = pl.splits > 1 ? (float*)ws : p.dw;
-  const dim3 grid((unsigned)(p.kh * p.kw * ((p.cin + 64 * pl.wm - 1) / (64 * pl.wm))), (unsigned)((p.cout + 64 * pl.wn - 1) / (64 * pl.wn)),
+  if (need > 0 && (!ws || ws_bytes < need || (((uintptr_t)ws) & 15))) {
+    lfdm_set_error("wgrad: workspace too small or not 16-byte aligned (lfdm_conv2d_wgrad_ws_bytes)");
+    return LFDM_EWORKSPACE;
+  }
+  const bool slabs = wgrad_needs_slabs(p, pl);
+  const int64_t n_dw = (int64_t)taps * p.cin * p.cout;
+  float* dst = slabs ? (float*)ws : p.dw;
+  float* bias_partial = p.dbias ? (float*)ws + (slabs ? (int64_t)pl.splits * n_dw : 0) : nullptr;
+  const dim3 grid((unsigned)(taps * ((p.cin + 64 * pl.wm - 1) / (64 * pl.wm))), (unsigned)((p.cout + 64 * pl.wn - 1) / (64 * pl.wn)),
                   (unsigned)pl.splits);
-  if (pl.wm == 2 && pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst);
-  else if (pl.wm == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst);
-  else if (pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst);
-  else LFDM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst);
+  if (pl.wm == 2 && pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+  else if (pl.wm == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+  else if (pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+  else LFDM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
   int rc = lfdm_check_launch("conv_wgrad");
   if (rc) return rc;
-  if (pl.splits > 1) return lfdm_sum_leading_f32((const float*)ws, p.dw, (int64_t)p.kh * p.kw * p.cin * p.cout, pl.splits, stream_);
+  if (p.dw_layout == 1) {
+    // input channels per workgroup: 16 for 1x1 filters (64-byte runs), else 4 - or 1 while that leaves fewer than 256 workgroups
+    const int co_tiles = (p.cout + 63) / 64;
+    int ci_t = taps == 1 ? 16 : 4;
+    if (ci_t == 4 && (int64_t)((p.cin + 3) / 4) * co_tiles < 256) ci_t = 1;
+    const int n_dw_blocks = ((p.cin + ci_t - 1) / ci_t) * co_tiles;
+    const int n_bias_blocks = p.dbias ? (p.cout + 255) / 256 : 0;
+    const dim3 rgrid((unsigned)(n_dw_blocks + n_bias_blocks));
+#define LFDM_WGRAD_REDUCE(CT)                                                                                                        \
+    LFDM_LAUNCH((wgrad_reduce_ref_kernel<CT>), rgrid, dim3(256), 0, stream, (const float*)ws, pl.splits, n_dw, taps, p.cin, p.cout, p.dw, \
+                p.dw_cin_total, p.dw_ci_off, (const float*)bias_partial, p.dbias, n_dw_blocks)
+    if (ci_t == 16) LFDM_WGRAD_REDUCE(16);
+    else if (ci_t == 4) LFDM_WGRAD_REDUCE(4);
+    else LFDM_WGRAD_REDUCE(1);
+#undef LFDM_WGRAD_REDUCE
+    return lfdm_check_launch("wgrad_reduce_ref");
+  }
+  if (pl.splits > 1) {
+    rc = lfdm_sum_leading_f32((const float*)ws, p.dw, n_dw, pl.splits, stream_);
+    if (rc) return rc;
+  }
+  if (p.dbias) return lfdm_sum_leading_f32(bias_partial, p.dbias, p.cout, pl.splits, stream_);
   return LFDM_OK;
 }
 

@@ -42,6 +42,8 @@ class FlatAdam(torch.optim.Optimizer):
                 fp[o:o + k].copy_(p.data.reshape(-1))
                 p.data = fp[o:o + k].view(p.shape)
                 gviews.append(fg[o:o + k].view(p.shape))
+                # autograd.grad_out: the native backward kernels write the step's first gradient of `p` straight into this slot
+                p._lfdm_grad_slot, p._lfdm_grad_slot_busy = gviews[-1], False
                 st = self.state[p]
                 if "exp_avg" in st:                    # state loaded before the first step
                     if st["exp_avg"].numel() != k or st["exp_avg_sq"].numel() != k:
@@ -83,6 +85,8 @@ class FlatAdam(torch.optim.Optimizer):
         views of the flat buffer) - and `stage_grads` gathers them into the flat buffer with a few multi-tensor copies."""
         self._staged = False
         for fl in self.ensure_flat():
+            for p in fl["params"]:
+                p._lfdm_grad_slot_busy = False
             if set_to_none:
                 for p in fl["params"]:
                     p.grad = None
@@ -108,6 +112,7 @@ class FlatAdam(torch.optim.Optimizer):
                     src.append(g if g.shape == slot.shape else g.reshape(slot.shape))
                     dst.append(slot)
                 p.grad = slot
+                p._lfdm_grad_slot_busy = False
             if dst:
                 torch._foreach_copy_(dst, src)
         if fl is None:

@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from ._native import WgradParams
+from ._native import ML_MAX, MultiLinearParams, WgradParams
 from .ops import _chk, _lib, _p, _stream
 
 
@@ -39,22 +39,34 @@ def colsum(x, out=None):
     return out
 
 
-def conv_wgrad(x, dy, n_img, hi, wi, hq, wq, kh, kw, stride=1, pad=None):
-    """dW in tap-major layout (kh*kw, cin, cout).  x: (n_img*hi*wi, cin) CL, dy: (n_img*hq*wq, cout) CL."""
+def conv_wgrad(x, dy, n_img, hi, wi, hq, wq, kh, kw, stride=1, pad=None, out=None, ci_off=0, dbias=None):
+    """Weight gradient.  x: (n_img*hi*wi, cin) CL, dy: (n_img*hq*wq, cout) CL.
+    out=None -> a new tensor in the tap-major layout (kh*kw, cin, cout).
+    out=(cout, cin_total, ...) contiguous -> the reference layout is written into it at input channels [ci_off, ci_off+cin)
+    (filters of <= 16 taps; lfdm_wgrad_params.dw_layout = 1) and `out` is returned.
+    dbias: optional (cout,) tensor that receives the bias gradient (column sums of dy) from the same pass."""
     lib = _lib()
-    _chk(lib, x, dy)
+    _chk(lib, x, dy, out, dbias)
     assert x.stride(1) == 1 and dy.stride(1) == 1
     cin, cout = x.shape[1], dy.shape[1]
     assert x.shape[0] == n_img * hi * wi and dy.shape[0] == n_img * hq * wq
     if pad is None:
         pad = (kh // 2, kw // 2)
-    dw = torch.empty(kh * kw, cin, cout, dtype=torch.float32, device=x.device)
     p = WgradParams()
+    if out is None:
+        dw = torch.empty(kh * kw, cin, cout, dtype=torch.float32, device=x.device)
+    else:
+        dw = out
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == cout and out.numel() % (cout * kh * kw) == 0
+        p.dw_layout, p.dw_cin_total, p.dw_ci_off = 1, out.numel() // (cout * kh * kw), ci_off
     p.x, p.cin, p.ldx = x.data_ptr(), cin, x.stride(0)
     p.n_img, p.hi, p.wi, p.hq, p.wq = n_img, hi, wi, hq, wq
     p.stride, p.kh, p.kw, p.pad_y, p.pad_x = stride, kh, kw, pad[0], pad[1]
     p.dy, p.cout, p.lddy = dy.data_ptr(), cout, dy.stride(0)
     p.dw = dw.data_ptr()
+    if dbias is not None:
+        assert dbias.is_contiguous() and dbias.numel() == cout
+        p.dbias = dbias.data_ptr()
     nbytes = lib.lfdm_conv2d_wgrad_ws_bytes(C.byref(p))
     ws = _ws(nbytes, x)
     lib.check(lib.lfdm_conv2d_wgrad_cl_f32(C.byref(p), _p(ws), nbytes, _stream(lib)), "lfdm_conv2d_wgrad_cl_f32")
@@ -81,15 +93,17 @@ def groupnorm_silu_train(x, batch, gamma, beta, scale_shift=None, residual=None,
     return y, ws[: batch * nchunk * groups * 2], nchunk
 
 
-def groupnorm_silu_bwd(x, dy, batch, gamma, beta, partial, nchunk, scale_shift=None, groups=8, eps=1e-5, silu=True):
-    """-> (dx, dgamma, dbeta, dscale_shift or None)."""
+def groupnorm_silu_bwd(x, dy, batch, gamma, beta, partial, nchunk, scale_shift=None, groups=8, eps=1e-5, silu=True, dgb=None):
+    """-> (dx, dgamma, dbeta, dscale_shift or None).  dgb: optional contiguous (2, C) tensor that receives [dgamma | dbeta]."""
     lib = _lib()
-    _chk(lib, x, dy, gamma, beta, partial, scale_shift)
+    _chk(lib, x, dy, gamma, beta, partial, scale_shift, dgb)
     rows, c = x.shape
     pixels = rows // batch
     assert x.is_contiguous() and dy.is_contiguous()
     dx = torch.empty_like(x)
-    dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    if dgb is None:
+        dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    assert dgb.is_contiguous() and dgb.numel() == 2 * c
     dss = torch.empty(batch, 2 * c, dtype=torch.float32, device=x.device) if scale_shift is not None else None
     nbytes = lib.lfdm_groupnorm_bwd_ws_bytes(batch, pixels, c)
     ws = _ws(nbytes, x)
@@ -100,14 +114,16 @@ def groupnorm_silu_bwd(x, dy, batch, gamma, beta, partial, nchunk, scale_shift=N
     return dx, dgb[0], dgb[1], dss
 
 
-def layernorm_bwd(x, dy, gamma, eps=1e-5):
-    """-> (dx, dgamma)."""
+def layernorm_bwd(x, dy, gamma, eps=1e-5, dgamma=None):
+    """-> (dx, dgamma).  dgamma: optional contiguous tensor of C elements that receives the gamma gradient."""
     lib = _lib()
-    _chk(lib, x, dy, gamma)
+    _chk(lib, x, dy, gamma, dgamma)
     rows, c = x.shape
     assert x.is_contiguous() and dy.is_contiguous()
     dx = torch.empty_like(x)
-    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    assert dgamma.is_contiguous() and dgamma.numel() == c
     nbytes = lib.lfdm_layernorm_bwd_ws_bytes(rows, c)
     ws = _ws(nbytes, x)
     lib.check(lib.lfdm_layernorm_bwd_cl_f32(_p(x), _p(dy), _p(dx), rows, c, _p(gamma), eps, _p(dgamma), _p(ws), nbytes,
@@ -143,6 +159,61 @@ def linear_attention_bwd(qkv, dout, n_frames, hw):
     lib.check(lib.lfdm_linear_attention_bwd_cl_f32(_p(qkv), _p(dout), _p(dqkv), n_frames, hw, _p(ws), nbytes, _stream(lib)),
               "lfdm_linear_attention_bwd_cl_f32")
     return dqkv
+
+
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+
+def _ml_params(x, weights, act):
+    rows, k = x.shape
+    assert x.is_contiguous() and 0 < len(weights) <= ML_MAX
+    p = MultiLinearParams()
+    p.n_blocks, p.rows, p.k, p.act, p.x = len(weights), rows, k, act, x.data_ptr()
+    for j, w in enumerate(weights):
+        assert w.is_contiguous() and w.dim() == 2 and w.shape[1] == k
+        p.w[j], p.n[j] = w.data_ptr(), w.shape[0]
+    return p
+
+
+def multi_linear(x, weights, biases, act=ACT_NONE):
+    """[act(x) @ w.T + b for w, b in zip(weights, biases)] in ONE launch (lfdm_multi_linear_f32).  x (rows <= 16, k <= 1024)."""
+    lib = _lib()
+    _chk(lib, x, *weights, *[b for b in biases if b is not None])
+    p = _ml_params(x, weights, act)
+    ys = []
+    for j, (w, b) in enumerate(zip(weights, biases)):
+        y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        ys.append(y)
+        p.y[j] = y.data_ptr()
+        if b is not None:
+            assert b.is_contiguous() and b.numel() == w.shape[0]
+            p.bias[j] = b.data_ptr()
+    lib.check(lib.lfdm_multi_linear_f32(C.byref(p), _stream(lib)), "lfdm_multi_linear_f32")
+    return ys
+
+
+def multi_linear_bwd(x, weights, dys, act=ACT_NONE, dws=None, dbs=None, want_dx=True):
+    """Backward of multi_linear.  dys[j]: (rows, n_j) or None (zero); dws[j] / dbs[j]: tensors to fill, or None (not wanted).
+    -> dx (rows, k) or None."""
+    lib = _lib()
+    n = len(weights)
+    dws = dws if dws is not None else [None] * n
+    dbs = dbs if dbs is not None else [None] * n
+    _chk(lib, x, *weights, *[t for t in list(dys) + list(dws) + list(dbs) if t is not None])
+    p = _ml_params(x, weights, act)
+    for j in range(n):
+        for name, t, numel in (("dy", dys[j], x.shape[0] * weights[j].shape[0]), ("dw", dws[j], weights[j].numel()),
+                               ("dbias", dbs[j], weights[j].shape[0])):
+            if t is not None:
+                assert t.is_contiguous() and t.numel() == numel, name
+                getattr(p, name)[j] = t.data_ptr()
+    dx = torch.empty_like(x) if want_dx else None
+    if dx is not None:
+        p.dx = dx.data_ptr()
+    nbytes = lib.lfdm_multi_linear_bwd_ws_bytes(C.byref(p))
+    ws = _ws(nbytes, x)
+    lib.check(lib.lfdm_multi_linear_bwd_f32(C.byref(p), _p(ws), nbytes, _stream(lib)), "lfdm_multi_linear_bwd_f32")
+    return dx
 
 
 def upsample2_pad(x, n_img, h, w, pad, reflect, backward=False):

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import autograd as A
-from . import ops
+from . import ops, train_ops
 from .unet import prob_mask_like, rel_pos_bias_table
 
 
@@ -24,22 +24,42 @@ def _time_embedding(unet, time):
     freq = torch.exp(torch.arange(half, device=time.device) * -(math.log(10000) / (half - 1)))
     e = time[:, None].float() * freq[None, :]
     e = torch.cat((e.sin(), e.cos()), dim=-1)
-    e = F.gelu(F.linear(e, unet.get("time_mlp.1.weight"), unet.get("time_mlp.1.bias")))
-    return F.linear(e, unet.get("time_mlp.3.weight"), unet.get("time_mlp.3.bias"))
+    # time_mlp (:441-447): Linear -> GELU -> Linear; the GELU is the input activation of the second native launch
+    (e,) = A.multi_linear(e, [unet.get("time_mlp.1.weight")], [unet.get("time_mlp.1.bias")])
+    (e,) = A.multi_linear(e, [unet.get("time_mlp.3.weight")], [unet.get("time_mlp.3.bias")], act=train_ops.ACT_GELU)
+    return e
+
+
+def _resblock_prefixes(unet):
+    """Every ResnetBlock of the forward, in execution order (the two output heads take no conditioning)."""
+    nl = len(unet.levels)
+    ps = ["downs.%d.%d." % (lvl, i) for lvl in range(nl) for i in (0, 1)] + ["mid_block1.", "mid_block2."]
+    return ps + ["ups.%d.%d." % (lvl, i) for lvl in range(nl) for i in (0, 1)]
+
+
+def _block_scale_shifts(unet, tc):
+    """{prefix: (B, 2*dim_out)} for every ResnetBlock with an mlp (:230-233, :240-245): all of them read SiLU(tc), so they run as one
+    native launch (and one backward) instead of a SiLU + Linear pair of vendor kernels per block."""
+    ps = [p for p in _resblock_prefixes(unet) if unet.has(p + "mlp.1.weight")]
+    out = {}
+    for i in range(0, len(ps), train_ops.ML_MAX):
+        chunk = ps[i:i + train_ops.ML_MAX]
+        ys = A.multi_linear(tc, [unet.get(p + "mlp.1.weight") for p in chunk], [unet.get(p + "mlp.1.bias") for p in chunk],
+                            act=train_ops.ACT_SILU)
+        out.update(zip(chunk, ys))
+    return out
 
 
 class _Ctx:
     pass
 
 
-def _resblock(unet, c, prefix, x, skip, res, cout, temb_cond):
+def _resblock(unet, c, prefix, x, skip, res, cout, ss_of):
     g = unet.get
     n_img = c.batch * c.frames
     h = A.conv_cl(x, g(prefix + "block1.proj.weight"), g(prefix + "block1.proj.bias"), x1=skip,
                   n_img=n_img, hi=res, wi=res)
-    ss = None
-    if temb_cond is not None and unet.has(prefix + "mlp.1.weight"):
-        ss = F.linear(F.silu(temb_cond), g(prefix + "mlp.1.weight"), g(prefix + "mlp.1.bias"))       # (B, 2*cout)
+    ss = None if ss_of is None else ss_of.get(prefix)                                                  # (B, 2*cout)
     h = A.GroupNormSiLU.apply(h, g(prefix + "block1.norm.weight"), g(prefix + "block1.norm.bias"), ss, None, c.batch, True)
     h = A.conv_cl(h, g(prefix + "block2.proj.weight"), g(prefix + "block2.proj.bias"), n_img=n_img, hi=res, wi=res)
     if unet.has(prefix + "res_conv.weight"):
@@ -126,6 +146,7 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
         tc = torch.cat((temb, cond), dim=-1)
     else:
         tc = temb
+    tc = _block_scale_shifts(unet, tc.contiguous())
 
     # --- relative position bias / rotary tables (:545, :395)
     c.bias = rel_pos_bias_table(g("time_rel_pos_bias.relative_attention_bias.weight"), t)

@@ -489,8 +489,13 @@ int lfdm_conv2d_smalln_cl_f32(const float* x, int ldx, int cin, int n_img, int h
  *   dw[(ky*kw + kx)][ci][co] = sum over output pixels r = (n, qy, qx) of
  *        x[n, qy*stride + ky - pad_y, qx*stride + kx - pad_x][ci] * dy[r][co]      (zeros outside)
  * x: CL rows (n_img*hi*wi, cin) stride ldx; dy: CL rows (n_img*hq*wq, cout) stride lddy.
- * The tap-major result is a plain permutation of the reference (cout, cin, 1, kh, kw) layout.
- * A ConvTranspose weight gradient is the same call with the roles of x and dy exchanged (stride 2). */
+ * The tap-major result (dw_layout = 0) is a plain permutation of the reference (cout, cin, 1, kh, kw) layout;
+ * dw_layout = 1 (filters of <= 16 taps) writes that layout directly - dw[(co*dw_cin_total + dw_ci_off + ci)*kh*kw + tap],
+ * so the two halves of a convolution over cat(x0, x1) land in one tensor and the result can BE the optimizer's
+ * gradient slot (no permute copy, no gradient staging copy).  dbias != NULL also returns the bias gradient
+ * (column sums of dy, video_flow_diffusion.py:199 bias=True) from the same pass over dy.
+ * A ConvTranspose weight gradient is the same call with the roles of x and dy exchanged (stride 2):
+ * dw_layout = 1 then yields the (cin, cout, 4, 4) ConvTranspose layout.  Sums are taken in a fixed order. */
 typedef struct lfdm_wgrad_params {
   const float* x;
   int cin, ldx;
@@ -499,7 +504,11 @@ typedef struct lfdm_wgrad_params {
   int stride, kh, kw, pad_y, pad_x;
   const float* dy;
   int cout, lddy;
-  float* dw;              /* [kh*kw][cin][cout] */
+  float* dw;              /* dw_layout 0: [kh*kw][cin][cout]; 1: [cout][dw_cin_total][kh*kw] */
+  int dw_layout;          /* 0 | 1 */
+  int dw_cin_total;       /* (layout 1) input channels of the whole filter */
+  int dw_ci_off;          /* (layout 1) this call's first input channel */
+  float* dbias;           /* optional (cout): sum over rows of dy */
 } lfdm_wgrad_params;
 size_t lfdm_conv2d_wgrad_ws_bytes(const lfdm_wgrad_params* p);
 int lfdm_conv2d_wgrad_cl_f32(const lfdm_wgrad_params* p, void* ws, size_t ws_bytes, lfdm_stream_t stream);
@@ -546,6 +555,31 @@ int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, 
 size_t lfdm_linear_attention_bwd_ws_bytes(int n_frames);
 int lfdm_linear_attention_bwd_cl_f32(const float* qkv, const float* dout, float* dqkv, int n_frames,
                                      int hw, void* ws, size_t ws_bytes, lfdm_stream_t stream);
+
+/* Small-batch Linear layers that share their INPUT, forward and backward in one launch each: the conditioning path of the
+ * training step - ResnetBlock.mlp = SiLU -> Linear(cond_dim, 2*dim_out) of every block applied to the same (B, cond_dim)
+ * vector (video_flow_diffusion.py:230-233,240-245,562) and time_mlp's Linear -> GELU -> Linear (:441-447).
+ *   forward   y[j] = act(x) w[j]^T + bias[j]                        (rows, n[j])
+ *   backward  dw[j] = dy[j]^T act(x); dbias[j] = colsum(dy[j]); dx = act'(x) * sum_j dy[j] w[j]
+ * act applies to the input: 0 none, 1 SiLU, 2 GELU (erf form).  rows <= 16, k % 4 == 0, k <= 1024, n_blocks <= 32; all
+ * tensors contiguous fp32, x / w / dw / dx 16-byte aligned.  Backward: dy[j] NULL = zero gradient; dw[j] / dbias[j] / dx
+ * NULL = not wanted.  Sums in a fixed order. */
+#define LFDM_MULTI_LINEAR_MAX 32
+typedef struct lfdm_multi_linear_params {
+  int n_blocks, rows, k, act;
+  const float* x;                              /* (rows, k) */
+  const float* w[LFDM_MULTI_LINEAR_MAX];       /* (n[j], k): torch Linear.weight */
+  const float* bias[LFDM_MULTI_LINEAR_MAX];    /* (n[j]) or NULL */
+  int n[LFDM_MULTI_LINEAR_MAX];
+  float* y[LFDM_MULTI_LINEAR_MAX];             /* forward output (rows, n[j]) */
+  const float* dy[LFDM_MULTI_LINEAR_MAX];      /* backward */
+  float* dw[LFDM_MULTI_LINEAR_MAX];
+  float* dbias[LFDM_MULTI_LINEAR_MAX];
+  float* dx;                                   /* (rows, k) or NULL */
+} lfdm_multi_linear_params;
+int lfdm_multi_linear_f32(const lfdm_multi_linear_params* p, lfdm_stream_t stream);
+size_t lfdm_multi_linear_bwd_ws_bytes(const lfdm_multi_linear_params* p);
+int lfdm_multi_linear_bwd_f32(const lfdm_multi_linear_params* p, void* ws, size_t ws_bytes, lfdm_stream_t stream);
 
 /* Fused Adam over one flat parameter buffer: torch.optim.Adam(betas, eps, weight_decay) semantics (no amsgrad),
  * video_flow_diffusion_model.py:113-114,188.  grad is multiplied by grad_scale first (1/world for the

@@ -88,6 +88,49 @@ def test_flat_adam_gradient_handling(backend):
     assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in pa)
 
 
+def test_native_backward_writes_into_the_flat_gradient_slots(backend):
+    """autograd.grad_out: with FlatAdam the convolution backward writes weight / bias gradients straight into the flat gradient buffer
+    (reference layout, fused bias sums) and autograd adopts them - p.grad IS the slot before any staging; a parameter used twice in one
+    step and a backward without zero_grad accumulate correctly; without FlatAdam the same Function returns ordinary tensors."""
+    from cvpr23_lfdm_amd import autograd as A
+    from util import to_cl
+    dev = backend
+    n, h, c0, c1, co = 2, 6, 8, 4, 12
+    x0, x1 = rnd(n, c0, h, h, seed=1), rnd(n, c1, h, h, seed=2)
+
+    def make():
+        return [torch.nn.Parameter((rnd(co, c0 + c1, 1, 3, 3, seed=3) * 0.1).to(dev)), torch.nn.Parameter(rnd(co, seed=4).to(dev)),
+                torch.nn.Parameter((rnd(co, co, seed=5) * 0.1).to(dev))]
+
+    def loss_of(ps, twice):
+        w, b, wl = ps
+        y = A.conv_cl(to_cl(x0).to(dev), w, b, x1=to_cl(x1).to(dev), n_img=n, hi=h, wi=h)
+        y = A.conv_cl(y, wl, None, n_img=n, hi=h, wi=h)
+        if twice:
+            y = A.conv_cl(y, wl, None, n_img=n, hi=h, wi=h)          # the 1x1 weight used a second time in the same step
+        return (y * y).sum()
+
+    pa, pb = make(), make()
+    opt = FlatAdam(pa, lr=1e-2)
+    flat = opt.flat_grads()[0]
+    for it, twice in enumerate((False, True, False)):
+        if it < 2:
+            opt.zero_grad()
+            for p in pb:
+                p.grad = None
+        loss_of(pa, twice).backward()
+        loss_of(pb, twice).backward()
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            if it == 0 or (it == 1 and i < 2):   # adopted without a copy: the gradient already lives in its slot (the engine sums the
+                                                 # two contributions of the twice-used weight into a tensor of its own; stage_grads copies it)
+                assert p.grad.data_ptr() == p._lfdm_grad_slot.data_ptr() and flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+            sc = float(q.grad.abs().max())
+            assert_close(p.grad.cpu() / sc, q.grad.cpu() / sc, 3e-4, "gradient in the slot (iteration %d)" % it)
+        if it == 1:
+            opt.stage_grads()          # no-op copies; it == 2 then accumulates onto the slots without zero_grad
+    opt.step()
+
+
 def test_packed_weights_follow_flat_adam(backend):
     """FlatAdam updates the parameters through a raw-pointer kernel, invisible to torch's `_version`.
     The sampling executor's packed-weight cache (and with it the captured hipGraph plan) must still rebuild."""

@@ -16,12 +16,12 @@ def big(dev):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,res", [(8, 12, 3, 1, 6), (68, 72, 3, 1, 5), (132, 8, 1, 1, 4),
-                                                   (8, 8, 4, 2, 8), (4, 64, 7, 1, 8), (36, 20, 3, 1, 3)])
+                                                   (8, 8, 4, 2, 8), (4, 64, 7, 1, 8), (36, 20, 3, 1, 3), (12, 16, 3, 1, 16)])
 def test_conv_wgrad(backend, cin, cout, k, stride, res):
     dev = backend
     n = 3
     if big(dev):
-        cin, cout, res, n = {8: (64, 64), 68: (256, 128), 132: (512, 768), 4: (4, 64), 36: (36, 20)}[cin] + (16, 10)
+        cin, cout, res, n = {8: (64, 64), 68: (256, 128), 132: (512, 768), 4: (4, 64), 36: (36, 20), 12: (128, 64)}[cin] + (16, 10)
         if cin == 36:
             res, n = 3, 1                     # M = 9 rows: less than one 32-row chunk
         if k == 4:
@@ -40,6 +40,20 @@ def test_conv_wgrad(backend, cin, cout, k, stride, res):
     db = train_ops.colsum(to_cl(dy).to(dev))
     ref_db = dy.sum(dim=(0, 2, 3))
     assert_close(db.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias grad")
+    if k * k <= 16:
+        # lfdm_wgrad_params.dw_layout = 1: the reference (cout, cin_total, k, k) layout written in two input-channel halves (a convolution
+        # over cat(x0, x1)), bias gradient from the same pass - bit-identical to the tap-major result and to colsum's order-independent parts
+        c0 = (cin // 8) * 4 or cin
+        xcl = to_cl(x).to(dev)
+        out = torch.full((cout, cin, k, k), float("nan"), device=dev)
+        db2 = torch.full((cout,), float("nan"), device=dev)
+        train_ops.conv_wgrad(xcl[:, :c0], to_cl(dy).to(dev), n, res, res, hq, hq, k, k, stride=stride, pad=(pad, pad), out=out, ci_off=0, dbias=db2)
+        if c0 < cin:
+            train_ops.conv_wgrad(xcl[:, c0:], to_cl(dy).to(dev), n, res, res, hq, hq, k, k, stride=stride, pad=(pad, pad), out=out, ci_off=c0)
+        assert_close(out.cpu() / scale, w.grad / scale, TOL, "conv wgrad, reference layout")
+        assert_close(db2.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias grad from the wgrad pass")
+        if c0 == cin:
+            assert torch.equal(out.cpu(), got.contiguous()), "layout 1 must be a pure permutation of layout 0"
 
 
 @pytest.mark.parametrize("c,with_ss,silu", [(32, True, True), (64, False, True), (32, False, False), (512, True, True)])
@@ -181,3 +195,42 @@ def test_depthwise_down(backend):
     ref = F.conv2d(F.pad(x, (ka, ka, ka, ka)), w, groups=c)[:, :, ::4, ::4]
     out = ops.depthwise_down_planar(x.to(dev), w.to(dev), 4, ka, ka)
     assert_close(out.cpu(), ref, 1e-5, "antialias down")
+
+
+@pytest.mark.parametrize("rows,k,ns,act", [(8, 1024, (128, 256, 2048, 128), 1), (2, 64, (256,), 0), (3, 256, (256,), 2),
+                                            (16, 32, (8, 24, 4), 1), (8, 8, tuple([8] * 32), 2)])
+def test_multi_linear(backend, rows, k, ns, act):
+    """lfdm_multi_linear_f32 / _bwd_f32 against torch: every ResnetBlock.mlp of a forward (SiLU -> Linear on the shared cat(time_emb,
+    cond), video_flow_diffusion.py:230-233,562) and the two time_mlp layers (:441-447), incl. a missing bias, an unused output (dy = None)
+    and a weight whose gradient is not wanted."""
+    from cvpr23_lfdm_amd import autograd as A
+    dev = backend
+    x = rnd(rows, k, seed=1).requires_grad_(True)
+    ws = [(rnd(n, k, seed=10 + j) * (k ** -0.5)).requires_grad_(j != 1 or len(ns) == 1) for j, n in enumerate(ns)]
+    bs = [None if j == 2 else rnd(n, seed=50 + j).requires_grad_(True) for j, n in enumerate(ns)]
+    fa = {0: lambda v: v, 1: F.silu, 2: F.gelu}[act]
+    refs = [F.linear(fa(x), w, b) for w, b in zip(ws, bs)]
+    gs = [rnd(rows, n, seed=90 + j) for j, n in enumerate(ns)]
+    used = [j for j in range(len(ns)) if j != 3]
+    sum((refs[j] * gs[j]).sum() for j in used).backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    wd = [w.detach().to(dev).requires_grad_(w.requires_grad) for w in ws]
+    bd = [None if b is None else b.detach().to(dev).requires_grad_(True) for b in bs]
+    ys = A.multi_linear(xd, wd, bd, act=act)
+    for j, (y, r) in enumerate(zip(ys, refs)):
+        sc = float(r.detach().abs().max())
+        assert_close(y.detach().cpu() / sc, r.detach() / sc, TOL, "multi_linear y[%d]" % j)
+    sum((ys[j] * gs[j].to(dev)).sum() for j in used).backward()
+    sc = float(x.grad.abs().max())
+    assert_close(xd.grad.cpu() / sc, x.grad / sc, TOL, "multi_linear dx")
+    for j in used:
+        if ws[j].requires_grad:
+            sc = float(ws[j].grad.abs().max())
+            assert_close(wd[j].grad.cpu() / sc, ws[j].grad / sc, TOL, "multi_linear dw[%d]" % j)
+        else:
+            assert wd[j].grad is None
+        if bs[j] is not None:
+            sc = float(bs[j].grad.abs().max())
+            assert_close(bd[j].grad.cpu() / sc, bs[j].grad / sc, TOL, "multi_linear dbias[%d]" % j)
+    if len(ns) > 3 and ws[3].requires_grad:        # the unused block: zero gradients, like autograd's
+        assert float(wd[3].grad.abs().max()) == 0.0
