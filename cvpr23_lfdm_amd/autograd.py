@@ -60,6 +60,33 @@ def _conv(x0, w4_direct, cout, kh, kw, n_img, hi, wi, *, weight_wino=None, **kw_
     return ops.conv2d_cl(x0, ops.pack_conv_weight_dev(*w4_direct), cout, kh, kw, n_img, hi, wi, weight_wino=weight_wino, **kw_)
 
 
+_PACKS = {}
+
+
+def _pack_wino(weight, w4, dgrad=False, part=None):
+    """ops.pack_wino_weight(w4) with a cache over the life of the weights: the frozen VGG-19 of LFAE stage-1 training convolves with the
+    same 13 filters 8 times forward and 4 times backward per step, the region predictor runs three times per step - each use re-packed
+    (1 290 pack launches per 5 steps, 4 % of a step).  Only leaf tensors (parameters) are cached, by object identity (a weak reference:
+    an address can be re-used by another tensor); an entry is valid while neither torch (`_version`) nor a raw-pointer optimizer step
+    (params.weights_epoch) has written the tensor.  weight: the tensor the caller passed to the Function; w4: the view of it to pack."""
+    if not weight.is_leaf:
+        return ops.pack_wino_weight(w4, dgrad=dgrad)
+    import weakref
+    from .params import weights_epoch
+    key = (id(weight), dgrad, part)
+    # (a frozen tensor is in no optimizer: only torch writes - load_state_dict, .to() - can change it)
+    tag = (weight._version, weights_epoch() if weight.requires_grad else -1, w4.data_ptr(), tuple(w4.shape))
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == tag:
+        return hit[2]
+    if len(_PACKS) > 2048:
+        for k in [k for k, v in _PACKS.items() if v[0]() is None]:
+            del _PACKS[k]
+    packed = ops.pack_wino_weight(w4, dgrad=dgrad)
+    _PACKS[key] = (weakref.ref(weight), tag, packed)
+    return packed
+
+
 def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):
     """Geometry the Winograd F(2x2,3x3) schedule covers (lfdm_conv_params.weight_wino); chans = reduction-channel counts."""
     return (kh == 3 and kw == 3 and stride == 1 and tuple(pad) == (1, 1) and hi % 2 == 0 and wi % 2 == 0 and
@@ -84,7 +111,7 @@ class ConvCL(Function):
             pad = geom.get("pad", (kh // 2, kw // 2))
             ww = None
             if _wino_ok(kh, kw, stride, pad, hi, wi, x0.shape[1], 0 if x1 is None else x1.shape[1]):
-                ww = ops.pack_wino_weight(_c(w4))
+                ww = _pack_wino(weight, _c(w4))
             y = _conv(_c(x0.detach()), (w4, 0), w4.shape[0], kh, kw, n_img, hi, wi,
                       src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
                       weight_wino=ww)
@@ -136,7 +163,7 @@ class ConvCL(Function):
                     continue
                 ws = w4[:, lo:hi_c]
                 if stride == 1:
-                    ww = ops.pack_wino_weight(ws, dgrad=True) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
+                    ww = _pack_wino(weight, ws, dgrad=True, part=(lo, hi_c)) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
                     g = _conv(dy, (ws, 1), hi_c - lo, kh, kw, n_img, hq, wq,
                               pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)                # filter (cin, cout, kh, kw)
                 else:

@@ -1,0 +1,507 @@
+"""LFAE stage-1 training: the reconstruction step of the latent-flow auto-encoder (reference LFAE/train.py:35-173 and
+LFAE/modules/model.py:141-217 `ReconstructionModel`) - region predictor, background-motion predictor and generator trained
+jointly on (source, driving) frame pairs with the pyramid perceptual loss (VGG-19 features, model.py:19-82) and the two
+equivariance losses (random affine + thin-plate-spline transform, model.py:85-136).
+
+How it runs here.  The step is >95 % convolution FLOPs (generator at full resolution, VGG-19 on four pyramid levels, three
+hourglasses): every Conv2d - forward, data gradient, weight gradient and bias gradient - is the library's native kernel family
+through `autograd.ConvCL` (channels-last rows, Winograd where the channel counts allow, gradients written into the optimizer's flat
+slots), the same `torch.autograd.Function`s the DM training step uses.  What connects the convolutions stays on tensors in
+channels-last memory format, so entering / leaving a convolution is a view: BatchNorm with batch statistics (per rank, as the
+reference's nn.DataParallel replicas compute them with `use_sync_bn: False`), ReLU, 2x2 pooling, nearest up-sampling, softmax
+heat-maps, `grid_sample` warps and the 2x2 SVD (on the host, exactly as region_predictor.py:16-26 does it).  Parameters live in the
+same `ParamTree`s as on the sampling path (reference state-dict keys: a reference checkpoint loads, a checkpoint written here loads
+into the reference).  The optimizer is the flat fused Adam (betas (0.5, 0.999), LFAE/train.py:38-40) with the DM path's bucketed
+gradient all-reduce for one-process-per-GPU data parallelism.
+
+Only the pca_based / affine-background / RGB configuration the LFDM yaml files use is covered (like lfae_predictors.py).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import autograd as A
+from . import params as P
+from .params import ParamTree
+
+
+# ------------------------------------------------------------------------------------------------ layers
+def _cl(x):
+    """NCHW tensor in channels-last memory (a no-op when it already is)."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def conv2d(x, weight, bias, padding):
+    """nn.Conv2d (stride 1, square kernel) through the native kernels.  x: (N, C, H, W); returns a channels-last (N, O, H', W').
+    Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded - the padded
+    filter slices receive zero gradient through autograd's own pad / slice backward."""
+    n, c, h, w = x.shape
+    cout, k = weight.shape[0], weight.shape[-1]
+    rows = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+    cp, op = -c % 4, -cout % 4
+    if cp:
+        rows = F.pad(rows, (0, cp))
+    if cp or op:
+        weight = F.pad(weight, (0, 0, 0, 0, 0, cp, 0, op))
+        bias = F.pad(bias, (0, op)) if bias is not None else None
+    y = A.conv_cl(rows, weight, bias, n_img=n, hi=h, wi=w, pad=(padding, padding))
+    ho, wo = h + 2 * padding - k + 1, w + 2 * padding - k + 1
+    y = y.view(n, ho, wo, cout + op).permute(0, 3, 1, 2)
+    return y[:, :cout] if op else y
+
+
+class _Net:
+    """Forward helpers over one ParamTree (reference state-dict keys); `training` selects batch statistics (and updates the running
+    ones, momentum 0.1 like nn.BatchNorm2d) or the stored statistics."""
+
+    def __init__(self, tree, training=True):
+        self.t, self.training = tree, training
+
+    def conv(self, x, prefix, padding):
+        return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding)
+
+    def bn(self, x, prefix):
+        g = self.t.get
+        if self.training:
+            nbt = g(prefix + "num_batches_tracked")
+            nbt += 1
+        return F.batch_norm(x, g(prefix + "running_mean"), g(prefix + "running_var"), g(prefix + "weight"), g(prefix + "bias"),
+                            self.training, 0.1, 1e-5)
+
+    def conv_bn_relu(self, x, prefix, padding=1):          # SameBlock2d / the body of Down- and UpBlock2d (util.py:95-150)
+        return F.relu(self.bn(self.conv(x, prefix + "conv.", padding), prefix + "norm."))
+
+    def down_block(self, x, prefix):                      # DownBlock2d: conv -> BN -> ReLU -> AvgPool 2x2
+        return F.avg_pool2d(self.conv_bn_relu(x, prefix), 2)
+
+    def up_block(self, x, prefix):                        # UpBlock2d: nearest x2 -> conv -> BN -> ReLU
+        return self.conv_bn_relu(F.interpolate(x, scale_factor=2), prefix)
+
+    def res_block(self, x, prefix):                       # ResBlock2d (util.py:70-92): pre-activation, identity skip
+        out = self.conv(F.relu(self.bn(x, prefix + "norm1.")), prefix + "conv1.", 1)
+        out = self.conv(F.relu(self.bn(out, prefix + "norm2.")), prefix + "conv2.", 1)
+        return out + x
+
+    def hourglass(self, x, prefix, num_blocks, decoder=True):
+        """Encoder / Decoder of util.py:153-214.  decoder=False returns the encoder's feature list."""
+        outs = [x]
+        for i in range(num_blocks):
+            outs.append(self.down_block(outs[-1], "%sencoder.down_blocks.%d." % (prefix, i)))
+        if not decoder:
+            return outs
+        out = outs.pop()
+        for j in range(num_blocks):
+            out = self.up_block(out, "%sdecoder.up_blocks.%d." % (prefix, j))
+            out = torch.cat([out, outs.pop()], dim=1)
+        return out
+
+
+def make_coordinate_grid(h, w, like):
+    """util.py:51-67: (h, w, 2) grid of (x, y) in [-1, 1]."""
+    x = 2 * (torch.arange(w, dtype=like.dtype, device=like.device) / (w - 1)) - 1
+    y = 2 * (torch.arange(h, dtype=like.dtype, device=like.device) / (h - 1)) - 1
+    return torch.stack((x.view(1, -1).expand(h, w), y.view(-1, 1).expand(h, w)), dim=2)
+
+
+def antialias_down(x, weight, scale):
+    """AntiAliasInterpolation2d (util.py:217-264): Gaussian blur (depthwise) then every 1/scale-th pixel."""
+    if scale == 1:
+        return x
+    ks = weight.shape[-1]
+    ka = ks // 2
+    kb = ka - 1 if ks % 2 == 0 else ka
+    out = F.conv2d(F.pad(x, (ka, kb, ka, kb)), weight=weight, groups=x.shape[1])
+    s = int(1 / scale)
+    return out[:, :, ::s, ::s]
+
+
+# The reference writes its per-pixel 2x2 / 3x3 algebra as torch.matmul over (B, K, h, w, 2, 2) operands: hundreds of thousands of
+# 2x2 products per call, which a GEMM library runs as a batched GEMM at ~1 ms each (39 % of a step when this file did the same,
+# profiles/r04_x_lfae_*).  The same sums written out as broadcast multiply-adds are a handful of element-wise launches.
+def _mat2_vec(m, v):
+    """(..., 2, 2) @ (..., 2) with broadcasting."""
+    return torch.stack((m[..., 0, 0] * v[..., 0] + m[..., 0, 1] * v[..., 1], m[..., 1, 0] * v[..., 0] + m[..., 1, 1] * v[..., 1]), dim=-1)
+
+
+def region2gaussian(center, covar, h, w):
+    """util.py:22-48 with a matrix covariance: exp(-0.5 d^T covar^-1 d) on the coordinate grid."""
+    grid = make_coordinate_grid(h, w, center).view(1, 1, h, w, 2)
+    d = grid - center.view(*center.shape[:2], 1, 1, 2)
+    inv = torch.inverse(covar).view(*covar.shape[:2], 1, 1, 2, 2)
+    dx, dy = d[..., 0], d[..., 1]
+    under = (dx * inv[..., 0, 0] + dy * inv[..., 1, 0]) * dx + (dx * inv[..., 0, 1] + dy * inv[..., 1, 1]) * dy
+    return torch.exp(-0.5 * under)
+
+
+# ------------------------------------------------------------------------------------------------ the three networks
+def region_predictor_forward(tree, x, cfg, training=True):
+    """RegionPredictor.forward, pca_based (region_predictor.py:52-117) -> shift, covar, affine, heatmap, u, d."""
+    net = _Net(tree, training)
+    x = antialias_down(x, tree.get("down.weight"), cfg["scale_factor"]) if cfg["scale_factor"] != 1 else x
+    fmap = net.hourglass(_cl(x), "predictor.", cfg["num_blocks"])
+    pred = net.conv(fmap, "regions.", cfg.get("pad", 3))
+    shp = pred.shape
+    region = F.softmax(pred.reshape(shp[0], shp[1], -1) / cfg["temperature"], dim=2).view(*shp)
+    grid = make_coordinate_grid(shp[2], shp[3], region).view(1, 1, shp[2], shp[3], 2)
+    r = region.unsqueeze(-1)
+    mean = (r * grid).sum(dim=(2, 3))
+    mean_sub = grid - mean.unsqueeze(-2).unsqueeze(-2)
+    covar = ((mean_sub.unsqueeze(-1) * mean_sub.unsqueeze(-2)) * r.unsqueeze(-1)).sum(dim=(2, 3))       # outer product per pixel
+    u, s, _ = torch.svd(covar.view(-1, 2, 2).cpu())                     # on the host, like region_predictor.py:21-25
+    u, s = u.to(covar.device), s.to(covar.device)
+    d = torch.diag_embed(s ** 0.5)
+    return {"shift": mean, "covar": covar, "heatmap": region, "affine": torch.matmul(u, d).view(*covar.shape), "u": u, "d": d}
+
+
+def bg_predictor_forward(tree, source, driving, cfg, training=True):
+    """BGMotionPredictor.forward, bg_type 'affine' (bg_motion_predictor.py:42-57) -> (B, 3, 3)."""
+    net = _Net(tree, training)
+    feats = net.hourglass(_cl(torch.cat([source, driving], dim=1)), "", cfg["num_blocks"], decoder=False)
+    pred = F.linear(feats[-1].mean(dim=(2, 3)), tree.get("fc.weight"), tree.get("fc.bias"))
+    out = torch.eye(3, dtype=pred.dtype, device=pred.device).unsqueeze(0).repeat(source.shape[0], 1, 1)
+    out[:, :2, :] = pred.view(-1, 2, 3)
+    return out
+
+
+def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, num_regions, revert_axis_swap=True, training=True):
+    """PixelwiseFlowPredictor.forward (pixelwise_flow_predictor.py:48-137; covariance heat-maps, deformed sources, occlusion)."""
+    net = _Net(tree, training)
+    p = "pixelwise_flow_predictor."
+    img = antialias_down(source_image, tree.get(p + "down.weight"), cfg["scale_factor"]) if cfg["scale_factor"] != 1 else source_image
+    bs, _, h, w = img.shape
+    k = num_regions
+    heat = region2gaussian(driving["shift"], driving["covar"], h, w) - region2gaussian(source["shift"], source["covar"], h, w)
+    heat = torch.cat([heat.new_zeros(bs, 1, h, w), heat], dim=1).unsqueeze(2)
+    ident = make_coordinate_grid(h, w, heat).view(1, 1, h, w, 2)
+    cg = ident - driving["shift"].view(bs, k, 1, 1, 2)
+    affine = torch.matmul(source["affine"], torch.inverse(driving["affine"]))
+    if revert_axis_swap:
+        affine = affine * torch.sign(affine[:, :, 0:1, 0:1])
+    cg = _mat2_vec(affine.unsqueeze(-3).unsqueeze(-3), cg)
+    d2s = cg + source["shift"].view(bs, k, 1, 1, 2)
+    bg = ident.repeat(bs, 1, 1, 1, 1)
+    if bg_params is not None:      # homogeneous 3x3 transform of the identity grid
+        m = bg_params.view(bs, 1, 1, 1, 3, 3)
+        gx, gy = bg[..., 0], bg[..., 1]
+        hom = [m[..., i, 0] * gx + m[..., i, 1] * gy + m[..., i, 2] for i in range(3)]
+        bg = torch.stack((hom[0] / hom[2], hom[1] / hom[2]), dim=-1)
+    sparse = torch.cat([bg, d2s], dim=1)
+    rep = img.unsqueeze(1).unsqueeze(1).repeat(1, k + 1, 1, 1, 1, 1).view(bs * (k + 1), -1, h, w)
+    deformed = F.grid_sample(rep, sparse.view(bs * (k + 1), h, w, -1), align_corners=False).view(bs, k + 1, -1, h, w)
+    inp = torch.cat([heat, deformed], dim=2).view(bs, -1, h, w)
+    pred = net.hourglass(_cl(inp), p + "hourglass.", cfg["num_blocks"])
+    mask = F.softmax(net.conv(pred, p + "mask.", 3), dim=1).unsqueeze(2)
+    out = {"optical_flow": (sparse.permute(0, 1, 4, 2, 3) * mask).sum(dim=1).permute(0, 2, 3, 1)}
+    if tree.has(p + "occlusion.weight"):
+        out["occlusion_map"] = torch.sigmoid(net.conv(pred, p + "occlusion.", 3))
+    return out
+
+
+def _deform(inp, flow):
+    """Generator.deform_input (generator.py:59-67): the flow is resized bilinearly to the feature map, then grid_sample."""
+    h, w = inp.shape[2:]
+    if flow.shape[1] != h or flow.shape[2] != w:
+        flow = F.interpolate(flow.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    return F.grid_sample(inp, flow, align_corners=False)
+
+
+def _apply_optical(prev, skip, motion):
+    """Generator.apply_optical (generator.py:69-88): warp the skip, blend with the decoder state through the occlusion map."""
+    skip = _deform(skip, motion["optical_flow"])
+    occ = motion.get("occlusion_map")
+    if occ is not None:
+        if occ.shape[2:] != skip.shape[2:]:
+            occ = F.interpolate(occ, size=skip.shape[2:], mode="bilinear", align_corners=False)
+        skip = skip * occ + prev * (1 - occ) if prev is not None else skip * occ
+    return skip
+
+
+def generator_forward(tree, source_image, driving, source, bg_params, cfg, num_regions, revert_axis_swap=True, training=True):
+    """Generator.forward (generator.py:90-128) -> prediction, deformed, optical_flow, occlusion_map, bottle_neck_feat."""
+    net = _Net(tree, training)
+    nd, use_skips = cfg["num_down_blocks"], cfg.get("skips", False)
+    out = net.conv_bn_relu(_cl(source_image), "first.", 3)
+    skips = [out]
+    for i in range(nd):
+        out = net.down_block(out, "down_blocks.%d." % i)
+        skips.append(out)
+    res = {"bottle_neck_feat": out}
+    motion = pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg["pixelwise_flow_predictor_params"], num_regions,
+                                    revert_axis_swap, training)
+    res["deformed"] = _deform(source_image, motion["optical_flow"])
+    res.update(motion)
+    out = _apply_optical(None, out, motion)
+    for i in range(cfg["num_bottleneck_blocks"]):
+        out = net.res_block(_cl(out), "bottleneck.r%d." % i)
+    for i in range(nd):
+        if use_skips:
+            out = _apply_optical(out, skips[-(i + 1)], motion)
+        out = net.up_block(_cl(out), "up_blocks.%d." % i)
+    if use_skips:
+        out = _apply_optical(out, skips[0], motion)
+    out = torch.sigmoid(net.conv(_cl(out), "final.", 3))
+    if use_skips:
+        out = _apply_optical(out, source_image, motion)
+    res["prediction"] = out
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ losses
+class Vgg19(ParamTree):
+    """The perceptual-loss network (model.py:19-59): frozen VGG-19 feature slices.  There is no network for the ImageNet weights:
+    `load_state_dict(params.vgg19_from_torchvision(torchvision_vgg19.state_dict()), strict=False)` takes a downloaded checkpoint."""
+
+    def __init__(self):
+        super().__init__()
+        P.build_tree(self, P.vgg19_spec())
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def features(self, x):
+        net = _Net(self, False)
+        x = _cl((x - self.get("mean")) / self.get("std"))
+        outs, cur = [], 1
+        for sl, idx, _, _ in P.VGG19_CONVS:
+            if sl != cur:
+                outs.append(x)
+                cur = sl
+            if idx in P.VGG19_POOLS_BEFORE:
+                x = F.max_pool2d(x, 2)
+            x = F.relu(net.conv(x, "slice%d.%d." % (sl, idx), 1))
+        outs.append(x)
+        return outs
+
+
+class Transform:
+    """Random affine + thin-plate-spline warp for the equivariance losses (model.py:85-136).  `noise` = (theta noise (B, 2, 3), tps
+    control parameters (B, 1, points^2)) replays recorded draws; by default they are drawn like the reference draws them."""
+
+    def __init__(self, bs, sigma_affine, sigma_tps=None, points_tps=None, noise=None, device="cpu"):
+        if noise is None:
+            theta_noise = torch.normal(mean=0, std=sigma_affine * torch.ones([bs, 2, 3]))
+            tps_noise = torch.normal(mean=0, std=sigma_tps * torch.ones([bs, 1, points_tps ** 2])) if sigma_tps is not None else None
+        else:
+            theta_noise, tps_noise = noise
+        self.theta = (theta_noise + torch.eye(2, 3).view(1, 2, 3)).to(device)
+        self.bs = bs
+        self.tps = tps_noise is not None
+        if self.tps:
+            self.control_points = make_coordinate_grid(points_tps, points_tps, self.theta).view(1, points_tps ** 2, 2)
+            self.control_params = tps_noise.to(device)
+
+    def warp_coordinates(self, coordinates):
+        theta = self.theta.unsqueeze(1)
+        out = _mat2_vec(theta[:, :, :, :2], coordinates) + theta[:, :, :, 2]
+        if self.tps:
+            dist = torch.abs(coordinates.view(coordinates.shape[0], -1, 1, 2) - self.control_points.view(1, 1, -1, 2)).sum(-1)
+            res = (dist ** 2) * torch.log(dist + 1e-6) * self.control_params
+            out = out + res.sum(dim=2).view(self.bs, coordinates.shape[1], 1)
+        return out
+
+    def transform_frame(self, frame):
+        h, w = frame.shape[2:]
+        grid = make_coordinate_grid(h, w, frame).view(1, h * w, 2)
+        grid = self.warp_coordinates(grid).view(self.bs, h, w, 2)
+        return F.grid_sample(frame, grid, padding_mode="reflection", align_corners=False)
+
+    def jacobian(self, coordinates):
+        new = self.warp_coordinates(coordinates)
+        gx = torch.autograd.grad(new[..., 0].sum(), coordinates, create_graph=True)
+        gy = torch.autograd.grad(new[..., 1].sum(), coordinates, create_graph=True)
+        return torch.cat([gx[0].unsqueeze(-2), gy[0].unsqueeze(-2)], dim=-2)
+
+
+class ReconstructionModel:
+    """model.py:141-217: one forward of the three networks on a (source, driving) batch and the loss terms.  `generator`,
+    `region_predictor`, `bg_predictor` are the package's ParamTrees (cvpr23_lfdm_amd.Generator / RegionPredictor / BGMotionPredictor or
+    anything with the reference state-dict keys); model_params / train_params follow config/*.yaml."""
+
+    def __init__(self, region_predictor, bg_predictor, generator, model_params, train_params, vgg=None):
+        self.region_predictor, self.bg_predictor, self.generator = region_predictor, bg_predictor, generator
+        self.mp, self.tp = model_params, train_params
+        self.scales = list(train_params["scales"])
+        self.loss_weights = train_params["loss_weights"]
+        nc = model_params["num_channels"]
+        self.pyramid_kernels = {s: (P.antialias_kernel(nc, s) if s != 1 else None) for s in self.scales}
+        self.vgg = vgg if vgg is not None else (Vgg19() if sum(self.loss_weights["perceptual"]) != 0 else None)
+        self.training = True
+
+    def to(self, device):
+        for k, v in self.pyramid_kernels.items():
+            self.pyramid_kernels[k] = None if v is None else v.to(device)
+        if self.vgg is not None:
+            self.vgg.to(device)
+        return self
+
+    def _regions(self, x):
+        return region_predictor_forward(self.region_predictor, x, self.mp["region_predictor_params"], self.training)
+
+    def pyramid(self, x):
+        return {s: (x if k is None else antialias_down(x, k, s)) for s, k in self.pyramid_kernels.items()}
+
+    def forward(self, x, transform_noise=None):
+        src, drv = x["source"], x["driving"]
+        mp, lw = self.mp, self.loss_weights
+        source_rp = self._regions(src)
+        driving_rp = self._regions(drv)
+        bg = bg_predictor_forward(self.bg_predictor, src, drv, mp["bg_predictor_params"], self.training)
+        gen = generator_forward(self.generator, src, driving_rp, source_rp, bg, mp["generator_params"], mp["num_regions"],
+                                mp.get("revert_axis_swap", True), self.training)
+        gen.update({"source_region_params": source_rp, "driving_region_params": driving_rp})
+        losses = {}
+        if sum(lw["perceptual"]) != 0:
+            pyr_real, pyr_gen = self.pyramid(drv), self.pyramid(gen["prediction"])
+            total = 0
+            for s in self.scales:
+                x_vgg = self.vgg.features(pyr_gen[s])
+                with torch.no_grad():
+                    y_vgg = self.vgg.features(pyr_real[s])
+                for i, wgt in enumerate(lw["perceptual"]):
+                    total = total + wgt * torch.abs(x_vgg[i] - y_vgg[i]).mean()
+            losses["perceptual"] = total
+        if lw["equivariance_shift"] + lw["equivariance_affine"] != 0:
+            tr = Transform(drv.shape[0], noise=transform_noise, device=drv.device, **self.tp["transform_params"])
+            frame = tr.transform_frame(drv)
+            trp = self._regions(frame)
+            gen["transformed_frame"], gen["transformed_region_params"] = frame, trp
+            if lw["equivariance_shift"] != 0:
+                losses["equivariance_shift"] = lw["equivariance_shift"] * torch.abs(driving_rp["shift"] - tr.warp_coordinates(trp["shift"])).mean()
+            if lw["equivariance_affine"] != 0:
+                value = torch.matmul(torch.inverse(driving_rp["affine"]), torch.matmul(tr.jacobian(trp["shift"]), trp["affine"]))
+                if mp.get("revert_axis_swap", True):
+                    value = value * torch.sign(value[:, :, 0:1, 0:1])
+                eye = torch.eye(2, dtype=value.dtype, device=value.device).view(1, 1, 2, 2)
+                losses["equivariance_affine"] = lw["equivariance_affine"] * torch.abs(eye - value).mean()
+        return losses, gen
+
+    __call__ = forward
+
+
+class LFAETrainer:
+    """The loop body of LFAE/train.py:96-104 - zero_grad, forward, sum of the loss terms, backward, Adam(betas=(0.5, 0.999)) - on
+    the flat fused optimizer, with the epoch-milestone learning-rate schedule (train.py:59, MultiStepLR gamma 0.1) and checkpoints in
+    the reference's format (train.py:136-160).  One process per GPU: `enable_data_parallel()` all-reduces the gradients (mean over
+    ranks = what nn.DataParallel's replica mean does, train.py:99-100) overlapped with backward; BatchNorm statistics stay per rank."""
+
+    def __init__(self, generator, region_predictor, bg_predictor, model_params, train_params, vgg=None):
+        from .optim import FlatAdam as Adam
+        self.generator, self.region_predictor, self.bg_predictor = generator, region_predictor, bg_predictor
+        self.model = ReconstructionModel(region_predictor, bg_predictor, generator, model_params, train_params, vgg=vgg)
+        self.train_params = train_params
+        params = [p for net in (generator, region_predictor, bg_predictor) for p in net.parameters() if p.requires_grad]
+        self.optimizer = Adam(params, lr=train_params["lr"], betas=(0.5, 0.999))
+        self.milestones = list(train_params.get("epoch_milestones", []))
+        self.base_lr = train_params["lr"]
+        self.epoch, self.examples = 0, 0
+        self._dp = None
+
+    def to(self, device):
+        for net in (self.generator, self.region_predictor, self.bg_predictor):
+            net.to(device)
+        self.model.to(device)
+        return self
+
+    def enable_data_parallel(self, bucket_bytes=64 << 20):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .optim import GradAllReduce
+            self._dp = GradAllReduce(self.optimizer, bucket_bytes=bucket_bytes)
+            self._dp.sync_replicas()
+        return self
+
+    def step(self, x, transform_noise=None):
+        """x: {'source': (B, 3, H, W), 'driving': (B, 3, H, W)} in [0, 1].  -> (loss terms (detached), generated)."""
+        self.optimizer.zero_grad()
+        if self._dp is not None:
+            self._dp.prepare()
+        losses, generated = self.model(x, transform_noise=transform_noise)
+        loss = sum(v.mean() for v in losses.values())
+        loss.backward()
+        if self._dp is not None:
+            self._dp.finish()
+        self.optimizer.step()
+        self.examples += x["source"].shape[0]
+        out = {k: v.detach() for k, v in losses.items()}
+        out["total"] = loss.detach()
+        return out, generated
+
+    def end_epoch(self):
+        """scheduler.step() of train.py:167: lr = base * 0.1 ** (milestones passed)."""
+        self.epoch += 1
+        lr = self.base_lr * (0.1 ** sum(1 for m in self.milestones if self.epoch >= m))
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+        return lr
+
+    def state_dict(self):
+        return {"example": self.examples, "epoch": self.epoch, "generator": self.generator.state_dict(),
+                "bg_predictor": self.bg_predictor.state_dict(), "region_predictor": self.region_predictor.state_dict(),
+                "optimizer": self.optimizer.state_dict()}
+
+    def load_state_dict(self, ckpt, set_start=True):
+        self.generator.load_state_dict(ckpt["generator"])
+        self.region_predictor.load_state_dict(ckpt["region_predictor"])
+        self.bg_predictor.load_state_dict(ckpt["bg_predictor"])
+        if "optimizer" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        if set_start:
+            self.examples, self.epoch = int(ckpt.get("example", 0)), int(ckpt.get("epoch", 0))
+            self.epoch -= 1
+            self.end_epoch()
+
+
+# ------------------------------------------------------------------------------------------------ data
+class FramePairs(torch.utils.data.Dataset):
+    """Training items of the reference's FramesDataset (LFAE/mug_dataset.py:60-140, is_train=True): two random frames of one video as
+    {'source', 'driving'} (3, H, W) float32 in [0, 1], with the yaml's augmentation_params (horizontal flip, time flip = the two frames
+    exchanged, one colour jitter for the pair).  `videos`: a list of frame-file lists, or a directory that is walked for folders of
+    *.jpg|png frames (any depth: MUG's <subject>/<expression>/<take>, MHAD's / NATOPS' flat folders)."""
+
+    def __init__(self, videos, frame_shape=128, horizontal_flip=True, time_flip=True, jitter=None, seed=None):
+        import os
+        if isinstance(videos, str):
+            found = []
+            for root, _, files in sorted(os.walk(videos)):
+                frames = sorted(f for f in files if f.lower().endswith(("jpg", "jpeg", "png")))
+                if len(frames) >= 2:
+                    found.append([os.path.join(root, f) for f in frames])
+            if not found:
+                raise FileNotFoundError("no folders with >= 2 *.jpg|png frames under %r" % (videos,))
+            videos = found
+        self.videos, self.frame_shape = videos, frame_shape
+        self.horizontal_flip, self.time_flip, self.jitter = horizontal_flip, time_flip, jitter
+        import numpy as np
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return len(self.videos)
+
+    def __getitem__(self, index):
+        import numpy as np
+        from .data import _rgb, color_jitter
+        from .io_compat import INTER_AREA, imread, resize
+        paths = self.videos[index]
+        i, j = np.sort(self.rng.choice(len(paths), size=2, replace=False))
+        frames = [_rgb(imread(paths[i])), _rgb(imread(paths[j]))]
+        if self.jitter:
+            frames = color_jitter(frames, bright=self.jitter.get("brightness", 0.1), contrast=self.jitter.get("contrast", 0.1),
+                                  sat=self.jitter.get("saturation", 0.1), hue=self.jitter.get("hue", 0.1))
+        frames = [resize(np.asarray(f, np.float32), self.frame_shape, interpolation=INTER_AREA) / 255.0 for f in frames]
+        if self.horizontal_flip and self.rng.random() < 0.5:
+            frames = [f[:, ::-1] for f in frames]
+        if self.time_flip and self.rng.random() < 0.5:
+            frames = frames[::-1]
+        src, drv = (torch.from_numpy(np.ascontiguousarray(np.transpose(f, (2, 0, 1)), dtype=np.float32)) for f in frames)
+        return {"source": src, "driving": drv, "frame": [paths[i], paths[j]]}
+
+
+def build_from_config(config):
+    """(generator, region_predictor, bg_predictor) ParamTrees for a config/*.yaml dict (`model_params`), as LFAE/run_mug.py:96-109."""
+    from .flow_diffusion import BGMotionPredictor, RegionPredictor
+    from .generator import Generator
+    mp = config["model_params"]
+    gen = Generator(num_regions=mp["num_regions"], num_channels=mp["num_channels"], revert_axis_swap=mp.get("revert_axis_swap", True),
+                    **mp["generator_params"])
+    reg = RegionPredictor(num_regions=mp["num_regions"], num_channels=mp["num_channels"], estimate_affine=mp.get("estimate_affine", True),
+                          **mp["region_predictor_params"])
+    bgp = BGMotionPredictor(num_channels=mp["num_channels"], **mp["bg_predictor_params"])
+    return gen, reg, bgp

@@ -299,3 +299,44 @@ def bg_predictor_spec(num_channels=3, block_expansion=32, max_features=1024, num
     co = min(max_features, block_expansion * (2 ** num_blocks))
     spec += [("fc.weight", (6, co), ("zeros",), False), ("fc.bias", (6,), ("zeros",), False)]
     return spec
+
+
+VGG19_CONVS = ((1, 0, 3, 64), (2, 2, 64, 64), (2, 5, 64, 128), (3, 7, 128, 128), (3, 10, 128, 256), (4, 12, 256, 256), (4, 14, 256, 256),
+               (4, 16, 256, 256), (4, 19, 256, 512), (5, 21, 512, 512), (5, 23, 512, 512), (5, 25, 512, 512), (5, 28, 512, 512))
+VGG19_POOLS_BEFORE = (5, 10, 19, 28)       # torchvision vgg19.features: a 2x2 max-pool sits in front of these convolutions
+
+
+def vgg19_spec():
+    """State-dict layout of the perceptual-loss network of LFAE stage-1 training (LFAE/modules/model.py:19-59): the first 30 layers of
+    torchvision's vgg19.features split into slice1..slice5, every layer keeping its torchvision index, plus the ImageNet mean / std
+    held as frozen parameters.  (slice, index, c_in, c_out) per convolution in VGG19_CONVS."""
+    spec = []
+    for sl, idx, ci, co in VGG19_CONVS:
+        spec += _conv_entries("slice%d.%d." % (sl, idx), co, ci, 3, 3)
+    spec += [("mean", (1, 3, 1, 1), ("const", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)), False),
+             ("std", (1, 3, 1, 1), ("const", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)), False)]
+    return spec
+
+
+def vgg19_from_torchvision(state_dict):
+    """torchvision `vgg19().state_dict()` (or its `.features` one) -> the keys of vgg19_spec: features.N.* -> sliceK.N.*"""
+    slice_of = {idx: sl for sl, idx, _, _ in VGG19_CONVS}
+    out = {}
+    for k, v in state_dict.items():
+        parts = k.split(".")
+        if parts[0] == "features":
+            parts = parts[1:]
+        if len(parts) == 2 and parts[0].isdigit() and int(parts[0]) in slice_of:
+            out["slice%d.%s.%s" % (slice_of[int(parts[0])], parts[0], parts[1])] = v
+    return out
+
+
+def synthetic_vgg19_state(seed=1919, gain=2.4):
+    """Deterministic stand-in for the ImageNet VGG-19 weights (no network): synthetic_state_dict scaled by `gain` so that the feature
+    magnitudes stay O(1) through the 13 convolutions (uniform +-1/sqrt(fan_in) alone shrinks them ~6x per layer and the deep slices
+    would not contribute to the perceptual loss)."""
+    sd = synthetic_state_dict(vgg19_spec(), seed)
+    for k in sd:
+        if k.endswith(".weight"):
+            sd[k] = sd[k] * gain
+    return sd

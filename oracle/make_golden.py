@@ -271,6 +271,68 @@ def c5_case(name, b=1, t=40, s=64, hw=256, steps=10, stride=2):
          out_stats=st, out_probes=pr)
 
 
+def lfae_train_case(name, kind):
+    """One LFAE stage-1 training step of the reference: ReconstructionModel.forward (LFAE/modules/model.py:162-217) on the unmodified
+    Generator / RegionPredictor / BGMotionPredictor in train() mode (BatchNorm batch statistics), sum of the loss terms, backward,
+    Adam(lr, betas=(0.5, 0.999)).step() as LFAE/train.py:38-40,96-104 does.  Synthetic checkpoints (tests/synth.lfae_states), the
+    VGG-19 of the perceptual loss = oracle/ref_shims/torchvision (torchvision's architecture, synthetic weights: no network), the two
+    torch.normal draws of the equivariance Transform replaced by recorded tensors."""
+    import importlib
+    model_mod = importlib.import_module("LFAE.modules.model")
+    rp_mod = importlib.import_module("LFAE.modules.region_predictor")
+    bg_mod = importlib.import_module("LFAE.modules.bg_motion_predictor")
+    mp, tp, hw, b = synth.lfae_train_setup(kind)
+    gen = ref.generator.Generator(num_regions=mp["num_regions"], num_channels=mp["num_channels"], revert_axis_swap=mp["revert_axis_swap"],
+                                  **mp["generator_params"])
+    reg = rp_mod.RegionPredictor(num_regions=mp["num_regions"], num_channels=mp["num_channels"], estimate_affine=mp["estimate_affine"],
+                                 **mp["region_predictor_params"])
+    bgp = bg_mod.BGMotionPredictor(num_channels=mp["num_channels"], **mp["bg_predictor_params"])
+    gsd, rsd, bsd = synth.lfae_states(mp)
+    gen.load_state_dict(gsd)
+    reg.load_state_dict(rsd)
+    bgp.load_state_dict(bsd)
+    for net in (gen, reg, bgp):
+        net.train()
+    model = model_mod.ReconstructionModel(reg, bgp, gen, tp)
+    opt = torch.optim.Adam(list(gen.parameters()) + list(reg.parameters()) + list(bgp.parameters()), lr=tp["lr"], betas=(0.5, 0.999))
+    src, drv, theta, tps = synth.lfae_train_inputs(b, hw, tp)
+    draws = [theta, tps]
+    normal = torch.normal
+    torch.normal = lambda *a, **k: draws.pop(0).clone()
+    try:
+        opt.zero_grad()
+        losses, generated = model({"source": src, "driving": drv})
+        vals = [v.mean() for v in losses.values()]
+        loss = sum(vals)
+        loss.backward()
+    finally:
+        torch.normal = normal
+    assert not draws
+    rng = np.random.Generator(np.random.PCG64(78))
+    names, gnorm, gprobe, small = [], [], [], {}
+    nets = (("generator", gen), ("region_predictor", reg), ("bg_predictor", bgp))
+    for nn_, net in nets:
+        for k, p_ in net.named_parameters():
+            names.append(nn_ + "/" + k)
+            g = p_.grad.detach().double() if p_.grad is not None else torch.zeros_like(p_).double()
+            probe = torch.from_numpy(rng.standard_normal(p_.numel())).view_as(g)
+            gnorm.append(float(g.norm()))
+            gprobe.append(float((g * probe).sum()))
+            if p_.numel() <= 64 and p_.grad is not None:
+                small["grad/" + nn_ + "/" + k] = p_.grad.detach().clone()
+    opt.step()
+    pnorm = [float(p_.detach().double().norm()) for _, net in nets for _, p_ in net.named_parameters()]
+    bn = {"bn/" + nn_ + "/" + k: v.detach().clone() for nn_, net in nets for k, v in net.state_dict().items()
+          if k.endswith("running_mean") and v.numel() <= 64}
+    sub = (lambda v: v.detach()) if kind == "tiny" else (lambda v: v.detach()[:, :, ::4, ::4].clone())
+    save(name, kind=np.array(kind), b=b, hw=hw, names=np.array(names), grad_norm=np.array(gnorm), grad_probe=np.array(gprobe),
+         param_norm_after=np.array(pnorm), loss_names=np.array(list(losses.keys())), losses=np.array([float(v) for v in vals]),
+         prediction=sub(generated["prediction"]), deformed=sub(generated["deformed"]), occlusion_map=generated["occlusion_map"].detach(),
+         optical_flow=generated["optical_flow"].detach(), driving_shift=generated["driving_region_params"]["shift"].detach(),
+         driving_affine=generated["driving_region_params"]["affine"].detach(), transformed_frame=sub(generated["transformed_frame"]),
+         **small, **bn)
+
+
 def op_cases():
     g = torch.Generator().manual_seed(21)
     emb = torch.randn(32, 8, generator=g)
@@ -296,6 +358,7 @@ def main():
     ap.add_argument("--variants", action="store_true", help="only the variant fixtures: static clipping, use_residual_flow (sampling and "
                     "training), stochastic null conditioning (0 < null_cond_prob < 1)")
     ap.add_argument("--focus", action="store_true", help="only the fixtures of the branches no LFDM script takes: focus_present_mask (unet_tiny_focus), Generator(skips=False)")
+    ap.add_argument("--lfae-train", choices=["tiny", "mug128", "both"], help="only the LFAE stage-1 training-step fixtures (lfae_train.py)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
     ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50", "c5b4"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
@@ -306,6 +369,10 @@ def main():
          "c5": lambda: c5_case("sample_ddim10_c5_256"),
          "c5b4": lambda: c5_case("sample_ddim50_c5_256_b4", b=4, steps=50, stride=4),      # configs[4] at its per-GPU batch (32 videos over 8 GPUs), ~35 min here
          "c5d50": lambda: c5_case("sample_ddim50_c5_256", steps=50)}[args.full]()      # the configuration's real step count (~8 min here)
+        return
+    if args.lfae_train:
+        for kind in (("tiny", "mug128") if args.lfae_train == "both" else (args.lfae_train,)):
+            lfae_train_case("lfae_train_" + kind, kind)
         return
     if args.focus:
         unet_focus_case("unet_tiny_focus")

@@ -107,3 +107,66 @@ def flow_inputs(batch, s, seed=5):
         rng.standard_normal((batch, s, s, 2)).astype(np.float32))
     occ = torch.from_numpy(rng.random((batch, 1, s, s), dtype=np.float32))
     return flow.clamp(-1.3, 1.3).contiguous(), occ
+
+
+# ---------------------------------------------------------------------------------------------- LFAE stage-1 training (lfae_train.py)
+LFAE_TRAIN_PARAMS = dict(lr=2.0e-4, epoch_milestones=[60, 90], scales=[1, 0.5, 0.25, 0.125],
+                         transform_params=dict(sigma_affine=0.05, sigma_tps=0.005, points_tps=5),
+                         loss_weights=dict(perceptual=[10, 10, 10, 10, 10], equivariance_shift=10, equivariance_affine=10))
+
+
+def lfae_train_setup(kind):
+    """(model_params, train_params, frame size, batch): 'mug128' = config/mug128.yaml as published (configs/lfae_128.yaml + its
+    train_params); 'tiny' = the same architecture family shrunk until the x86 emulator runs a step in seconds."""
+    import copy
+    import yaml
+    if kind == "mug128":
+        with open(CONFIG) as f:
+            mp = yaml.safe_load(f)["model_params"]
+        return mp, copy.deepcopy(LFAE_TRAIN_PARAMS), 128, 2
+    mp = dict(num_regions=4, num_channels=3, estimate_affine=True, revert_axis_swap=True,
+              bg_predictor_params=dict(block_expansion=8, max_features=32, num_blocks=2, bg_type="affine"),
+              region_predictor_params=dict(temperature=0.1, block_expansion=8, max_features=32, scale_factor=0.25, num_blocks=2,
+                                           pca_based=True, fast_svd=False),
+              generator_params=dict(block_expansion=16, max_features=32, num_down_blocks=2, num_bottleneck_blocks=2, skips=True,
+                                    pixelwise_flow_predictor_params=dict(block_expansion=8, max_features=32, num_blocks=2, scale_factor=0.25,
+                                                                         use_deformed_source=True, use_covar_heatmap=True,
+                                                                         estimate_occlusion_map=True)))
+    tp = copy.deepcopy(LFAE_TRAIN_PARAMS)
+    tp["scales"] = [1, 0.5]
+    return mp, tp, 32, 2
+
+
+def lfae_states(mp):
+    """Synthetic checkpoints of the three LFAE networks for a model_params block."""
+    gp, fp = mp["generator_params"], mp["generator_params"]["pixelwise_flow_predictor_params"]
+    gen = P.synthetic_state_dict(P.generator_spec(
+        num_channels=mp["num_channels"], block_expansion=gp["block_expansion"], max_features=gp["max_features"],
+        num_down_blocks=gp["num_down_blocks"], num_bottleneck_blocks=gp["num_bottleneck_blocks"], num_regions=mp["num_regions"],
+        fp_block_expansion=fp["block_expansion"], fp_max_features=fp["max_features"], fp_num_blocks=fp["num_blocks"]), 4321)
+    rp = mp["region_predictor_params"]
+    reg = P.synthetic_state_dict(P.region_predictor_spec(num_regions=mp["num_regions"], num_channels=mp["num_channels"], **rp), 5151)
+    bgp = mp["bg_predictor_params"]
+    bg = P.synthetic_state_dict(P.bg_predictor_spec(num_channels=mp["num_channels"], **bgp), 6161)
+    bg["fc.weight"] = bg["fc.weight"] * 0.02
+    bg["fc.bias"] = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32) + 0.2 * bg["fc.bias"]
+    return gen, reg, bg
+
+
+def vgg_state():
+    return P.synthetic_vgg19_state()
+
+
+def lfae_train_inputs(batch, hw, tp, seed=21):
+    """source / driving frames (smooth random images, the driving one a perturbed shift of the source) and the recorded draws of the
+    equivariance transform (theta noise (B, 2, 3), tps control parameters (B, 1, points^2))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = torch.from_numpy(rng.random((batch, 3, hw // 4, hw // 4), dtype=np.float32))
+    pert = torch.from_numpy(rng.random((batch, 3, hw // 4, hw // 4), dtype=np.float32))
+    up = lambda v: torch.nn.functional.interpolate(v, size=(hw, hw), mode="bilinear", align_corners=False)
+    src = up(base)
+    drv = (0.8 * torch.roll(src, shifts=(hw // 16, -(hw // 16)), dims=(2, 3)) + 0.2 * up(pert)).clamp(0, 1)
+    t = tp["transform_params"]
+    theta = torch.from_numpy(rng.standard_normal((batch, 2, 3)).astype(np.float32)) * t["sigma_affine"]
+    tps = torch.from_numpy(rng.standard_normal((batch, 1, t["points_tps"] ** 2)).astype(np.float32)) * t["sigma_tps"]
+    return src, drv, theta, tps

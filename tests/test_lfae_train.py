@@ -1,0 +1,124 @@
+"""LFAE stage-1 training step (cvpr23_lfdm_amd/lfae_train.py) against the UNMODIFIED reference's ReconstructionModel + Adam step
+(fixtures minted by `oracle/make_golden.py --lfae-train`, LFAE/train.py:96-104, LFAE/modules/model.py:162-217): the three loss terms,
+every parameter's gradient norm and random projection, every parameter's norm after the update, the generated frame and the BatchNorm
+running statistics.  'tiny' runs on the x86 emulation of the kernels (CPU), 'mug128' = config/mug128.yaml at 128x128 on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from cvpr23_lfdm_amd import Generator, lfae_train
+from cvpr23_lfdm_amd.flow_diffusion import BGMotionPredictor, RegionPredictor
+from util import assert_close
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _build(kind, dev):
+    mp, tp, hw, b = synth.lfae_train_setup(kind)
+    gen = Generator(num_regions=mp["num_regions"], num_channels=mp["num_channels"], revert_axis_swap=mp["revert_axis_swap"],
+                    **mp["generator_params"])
+    reg = RegionPredictor(num_regions=mp["num_regions"], num_channels=mp["num_channels"], estimate_affine=mp["estimate_affine"],
+                          **mp["region_predictor_params"])
+    bgp = BGMotionPredictor(num_channels=mp["num_channels"], **mp["bg_predictor_params"])
+    gsd, rsd, bsd = synth.lfae_states(mp)
+    gen.load_state_dict(gsd)
+    reg.load_state_dict(rsd)
+    bgp.load_state_dict(bsd)
+    vgg = lfae_train.Vgg19()
+    vgg.load_state_dict(synth.vgg_state())
+    trainer = lfae_train.LFAETrainer(gen, reg, bgp, mp, tp, vgg=vgg).to(dev)
+    return trainer, (mp, tp, hw, b)
+
+
+def _check(kind, dev, tol):
+    gold = np.load(os.path.join(GOLDEN, "lfae_train_%s.npz" % kind))
+    trainer, (mp, tp, hw, b) = _build(kind, dev)
+    src, drv, theta, tps = synth.lfae_train_inputs(b, hw, tp)
+    losses, gen = trainer.step({"source": src.to(dev), "driving": drv.to(dev)}, transform_noise=(theta, tps))
+    for name, ref in zip(gold["loss_names"], gold["losses"]):
+        assert abs(float(losses[str(name)]) - float(ref)) <= tol * max(1.0, abs(float(ref))), (name, float(losses[str(name)]), float(ref))
+    sub = (lambda v: v) if kind == "tiny" else (lambda v: v[:, :, ::4, ::4])
+    for key, got in (("prediction", sub(gen["prediction"])), ("deformed", sub(gen["deformed"])), ("occlusion_map", gen["occlusion_map"]),
+                     ("optical_flow", gen["optical_flow"]), ("driving_shift", gen["driving_region_params"]["shift"]),
+                     ("driving_affine", gen["driving_region_params"]["affine"]), ("transformed_frame", sub(gen["transformed_frame"]))):
+        assert_close(got.detach().cpu(), torch.from_numpy(gold[key]), tol, key)
+    nets = {"generator": trainer.generator, "region_predictor": trainer.region_predictor, "bg_predictor": trainer.bg_predictor}
+    params = {n + "/" + k: p for n, net in nets.items() for k, p in net.named_parameters()}
+    assert set(params) == set(str(n) for n in gold["names"])
+    rng = np.random.Generator(np.random.PCG64(78))
+    gscale = float(np.max(gold["grad_norm"]))
+    worst = 0.0
+    for name, gn, gp, pn in zip(gold["names"], gold["grad_norm"], gold["grad_probe"], gold["param_norm_after"]):
+        p = params[str(name)]
+        probe = torch.from_numpy(rng.standard_normal(p.numel())).view(p.shape)
+        g = p.grad.detach().double().cpu()
+        sc = max(float(gn), 1e-3 * gscale)
+        e1 = abs(float(g.norm()) - float(gn)) / sc
+        e3 = abs(float(p.detach().double().norm()) - float(pn)) / max(float(pn), 1e-6)
+        assert e1 <= 5 * tol, (str(name), "gradient norm", e1)
+        assert abs(float((g * probe).sum()) - float(gp)) <= 5 * tol * max(sc * float(probe.norm()), 1e-9), (str(name), "gradient projection")
+        # A convolution bias in front of a BatchNorm has an exactly-zero gradient; what both implementations hold there is rounding
+        # noise (~1e-8 of the scale), which Adam's g / (|g| + eps) turns into +-lr steps of arbitrary sign: no update to compare.
+        if float(gn) > 1e-5 * gscale:
+            assert e3 <= tol, (str(name), "parameter norm after the Adam step", e3)
+            worst = max(worst, e3)
+        worst = max(worst, e1)
+    for key in gold.files:
+        if key.startswith("grad/"):
+            ref = torch.from_numpy(gold[key])
+            sc = max(float(ref.abs().max()), 1e-3 * gscale)
+            assert_close(params[key[5:]].grad.detach().cpu() / sc, ref / sc, 5 * tol, key)
+        if key.startswith("bn/"):
+            n, k = key[3:].split("/", 1)
+            assert_close(nets[n].state_dict()[k].cpu(), torch.from_numpy(gold[key]), tol, key)
+    return worst
+
+
+def test_lfae_train_step_tiny(backend):
+    if backend != "cpu":
+        pytest.skip("the tiny configuration is the CPU (emulator) case; the GPU runs config/mug128.yaml")
+    _check("tiny", "cpu", 2e-3)
+
+
+@pytest.mark.gpu
+def test_lfae_train_step_mug128():
+    _check("mug128", "cuda", 5e-3)
+
+
+def test_checkpoint_format_and_schedule():
+    """train.py:136-160 checkpoint keys; MultiStepLR(milestones, 0.1) via end_epoch()."""
+    trainer, _ = _build("tiny", "cpu")
+    sd = trainer.state_dict()
+    assert set(sd) == {"example", "epoch", "generator", "bg_predictor", "region_predictor", "optimizer"}
+    assert "first.conv.weight" in sd["generator"] and "regions.weight" in sd["region_predictor"] and "fc.bias" in sd["bg_predictor"]
+    lrs = []
+    for _ in range(91):
+        lrs.append(trainer.end_epoch())
+    assert abs(lrs[58] - 2e-4) < 1e-12 and abs(lrs[59] - 2e-5) < 1e-12 and abs(lrs[89] - 2e-6) < 1e-12
+    t2, _ = _build("tiny", "cpu")
+    t2.load_state_dict(sd)
+    for a, b in zip(t2.generator.parameters(), trainer.generator.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_frame_pairs_dataset(tmp_path):
+    """FramePairs (LFAE/mug_dataset.py items): walks nested video folders, two distinct frames of ONE video, [0, 1] floats, flips."""
+    from PIL import Image
+    for vid, n in (("s1/anger/take0", 5), ("s2/take1", 3)):
+        d = tmp_path / vid
+        d.mkdir(parents=True)
+        for i in range(n):
+            Image.fromarray(np.full((20, 24, 3), 10 * i + (100 if "s2" in vid else 0), np.uint8)).save(str(d / ("%03d.png" % i)))
+    ds = lfae_train.FramePairs(str(tmp_path), frame_shape=16, jitter=None, seed=3)
+    assert len(ds) == 2
+    for idx in range(2):
+        for _ in range(4):
+            it = ds[idx]
+            assert it["source"].shape == (3, 16, 16) and it["driving"].dtype == torch.float32
+            assert 0.0 <= float(it["source"].min()) and float(it["driving"].max()) <= 1.0
+            assert os.path.dirname(it["frame"][0]) == os.path.dirname(it["frame"][1]) and it["frame"][0] != it["frame"][1]
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert batch["source"].shape == (2, 3, 16, 16)
