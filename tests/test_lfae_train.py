@@ -122,3 +122,53 @@ def test_frame_pairs_dataset(tmp_path):
             assert os.path.dirname(it["frame"][0]) == os.path.dirname(it["frame"][1]) and it["frame"][0] != it["frame"][1]
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
     assert batch["source"].shape == (2, 3, 16, 16)
+
+
+_DP_WORKER = r'''
+import json, os, sys
+repo = sys.argv[1]
+sys.path.insert(0, repo); sys.path.insert(0, os.path.join(repo, "tests"))
+import torch
+import torch.distributed as dist
+import synth
+from cvpr23_lfdm_amd import _build, _native
+_native._set_library_for_tests(_native.NativeLibrary(_build.build_emu(), "emu"))
+import test_lfae_train as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+trainer, (mp, tp, hw, b) = T._build("tiny", "cpu")
+if rank == 1:                        # different start: the start-up broadcast must pull it onto rank 0's weights
+    with torch.no_grad():
+        trainer.generator.get("final.bias").add_(0.5)
+trainer.enable_data_parallel()
+src, drv, theta, tps = synth.lfae_train_inputs(b, hw, tp, seed=21 + rank)      # every rank its own pairs (weak scaling)
+losses, _ = trainer.step({"source": src, "driving": drv}, transform_noise=(theta, tps))
+g = [p.grad.detach().double().flatten() for net in (trainer.generator, trainer.region_predictor, trainer.bg_predictor) for p in net.parameters()]
+out = {"rank": rank, "loss": float(losses["total"]), "spread": trainer._dp.replica_checksum(),
+       "grad_sum": float(sum(float(v.sum()) for v in g)), "final_bias": trainer.generator.get("final.bias").detach().double().tolist()}
+open(os.path.join(os.environ["LFAE_DP_OUT"], "rank%d.json" % rank), "w").write(json.dumps(out))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_lfae_trainer_two_ranks_gloo(tmp_path):
+    """One process per GPU (here: two CPU ranks over gloo on the emulator): the start-up broadcast aligns the replicas, each rank trains
+    on its own pairs with its own BatchNorm statistics (the reference's nn.DataParallel replicas, use_sync_bn: False), the bucketed
+    all-reduce hands both the SAME mean gradient and after the fused Adam step the replicas are bit-identical."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / "lfae_dp_worker.py"
+    script.write_text(_DP_WORKER)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFAE_DP_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", PYTHONPATH=os.path.join(repo, "tests"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29631", str(script), repo]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    a, b = (json.load(open(str(tmp_path / ("rank%d.json" % i)))) for i in (0, 1))
+    assert a["spread"] == 0.0 and b["spread"] == 0.0
+    assert a["grad_sum"] == b["grad_sum"] and a["final_bias"] == b["final_bias"]
+    assert a["loss"] != b["loss"] and np.isfinite(a["loss"]) and np.isfinite(b["loss"])

@@ -16,3 +16,5 @@ timeout 400 bash tools/prof_step_pmc.sh $TAG > $O/pmc.txt 2>&1; head -n 3 $O/ste
 # all-reduce across two ranks and its exposed-communication figure
 timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline --no-roofline > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 700 $O/bench_n2_one_gpu.json; echo
 timeout 300 bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt gpurun_out/p3/train_top_launches.txt $O/; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
+# LFAE stage-1 training (lfae_train.py): one line of frame pairs / s at the per-GPU batch where the step is GPU-bound
+timeout 200 python tools/train_lfae.py --batch 32 --steps 8 --warmup 3 --bench > $O/lfae_train_bench.json 2> $O/lfae_train_bench.err; tail -c 400 $O/lfae_train_bench.json
