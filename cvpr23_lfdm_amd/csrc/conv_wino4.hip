@@ -386,6 +386,289 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(lfdm_conv_params p, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// STAGED flavour (round 4): the workgroup's 32 tiles form an 8 x 4 block of the image, and the block's UNIQUE input pixels of a
+// 16-channel period - 34 x 18 (10 x 18 physical pixels behind the virtual x2 upsample) instead of 32 overlapping 6 x 6 patches, 39 KB
+// instead of 74 KB - are copied global -> registers -> LDS once (16-byte coalesced loads, out-of-image pixels = out-of-range offsets =
+// zeros: no validity masks anywhere) and the producers cut their patches out of LDS.  After the priority fix the launch sat on L2 -> L1
+// delivery (147 KB per period and workgroup, profiles/r04_w_wino4_stamps.txt); this takes a quarter of it away.  LDS: the raw tile is
+// double-buffered (2 x 40 KB, quad-major [4 channel quads][625 pixels][16 B]: quad stride = 1 pixel mod 16, so the 8-byte patch reads
+// of a half-wave - 4 tiles x 4 quads x 2 halves - hit 64 different banks), which leaves room for ONE V buffer (73.7 KB): a period is
+//   phase A  consumers multiply V(k)  ||  producers: patches of raw(k+1) from LDS -> B^T d B in registers; raw(k+2) registers -> LDS;
+//                                                    loads of raw(k+3) issued
+//   barrier; phase B  producers store V(k+1) (the matrix pipe idles for these ~1 000 cycles);  barrier.
+// Conditions (lfdm_conv_wino4_launch): tiles per row % 8 == 0, tile rows % 4 == 0 - every LFAE decode shape.
+constexpr int W4S_NPXP = 625;                           // padded pixel count of a raw tile (612 used; 625 = 1 mod 16)
+constexpr int W4S_QS = W4S_NPXP * 4;                    // floats per channel-quad plane
+constexpr int W4S_RAW = 4 * W4S_QS;                     // floats per raw buffer (40 000 B)
+
+template <bool ACT, bool UP>
+__global__ __launch_bounds__(512) void conv_wino4s_kernel(lfdm_conv_params p, int gx, int ny, int ablate) {
+  constexpr int SMEM4S = V4SZ + 2 * W4S_RAW > 36 * W4T * W4N ? V4SZ + 2 * W4S_RAW : 36 * W4T * W4N;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM4S];      // V (73.7 KB) | raw0 | raw1 (40 KB each); the epilogue's planes (147 KB) alias all of it
+  constexpr int RW = UP ? 18 : 34, RH = UP ? 10 : 18;              // raw tile in (physical) pixels
+  constexpr int NPIX = RW * RH, NPIECE = NPIX * 4, NLD = (NPIECE + 255) / 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = lfdm_uniform(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int th = p.hq >> 2, tw = p.wq >> 2;
+  const int bw = tw >> 3, bpi = bw * (th >> 2);                    // tile blocks per row / per image
+  const int id = blockIdx.x, slot = id >> 3;
+  const int bx = (id & 7) + 8 * (slot / ny), by = slot % ny;       // (same XCD-aware order as conv_wino4_kernel)
+  if (bx >= gx) return;
+  const int blk_n = bx / bpi, blk_r = bx - blk_n * bpi;
+  const int blk_y = blk_r / bw, blk_x = blk_r - blk_y * bw;
+  const int n0 = by * W4N;
+  const int cin = p.c0;
+  const int nch = cin / W4K, nper = cin / W4C;
+  const int last = nch - 1, lastp = nper - 1;
+  auto clampc = [&](int c) { return c < last ? c : last; };
+  auto clampp = [&](int c) { return c < lastp ? c : lastp; };
+  float* const V = smem;
+  float* const R0 = smem + V4SZ;
+  float* const R1 = R0 + W4S_RAW;
+
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- PRODUCERS
+#if !defined(LFDM_EMU_BUILD)
+    if (ablate & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+    const int pt = tid - 256;
+    const int x_tile = pt >> 3, x_pair = pt & 7;
+    const int ltx = x_tile & 7, lty = x_tile >> 3;
+    const int64_t in_rows = (int64_t)p.n_img * p.hi * p.wi;
+    const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
+    // raw pieces of this thread: piece j = pt + 256 i = (pixel j >> 2, channel quad j & 3); physical pixel of the block's corner
+    const int py0 = (UP ? 8 : 16) * blk_y - 1, px0 = (UP ? 16 : 32) * blk_x - 1;
+    uint32_t rvoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int j = pt + 256 * i, pix = j >> 2, quad = j & 3;
+      const int pr = pix / RW, pc = pix - pr * RW;
+      const int gy = py0 + pr, gx_ = px0 + pc;
+      const bool ok = j < NPIECE && gy >= 0 && gy < p.hi && gx_ >= 0 && gx_ < p.wi;
+      rvoff[i] = ok ? (uint32_t)(((((int64_t)blk_n * p.hi + gy) * p.wi + gx_) * p.ld0 + 4 * quad) * 4) : LFDM_BUF_OOB;
+    }
+    float4 rreg[NLD];
+    auto load_raw = [&](int per) {
+      const uint32_t cb = (uint32_t)per * (W4C * 4u);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) rreg[i] = lfdm_buf_load_f4(buf0, rvoff[i] == LFDM_BUF_OOB ? LFDM_BUF_OOB : rvoff[i] + cb);
+    };
+    auto store_raw = [&](float* R) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int j = pt + 256 * i;
+        if (j < NPIECE) *reinterpret_cast<float4*>(R + (j & 3) * W4S_QS + (j >> 2) * 4) = rreg[i];
+      }
+    };
+    // this thread's patch inside the raw tile: pixel (row0 + dr(r), col0 + dc(c)), its channel pair = quad x_pair >> 1, half x_pair & 1
+    const int row0 = UP ? 2 * lty : 4 * lty, col0 = UP ? 2 * ltx : 4 * ltx;
+    const int pbase = (x_pair >> 1) * W4S_QS + (row0 * RW + col0) * 4 + 2 * (x_pair & 1);
+    f32x2 d[36];
+    auto read_patch = [&](const float* R) {
+#pragma unroll
+      for (int q = 0; q < 36; ++q) {
+        const int r = q / 6, c = q % 6;
+        const int dr = UP ? (r + 1) >> 1 : r, dc = UP ? (c + 1) >> 1 : c;
+        d[q] = *reinterpret_cast<const f32x2*>(R + pbase + (dr * RW + dc) * 4);
+      }
+    };
+    auto transform = [&]() {      // B^T d B in place: columns, then rows
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        bt6(d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c], d[c], d[6 + c], d[12 + c], d[18 + c], d[24 + c], d[30 + c]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        bt6(d[6 * i], d[6 * i + 1], d[6 * i + 2], d[6 * i + 3], d[6 * i + 4], d[6 * i + 5], d[6 * i], d[6 * i + 1], d[6 * i + 2], d[6 * i + 3],
+            d[6 * i + 4], d[6 * i + 5]);
+    };
+    auto store_v = [&]() {
+      float* dst = V + x_tile * LDV4 + 4 * ((x_pair >> 1) ^ ((x_tile >> 2) & 3)) + 2 * (x_pair & 1);      // swizzled 16-byte slot
+#pragma unroll
+      for (int q = 0; q < 36; ++q) *reinterpret_cast<f32x2*>(dst + q * (W4T * LDV4)) = d[q];
+    };
+    load_raw(0);
+    store_raw(R0);
+    load_raw(clampp(1));
+    __syncthreads();                                  // raw(0) complete
+    read_patch(R0);
+    transform();
+    store_v();                                        // V(0)
+    store_raw(R1);                                    // raw(1)
+    load_raw(clampp(2));
+    __syncthreads();
+#ifdef LFDM_W4_STAMP
+    long long s_a1 = 0, s_a2 = 0, s_w1 = 0, s_b = 0, s_w2 = 0, s_t = clock64();
+#define LFDM_W4S_LAP(acc) { const long long now_ = clock64(); acc += now_ - s_t; s_t = now_; }
+#else
+#define LFDM_W4S_LAP(acc)
+#endif
+    for (int k = 0; k < nper; ++k) {
+      // phase A (the consumers multiply V(k))
+      read_patch((k & 1) ? R0 : R1);                  // raw(k+1)
+      transform();
+      LFDM_W4S_LAP(s_a1)
+      store_raw((k & 1) ? R1 : R0);                   // raw(k+2) -> the buffer raw(k) has left
+      load_raw(clampp(k + 3));
+      LFDM_W4S_LAP(s_a2)
+      __syncthreads();
+      LFDM_W4S_LAP(s_w1)
+      store_v();                                      // phase B: V(k+1)
+      LFDM_W4S_LAP(s_b)
+      __syncthreads();
+      LFDM_W4S_LAP(s_w2)
+    }
+#ifdef LFDM_W4_STAMP
+    if (lane == 0 && blockIdx.x < 256) {
+      long long* st = (long long*)p.gn_in_gamma + ((int64_t)blockIdx.x * 8 + wave) * 8;
+      st[0] = s_a1; st[1] = s_a2; st[2] = s_w1; st[3] = s_b; st[4] = s_w2;
+    }
+#endif
+    __syncthreads();                                  // the consumers' epilogue: one more barrier
+    return;
+  }
+
+  // ---------------------------------------------------------------- CONSUMERS (as in conv_wino4_kernel, one V buffer)
+  const lfdm_buf bufw = lfdm_make_buf(p.weight_wino4, (uint32_t)((int64_t)36 * nch * p.coutp * W4K * 4));
+  const int cw = wave;
+  const int ncol = n0 + l31;
+  float4 bfr[3][3];
+  const uint32_t chunk_bytes = (uint32_t)p.coutp * (W4K * 4u);
+  const uint32_t pos_bytes = (uint32_t)nch * chunk_bytes;
+  const uint32_t b_lane = ((uint32_t)ncol * W4K + 4u * kh) * 4u;
+  auto fetch_bg = [&](float4 (&dst)[3], int g, int chunk) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const uint32_t uni = (uint32_t)(9 * cw + 3 * g + u) * pos_bytes + (uint32_t)chunk * chunk_bytes;
+      dst[u] = lfdm_buf_load_f4(bufw, uni + b_lane);
+    }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int a_swz = (l31 >> 2) & 3;
+  auto load_a = [&](float4 (&a)[3], int half, int g) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      a[u] = *reinterpret_cast<const float4*>(V + ((9 * cw + 3 * g + u) * W4T + l31) * LDV4 + 4 * ((2 * half + kh) ^ a_swz));
+  };
+  auto consume = [&](int half, int chunk, int next_chunk) {
+    float4 a[2][3];
+    load_a(a[0], half, 0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (g < 2) load_a(a[(g + 1) & 1], half, g + 1);
+      if (g == 0) fetch_bg(bfr[2], 2, chunk);
+      else fetch_bg(bfr[g - 1], g - 1, next_chunk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const float4 bq = bfr[g][u], aq = a[g & 1][u];
+          const float av = e == 0 ? aq.x : e == 1 ? aq.y : e == 2 ? aq.z : aq.w;
+          const float bv = e == 0 ? bq.x : e == 1 ? bq.y : e == 2 ? bq.z : bq.w;
+          acc[3 * g + u] = mfma_32x32x2(av, bv, acc[3 * g + u]);
+        }
+#if !defined(LFDM_EMU_BUILD)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  };
+  fetch_bg(bfr[0], 0, 0);
+  fetch_bg(bfr[1], 1, 0);
+  __syncthreads();
+  __syncthreads();
+#ifdef LFDM_W4_STAMP
+  long long s_a1 = 0, s_w1 = 0, s_w2 = 0, s_t = clock64();
+#endif
+  for (int k = 0; k < nper; ++k) {
+    consume(0, 2 * k, 2 * k + 1);
+    consume(1, 2 * k + 1, clampc(2 * k + 2));
+    LFDM_W4S_LAP(s_a1)
+    __syncthreads();
+    LFDM_W4S_LAP(s_w1)
+    __syncthreads();
+    LFDM_W4S_LAP(s_w2)
+  }
+#ifdef LFDM_W4_STAMP
+  if (lane == 0 && blockIdx.x < 256) {
+    long long* st = (long long*)p.gn_in_gamma + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    st[0] = s_a1; st[2] = s_w1; st[4] = s_w2;
+  }
+#endif
+
+  // ---------------------------------------------------------------- output transform A^T M A through LDS (as in conv_wino4_kernel)
+  float* const Ms = smem;
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Ms[((9 * cw + q) * W4T + tile) * W4N + l31] = acc[q][r];
+    }
+  const int e_quad = tid & 7, e_tile = tid >> 3;
+  const int my_n = blk_n, my_ty = 4 * blk_y + (e_tile >> 3), my_tx = 8 * blk_x + (e_tile & 7);
+  const int co = n0 + 4 * e_quad;
+  const bool live = co < p.cout;
+  const int64_t orow0 = ((int64_t)my_n * p.hq + 4 * my_ty) * p.wq + 4 * my_tx;
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + co);
+  float4 res[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    res[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && p.residual) res[o] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (o >> 2) * p.wq + (o & 3)) * p.ldr + co);
+  }
+  __syncthreads();
+  if (!live) return;
+  float4 T[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float4 m[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const float4*>(Ms + ((6 * i + j) * W4T + e_tile) * W4N + 4 * e_quad);
+#define LFDM_W4_COL(f)                                                                                          \
+    {                                                                                                           \
+      const float s12 = m[1].f + m[2].f, d12 = m[1].f - m[2].f, s34 = m[3].f + m[4].f, d34 = m[3].f - m[4].f;  \
+      T[i][0].f = m[0].f + s12 + s34;                                                                           \
+      T[i][1].f = d12 + 2.0f * d34;                                                                             \
+      T[i][2].f = s12 + 4.0f * s34;                                                                             \
+      T[i][3].f = d12 + 8.0f * d34 + m[5].f;                                                                    \
+    }
+    LFDM_W4_COL(x) LFDM_W4_COL(y) LFDM_W4_COL(z) LFDM_W4_COL(w)
+#undef LFDM_W4_COL
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float4 y[4];
+#define LFDM_W4_ROW(f)                                                                                                            \
+    {                                                                                                                             \
+      const float s12 = T[1][b].f + T[2][b].f, d12 = T[1][b].f - T[2][b].f, s34 = T[3][b].f + T[4][b].f, d34 = T[3][b].f - T[4][b].f; \
+      y[0].f = T[0][b].f + s12 + s34;                                                                                             \
+      y[1].f = d12 + 2.0f * d34;                                                                                                  \
+      y[2].f = s12 + 4.0f * s34;                                                                                                  \
+      y[3].f = d12 + 8.0f * d34 + T[5][b].f;                                                                                      \
+    }
+    LFDM_W4_ROW(x) LFDM_W4_ROW(y) LFDM_W4_ROW(z) LFDM_W4_ROW(w)
+#undef LFDM_W4_ROW
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t orow = orow0 + a * p.wq + b;
+      const float4 rr = res[4 * a + b];
+      float4 v = make_float4(y[a].x + bb.x + rr.x, y[a].y + bb.y + rr.y, y[a].z + bb.z + rr.z, y[a].w + bb.w + rr.w);
+      if (ACT) {
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+      }
+      *reinterpret_cast<float4*>(p.out + orow * p.ldo + co) = v;
+    }
+  }
+}
+
 // U = G g G^T (6x6 per filter), one thread per (input channel k, output channel n)
 __global__ __launch_bounds__(256) void pack_wino4_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
                                                          float* __restrict__ out) {
@@ -442,7 +725,20 @@ int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream) {
   const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny));
   // producer-wave priority (kernel argument `ablate`, bit 0): on by default, LFDM_W4_PRIO=0 switches it off (A/B: profiles/r04_w_wino4_stamps.txt)
   static const int ablate = []() { const char* e = getenv("LFDM_W4_PRIO"); return e ? atoi(e) : 1; }();
-  if (p.act != LFDM_ACT_NONE) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+  // staged flavour (unique pixels of an 8 x 4 tile block through LDS): whenever the tile grid allows; LFDM_W4_STAGED=0 keeps the direct one
+  static const bool staged_on = []() { const char* e = getenv("LFDM_W4_STAGED"); return !e || atoi(e) != 0; }();
+  const bool act = p.act != LFDM_ACT_NONE;
+  if (staged_on && (p.wq / 4) % 8 == 0 && (p.hq / 4) % 4 == 0) {
+    if (p.upsample) {
+      if (act) LFDM_LAUNCH((conv_wino4s_kernel<true, true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+      else LFDM_LAUNCH((conv_wino4s_kernel<false, true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+    } else {
+      if (act) LFDM_LAUNCH((conv_wino4s_kernel<true, false>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+      else LFDM_LAUNCH((conv_wino4s_kernel<false, false>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
+    }
+    return lfdm_check_launch("conv_wino4s");
+  }
+  if (act) LFDM_LAUNCH((conv_wino4_kernel<true>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
   else LFDM_LAUNCH((conv_wino4_kernel<false>), grid, dim3(512), 0, stream, p, gx, ny, ablate);
   return lfdm_check_launch("conv_wino4");
 }

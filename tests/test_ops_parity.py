@@ -1074,6 +1074,9 @@ def test_pack_wino_weight(backend):
     dict(cin=32, cout=40, n=10, h=8, w=8, residual=True, act=1),                   # 40 tiles: two workgroups, padded columns
     dict(cin=64, cout=64, n=3, h=4, w=12, upsample=True, act=1),                   # through the virtual x2 upsample (8 x 24 image)
     dict(cin=96, cout=32, n=1, h=16, w=4, residual=True),                          # one tile per image row; 6 periods
+    dict(cin=64, cout=40, n=3, h=16, w=32, residual=True, act=1),                  # STAGED flavour (8 x 4 tile blocks): one block per image, 4 periods
+    dict(cin=32, cout=32, n=1, h=32, w=64),                                        # STAGED: 2 x 2 blocks per image (interior block borders), 2 periods
+    dict(cin=96, cout=64, n=2, h=8, w=32, upsample=True, act=1),                   # STAGED through the virtual x2 upsample (16 x 64 image: 1 x 2 blocks)
     dict(cin=256, cout=256, n=40, h=32, w=32, residual=True, gpu_only=True),       # LFAE bottleneck ResBlock2d convolution
     dict(cin=256, cout=128, n=40, h=32, w=32, upsample=True, act=1, gpu_only=True),   # UpBlock2d
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))

@@ -21,7 +21,8 @@ res = torch.randn(n * h * w, cout, generator=g).to(dev)
 ww, w4 = ops.pack_wino_weight(wt), ops.pack_wino4_weight(wt)
 out = torch.empty(n * h * w, cout, device=dev)
 pp, _ = ops.conv_params(x, None, cout, 3, 3, n, h, w, residual=res, out=out, weight_wino=ww, weight_wino4=w4)
-stamps = torch.zeros(2 * 256 * 8 * 2, dtype=torch.int64, device=dev)
+staged = os.environ.get("LFDM_W4_STAGED", "1") != "0"
+stamps = torch.zeros(256 * 8 * 8 if staged else 2 * 256 * 8 * 2, dtype=torch.int64, device=dev)
 pp.gn_in_gamma = stamps.data_ptr()
 for _ in range(3):
     ops.conv_launch(pp)
@@ -29,6 +30,15 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.conv_launch(pp); e1.record(); torch.cuda.synchronize()
 print("launch us", e0.elapsed_time(e1) * 1e3)
+if staged:
+    st = stamps.cpu().view(256, 8, 8).double().mean(0) / 16
+    print("STAGED flavour, cycles per period (mean over 256 workgroups):")
+    for wv in range(4):
+        print("consumer wave %d: MFMA phase %6.0f | barrier 1 %6.0f | phase B + barrier 2 %6.0f" % (wv, st[wv, 0], st[wv, 2], st[wv, 4]))
+    for wv in range(4, 8):
+        print("producer wave %d: patches + transform %6.0f | raw store + next loads %6.0f | barrier 1 %6.0f | V store %6.0f | barrier 2 %6.0f" % (
+            wv, st[wv, 0], st[wv, 1], st[wv, 2], st[wv, 3], st[wv, 4]))
+    sys.exit(0)
 st = stamps.cpu()[:4096].view(256, 8, 2).double(); s2 = stamps.cpu()[4096:].view(256, 8, 2).double()
 print("per-wave cycle sums over the 16-period loop (mean over 256 workgroups):")
 for wv in range(8):
