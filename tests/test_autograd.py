@@ -91,3 +91,41 @@ def test_upsample2_pad_function(backend, reflect):
     _cmp(from_cl(y, n, 2 * h + 2, 2 * w + 2), ref, "upsample+pad fwd")
     y.backward(to_cl(dy).to(dev))
     _cmp(from_cl(kx.grad, n, h, w), x.grad, "upsample+pad bwd")
+
+
+def test_filter_pack_cache_follows_the_weights(backend):
+    """autograd._pack_wino caches the Winograd packs of LEAF weights (LFAE stage-1 training: the frozen VGG-19 convolves 12 times per step with
+    the same filters).  The cache must notice every way a weight can change: an in-place torch write (`_version`), a raw-pointer optimizer
+    step (params.weights_epoch) - and must never serve a pack to a different tensor that happens to live at the same address."""
+    from cvpr23_lfdm_amd import params as P
+    dev = backend
+    n, h, c = 1, 4, 16
+    x = to_cl(rnd(n, c, h, h, seed=1)).to(dev)
+
+    def run(w):
+        return A.conv_cl(x, w, None, n_img=n, hi=h, wi=h).detach().cpu()
+
+    w = torch.nn.Parameter((rnd(c, c, 3, 3, seed=2) * 0.1).to(dev), requires_grad=False)       # frozen leaf: cached
+    y0 = run(w)
+    assert torch.equal(run(w), y0)
+    with torch.no_grad():
+        w.mul_(2.0)                                        # torch write: _version moves
+    assert_close(run(w), 2 * y0, 1e-5, "pack rebuilt after an in-place write")
+    wt = torch.nn.Parameter((rnd(c, c, 3, 3, seed=3) * 0.1).to(dev))                            # trainable leaf
+    y1 = run(wt)
+    with torch.no_grad():
+        wt.copy_((rnd(c, c, 3, 3, seed=4) * 0.1).to(dev))                                     # what load_state_dict does (an in-place write THROUGH
+    y2 = run(wt)                                                                              # `.data` is invisible to torch's counter: INTEGRATION.md)
+    ref2 = F.conv2d(from_cl(x.cpu(), n, h, h), wt.detach().cpu(), padding=1)
+    assert_close(from_cl(y2, n, h, h), ref2, TOL, "pack rebuilt after copy_")
+    before = P.weights_epoch()
+    P.bump_weights_epoch()                                 # what FlatAdam.step does after its raw-pointer update
+    assert P.weights_epoch() == before + 1
+    assert_close(from_cl(run(wt), n, h, h), ref2, TOL, "same weights, new epoch: same result")
+    del w, wt                                               # freed tensors: a new parameter at a recycled address must not hit their packs
+    for seed in range(5, 9):
+        wn = torch.nn.Parameter((rnd(c, c, 3, 3, seed=seed) * 0.1).to(dev), requires_grad=False)
+        ref = F.conv2d(from_cl(x.cpu(), n, h, h), wn.detach().cpu(), padding=1)
+        assert_close(from_cl(run(wn), n, h, h), ref, TOL, "fresh parameter %d" % seed)
+        del wn
+    assert not torch.equal(y1, y2)
