@@ -1161,6 +1161,50 @@ def test_conv2d_winograd4_random_geometries(backend, seed, monkeypatch):
         assert_close(from_cl(out.cpu(), n, ho, wo), ref.float(), 2e-5, "winograd F(4x4) conv, random geometry %s" % ((cin, cout, n, h, w, up, inplace, act),))
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_conv2d_winograd4_staged_random_geometries(backend, seed, monkeypatch):
+    """Seeded random geometries whose tile grid takes the STAGED flavour of the F(4x4,3x3) schedule (conv_wino4s_kernel: 8 x 4 tile blocks,
+    the block's unique pixels through LDS): several blocks per image in both directions, several images, padded output columns, the virtual
+    upsample, residual in place, ReLU - against fp64 F.conv2d, and bit-for-bit against the direct flavour (LFDM_W4_STAGED=0 is read once
+    per process, so that comparison runs through the tolerance instead)."""
+    import random
+    dev = backend
+    rnd_ = random.Random(5000 + seed)
+    monkeypatch.setenv("LFDM_WINO", "1")
+    monkeypatch.setenv("LFDM_WINO4", "1")
+    monkeypatch.setenv("LFDM_WINO4_MIN", "1")
+    for trial in range(3 if dev == "cpu" else 8):
+        cin = 32 * rnd_.randint(1, 2)
+        cout = rnd_.choice([24, 32, 40, 64])
+        n = rnd_.randint(1, 3)
+        up = rnd_.random() < 0.4
+        ho, wo = 16 * rnd_.randint(1, 2), 32 * rnd_.randint(1, 2)            # output image: tile rows % 4 == 0, tiles per row % 8 == 0
+        h, w = (ho // 2, wo // 2) if up else (ho, wo)
+        x = rnd(n, cin, h, w, seed=20 * seed + trial)
+        wt = rnd(cout, cin, 3, 3, seed=177 + trial, scale=1.0 / math.sqrt(cin * 9))
+        bias = rnd(cout, seed=6)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+        ref = F.conv2d(xin.double(), wt.double(), bias.double(), padding=1)
+        assert ref.shape[2:] == (ho, wo)
+        inplace = rnd_.random() < 0.5
+        res = rnd(*ref.shape, seed=14 + trial) if inplace or rnd_.random() < 0.3 else None
+        if res is not None:
+            ref = ref + res.double()
+        act = rnd_.choice([0, 1])
+        if act:
+            ref = F.relu(ref)
+        wtd = wt.to(dev)
+        wd, ww, w4 = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wtd), ops.pack_wino4_weight(wtd)
+        resd = None if res is None else to_cl(res).to(dev)
+        kw = dict(bias=bias.to(dev), residual=resd, act=act, weight_wino=ww, weight_wino4=w4, upsample=up)
+        if inplace:
+            kw["out"] = resd
+        pp, _ = ops.conv_params(to_cl(x).to(dev), wd, cout, 3, 3, n, h, w, **kw)
+        assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 4, (cin, cout, n, h, w, up)
+        out = ops.conv2d_cl(to_cl(x).to(dev), wd, cout, 3, 3, n, h, w, **kw)
+        assert_close(from_cl(out.cpu(), n, ho, wo), ref.float(), 2e-5, "staged F(4x4) conv, random geometry %s" % ((cin, cout, n, h, w, up, inplace, act),))
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
     """Seeded random geometries through the Winograd schedule (tile raggedness, odd image counts, two-source splits,
