@@ -516,6 +516,25 @@ def warp_bench(model, img, iters=20):
                                            % (pmc, pmc_launches)}}
 
 
+def dp_diagnostics(dp, steps, world):
+    """N > 1 self-diagnosis of a data-parallel training leg (every rank calls it): the exchange's bucket layout, the exposed all-reduce time
+    of EVERY rank (all-gathered) and the replica checksum after the timed steps (0.0 = the replicas hold identical parameters)."""
+    import torch.distributed as dist
+    exposed = dp.exposed_ms(last=steps) or []
+    mine = sum(exposed) / max(1, len(exposed))
+    worst = max(exposed) if exposed else 0.0
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([mine, worst], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    return dict(dp.describe(), exposed_allreduce_ms_per_step=round(mine, 3), exposed_allreduce_ms_max=round(worst, 3) if exposed else None,
+                exposed_allreduce_ms_per_step_per_rank=[round(float(v[0]), 3) for v in every],
+                exposed_allreduce_ms_max_per_rank=[round(float(v[1]), 3) for v in every],
+                replica_checksum=dp.replica_checksum(), backend=dist.get_backend(),
+                note="exposed = time the compute stream waited in GradAllReduce.finish() (events around the bucket waits); the un-suffixed figures are "
+                     "rank 0's; replica_checksum = (max - min) over ranks of the fp64 parameter sum after the timed steps (0.0 = replicas identical)")
+
+
 def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
     """BASELINE.json configs[3] per GPU: one DM training step = frozen-LFAE pseudo ground truth of all B*T frames +
     UNet forward/backward (native kernels under autograd) + [RCCL gradient all-reduce when world > 1] + fused Adam,
@@ -550,11 +569,8 @@ def train_bench(dev, rank, world, steps, warmup, batch, lazy_extra=True):
     elapsed = timed_region(step, steps, warmup, world, torch.cuda.synchronize, per_rank)
     vals = [float(v) for v in losses]
     comm = None
-    if m._dp is not None:       # what the gradient exchange looks like and how much of it backward did not hide
-        exposed = m._dp.exposed_ms(last=steps) or []
-        comm = dict(m._dp.describe(), exposed_allreduce_ms_per_step=round(sum(exposed) / max(1, len(exposed)), 3),
-                    exposed_allreduce_ms_max=round(max(exposed), 3) if exposed else None,
-                    note="exposed = time the compute stream waited in GradAllReduce.finish() (events around the bucket waits), rank 0")
+    if m._dp is not None:       # what the gradient exchange looks like and how much of it backward did not hide, per rank
+        comm = dp_diagnostics(m._dp, steps, world)
         m._dp.profile = False
     # not the headline: the same step with the pseudo-ground-truth decode (real_out_vid / real_warped_vid: read by no loss, only by
     # the scripts' sample images) deferred until it is read (FlowDiffusion.lazy_real_decode)
@@ -639,6 +655,162 @@ def cpu_baseline():
                       % (best, n_unet, b, t, s, s, t_unet, min(times), max(times), t_fea, n_dec, t_dec, WORKLOAD["sampling_timesteps"], t)}
 
 
+def gpu_eager_baseline(dev, budget_s=90.0):
+    """The "context baseline" BASELINE.md section 3 planned: the same torch restatement that `cpu_baseline` times (oracle/lfdm_oracle.py =
+    the reference dataflow, video_flow_diffusion_model.py:190-216: per-step 3-D convolutions, einops-style transposes, per-frame decode)
+    run as stock eager PyTorch-ROCm on this GPU - MIOpen / rocBLAS / ATen kernels, no code of this repository on the device.  It is what
+    "just use the GPU" gives; the headline over it is what the hand-written kernels buy.  Outside the timed region, rank 0, bounded:
+    1 warm-up + up to 5 UNet forwards at the C2 shape, compute_fea, 40 decoded frames (per frame, as the reference loops) and the same 40
+    frames as one batch (the friendlier form for a GPU), extrapolated linearly to one video."""
+    sys.path.insert(0, os.path.join(REPO_ROOT, "oracle"))
+    import lfdm_oracle as O
+    import synth
+    torch.manual_seed(0)
+    b, t, s, hw = WORKLOAD["batch"], WORKLOAD["frames"], WORKLOAD["latent"], WORKLOAD["image"]
+    t_start = time.perf_counter()
+    with torch.device(dev), torch.no_grad():
+        dsd = {"denoise_fn." + k: v.to(dev) for k, v in synth.unet_state().items()}
+        gsd = {k: v.to(dev) for k, v in synth.generator_state().items()}
+        img, cond = (v.to(dev) for v in synth.inputs(b, hw))
+        x = torch.randn(b, 259, t, s, s)
+        tt = torch.full((b,), 500, dtype=torch.long)
+        O.unet_forward(dsd, x, tt, cond)                  # warm-up: MIOpen solver selection, allocator
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            O.unet_forward(dsd, x, tt, cond)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s:
+                break
+        t_unet = sum(times) / len(times)
+        log("gpu_eager_baseline: %d UNet forwards, %.1f ms each" % (len(times), 1e3 * t_unet))
+        O.generator_compute_fea(gsd, img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.generator_compute_fea(gsd, img)
+        torch.cuda.synchronize()
+        t_fea = time.perf_counter() - t0
+        flow = torch.rand(b, s, s, 2) * 2 - 1
+        occ = torch.rand(b, 1, s, s)
+        O.generator_forward_with_flow(gsd, img, flow, occ)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(t):
+            O.generator_forward_with_flow(gsd, img, flow, occ)
+        torch.cuda.synchronize()
+        t_dec_loop = time.perf_counter() - t0
+        imgs, flows, occs = img.repeat(t, 1, 1, 1), flow.repeat(t, 1, 1, 1), occ.repeat(t, 1, 1, 1)
+        O.generator_forward_with_flow(gsd, imgs, flows, occs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.generator_forward_with_flow(gsd, imgs, flows, occs)
+        torch.cuda.synchronize()
+        t_dec_batched = time.perf_counter() - t0
+    per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t_dec_loop
+    per_video_batched = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t_dec_batched
+    return {"value": round(b / per_video, 4), "unit": "videos/s", "kind": "port on torch-rocm (eager MIOpen / rocBLAS / ATen; no kernel of this repository)",
+            "ms_per_unet_forward": round(1e3 * t_unet, 2), "ms_per_unet_forward_min": round(1e3 * min(times), 2), "unet_forwards_timed": len(times),
+            "ms_compute_fea": round(1e3 * t_fea, 2), "ms_decode_40_frames_per_frame_loop": round(1e3 * t_dec_loop, 2),
+            "ms_decode_40_frames_one_batch": round(1e3 * t_dec_batched, 2),
+            "value_with_batched_decode": round(b / per_video_batched, 4),
+            "sample": "oracle/lfdm_oracle.py on %s through stock eager PyTorch-ROCm: %d UNet fwd @ (%d,259,%d,%d,%d) after one warm-up, compute_fea, 40 decode "
+                      "frames (the reference's per-frame loop; the one-batch form beside it); extrapolated to %d steps" % (
+                          dev, len(times), b, t, s, s, WORKLOAD["sampling_timesteps"]),
+            "note": "no hipGraph, no fusion, the reference's transposes and per-step fea convolution included: the dataflow of "
+                    "video_flow_diffusion_model.py:190-216 as written.  headline / this = what the hand-written path buys over merely using the GPU"}
+
+
+def kernel_census(step, dev):
+    """Kernel launches of ONE call of `step` (torch.profiler, device activities): count, and the share of the device time spent in this
+    library's kernels vs vendor code (ATen / MIOpen / composable_kernel / Tensile).  A library kernel = a symbol liblfdm_hip.so defines."""
+    import re
+    import subprocess
+    from torch.profiler import ProfilerActivity, profile
+    from cvpr23_lfdm_amd._native import HIP_LIB_PATH
+    native = set()
+    out = subprocess.run(["nm", "-C", "--defined-only", HIP_LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60).stdout
+    for ln in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ \w (?:void )?(?:\(anonymous namespace\)::)?([A-Za-z_][A-Za-z_0-9]*)", ln)
+        if m and ("_kernel" in m.group(1) or m.group(1).startswith("lfdm_")):
+            native.add(m.group(1))
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    rows = {}
+    for ev in prof.events():
+        if getattr(ev, "device_type", None) is not None and str(ev.device_type).endswith("CUDA"):
+            r = rows.setdefault(ev.name, [0, 0.0])
+            r[0] += 1
+            r[1] += float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
+    launches = sum(r[0] for r in rows.values())
+    total_us = sum(r[1] for r in rows.values())
+
+    def base(name):
+        m = re.match(r"^(?:void )?(?:\(anonymous namespace\)::)?([A-Za-z_][A-Za-z_0-9]*)", name)
+        return m.group(1) if m else name
+
+    is_native = lambda n: base(n) in native
+    nat_us = sum(r[1] for n, r in rows.items() if is_native(n))
+    nat_n = sum(r[0] for n, r in rows.items() if is_native(n))
+    vendor = sorted(((n, r) for n, r in rows.items() if not is_native(n)), key=lambda kv: -kv[1][1])
+    return {"launches_per_step": launches, "native_launches": nat_n, "device_us_per_step": round(total_us, 1),
+            "native_time_share": round(nat_us / total_us, 4) if total_us else None,
+            "vendor_top": [{"kernel": n[:90], "calls": r[0], "us": round(r[1], 1)} for n, r in vendor[:8]],
+            "vendor_families": sorted({f for n, _ in vendor for f in ("miopen", "MIOpen", "ck::", "grid_sampler_2d", "Cijk_")
+                                       if f in n}),
+            "how": "torch.profiler device events of one step; native = kernel symbols defined in liblfdm_hip.so"}
+
+
+def lfae_train_bench(dev, rank, world, steps, warmup, batch):
+    """one LFAE stage-1 training step (LFAE/train.py:96-104 on config mug128: region predictor x3, background
+    predictor, generator, VGG-19 pyramid perceptual loss, equivariance losses, backward, Adam) on `batch` synthetic 128x128 frame pairs per
+    GPU; gradients all-reduced over RCCL when world > 1."""
+    import yaml
+    from cvpr23_lfdm_amd import lfae_train, params as P
+    with open(os.path.join(REPO_ROOT, "configs", "lfae_128.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    torch.manual_seed(1234 + rank)
+    gen, reg, bgp = lfae_train.build_from_config(cfg)
+    vgg = lfae_train.Vgg19()
+    vgg.load_state_dict(P.synthetic_vgg19_state())
+    trainer = lfae_train.LFAETrainer(gen, reg, bgp, cfg["model_params"], cfg["train_params"], vgg=vgg).to(dev)
+    trainer.enable_data_parallel()
+    hw = 128
+    g = torch.Generator().manual_seed(77 + rank)
+    base = torch.rand(batch, 3, hw // 8, hw // 8, generator=g)
+    src = torch.nn.functional.interpolate(base, size=(hw, hw), mode="bilinear", align_corners=False)
+    drv = (0.8 * torch.roll(src, shifts=(hw // 16, -(hw // 16)), dims=(2, 3)) + 0.2 * torch.rand(batch, 3, hw, hw, generator=g)).clamp(0, 1)
+    x = {"source": src.to(dev), "driving": drv.to(dev)}
+    last = {}
+
+    def step():
+        last["loss"] = trainer.step(x)[0]["total"]
+
+    per_rank = []
+    if trainer._dp is not None:
+        trainer._dp.profile = True
+    elapsed = timed_region(step, steps, warmup, world, torch.cuda.synchronize, per_rank)
+    comm = None
+    if trainer._dp is not None:
+        comm = dp_diagnostics(trainer._dp, steps, world)
+        trainer._dp.profile = False
+    out = {"allreduce": comm,
+           "value": round(steps * batch * world / elapsed, 2), "unit": "LFAE stage-1 training frame pairs/s (128x128, config mug128)",
+           "ms_per_step": round(1e3 * elapsed / steps, 1), "ms_per_step_per_rank": [round(1e3 * v / steps, 1) for v in per_rank],
+           "batch_per_gpu": batch, "global_batch": batch * world, "steps": steps, "warmup": warmup,
+           "loss_last": round(float(last["loss"]), 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if rank == 0 and world == 1:
+        try:
+            out["kernels"] = kernel_census(step, dev)
+        except Exception as e:
+            out["kernels"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -649,6 +821,9 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10, help="timed DM training steps for the extra `train` object (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=8, help="training videos per GPU per step")
     ap.add_argument("--train-timeout", type=int, default=240, help="seconds before the training measurement is abandoned")
+    ap.add_argument("--no-gpu-eager-baseline", action="store_true", help="skip the stock eager PyTorch-ROCm context baseline")
+    ap.add_argument("--lfae-train-steps", type=int, default=6, help="timed LFAE stage-1 training steps for the extra `lfae_train` object (0 = skip)")
+    ap.add_argument("--lfae-train-batch", type=int, default=32, help="frame pairs per GPU per LFAE training step")
     ap.add_argument("--blocks", type=int, default=3, help="timed blocks of K steps: block 0 is the headline, the others are reported beside it")
     ap.add_argument("--batch", type=int, default=1,
                     help="videos per GPU per step; 1 = BASELINE.json configs[1] (latency mode), >1 = throughput mode")
@@ -767,6 +942,12 @@ def main():
             log("roofline done")
             line["warp"] = guarded(warp_bench, model, img)
             log("warp done")
+        if world == 1 and not args.no_gpu_eager_baseline:
+            line["gpu_eager_baseline"] = guarded(gpu_eager_baseline, dev)
+            if isinstance(line["gpu_eager_baseline"], dict) and line["gpu_eager_baseline"].get("value"):
+                line["gpu_eager_baseline"]["headline_over_this"] = round(value / line["gpu_eager_baseline"]["value"], 2)
+            torch.cuda.empty_cache()
+            log("gpu eager baseline done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded(cpu_baseline)
             log("cpu baseline done")
@@ -791,9 +972,33 @@ def main():
             train = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         watchdog.cancel()
         log("train done")
+    lfae = None
+    if args.lfae_train_steps > 0:            # SURVEY.md 8 row f4 under the same clock; every rank takes part
+        torch.cuda.empty_cache()
+        import threading
+
+        def on_lfae_timeout():
+            if rank == 0:
+                if train is not None:
+                    line["train"] = train
+                line["lfae_train"] = {"error": "timeout after %d s" % args.train_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.train_timeout, on_lfae_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            lfae = lfae_train_bench(dev, rank, world, args.lfae_train_steps, 2, args.lfae_train_batch)
+        except Exception as e:
+            lfae = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        watchdog.cancel()
+        log("lfae_train done")
     if rank == 0:
         if train is not None:
             line["train"] = train
+        if lfae is not None:
+            line["lfae_train"] = lfae
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -268,13 +268,22 @@ class MultiLinear(Function):
     """(y_0, ..., y_{n-1}) with y_j = act(x) @ w_j.T + b_j: Linear layers that share their input - every ResnetBlock.mlp of a UNet
     forward (SiLU -> Linear on cat(time_emb, cond), :230-233,240-245,562) or one layer of time_mlp (:441-447) - one native launch forward,
     three backward (weight / bias gradients into the optimizer's slots, the input gradient summed over all blocks in a fixed order).
-    apply(x, act, n, w_0..w_{n-1}, b_0..b_{n-1}); a bias may be None."""
+    apply(x, act, n, w_0..w_{n-1}, b_0..b_{n-1}); a bias may be None.  The kernels take up to train_ops.ML_ROWS (16) rows per launch:
+    a larger per-process batch (the reference's mhad script trains with 20 videos) runs as ceil(rows / 16) launches over row slices,
+    weight / bias gradients summed over the slices in slice order."""
 
     @staticmethod
     def forward(ctx, x, act, n, *wb):
         ws, bs = wb[:n], wb[n:]
         xs = _c(x.detach())
-        ys = train_ops.multi_linear(xs, [_c(w.detach()) for w in ws], [None if b is None else _c(b.detach()) for b in bs], act)
+        wd = [_c(w.detach()) for w in ws]
+        bd = [None if b is None else _c(b.detach()) for b in bs]
+        rows, step = xs.shape[0], train_ops.ML_ROWS
+        if rows <= step:
+            ys = train_ops.multi_linear(xs, wd, bd, act)
+        else:
+            parts = [train_ops.multi_linear(xs[r:r + step], wd, bd, act) for r in range(0, rows, step)]
+            ys = [torch.cat([p[j] for p in parts], dim=0) for j in range(n)]
         ctx.save_for_backward(xs, *ws)
         ctx.bias_params = bs
         ctx.meta = (act, n)
@@ -288,12 +297,36 @@ class MultiLinear(Function):
         need = ctx.needs_input_grad
         dws = [grad_out(w) if need[3 + j] else None for j, w in enumerate(ws)]
         dbs = [grad_out(b) if (b is not None and need[3 + n + j]) else None for j, b in enumerate(bs)]
-        dx = train_ops.multi_linear_bwd(xs, [_c(w.detach()) for w in ws], [None if d is None else _c(d) for d in dys], act, dws, dbs,
-                                        want_dx=need[0])
+        wd = [_c(w.detach()) for w in ws]
+        dyc = [None if d is None else _c(d) for d in dys]
+        rows, step = xs.shape[0], train_ops.ML_ROWS
+        if rows <= step:
+            dx = train_ops.multi_linear_bwd(xs, wd, dyc, act, dws, dbs, want_dx=need[0])
+        else:
+            dxs = []
+            for r in range(0, rows, step):
+                first = r == 0
+                tw = [None if d is None else (d if first else torch.empty_like(d)) for d in dws]
+                tb = [None if d is None else (d if first else torch.empty_like(d)) for d in dbs]
+                dxs.append(train_ops.multi_linear_bwd(xs[r:r + step], wd, [None if d is None else d[r:r + step] for d in dyc], act, tw, tb,
+                                                      want_dx=need[0]))
+                if not first:
+                    for acc, part in zip(dws + dbs, tw + tb):
+                        if acc is not None:
+                            acc.add_(part)
+            dx = torch.cat(dxs, dim=0) if need[0] else None
         return (dx, None, None, *dws, *dbs)
 
 
 def multi_linear(x, weights, biases, act=train_ops.ACT_NONE):
+    """Linear layers sharing their input (MultiLinear).  The native kernels need an input width k <= train_ops.ML_KMAX (1024) that is a
+    multiple of 4 - the MUG / MHAD / NATOPS models sit at or below it (dim * 4 + 768 = 1024); a wider conditioning vector (dim = 128)
+    runs the same arithmetic as torch ops on the device."""
+    k = x.shape[1]
+    if k > train_ops.ML_KMAX or k % 4:
+        import torch.nn.functional as F
+        a = {train_ops.ACT_NONE: lambda v: v, train_ops.ACT_SILU: F.silu, train_ops.ACT_GELU: F.gelu}[act](x)
+        return tuple(F.linear(a, w, b) for w, b in zip(weights, biases))
     return MultiLinear.apply(x, act, len(weights), *weights, *biases)
 
 

@@ -298,7 +298,8 @@ class FlowDiffusion(nn.Module):
         if empty:
             dev = next(self.unet.parameters()).device
             s = self.diffusion.image_size
-            self.diffusion.skip_step_draws(self._slice[2], (3, self.diffusion.num_frames, s, s), dev)
+            # (forward() calls self.diffusion(x, fea, text) without focus arguments: prob_focus_present = 0, no focus-mask draw to replay)
+            self.diffusion.skip_step_draws(self._slice[2], (3, self.diffusion.num_frames, s, s), dev, prob_focus_present=0.)
             self.unet.null_cond_mask = torch.zeros(0, dtype=torch.bool, device=dev)
             self.loss = torch.zeros((), device=dev)
             self.rec_loss, self.rec_warp_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)

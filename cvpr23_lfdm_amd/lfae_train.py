@@ -419,7 +419,7 @@ class LFAETrainer:
         if self._dp is not None:
             self._dp.finish()
         self.optimizer.step()
-        self.examples += x["source"].shape[0]
+        self.examples += x["source"].shape[0] * (self._dp.world if self._dp is not None else 1)     # global count, like train.py's 'example'
         out = {k: v.detach() for k, v in losses.items()}
         out["total"] = loss.detach()
         return out, generated
@@ -469,8 +469,25 @@ class FramePairs(torch.utils.data.Dataset):
             videos = found
         self.videos, self.frame_shape = videos, frame_shape
         self.horizontal_flip, self.time_flip, self.jitter = horizontal_flip, time_flip, jitter
+        self.seed = seed
+        self._rng, self._rng_key = None, None
+
+    def _generator(self):
+        """The item's random source.  The reference draws from the global np.random, which torch's DataLoader re-seeds per worker
+        and per epoch; a generator object copied into every forked worker would replay the same draws in all of them.  Here: one
+        generator per (process, DataLoader worker seed) - the worker seed changes with the worker and with every new iterator -
+        mixed with the dataset's own seed."""
+        import os
         import numpy as np
-        self.rng = np.random.default_rng(seed)
+        info = torch.utils.data.get_worker_info()
+        key = (os.getpid(), None if info is None else info.seed)
+        if self._rng is None or self._rng_key != key:
+            mix = [] if self.seed is None else [int(self.seed)]
+            if info is not None:
+                mix.append(int(info.seed) % (1 << 63))
+            self._rng = np.random.default_rng(mix if mix else None)
+            self._rng_key = key
+        return self._rng
 
     def __len__(self):
         return len(self.videos)
@@ -480,15 +497,16 @@ class FramePairs(torch.utils.data.Dataset):
         from .data import _rgb, color_jitter
         from .io_compat import INTER_AREA, imread, resize
         paths = self.videos[index]
-        i, j = np.sort(self.rng.choice(len(paths), size=2, replace=False))
+        rng = self._generator()
+        i, j = np.sort(rng.choice(len(paths), size=2, replace=True))         # replace=True: mug_dataset.py:94
         frames = [_rgb(imread(paths[i])), _rgb(imread(paths[j]))]
         if self.jitter:
             frames = color_jitter(frames, bright=self.jitter.get("brightness", 0.1), contrast=self.jitter.get("contrast", 0.1),
                                   sat=self.jitter.get("saturation", 0.1), hue=self.jitter.get("hue", 0.1))
         frames = [resize(np.asarray(f, np.float32), self.frame_shape, interpolation=INTER_AREA) / 255.0 for f in frames]
-        if self.horizontal_flip and self.rng.random() < 0.5:
+        if self.horizontal_flip and rng.random() < 0.5:
             frames = [f[:, ::-1] for f in frames]
-        if self.time_flip and self.rng.random() < 0.5:
+        if self.time_flip and rng.random() < 0.5:
             frames = frames[::-1]
         src, drv = (torch.from_numpy(np.ascontiguousarray(np.transpose(f, (2, 0, 1)), dtype=np.float32)) for f in frames)
         return {"source": src, "driving": drv, "frame": [paths[i], paths[j]]}

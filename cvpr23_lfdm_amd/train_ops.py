@@ -162,6 +162,7 @@ def linear_attention_bwd(qkv, dout, n_frames, hw):
 
 
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ML_ROWS, ML_KMAX = 16, 1024       # limits of one lfdm_multi_linear_* launch (csrc/train_linear.hip: ml_check)
 
 
 def _ml_params(x, weights, act):

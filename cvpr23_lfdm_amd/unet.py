@@ -325,10 +325,13 @@ class Unet3D(ParamTree):
         if gn is not None:
             p.gn_partial = 1      # (placeholder: "fused statistics wanted" changes the plan - schedules 3 / 4 have none; include/lfdm_hip.h)
         tile_rows, ksplit = ops.conv_plan(p)
+        # (sized while the placeholder is still set: the slab buffer must belong to the plan the launch will re-derive with the real
+        # gn_partial - without it schedules 3 / 4 would plan ksplit = 1 and size it 0)
+        partial_floats = ops.conv_partial_floats(p) if ksplit > 1 else 0
         p.gn_partial = None
         m = n_img * p.hq * p.wq
         if ksplit > 1:
-            part = self._buf(scratch, 1, ops.conv_partial_floats(p))      # slabs (+ LayerNorm row statistics)
+            part = self._buf(scratch, 1, partial_floats)      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
         if (gn is not None and _GN_COOP and src0.is_cuda and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and

@@ -85,6 +85,8 @@ def test_lfae_train_step_tiny(backend):
 
 @pytest.mark.gpu
 def test_lfae_train_step_mug128():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
     _check("mug128", "cuda", 5e-3)
 
 
@@ -119,9 +121,21 @@ def test_frame_pairs_dataset(tmp_path):
             it = ds[idx]
             assert it["source"].shape == (3, 16, 16) and it["driving"].dtype == torch.float32
             assert 0.0 <= float(it["source"].min()) and float(it["driving"].max()) <= 1.0
-            assert os.path.dirname(it["frame"][0]) == os.path.dirname(it["frame"][1]) and it["frame"][0] != it["frame"][1]
+            # (the two indices are drawn WITH replacement, mug_dataset.py:94: the same frame twice is a legal item)
+            assert os.path.dirname(it["frame"][0]) == os.path.dirname(it["frame"][1]) and it["frame"][0] <= it["frame"][1]
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
     assert batch["source"].shape == (2, 3, 16, 16)
+    # forked DataLoader workers must not replay one another's draws, and a new iterator (= a new epoch in tools/train_lfae.py) must not
+    # replay the previous one: 12 items of the 5-frame video per worker and epoch
+    big = lfae_train.FramePairs([ds.videos[0]] * 24, frame_shape=16, jitter=None, seed=3)
+    seen = []
+    for _ in range(2):
+        frames = [[], []]
+        for i, item in enumerate(torch.utils.data.DataLoader(big, batch_size=1, num_workers=2)):
+            frames[i % 2].append((item["frame"][0][0], item["frame"][1][0], float(item["source"][0, 0, 0, 0]) > float(item["source"][0, 0, 0, -1])))
+        assert frames[0] != frames[1], "both workers drew the same sequence"
+        seen.append(frames)
+    assert seen[0] != seen[1], "the second epoch replayed the first"
 
 
 _DP_WORKER = r'''

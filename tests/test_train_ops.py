@@ -198,7 +198,8 @@ def test_depthwise_down(backend):
 
 
 @pytest.mark.parametrize("rows,k,ns,act", [(8, 1024, (128, 256, 2048, 128), 1), (2, 64, (256,), 0), (3, 256, (256,), 2),
-                                            (16, 32, (8, 24, 4), 1), (8, 8, tuple([8] * 32), 2)])
+                                            (16, 32, (8, 24, 4), 1), (8, 8, tuple([8] * 32), 2),
+                                            (20, 64, (16, 24, 8, 4), 1), (37, 32, (12,), 2), (5, 1030, (8, 4), 1)])
 def test_multi_linear(backend, rows, k, ns, act):
     """lfdm_multi_linear_f32 / _bwd_f32 against torch: every ResnetBlock.mlp of a forward (SiLU -> Linear on the shared cat(time_emb,
     cond), video_flow_diffusion.py:230-233,562) and the two time_mlp layers (:441-447), incl. a missing bias, an unused output (dy = None)
