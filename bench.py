@@ -759,8 +759,10 @@ def kernel_census(step, dev):
     vendor = sorted(((n, r) for n, r in rows.items() if not is_native(n)), key=lambda kv: -kv[1][1])
     return {"launches_per_step": launches, "native_launches": nat_n, "device_us_per_step": round(total_us, 1),
             "native_time_share": round(nat_us / total_us, 4) if total_us else None,
-            "vendor_top": [{"kernel": n[:90], "calls": r[0], "us": round(r[1], 1)} for n, r in vendor[:8]],
-            "vendor_families": sorted({f for n, _ in vendor for f in ("miopen", "MIOpen", "ck::", "grid_sampler_2d", "Cijk_")
+            "vendor_top": [{"kernel": n[:160], "calls": r[0], "us": round(r[1], 1)} for n, r in vendor[:int(os.environ.get("LFDM_CENSUS_TOP", "8"))]],
+            "native_top": [{"kernel": n[:100], "calls": r[0], "us": round(r[1], 1)}
+                           for n, r in sorted(((n, r) for n, r in rows.items() if is_native(n)), key=lambda kv: -kv[1][1])[:int(os.environ.get("LFDM_CENSUS_TOP", "8"))]],
+            "vendor_families": sorted({f for n, _ in vendor for f in ("miopen", "MIOpen", "ck::", "_ZN2ck", "grid_sampler_2d", "Cijk_")
                                        if f in n}),
             "how": "torch.profiler device events of one step; native = kernel symbols defined in liblfdm_hip.so"}
 

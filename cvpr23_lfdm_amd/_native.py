@@ -89,6 +89,38 @@ class MultiLinearParams(C.Structure):
     ]
 
 
+class BlurParams(C.Structure):
+    _fields_ = [
+        ("x", f32p), ("wgt", f32p), ("out", f32p), ("dy", f32p), ("dx", f32p),
+        ("xs_n", i64), ("xs_c", i64), ("xs_h", i64), ("xs_w", i64), ("os_n", i64), ("os_c", i64), ("os_h", i64), ("os_w", i64),
+        ("n_img", i32), ("channels", i32), ("c_store", i32), ("h", i32), ("w", i32), ("k", i32), ("pad_lo", i32), ("pad_hi", i32),
+        ("stride", i32),
+        ("scale", f32p), ("bias", f32p),
+    ]
+
+
+class WarpBwdParams(C.Structure):
+    _fields_ = [
+        ("src", f32p), ("dout", f32p), ("prev", f32p), ("dprev", f32p), ("dsrc_fix", C.c_void_p), ("amax_bits", C.c_void_p),
+        ("dmaps", f32p), ("flow_x", f32p), ("flow_y", f32p), ("occ", f32p),
+        ("n_img", i32), ("h", i32), ("w", i32), ("c", i32), ("fh", i32), ("fw", i32), ("n_div", i32), ("layout_cl", i32),
+        ("fsn", i64),
+        ("ld_src", i32), ("ld_dout", i32), ("ld_prev", i32), ("ld_dprev", i32),
+        ("ss_n", i64), ("ss_c", i64), ("ss_h", i64), ("ss_w", i64), ("ds_n", i64), ("ds_c", i64), ("ds_h", i64), ("ds_w", i64),
+        ("ps_n", i64), ("ps_c", i64), ("ps_h", i64), ("ps_w", i64), ("dps_n", i64), ("dps_c", i64), ("dps_h", i64), ("dps_w", i64),
+    ]
+
+
+class GridSampleParams(C.Structure):
+    _fields_ = [
+        ("x", f32p), ("grid", f32p), ("out", f32p), ("dout", f32p), ("dgrid", f32p),
+        ("xs_n", i64), ("xs_c", i64), ("xs_h", i64), ("xs_w", i64), ("os_n", i64), ("os_c", i64), ("os_h", i64), ("os_w", i64),
+        ("n_img", i32), ("channels", i32), ("h", i32), ("w", i32), ("ho", i32), ("wo", i32), ("n_div", i32), ("pad_mode", i32),
+    ]
+
+
+BN_TICKETS = 1024
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "lfdm_last_error": (C.c_char_p, []),
@@ -174,6 +206,21 @@ _SIGNATURES = {
     "lfdm_upsample2_pad_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, i32, i32, i32, stream_t]),
     "lfdm_layernorm_bwd_ws_bytes": (sz, [i64, i32]),
     "lfdm_layernorm_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, f32p, f32, f32p, C.c_void_p, sz, stream_t]),
+    # ---- LFAE stage-1 training glue (ABI 10)
+    "lfdm_batchnorm_train_ws_bytes": (sz, [i64, i32]),
+    "lfdm_batchnorm_train_fwd_cl_f32": (i32, [f32p, f32p, i64, i32, i32, i32, f32p, f32p, f32p, f32p, f32, f32, i32, f32p, C.c_void_p, sz,
+                                            C.c_void_p, stream_t]),
+    "lfdm_batchnorm_train_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32p, C.c_void_p, sz,
+                                            C.c_void_p, stream_t]),
+    "lfdm_blur_down_fwd_f32": (i32, [C.POINTER(BlurParams), stream_t]),
+    "lfdm_blur_down_bwd_f32": (i32, [C.POINTER(BlurParams), stream_t]),
+    "lfdm_warp_bwd_f32": (i32, [C.POINTER(WarpBwdParams), stream_t]),
+    "lfdm_absmax_f32": (i32, [f32p, i64, i32, i64, C.c_void_p, stream_t]),
+    "lfdm_fix_finalize_f32": (i32, [C.c_void_p, f32p, i64, i32, i64, C.c_void_p, i64, C.c_void_p, stream_t]),
+    "lfdm_resize_adjoint_f32": (i32, [f32p, f32p, i32, i32, i32, i32, i32, stream_t]),
+    "lfdm_grid_sample_fwd_f32": (i32, [C.POINTER(GridSampleParams), stream_t]),
+    "lfdm_grid_sample_bwd_f32": (i32, [C.POINTER(GridSampleParams), stream_t]),
+    "lfdm_svd2x2_sym_bwd_f32": (i32, [f32p, f32p, f32p, f32p, f32p, i64, stream_t]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

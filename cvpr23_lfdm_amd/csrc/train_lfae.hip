@@ -1,0 +1,913 @@
+// Native glue of LFAE stage-1 training (include/lfdm_hip.h, ABI version 10): what connects the convolutions of
+// LFAE/modules/model.py:141-217 - everything the round-4 trainer left to MIOpen / composable_kernel / ATen kernels.
+//
+//  lfdm_batchnorm_train_{fwd,bwd}_cl_f32  nn.BatchNorm2d with BATCH statistics (+ ReLU) on channels-last rows (util.py:70-150: ResBlock2d,
+//      UpBlock2d, DownBlock2d, SameBlock2d), forward and backward as TWO launches each: a row-chunk reduce whose last workgroup per
+//      32-chunk group folds its group (ticket, fixed order: run-to-run identical), and an apply pass whose workgroups finish the merge for
+//      their 64 channels.  Replaces 6 MIOpenBatchNorm* + clamp + threshold kernels x 62 layers per step.  HBM-bound: forward reads x
+//      twice and writes y (12 B / element), backward reads x and dy twice and writes dx (20 B / element).
+//  lfdm_blur_down_{fwd,bwd}_f32           AntiAliasInterpolation2d (util.py:217-264) and the ImagePyramide levels (model.py:62-82): depth-wise
+//      Gaussian + every s-th pixel, any input / output strides (an NCHW image or the 4-channel rows a convolution wants), optional per-
+//      channel affine epilogue (the VGG input normalisation, model.py:52).  Only kept outputs are computed.
+//  lfdm_warp_bwd_f32 (+ absmax / fixed-point finalize / resize adjoint)   backward of deform_input + apply_optical (generator.py:59-88):
+//      gradient of grid_sample (bilinear, zeros) w.r.t. the sampled tensor, the flow, the occlusion map and the blended tensor.  The
+//      scatter into the sampled tensor's gradient accumulates 64-bit FIXED-POINT integers (integer atomics commute: the result does not
+//      depend on the order the workgroups arrive in, unlike ATen's float atomics), scaled per call from max |dout| so that the rounding
+//      step is ~2^-40 of that maximum.
+//  lfdm_grid_sample_{fwd,bwd}_f32         F.grid_sample on small-channel planar tensors with an explicit grid (pixelwise_flow_predictor.py:95-
+//      102 deformed sources - gradient w.r.t. the grid only; model.py:118-122 Transform.transform_frame with reflection padding).
+//  lfdm_svd2x2_sym_bwd_f32                backward of torch.svd on the 2x2 region covariances (region_predictor.py:16-26), closed form.
+#include <math.h>
+
+#include "lfdm_device.h"
+#include "../../include/lfdm_hip.h"
+
+namespace {
+
+// =====================================================================================================================================
+// BatchNorm (batch statistics) + ReLU
+// =====================================================================================================================================
+constexpr int BN_GROUP = 32;          // chunks folded by one level-1 finalizer
+constexpr int BN_MAX_CHUNKS = 1024;   // -> at most 32 level-2 partials per channel
+constexpr int BN_MIN_ROWS = 128;      // rows per chunk, at least
+
+struct BnGeom {
+  int q, lanes, tw, ctiles, nchunk, chunk_rows, ngroups;
+};
+
+BnGeom bn_geom(int64_t rows, int c) {
+  BnGeom g;
+  g.q = c > 32 ? 16 : (c > 16 ? 8 : 4);            // float4 lanes per row inside a workgroup
+  g.lanes = 256 / g.q;
+  g.tw = 4 * g.q;                                  // channels per workgroup column
+  g.ctiles = (c + g.tw - 1) / g.tw;
+  int64_t want = (rows + BN_MIN_ROWS - 1) / BN_MIN_ROWS;
+  if (want < 1) want = 1;
+  if (want > BN_MAX_CHUNKS) want = BN_MAX_CHUNKS;
+  g.chunk_rows = (int)((rows + want - 1) / want);
+  g.nchunk = (int)((rows + g.chunk_rows - 1) / g.chunk_rows);
+  g.ngroups = (g.nchunk + BN_GROUP - 1) / BN_GROUP;
+  return g;
+}
+
+struct BnArgs {
+  const float* x;
+  const float* dy;          // backward only
+  float* out;               // y (forward) / dx (backward)
+  int64_t rows;
+  int c, ldx, lddy, ldo;
+  const float* gamma;
+  const float* beta;
+  float* stat;              // [mean (c) | rstd (c)]: written by the forward, read by the backward
+  float* running_mean;      // forward, may be null
+  float* running_var;
+  float momentum, eps;
+  int relu;
+  int q, chunk_rows, nchunk, ngroups;
+  float* part1;             // [ctile][chunk][2][tw] float
+  double* part2;            // [ctile][group][2][tw] double
+  unsigned* tickets;        // [ctile][group], zero between launches
+  float* dgamma;            // backward
+  float* dbeta;
+};
+
+// MODE 0: (sum (x - x[row 0]), sum (x - x[row 0])^2).  MODE 1: (sum g, sum g * xhat) with g = dy masked by the ReLU of the recomputed forward.
+// grid (nchunk, ctiles), 256 threads = `lanes` row lanes x q float4 columns.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(BnArgs a) {
+  __shared__ float sm[2][256 * 4];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, q = a.q, lanes = 256 / q, tw = 4 * q;
+  const int quad = tid & (q - 1), rl = tid / q;
+  const int chunk = blockIdx.x, ct = blockIdx.y;
+  const int ch = ct * tw + quad * 4;
+  const bool cvalid = ch < a.c;
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  const int64_t r1 = r0 + a.chunk_rows < a.rows ? r0 + a.chunk_rows : a.rows;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  float4 mu = s0, rs = s0, ga = s0, be = s0;
+  if (MODE == 0 && cvalid) mu = *reinterpret_cast<const float4*>(a.x + ch);      // pivot = row 0: sums of (x - pivot) do not cancel in E[x^2] - E[x]^2
+  if (MODE == 1 && cvalid) {
+    mu = *reinterpret_cast<const float4*>(a.stat + ch);
+    rs = *reinterpret_cast<const float4*>(a.stat + a.c + ch);
+    ga = *reinterpret_cast<const float4*>(a.gamma + ch);
+    be = *reinterpret_cast<const float4*>(a.beta + ch);
+  }
+  if (cvalid) {
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
+      if (MODE == 0) {
+        const float dx_ = v.x - mu.x, dy_ = v.y - mu.y, dz_ = v.z - mu.z, dw_ = v.w - mu.w;
+        s0.x += dx_; s0.y += dy_; s0.z += dz_; s0.w += dw_;
+        s1.x = fmaf(dx_, dx_, s1.x); s1.y = fmaf(dy_, dy_, s1.y); s1.z = fmaf(dz_, dz_, s1.z); s1.w = fmaf(dw_, dw_, s1.w);
+      } else {
+        float4 g = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch);
+        const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z, hw = (v.w - mu.w) * rs.w;
+        if (a.relu) {
+          if (!(fmaf(hx, ga.x, be.x) > 0.f)) g.x = 0.f;
+          if (!(fmaf(hy, ga.y, be.y) > 0.f)) g.y = 0.f;
+          if (!(fmaf(hz, ga.z, be.z) > 0.f)) g.z = 0.f;
+          if (!(fmaf(hw, ga.w, be.w) > 0.f)) g.w = 0.f;
+        }
+        s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+        s1.x = fmaf(g.x, hx, s1.x); s1.y = fmaf(g.y, hy, s1.y); s1.z = fmaf(g.z, hz, s1.z); s1.w = fmaf(g.w, hw, s1.w);
+      }
+    }
+  }
+  float* m0 = &sm[0][tid * 4];
+  float* m1 = &sm[1][tid * 4];
+  m0[0] = s0.x; m0[1] = s0.y; m0[2] = s0.z; m0[3] = s0.w;
+  m1[0] = s1.x; m1[1] = s1.y; m1[2] = s1.z; m1[3] = s1.w;
+  __syncthreads();
+  const int which = tid / tw, chn = tid - which * tw;        // tid < 2 * tw: one (sum, channel) each
+  float* p1 = a.part1 + (((int64_t)ct * a.nchunk + chunk) * 2) * tw;
+  if (tid < 2 * tw) {
+    const int qd = chn >> 2, comp = chn & 3;
+    float acc = 0.f;
+    for (int l = 0; l < lanes; ++l) acc += sm[which][(l * q + qd) * 4 + comp];      // fixed order
+    p1[which * tw + chn] = acc;
+  }
+  // level-1 fold by the workgroup that completes its group of BN_GROUP chunks (lfdm_device.h: ticket hand-off)
+  LFDM_DRAIN_STORES();
+  __syncthreads();
+  const int grp = chunk / BN_GROUP;
+  const int c0 = grp * BN_GROUP, c1 = c0 + BN_GROUP < a.nchunk ? c0 + BN_GROUP : a.nchunk;
+  if (tid == 0) {
+    LFDM_FENCE_RELEASE_AGENT();
+    LFDM_DRAIN_STORES();
+    unsigned* cnt = a.tickets + ct * a.ngroups + grp;
+    const bool last = lfdm_ticket_take(cnt) == (unsigned)(c1 - c0 - 1);
+    if (last) {
+      lfdm_ticket_reset(cnt);
+      LFDM_FENCE_ACQUIRE_AGENT();
+    }
+    s_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid < 2 * tw) {
+    double acc = 0.0;
+    for (int k = c0; k < c1; ++k) acc += (double)a.part1[(((int64_t)ct * a.nchunk + k) * 2 + which) * tw + chn];
+    a.part2[(((int64_t)ct * a.ngroups + grp) * 2 + which) * tw + chn] = acc;
+  }
+}
+
+// grid (nchunk, ctiles).  MODE 0: y = relu(xhat * gamma + beta), statistics + running statistics written by chunk 0.
+// MODE 1: dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), dgamma / dbeta written by chunk 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
+  __shared__ float s_mu[64], s_rs[64], s_ga[64], s_be[64], s_k1[64], s_k2[64];
+  const int tid = threadIdx.x, q = a.q, lanes = 256 / q, tw = 4 * q;
+  const int chunk = blockIdx.x, ct = blockIdx.y;
+  if (tid < tw) {
+    const int channel = ct * tw + tid;
+    if (channel < a.c) {
+      double S0 = 0.0, S1 = 0.0;
+      for (int g = 0; g < a.ngroups; ++g) {
+        S0 += a.part2[(((int64_t)ct * a.ngroups + g) * 2 + 0) * tw + tid];
+        S1 += a.part2[(((int64_t)ct * a.ngroups + g) * 2 + 1) * tw + tid];
+      }
+      const double m = (double)a.rows;
+      if (MODE == 0) {
+        const double shifted = S0 / m;                 // mean of (x - pivot), pivot = row 0 (bn_reduce_kernel)
+        const double mean = (double)a.x[channel] + shifted;
+        double var = S1 / m - shifted * shifted;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        s_mu[tid] = (float)mean;
+        s_rs[tid] = rstd;
+        if (chunk == 0) {
+          a.stat[channel] = (float)mean;
+          a.stat[a.c + channel] = rstd;
+          if (a.running_mean) {
+            const double unbiased = a.rows > 1 ? var * m / (m - 1.0) : var;
+            a.running_mean[channel] = (float)((1.0 - a.momentum) * (double)a.running_mean[channel] + a.momentum * mean);
+            a.running_var[channel] = (float)((1.0 - a.momentum) * (double)a.running_var[channel] + a.momentum * unbiased);
+          }
+        }
+      } else {
+        s_mu[tid] = a.stat[channel];
+        s_rs[tid] = a.stat[a.c + channel];
+        s_k1[tid] = (float)(S0 / m);
+        s_k2[tid] = (float)(S1 / m);
+        if (chunk == 0) {
+          if (a.dbeta) a.dbeta[channel] = (float)S0;
+          if (a.dgamma) a.dgamma[channel] = (float)S1;
+        }
+      }
+      s_ga[tid] = a.gamma[channel];
+      s_be[tid] = a.beta[channel];
+    }
+  }
+  __syncthreads();
+  const int quad = tid & (q - 1), rl = tid / q;
+  const int ch = ct * tw + quad * 4;
+  if (ch >= a.c) return;
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  const int64_t r1 = r0 + a.chunk_rows < a.rows ? r0 + a.chunk_rows : a.rows;
+  float mu[4], rs[4], ga[4], be[4], k1[4], k2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mu[i] = s_mu[quad * 4 + i]; rs[i] = s_rs[quad * 4 + i]; ga[i] = s_ga[quad * 4 + i]; be[i] = s_be[quad * 4 + i];
+    k1[i] = MODE == 1 ? s_k1[quad * 4 + i] : 0.f;
+    k2[i] = MODE == 1 ? s_k2[quad * 4 + i] : 0.f;
+  }
+  for (int64_t r = r0 + rl; r < r1; r += lanes) {
+    const float4 v4 = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float o[4];
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z = fmaf((v[i] - mu[i]) * rs[i], ga[i], be[i]);
+        o[i] = (a.relu && !(z > 0.f)) ? 0.f : z;
+      }
+    } else {
+      const float4 g4 = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float h = (v[i] - mu[i]) * rs[i];
+        float gi = g[i];
+        if (a.relu && !(fmaf(h, ga[i], be[i]) > 0.f)) gi = 0.f;
+        o[i] = ga[i] * rs[i] * (gi - k1[i] - h * k2[i]);
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + r * a.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// =====================================================================================================================================
+// depth-wise blur + subsample, any strides
+// =====================================================================================================================================
+constexpr int BLUR_MAX_TAPS = 32 * 32;
+
+struct BlurArgs {
+  const float* x;           // forward input / backward: unused
+  const float* wgt;         // (C, k, k)
+  float* out;               // forward output
+  const float* dy;          // backward: gradient of the forward output (out strides)
+  float* dx;                // backward: gradient of the input (x strides)
+  int64_t xs_n, xs_c, xs_h, xs_w, os_n, os_c, os_h, os_w;
+  int channels, c_store, h, w, k, pad, stride, ho, wo;
+  const float* scale;       // per channel, or null (1)
+  const float* bias;        // per channel, or null (0)
+};
+
+// grid (ceil(ho*wo/256), c_store, N): out = scale[c] * (blur(x))[every stride-th] + bias[c]; channels >= `channels` store zeros
+__global__ __launch_bounds__(256) void blur_down_kernel(BlurArgs a) {
+  __shared__ float s_w[BLUR_MAX_TAPS];
+  const int c = blockIdx.y, n = blockIdx.z, k = a.k;
+  const bool real = c < a.channels;
+  if (real)
+    for (int i = threadIdx.x; i < k * k; i += 256) s_w[i] = a.wgt[(int64_t)c * k * k + i];
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.ho * a.wo) return;
+  const int oy = o / a.wo, ox = o - oy * a.wo;
+  float acc = 0.f;
+  if (real) {
+    const float* plane = a.x + n * a.xs_n + c * a.xs_c;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * a.stride + ky - a.pad;
+      if (iy < 0 || iy >= a.h) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * a.stride + kx - a.pad;
+        if (ix >= 0 && ix < a.w) acc = fmaf(plane[iy * a.xs_h + ix * a.xs_w], s_w[ky * k + kx], acc);
+      }
+    }
+    if (a.scale) acc *= a.scale[c];
+    if (a.bias) acc += a.bias[c];
+  }
+  a.out[n * a.os_n + c * a.os_c + oy * a.os_h + ox * a.os_w] = acc;
+}
+
+// grid (ceil(h*w/256), channels, N): dx[y, x] = scale[c] * sum over the outputs whose window covers (y, x) of w[ky][kx] * dy[oy, ox]
+__global__ __launch_bounds__(256) void blur_down_bwd_kernel(BlurArgs a) {
+  __shared__ float s_w[BLUR_MAX_TAPS];
+  const int c = blockIdx.y, n = blockIdx.z, k = a.k, s = a.stride;
+  for (int i = threadIdx.x; i < k * k; i += 256) s_w[i] = a.wgt[(int64_t)c * k * k + i];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.h * a.w) return;
+  const int y = i / a.w, x = i - y * a.w;
+  // ky = y + pad - oy*s in [0, k)  <=>  oy in [ceil((y + pad - k + 1) / s), floor((y + pad) / s)]
+  const int ty = y + a.pad, tx = x + a.pad;
+  int oy0 = ty - k + 1 <= 0 ? 0 : (ty - k + 1 + s - 1) / s, oy1 = ty / s;
+  int ox0 = tx - k + 1 <= 0 ? 0 : (tx - k + 1 + s - 1) / s, ox1 = tx / s;
+  if (oy1 > a.ho - 1) oy1 = a.ho - 1;
+  if (ox1 > a.wo - 1) ox1 = a.wo - 1;
+  const float* plane = a.dy + n * a.os_n + c * a.os_c;
+  float acc = 0.f;
+  for (int oy = oy0; oy <= oy1; ++oy)
+    for (int ox = ox0; ox <= ox1; ++ox)
+      acc = fmaf(plane[oy * a.os_h + ox * a.os_w], s_w[(ty - oy * s) * k + (tx - ox * s)], acc);
+  if (a.scale) acc *= a.scale[c];
+  a.dx[n * a.xs_n + c * a.xs_c + y * a.xs_h + x * a.xs_w] = acc;
+}
+
+// =====================================================================================================================================
+// grid_sample / warp backward
+// =====================================================================================================================================
+// ATen upsample_bilinear2d (align_corners=False) source index - the same arithmetic as warp.hip's forward
+__device__ __forceinline__ void resize_src(int dst, int n_in, int n_out, int& i0, int& i1, float& l1) {
+  const float scale = (float)n_in / (float)n_out;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+struct WTaps {
+  int x0, y0;
+  float wx0, wx1, wy0, wy1;
+  float occ;
+};
+
+__device__ __forceinline__ float bilerp4(const float* m, int fw, int y0, int y1, int x0, int x1, float ly, float lx) {
+  const float v00 = m[y0 * fw + x0], v01 = m[y0 * fw + x1];
+  const float v10 = m[y1 * fw + x0], v11 = m[y1 * fw + x1];
+  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+// the forward's per-pixel set-up (warp.hip: pixel_taps), frames == 1 per sample
+__device__ __forceinline__ WTaps warp_taps(const lfdm_warp_bwd_params& p, int n, int oy, int ox) {
+  const int64_t moff = (int64_t)n * p.fsn;
+  float gx, gy, o = 1.f;
+  if (p.fh == p.h && p.fw == p.w) {
+    gx = p.flow_x[moff + oy * p.fw + ox];
+    gy = p.flow_y[moff + oy * p.fw + ox];
+    if (p.occ) o = p.occ[moff + oy * p.fw + ox];
+  } else {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    resize_src(oy, p.fh, p.h, y0, y1, ly);
+    resize_src(ox, p.fw, p.w, x0, x1, lx);
+    gx = bilerp4(p.flow_x + moff, p.fw, y0, y1, x0, x1, ly, lx);
+    gy = bilerp4(p.flow_y + moff, p.fw, y0, y1, x0, x1, ly, lx);
+    if (p.occ) o = bilerp4(p.occ + moff, p.fw, y0, y1, x0, x1, ly, lx);
+  }
+  float ix = ((gx + 1.f) * (float)p.w - 1.f) * 0.5f;
+  float iy = ((gy + 1.f) * (float)p.h - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  WTaps r;
+  r.x0 = (int)fx;
+  r.y0 = (int)fy;
+  r.wx1 = ix - fx;
+  r.wx0 = (fx + 1.f) - ix;
+  r.wy1 = iy - fy;
+  r.wy0 = (fy + 1.f) - iy;
+  r.occ = o;
+  return r;
+}
+
+// exponent k of the fixed-point scale 2^k for a scatter whose terms are bounded by `amax` and whose per-address count is bounded by
+// `count`: count * amax * 2^k < 2^62
+__device__ __forceinline__ int fix_exponent(unsigned amax_bits, int64_t count) {
+  const float amax = __uint_as_float(amax_bits);
+  if (!(amax > 0.f)) return 0;
+  int e;
+  frexpf(amax, &e);                     // amax = m * 2^e, m in [0.5, 1)  ->  amax < 2^e
+  int lc = 0;
+  while (((int64_t)1 << lc) < count) ++lc;
+  int k = 62 - lc - e;
+  if (k > 120) k = 120;
+  if (k < -120) k = -120;
+  return k;
+}
+
+__device__ __forceinline__ void fix_add(long long* acc, float v, int k) {
+  if (v == 0.f) return;
+  const long long q = (long long)rintf(ldexpf(v, k));
+#if defined(LFDM_EMU_BUILD)
+  __atomic_fetch_add(acc, q, __ATOMIC_SEQ_CST);
+#else
+  __hip_atomic_fetch_add(acc, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// max |x| over a strided (rows, c) matrix as the bit pattern of a non-negative float (integer max: order independent)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int c, int64_t ld, unsigned* out) {
+  __shared__ float s_m[4];
+  float m = 0.f;
+  const int64_t total = rows * c;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c;
+    const float v = fabsf(x[r * ld + (i - r * c)]);
+    if (v > m) m = v;                   // NaN never wins: a NaN gradient stays a NaN through the float paths of the caller
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    atomicMax(out, __float_as_uint(m));
+  }
+}
+
+// fixed-point accumulator -> float (+= nothing: plain store), accumulator re-zeroed for the next call.  The LAST workgroup also clears
+// the max word (ticket), so the workspace is ready for the next backward without a memset launch.
+__global__ __launch_bounds__(256) void fix_finalize_kernel(long long* __restrict__ acc, float* __restrict__ out, int64_t rows, int c, int64_t ld,
+                                                           unsigned* amax_bits, int64_t count, unsigned* ticket) {
+  const int k = fix_exponent(*amax_bits, count);
+  const int64_t total = rows * c;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const long long q = acc[i];
+    acc[i] = 0;
+    const int64_t r = i / c;
+    out[r * ld + (i - r * c)] = (float)ldexp((double)q, -k);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (lfdm_ticket_take(ticket) == gridDim.x - 1) {
+      lfdm_ticket_reset(ticket);
+      *amax_bits = 0u;
+    }
+  }
+}
+
+// Channels-last backward of out = warp(src; flow) * occ + prev * (1 - occ).  A pixel is served by G = C/4 adjacent lanes (a power of two
+// <= 64).  Per pixel: d_prev = dout * (1 - occ); d_src[tap] += w_tap * occ * dout (fixed point); the three map gradients
+// (d flow_x, d flow_y, d occ) at OUTPUT resolution into dmaps (N, 3, H, W) - lfdm_resize_adjoint folds them to the map resolution.
+// grid (blocks over h*w*G lane items, N)
+__global__ __launch_bounds__(256) void warp_bwd_cl_kernel(lfdm_warp_bwd_params p) {
+  const int g = p.c >> 2;
+  const int gshift = __builtin_ctz(g);
+  const int hw = p.h * p.w;
+  const int per_img = hw * g;
+  const int n = blockIdx.y;
+  const int kfix = p.dsrc_fix ? fix_exponent(*p.amax_bits, (int64_t)4 * hw) : 0;
+  for (int idx0 = blockIdx.x * 256; idx0 < per_img; idx0 += gridDim.x * 256) {
+    const int idx = idx0 + threadIdx.x;
+    const bool live = idx < per_img;          // (per_img is a multiple of 64 whenever hw * g is; keep the shuffles convergent anyway)
+    const int pix = live ? (idx >> gshift) : 0;
+    const int c = (idx - ((idx >> gshift) << gshift)) * 4;
+    const int oy = pix / p.w, ox = pix - oy * p.w;
+    const int64_t gp = (int64_t)n * hw + pix;
+    float dfx = 0.f, dfy = 0.f, dob = 0.f;
+    if (live) {
+      const WTaps tp = warp_taps(p, n, oy, ox);
+      const float4 d4 = *reinterpret_cast<const float4*>(p.dout + gp * p.ld_dout + c);
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+      const float o = tp.occ, om = 1.f - o;
+      float pv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.prev) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.prev + gp * p.ld_prev + c);
+        pv[0] = t4.x; pv[1] = t4.y; pv[2] = t4.z; pv[3] = t4.w;
+      }
+      if (p.dprev) *reinterpret_cast<float4*>(p.dprev + gp * p.ld_dprev + c) = make_float4(d[0] * om, d[1] * om, d[2] * om, d[3] * om);
+      float v[4][4];
+      bool in[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+        in[k] = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[k]) t4 = *reinterpret_cast<const float4*>(p.src + ((int64_t)n * hw + yy * p.w + xx) * p.ld_src + c);
+        v[k][0] = t4.x; v[k][1] = t4.y; v[k][2] = t4.z; v[k][3] = t4.w;
+      }
+      const float wk[4] = {tp.wx0 * tp.wy0, tp.wx1 * tp.wy0, tp.wx0 * tp.wy1, tp.wx1 * tp.wy1};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dw = d[i] * o;                                   // gradient of the warped value
+        // warped value in the forward's order: taps (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+        float wv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv = fmaf(v[k][i], in[k] ? wk[k] : 0.f, wv);
+        dob += d[i] * (wv - pv[i]);
+        // d warped / d ix, d iy (grid_sampler_2d_backward: out-of-range taps contribute zero)
+        const float gx_ = (v[1][i] - v[0][i]) * tp.wy0 + (v[3][i] - v[2][i]) * tp.wy1;
+        const float gy_ = (v[2][i] - v[0][i]) * tp.wx0 + (v[3][i] - v[1][i]) * tp.wx1;
+        dfx = fmaf(dw, gx_, dfx);
+        dfy = fmaf(dw, gy_, dfy);
+      }
+      if (p.dsrc_fix) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!in[k]) continue;
+          const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+          long long* dst = p.dsrc_fix + ((int64_t)n * hw + yy * p.w + xx) * p.c + c;
+          const float wo = wk[k] * o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fix_add(dst + i, d[i] * wo, kfix);
+        }
+      }
+    }
+    // sum over the pixel's G lanes (adjacent lanes of one wavefront; G <= 64 is a power of two)
+    for (int m = 1; m < g; m <<= 1) {
+      dfx += __shfl_xor(dfx, m);
+      dfy += __shfl_xor(dfy, m);
+      dob += __shfl_xor(dob, m);
+    }
+    if (live && c == 0 && p.dmaps) {
+      float* dm = p.dmaps + (int64_t)n * 3 * hw + pix;
+      dm[0] = dfx * (0.5f * (float)p.w);
+      dm[hw] = dfy * (0.5f * (float)p.h);
+      dm[2 * hw] = dob;
+    }
+  }
+}
+
+// The same backward for tensors with few channels and any strides (the RGB image of generator.py:126-128; the deformed sources of
+// pixelwise_flow_predictor.py:95-102 with src shared by `n_div` consecutive samples): one thread per output pixel loops over the channels.
+// d_src is not produced (the sampled tensor is an input image).  grid (ceil(h*w/256), N)
+__global__ __launch_bounds__(256) void warp_bwd_px_kernel(lfdm_warp_bwd_params p) {
+  const int hw = p.h * p.w;
+  const int n = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= hw) return;
+  const int oy = pix / p.w, ox = pix - oy * p.w;
+  const WTaps tp = warp_taps(p, n, oy, ox);
+  const float o = tp.occ, om = 1.f - o;
+  const float wk[4] = {tp.wx0 * tp.wy0, tp.wx1 * tp.wy0, tp.wx0 * tp.wy1, tp.wx1 * tp.wy1};
+  bool in[4];
+  int64_t off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+    in[k] = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+    off[k] = in[k] ? yy * p.ss_h + xx * p.ss_w : 0;
+  }
+  const float* sb = p.src + (int64_t)(n / p.n_div) * p.ss_n;
+  float dfx = 0.f, dfy = 0.f, dob = 0.f;
+  for (int c = 0; c < p.c; ++c) {
+    const float d = p.dout[n * p.ds_n + c * p.ds_c + oy * p.ds_h + ox * p.ds_w];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = in[k] ? sb[c * p.ss_c + off[k]] : 0.f;
+    float wv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv = fmaf(v[k], in[k] ? wk[k] : 0.f, wv);
+    float pv = 0.f;
+    if (p.prev) pv = p.prev[n * p.ps_n + c * p.ps_c + oy * p.ps_h + ox * p.ps_w];
+    if (p.dprev) p.dprev[n * p.dps_n + c * p.dps_c + oy * p.dps_h + ox * p.dps_w] = d * om;
+    dob += d * (wv - pv);
+    const float dw = d * o;
+    dfx = fmaf(dw, (v[1] - v[0]) * tp.wy0 + (v[3] - v[2]) * tp.wy1, dfx);
+    dfy = fmaf(dw, (v[2] - v[0]) * tp.wx0 + (v[3] - v[1]) * tp.wx1, dfy);
+  }
+  float* dm = p.dmaps + (int64_t)n * 3 * hw + pix;
+  dm[0] = dfx * (0.5f * (float)p.w);
+  dm[hw] = dfy * (0.5f * (float)p.h);
+  dm[2 * hw] = dob;
+}
+
+// Adjoint of the bilinear resize (fh, fw) -> (h, w) that the warp applies to its three maps: dlow[m, y, x] = sum over the output pixels
+// whose two source rows / columns include (y, x) of their weight * dhigh.  Gather form (each low-resolution pixel scans the few
+// output rows / columns that can read it: run-to-run identical, no atomics).  grid (ceil(fh*fw/256), planes = N*3)
+__global__ __launch_bounds__(256) void resize_adjoint_kernel(const float* __restrict__ dhigh, float* __restrict__ dlow, int h, int w,
+                                                             int fh, int fw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= fh * fw) return;
+  const int y = i / fw, x = i - y * fw;
+  const float* src = dhigh + (int64_t)blockIdx.y * h * w;
+  // output rows that can touch low row y: src = s*(oy+0.5)-0.5 in (y-1, y+1)  ->  oy in ((y-0.5)/s - 0.5, (y+1.5)/s - 0.5); widen by one
+  const float sy = (float)fh / (float)h, sx = (float)fw / (float)w;
+  int oy_lo = (int)floorf(((float)y - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)y + 1.5f) / sy - 0.5f) + 1;
+  int ox_lo = (int)floorf(((float)x - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)x + 1.5f) / sx - 0.5f) + 1;
+  if (oy_lo < 0) oy_lo = 0;
+  if (ox_lo < 0) ox_lo = 0;
+  if (oy_hi > h - 1) oy_hi = h - 1;
+  if (ox_hi > w - 1) ox_hi = w - 1;
+  float acc = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    int y0, y1;
+    float ly;
+    resize_src(oy, fh, h, y0, y1, ly);
+    const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      int x0, x1;
+      float lx;
+      resize_src(ox, fw, w, x0, x1, lx);
+      const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+      if (wx != 0.f) acc = fmaf(src[oy * w + ox], wy * wx, acc);
+    }
+  }
+  dlow[(int64_t)blockIdx.y * fh * fw + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// F.grid_sample (bilinear, align_corners=False) with an explicit grid (N, ho, wo, 2) on strided small-channel tensors; padding zeros (0)
+// or reflection (1).  grid (ceil(ho*wo/256), N)
+__device__ __forceinline__ float reflect_coord(float v, int size) {
+  // ATen reflect_coordinates(in, -1, 2*size - 1) for align_corners=False, then clip_coordinates
+  const float twice_low = -1.f, twice_high = 2.f * (float)size - 1.f;
+  const float mn = twice_low * 0.5f, span = (twice_high - twice_low) * 0.5f;
+  float in = fabsf(v - mn);
+  const float extra = fmodf(in, span);
+  const int flips = (int)floorf(in / span);
+  float r = (flips % 2 == 0) ? extra + mn : span - extra + mn;
+  return fminf((float)(size - 1), fmaxf(r, 0.f));
+}
+
+struct GsArgs {
+  const float* x;
+  const float* grid;
+  float* out;
+  const float* dout;
+  float* dgrid;
+  int64_t xs_n, xs_c, xs_h, xs_w, os_n, os_c, os_h, os_w;
+  int c, h, w, ho, wo, n_div, pad_mode;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void grid_sample_kernel(GsArgs a) {
+  const int n = blockIdx.y;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.ho * a.wo) return;
+  const int oy = o / a.wo, ox = o - oy * a.wo;
+  const float* gp = a.grid + ((int64_t)n * a.ho * a.wo + o) * 2;
+  float ix = ((gp[0] + 1.f) * (float)a.w - 1.f) * 0.5f;
+  float iy = ((gp[1] + 1.f) * (float)a.h - 1.f) * 0.5f;
+  if (a.pad_mode == 1) {
+    ix = reflect_coord(ix, a.w);
+    iy = reflect_coord(iy, a.h);
+  }
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+  const float wk[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+  bool in[4];
+  int64_t off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+    in[k] = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+    off[k] = in[k] ? yy * a.xs_h + xx * a.xs_w : 0;
+  }
+  const float* sb = a.x + (int64_t)(n / a.n_div) * a.xs_n;
+  float dfx = 0.f, dfy = 0.f;
+  for (int c = 0; c < a.c; ++c) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = in[k] ? sb[c * a.xs_c + off[k]] : 0.f;
+    if (!BWD) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = fmaf(v[k], in[k] ? wk[k] : 0.f, acc);
+      a.out[n * a.os_n + c * a.os_c + oy * a.os_h + ox * a.os_w] = acc;
+    } else {
+      const float d = a.dout[n * a.os_n + c * a.os_c + oy * a.os_h + ox * a.os_w];
+      dfx = fmaf(d, (v[1] - v[0]) * wy0 + (v[3] - v[2]) * wy1, dfx);
+      dfy = fmaf(d, (v[2] - v[0]) * wx0 + (v[3] - v[1]) * wx1, dfy);
+    }
+  }
+  if (BWD) {
+    float* dg = a.dgrid + ((int64_t)n * a.ho * a.wo + o) * 2;
+    dg[0] = dfx * (0.5f * (float)a.w);
+    dg[1] = dfy * (0.5f * (float)a.h);
+  }
+}
+
+// =====================================================================================================================================
+// 2x2 symmetric SVD backward:  gA = U [[gs0, k s1 / (s1^2 - s0^2)], [k s0 / (s1^2 - s0^2), gs1]] U^T,  k = (U^T gU)_01 - (U^T gU)_10
+// (torch's svd_backward with V = U - a positive semi-definite input - and no gradient through V)
+// =====================================================================================================================================
+__global__ __launch_bounds__(256) void svd2x2_sym_bwd_kernel(const float* __restrict__ u, const float* __restrict__ s, const float* __restrict__ gu,
+                                                            const float* __restrict__ gs, float* __restrict__ ga, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float u00 = u[4 * i], u01 = u[4 * i + 1], u10 = u[4 * i + 2], u11 = u[4 * i + 3];
+  const float s0 = s[2 * i], s1 = s[2 * i + 1];
+  float m00 = 0.f, m11 = 0.f, m01 = 0.f, m10 = 0.f;
+  if (gs) { m00 = gs[2 * i]; m11 = gs[2 * i + 1]; }
+  if (gu) {
+    const float g00 = gu[4 * i], g01 = gu[4 * i + 1], g10 = gu[4 * i + 2], g11 = gu[4 * i + 3];
+    const float k = (u00 * g01 + u10 * g11) - (u01 * g00 + u11 * g10);          // (U^T gU)_01 - (U^T gU)_10
+    const float den = s1 * s1 - s0 * s0;
+    m01 = k / den * s1;
+    m10 = k / den * s0;
+  }
+  // T = U * M, gA = T * U^T
+  const float t00 = u00 * m00 + u01 * m10, t01 = u00 * m01 + u01 * m11;
+  const float t10 = u10 * m00 + u11 * m10, t11 = u10 * m01 + u11 * m11;
+  ga[4 * i] = t00 * u00 + t01 * u01;
+  ga[4 * i + 1] = t00 * u10 + t01 * u11;
+  ga[4 * i + 2] = t10 * u00 + t11 * u01;
+  ga[4 * i + 3] = t10 * u10 + t11 * u11;
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// =====================================================================================================================================
+// C ABI
+// =====================================================================================================================================
+extern "C" size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels) {
+  if (rows <= 0 || channels <= 0) return 0;
+  const BnGeom g = bn_geom(rows, channels);
+  return (size_t)g.ctiles * g.nchunk * 2 * g.tw * sizeof(float) + (size_t)g.ctiles * g.ngroups * 2 * g.tw * sizeof(double) + 16;
+}
+
+namespace {
+int bn_fill(BnArgs& a, const float* x, int64_t rows, int channels, int ldx, const float* gamma, const float* beta, void* ws, size_t ws_bytes,
+            unsigned* tickets, const char* who) {
+  if (!x || !gamma || !beta || !ws || !tickets || rows <= 0 || channels <= 0 || channels % 4 != 0 || channels > 64 * 32 || ldx % 4 != 0 ||
+      ldx < channels || !aligned16(x) || !aligned16(gamma) || !aligned16(beta) || ws_bytes < lfdm_batchnorm_train_ws_bytes(rows, channels)) {
+    (void)who;
+    lfdm_set_error("batchnorm_train: rows > 0, channels % 4 == 0 (<= 2048), 16-byte aligned x / gamma / beta, workspace of "
+                   "lfdm_batchnorm_train_ws_bytes and a zeroed ticket array of LFDM_BN_TICKETS words");
+    return LFDM_EINVAL;
+  }
+  const BnGeom g = bn_geom(rows, channels);
+  a.x = x; a.rows = rows; a.c = channels; a.ldx = ldx; a.gamma = gamma; a.beta = beta;
+  a.q = g.q; a.chunk_rows = g.chunk_rows; a.nchunk = g.nchunk; a.ngroups = g.ngroups;
+  // doubles first (alignment), then the float partials
+  a.part2 = reinterpret_cast<double*>((((uintptr_t)ws) + 15) & ~(uintptr_t)15);
+  a.part1 = reinterpret_cast<float*>(a.part2 + (size_t)g.ctiles * g.ngroups * 2 * g.tw);
+  a.tickets = tickets;
+  return LFDM_OK;
+}
+}  // namespace
+
+extern "C" int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int ldx, int ldy, const float* gamma,
+                                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                               int relu, float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BnArgs a = {};
+  const int rc = bn_fill(a, x, rows, channels, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_fwd");
+  if (rc) return rc;
+  if (!y || !stat || ldy % 4 != 0 || ldy < channels || !aligned16(y) || ((running_mean == nullptr) != (running_var == nullptr))) {
+    lfdm_set_error("batchnorm_train_fwd: y (16-byte aligned, ldy % 4 == 0) and stat (2 * channels floats) are required; running_mean and "
+                   "running_var come together");
+    return LFDM_EINVAL;
+  }
+  a.out = y; a.ldo = ldy; a.stat = stat; a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
+  a.relu = relu;
+  const BnGeom g = bn_geom(rows, channels);
+  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles);
+  LFDM_LAUNCH((bn_reduce_kernel<0>), grid, dim3(256), 0, stream, a);
+  LFDM_LAUNCH((bn_apply_kernel<0>), grid, dim3(256), 0, stream, a);
+  return lfdm_check_launch("batchnorm_train_fwd");
+}
+
+extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int ldx, int lddy,
+                                               int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma,
+                                               float* dbeta, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BnArgs a = {};
+  const int rc = bn_fill(a, x, rows, channels, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_bwd");
+  if (rc) return rc;
+  if (!dy || !dx || !stat || lddy % 4 != 0 || lddx % 4 != 0 || lddy < channels || lddx < channels || !aligned16(dy) || !aligned16(dx) ||
+      !aligned16(stat)) {
+    lfdm_set_error("batchnorm_train_bwd: dy, dx (16-byte aligned, leading dimensions % 4 == 0) and the forward's stat are required");
+    return LFDM_EINVAL;
+  }
+  a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.stat = const_cast<float*>(stat); a.relu = relu; a.dgamma = dgamma; a.dbeta = dbeta;
+  const BnGeom g = bn_geom(rows, channels);
+  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles);
+  LFDM_LAUNCH((bn_reduce_kernel<1>), grid, dim3(256), 0, stream, a);
+  LFDM_LAUNCH((bn_apply_kernel<1>), grid, dim3(256), 0, stream, a);
+  return lfdm_check_launch("batchnorm_train_bwd");
+}
+
+namespace {
+int blur_fill(BlurArgs& a, const lfdm_blur_params* p, bool bwd) {
+  if (!p || !p->wgt || p->n_img <= 0 || p->n_img > 65535 || p->channels <= 0 || p->c_store < p->channels || p->c_store > 65535 || p->h <= 0 ||
+      p->w <= 0 || p->k <= 0 || p->k * p->k > BLUR_MAX_TAPS || p->stride <= 0 || p->pad_lo < 0 || p->pad_hi < 0 ||
+      (bwd ? (!p->dy || !p->dx) : (!p->x || !p->out))) {
+    lfdm_set_error("blur_down: bad arguments (n_img, c_store <= 65535; k*k <= 1024)");
+    return LFDM_EINVAL;
+  }
+  const int hf = p->h + p->pad_lo + p->pad_hi - p->k + 1, wf = p->w + p->pad_lo + p->pad_hi - p->k + 1;
+  if (hf <= 0 || wf <= 0) { lfdm_set_error("blur_down: kernel larger than the padded input"); return LFDM_EINVAL; }
+  a.x = p->x; a.wgt = p->wgt; a.out = p->out; a.dy = p->dy; a.dx = p->dx;
+  a.xs_n = p->xs_n; a.xs_c = p->xs_c; a.xs_h = p->xs_h; a.xs_w = p->xs_w;
+  a.os_n = p->os_n; a.os_c = p->os_c; a.os_h = p->os_h; a.os_w = p->os_w;
+  a.channels = p->channels; a.c_store = p->c_store; a.h = p->h; a.w = p->w; a.k = p->k; a.pad = p->pad_lo; a.stride = p->stride;
+  a.ho = (hf + p->stride - 1) / p->stride; a.wo = (wf + p->stride - 1) / p->stride;
+  a.scale = p->scale; a.bias = p->bias;
+  return LFDM_OK;
+}
+}  // namespace
+
+extern "C" int lfdm_blur_down_fwd_f32(const lfdm_blur_params* p, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlurArgs a = {};
+  const int rc = blur_fill(a, p, false);
+  if (rc) return rc;
+  LFDM_LAUNCH(blur_down_kernel, dim3((unsigned)((a.ho * a.wo + 255) / 256), (unsigned)a.c_store, (unsigned)p->n_img), dim3(256), 0, stream, a);
+  return lfdm_check_launch("blur_down_fwd");
+}
+
+extern "C" int lfdm_blur_down_bwd_f32(const lfdm_blur_params* p, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlurArgs a = {};
+  const int rc = blur_fill(a, p, true);
+  if (rc) return rc;
+  LFDM_LAUNCH(blur_down_bwd_kernel, dim3((unsigned)((a.h * a.w + 255) / 256), (unsigned)a.channels, (unsigned)p->n_img), dim3(256), 0, stream, a);
+  return lfdm_check_launch("blur_down_bwd");
+}
+
+extern "C" int lfdm_absmax_f32(const float* x, int64_t rows, int channels, int64_t ld, unsigned* out_bits, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out_bits || rows <= 0 || channels <= 0 || ld < channels) { lfdm_set_error("absmax: bad arguments"); return LFDM_EINVAL; }
+  int64_t blocks = (rows * channels + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  LFDM_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, rows, channels, ld, out_bits);
+  return lfdm_check_launch("absmax");
+}
+
+extern "C" int lfdm_warp_bwd_f32(const lfdm_warp_bwd_params* pp, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!pp) { lfdm_set_error("warp_bwd: null params"); return LFDM_EINVAL; }
+  const lfdm_warp_bwd_params& p = *pp;
+  if (!p.src || !p.dout || !p.flow_x || !p.flow_y || !p.dmaps || p.n_img <= 0 || p.n_img > 65535 || p.h <= 0 || p.w <= 0 || p.c <= 0 || p.fh <= 0 ||
+      p.fw <= 0 || p.n_div <= 0) {
+    lfdm_set_error("warp_bwd: src, dout, flow_x, flow_y, dmaps and positive sizes are required (n_img <= 65535)");
+    return LFDM_EINVAL;
+  }
+  const int hw = p.h * p.w;
+  if (p.layout_cl) {
+    const int g = p.c / 4;
+    if (p.c % 4 != 0 || g > 64 || (g & (g - 1)) != 0 || (256 % g) != 0 || p.n_div != 1 || p.ld_src % 4 != 0 || p.ld_dout % 4 != 0 ||
+        (p.prev && p.ld_prev % 4 != 0) || (p.dprev && p.ld_dprev % 4 != 0) || !aligned16(p.src) || !aligned16(p.dout) ||
+        (p.prev && !aligned16(p.prev)) || (p.dprev && !aligned16(p.dprev)) || (p.dsrc_fix && (!p.amax_bits || (((uintptr_t)p.dsrc_fix) & 7))) ||
+        (int64_t)hw * g > 0x7fffffff) {
+      lfdm_set_error("warp_bwd (channels-last): C / 4 a power of two <= 64, 16-byte aligned rows, n_div == 1, dsrc_fix needs amax_bits");
+      return LFDM_EINVAL;
+    }
+    int64_t blocks = ((int64_t)hw * g + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    LFDM_LAUNCH(warp_bwd_cl_kernel, dim3((unsigned)blocks, (unsigned)p.n_img), dim3(256), 0, stream, p);
+  } else {
+    if (p.dsrc_fix) { lfdm_set_error("warp_bwd (strided): the gradient of the sampled tensor is only produced by the channels-last form"); return LFDM_EINVAL; }
+    LFDM_LAUNCH(warp_bwd_px_kernel, dim3((unsigned)((hw + 255) / 256), (unsigned)p.n_img), dim3(256), 0, stream, p);
+  }
+  return lfdm_check_launch("warp_bwd");
+}
+
+extern "C" int lfdm_fix_finalize_f32(long long* acc, float* out, int64_t rows, int channels, int64_t ld, unsigned* amax_bits, int64_t count,
+                                     unsigned* ticket, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!acc || !out || !amax_bits || !ticket || rows <= 0 || channels <= 0 || ld < channels || count <= 0) {
+    lfdm_set_error("fix_finalize: bad arguments");
+    return LFDM_EINVAL;
+  }
+  int64_t blocks = (rows * channels + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  LFDM_LAUNCH(fix_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, acc, out, rows, channels, ld, amax_bits, count, ticket);
+  return lfdm_check_launch("fix_finalize");
+}
+
+extern "C" int lfdm_resize_adjoint_f32(const float* dhigh, float* dlow, int planes, int h, int w, int fh, int fw, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dhigh || !dlow || planes <= 0 || planes > 65535 || h <= 0 || w <= 0 || fh <= 0 || fw <= 0) {
+    lfdm_set_error("resize_adjoint: bad arguments (planes <= 65535)");
+    return LFDM_EINVAL;
+  }
+  LFDM_LAUNCH(resize_adjoint_kernel, dim3((unsigned)((fh * fw + 255) / 256), (unsigned)planes), dim3(256), 0, stream, dhigh, dlow, h, w, fh, fw);
+  return lfdm_check_launch("resize_adjoint");
+}
+
+namespace {
+int gs_fill(GsArgs& a, const lfdm_grid_sample_params* p, bool bwd) {
+  if (!p || !p->x || !p->grid || p->n_img <= 0 || p->n_img > 65535 || p->channels <= 0 || p->h <= 0 || p->w <= 0 || p->ho <= 0 || p->wo <= 0 ||
+      p->n_div <= 0 || p->pad_mode < 0 || p->pad_mode > 1 || (bwd ? (!p->dout || !p->dgrid) : !p->out)) {
+    lfdm_set_error("grid_sample: bad arguments (n_img <= 65535, pad_mode 0 zeros / 1 reflection)");
+    return LFDM_EINVAL;
+  }
+  a.x = p->x; a.grid = p->grid; a.out = p->out; a.dout = p->dout; a.dgrid = p->dgrid;
+  a.xs_n = p->xs_n; a.xs_c = p->xs_c; a.xs_h = p->xs_h; a.xs_w = p->xs_w;
+  a.os_n = p->os_n; a.os_c = p->os_c; a.os_h = p->os_h; a.os_w = p->os_w;
+  a.c = p->channels; a.h = p->h; a.w = p->w; a.ho = p->ho; a.wo = p->wo; a.n_div = p->n_div; a.pad_mode = p->pad_mode;
+  return LFDM_OK;
+}
+}  // namespace
+
+extern "C" int lfdm_grid_sample_fwd_f32(const lfdm_grid_sample_params* p, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GsArgs a = {};
+  const int rc = gs_fill(a, p, false);
+  if (rc) return rc;
+  LFDM_LAUNCH((grid_sample_kernel<false>), dim3((unsigned)((a.ho * a.wo + 255) / 256), (unsigned)p->n_img), dim3(256), 0, stream, a);
+  return lfdm_check_launch("grid_sample_fwd");
+}
+
+extern "C" int lfdm_grid_sample_bwd_f32(const lfdm_grid_sample_params* p, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  GsArgs a = {};
+  const int rc = gs_fill(a, p, true);
+  if (rc) return rc;
+  if (p->pad_mode != 0) { lfdm_set_error("grid_sample_bwd: zeros padding only (the reflection warp of model.py:118-122 has no gradient)"); return LFDM_EINVAL; }
+  LFDM_LAUNCH((grid_sample_kernel<true>), dim3((unsigned)((a.ho * a.wo + 255) / 256), (unsigned)p->n_img), dim3(256), 0, stream, a);
+  return lfdm_check_launch("grid_sample_bwd");
+}
+
+extern "C" int lfdm_svd2x2_sym_bwd_f32(const float* u, const float* s, const float* gu, const float* gs, float* ga, int64_t n,
+                                       lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!u || !s || !ga || n <= 0 || (!gu && !gs)) { lfdm_set_error("svd2x2_sym_bwd: u, s, ga and at least one of gu / gs are required"); return LFDM_EINVAL; }
+  LFDM_LAUNCH(svd2x2_sym_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, s, gu, gs, ga, n);
+  return lfdm_check_launch("svd2x2_sym_bwd");
+}

@@ -20,6 +20,8 @@ import torch
 import torch.nn.functional as F
 
 from . import autograd as A
+from . import lfae_ops as L
+from . import ops
 from . import params as P
 from .params import ParamTree
 
@@ -30,6 +32,20 @@ def _cl(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+_NBT_PENDING = []      # num_batches_tracked buffers touched by the current forward (one multi-tensor add at its end, not one launch per layer)
+
+
+def flush_batches_tracked():
+    """num_batches_tracked += (uses this forward) for every BatchNorm that ran in training mode (nn.BatchNorm2d does it per call)."""
+    if not _NBT_PENDING:
+        return
+    seen = {}
+    for t in _NBT_PENDING:
+        seen.setdefault(id(t), [t, 0])[1] += 1
+    del _NBT_PENDING[:]
+    torch._foreach_add_([v[0] for v in seen.values()], [v[1] for v in seen.values()])
+
+
 def conv2d(x, weight, bias, padding):
     """nn.Conv2d (stride 1, square kernel) through the native kernels.  x: (N, C, H, W); returns a channels-last (N, O, H', W').
     Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded - the padded
@@ -37,9 +53,11 @@ def conv2d(x, weight, bias, padding):
     n, c, h, w = x.shape
     cout, k = weight.shape[0], weight.shape[-1]
     rows = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
-    cp, op = -c % 4, -cout % 4
-    if cp:
+    cin = weight.shape[1]
+    cp, op = -cin % 4, -cout % 4
+    if c == cin and cp:                 # (c == cin + cp: the producer already wrote zero pad channels - lfae_ops.blur_down(rows4=True))
         rows = F.pad(rows, (0, cp))
+    assert rows.shape[1] == cin + cp
     if cp or op:
         weight = F.pad(weight, (0, 0, 0, 0, 0, cp, 0, op))
         bias = F.pad(bias, (0, op)) if bias is not None else None
@@ -59,16 +77,19 @@ class _Net:
     def conv(self, x, prefix, padding):
         return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding)
 
-    def bn(self, x, prefix):
+    def bn_relu(self, x, prefix):
+        """BatchNorm2d -> ReLU (every BatchNorm of the LFAE networks is followed by one: util.py:84-90, 108-112, 128-133, 146-150).  Training:
+        one native forward (batch statistics, running statistics updated in place), one native backward (lfae_ops.BatchNormReLU)."""
         g = self.t.get
         if self.training:
-            nbt = g(prefix + "num_batches_tracked")
-            nbt += 1
-        return F.batch_norm(x, g(prefix + "running_mean"), g(prefix + "running_var"), g(prefix + "weight"), g(prefix + "bias"),
-                            self.training, 0.1, 1e-5)
+            _NBT_PENDING.append(g(prefix + "num_batches_tracked"))
+            return L.BatchNormReLU.apply(x, g(prefix + "weight"), g(prefix + "bias"), g(prefix + "running_mean"), g(prefix + "running_var"),
+                                         0.1, 1e-5, True)
+        return F.relu(F.batch_norm(x, g(prefix + "running_mean"), g(prefix + "running_var"), g(prefix + "weight"), g(prefix + "bias"),
+                                   False, 0.1, 1e-5))
 
     def conv_bn_relu(self, x, prefix, padding=1):          # SameBlock2d / the body of Down- and UpBlock2d (util.py:95-150)
-        return F.relu(self.bn(self.conv(x, prefix + "conv.", padding), prefix + "norm."))
+        return self.bn_relu(self.conv(x, prefix + "conv.", padding), prefix + "norm.")
 
     def down_block(self, x, prefix):                      # DownBlock2d: conv -> BN -> ReLU -> AvgPool 2x2
         return F.avg_pool2d(self.conv_bn_relu(x, prefix), 2)
@@ -77,8 +98,8 @@ class _Net:
         return self.conv_bn_relu(F.interpolate(x, scale_factor=2), prefix)
 
     def res_block(self, x, prefix):                       # ResBlock2d (util.py:70-92): pre-activation, identity skip
-        out = self.conv(F.relu(self.bn(x, prefix + "norm1.")), prefix + "conv1.", 1)
-        out = self.conv(F.relu(self.bn(out, prefix + "norm2.")), prefix + "conv2.", 1)
+        out = self.conv(self.bn_relu(x, prefix + "norm1."), prefix + "conv1.", 1)
+        out = self.conv(self.bn_relu(out, prefix + "norm2."), prefix + "conv2.", 1)
         return out + x
 
     def hourglass(self, x, prefix, num_blocks, decoder=True):
@@ -102,16 +123,17 @@ def make_coordinate_grid(h, w, like):
     return torch.stack((x.view(1, -1).expand(h, w), y.view(-1, 1).expand(h, w)), dim=2)
 
 
-def antialias_down(x, weight, scale):
-    """AntiAliasInterpolation2d (util.py:217-264): Gaussian blur (depthwise) then every 1/scale-th pixel."""
-    if scale == 1:
+def antialias_down(x, weight, scale, rows4=False, affine=None):
+    """AntiAliasInterpolation2d (util.py:217-264): Gaussian blur (depthwise) then every 1/scale-th pixel - one native launch that computes
+    only the kept pixels (lfae_ops.BlurDown; backward native too).  rows4: the result as the zero-padded 4-channel rows the next
+    convolution reads; affine = (scale, bias) per channel folded into the same launch.  scale == 1 with rows4 / affine is the identity
+    "blur" (a 1x1 kernel): the re-layout / normalisation alone."""
+    if scale == 1 and not rows4 and affine is None:
         return x
-    ks = weight.shape[-1]
-    ka = ks // 2
-    kb = ka - 1 if ks % 2 == 0 else ka
-    out = F.conv2d(F.pad(x, (ka, kb, ka, kb)), weight=weight, groups=x.shape[1])
-    s = int(1 / scale)
-    return out[:, :, ::s, ::s]
+    if scale == 1:
+        weight = x.new_ones(x.shape[1], 1, 1)
+    sc, bi = affine if affine is not None else (None, None)
+    return L.BlurDown.apply(x, weight, int(round(1 / scale)), rows4, sc, bi)
 
 
 # The reference writes its per-pixel 2x2 / 3x3 algebra as torch.matmul over (B, K, h, w, 2, 2) operands: hundreds of thousands of
@@ -136,7 +158,7 @@ def region2gaussian(center, covar, h, w):
 def region_predictor_forward(tree, x, cfg, training=True):
     """RegionPredictor.forward, pca_based (region_predictor.py:52-117) -> shift, covar, affine, heatmap, u, d."""
     net = _Net(tree, training)
-    x = antialias_down(x, tree.get("down.weight"), cfg["scale_factor"]) if cfg["scale_factor"] != 1 else x
+    x = antialias_down(x, tree.get("down.weight") if cfg["scale_factor"] != 1 else None, cfg["scale_factor"], rows4=x.shape[1] == 3)
     fmap = net.hourglass(_cl(x), "predictor.", cfg["num_blocks"])
     pred = net.conv(fmap, "regions.", cfg.get("pad", 3))
     shp = pred.shape
@@ -146,8 +168,9 @@ def region_predictor_forward(tree, x, cfg, training=True):
     mean = (r * grid).sum(dim=(2, 3))
     mean_sub = grid - mean.unsqueeze(-2).unsqueeze(-2)
     covar = ((mean_sub.unsqueeze(-1) * mean_sub.unsqueeze(-2)) * r.unsqueeze(-1)).sum(dim=(2, 3))       # outer product per pixel
-    u, s, _ = torch.svd(covar.view(-1, 2, 2).cpu())                     # on the host, like region_predictor.py:21-25
-    u, s = u.to(covar.device), s.to(covar.device)
+    # region_predictor.py:21-25 moves the covariances to the host for torch.svd; here: LAPACK's 2x2 path in closed form on the device,
+    # analytic backward (lfae_ops.Svd2x2Sym) - no host round trip in the step
+    u, s = L.Svd2x2Sym.apply(covar.reshape(-1, 2, 2))
     d = torch.diag_embed(s ** 0.5)
     return {"shift": mean, "covar": covar, "heatmap": region, "affine": torch.matmul(u, d).view(*covar.shape), "u": u, "d": d}
 
@@ -185,8 +208,8 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
         hom = [m[..., i, 0] * gx + m[..., i, 1] * gy + m[..., i, 2] for i in range(3)]
         bg = torch.stack((hom[0] / hom[2], hom[1] / hom[2]), dim=-1)
     sparse = torch.cat([bg, d2s], dim=1)
-    rep = img.unsqueeze(1).unsqueeze(1).repeat(1, k + 1, 1, 1, 1, 1).view(bs * (k + 1), -1, h, w)
-    deformed = F.grid_sample(rep, sparse.view(bs * (k + 1), h, w, -1), align_corners=False).view(bs, k + 1, -1, h, w)
+    # (pixelwise_flow_predictor.py:95-102 repeats the source K+1 times; the native kernel reads one source per K+1 grids)
+    deformed = L.GridSample.apply(img, sparse.reshape(bs * (k + 1), h, w, 2), k + 1, False).view(bs, k + 1, -1, h, w)
     inp = torch.cat([heat, deformed], dim=2).view(bs, -1, h, w)
     pred = net.hourglass(_cl(inp), p + "hourglass.", cfg["num_blocks"])
     mask = F.softmax(net.conv(pred, p + "mask.", 3), dim=1).unsqueeze(2)
@@ -196,30 +219,18 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
     return out
 
 
-def _deform(inp, flow):
-    """Generator.deform_input (generator.py:59-67): the flow is resized bilinearly to the feature map, then grid_sample."""
-    h, w = inp.shape[2:]
-    if flow.shape[1] != h or flow.shape[2] != w:
-        flow = F.interpolate(flow.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
-    return F.grid_sample(inp, flow, align_corners=False)
-
-
-def _apply_optical(prev, skip, motion):
-    """Generator.apply_optical (generator.py:69-88): warp the skip, blend with the decoder state through the occlusion map."""
-    skip = _deform(skip, motion["optical_flow"])
-    occ = motion.get("occlusion_map")
-    if occ is not None:
-        if occ.shape[2:] != skip.shape[2:]:
-            occ = F.interpolate(occ, size=skip.shape[2:], mode="bilinear", align_corners=False)
-        skip = skip * occ + prev * (1 - occ) if prev is not None else skip * occ
-    return skip
+def _apply_optical(prev, skip, maps):
+    """Generator.deform_input + apply_optical (generator.py:59-88): the flow / occlusion maps resized bilinearly to the feature map,
+    grid_sample, blend with the decoder state - ONE native launch forward (the sampling path's warp kernel), native backward
+    (lfae_ops.ApplyOpticalCL).  maps: (N, 3, fh, fw) planes [flow_x, flow_y, occlusion]."""
+    return L.ApplyOpticalCL.apply(_cl(skip), None if prev is None else _cl(prev), maps)
 
 
 def generator_forward(tree, source_image, driving, source, bg_params, cfg, num_regions, revert_axis_swap=True, training=True):
     """Generator.forward (generator.py:90-128) -> prediction, deformed, optical_flow, occlusion_map, bottle_neck_feat."""
     net = _Net(tree, training)
     nd, use_skips = cfg["num_down_blocks"], cfg.get("skips", False)
-    out = net.conv_bn_relu(_cl(source_image), "first.", 3)
+    out = net.conv_bn_relu(antialias_down(source_image, None, 1, rows4=source_image.shape[1] == 3), "first.", 3)
     skips = [out]
     for i in range(nd):
         out = net.down_block(out, "down_blocks.%d." % i)
@@ -227,20 +238,25 @@ def generator_forward(tree, source_image, driving, source, bg_params, cfg, num_r
     res = {"bottle_neck_feat": out}
     motion = pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg["pixelwise_flow_predictor_params"], num_regions,
                                     revert_axis_swap, training)
-    res["deformed"] = _deform(source_image, motion["optical_flow"])
+    flow, occ = motion["optical_flow"], motion.get("occlusion_map")
+    with torch.no_grad():       # generator.py:104: logged only, feeds no loss
+        fh, fw = flow.shape[1], flow.shape[2]
+        fpl = flow.permute(0, 3, 1, 2).contiguous()
+        res["deformed"] = ops.warp_planar(source_image.contiguous(), 1, fpl[:, 0], fpl[:, 1], None, fh, fw, 2 * fh * fw, 0).view(source_image.shape)
     res.update(motion)
-    out = _apply_optical(None, out, motion)
+    maps = L._maps_planar(flow, occ)
+    out = _apply_optical(None, out, maps)
     for i in range(cfg["num_bottleneck_blocks"]):
         out = net.res_block(_cl(out), "bottleneck.r%d." % i)
     for i in range(nd):
         if use_skips:
-            out = _apply_optical(out, skips[-(i + 1)], motion)
+            out = _apply_optical(out, skips[-(i + 1)], maps)
         out = net.up_block(_cl(out), "up_blocks.%d." % i)
     if use_skips:
-        out = _apply_optical(out, skips[0], motion)
+        out = _apply_optical(out, skips[0], maps)
     out = torch.sigmoid(net.conv(_cl(out), "final.", 3))
     if use_skips:
-        out = _apply_optical(out, source_image, motion)
+        out = L.ApplyOpticalImage.apply(source_image, out, maps)
     res["prediction"] = out
     return res
 
@@ -256,9 +272,11 @@ class Vgg19(ParamTree):
         for p in self.parameters():
             p.requires_grad = False
 
-    def features(self, x):
+    def features(self, x, prepared=False):
+        """prepared: x is already normalised, zero-padded 4-channel rows (ReconstructionModel.pyramid(vgg_input=True))."""
         net = _Net(self, False)
-        x = _cl((x - self.get("mean")) / self.get("std"))
+        if not prepared:
+            x = _cl((x - self.get("mean")) / self.get("std"))
         outs, cur = [], 1
         for sl, idx, _, _ in P.VGG19_CONVS:
             if sl != cur:
@@ -301,7 +319,7 @@ class Transform:
         h, w = frame.shape[2:]
         grid = make_coordinate_grid(h, w, frame).view(1, h * w, 2)
         grid = self.warp_coordinates(grid).view(self.bs, h, w, 2)
-        return F.grid_sample(frame, grid, padding_mode="reflection", align_corners=False)
+        return L.GridSample.apply(frame, grid, 1, True)          # F.grid_sample(padding_mode="reflection"); no gradient flows here
 
     def jacobian(self, coordinates):
         new = self.warp_coordinates(coordinates)
@@ -324,8 +342,10 @@ class ReconstructionModel:
         self.pyramid_kernels = {s: (P.antialias_kernel(nc, s) if s != 1 else None) for s in self.scales}
         self.vgg = vgg if vgg is not None else (Vgg19() if sum(self.loss_weights["perceptual"]) != 0 else None)
         self.training = True
+        self._vgg_affine = None
 
     def to(self, device):
+        self._vgg_affine = None
         for k, v in self.pyramid_kernels.items():
             self.pyramid_kernels[k] = None if v is None else v.to(device)
         if self.vgg is not None:
@@ -335,8 +355,15 @@ class ReconstructionModel:
     def _regions(self, x):
         return region_predictor_forward(self.region_predictor, x, self.mp["region_predictor_params"], self.training)
 
-    def pyramid(self, x):
-        return {s: (x if k is None else antialias_down(x, k, s)) for s, k in self.pyramid_kernels.items()}
+    def pyramid(self, x, vgg_input=False):
+        """ImagePyramide (model.py:62-82).  vgg_input: every level leaves its launch as the perceptual network's input - normalised
+        ((x - mean) / std, model.py:52) zero-padded 4-channel rows."""
+        if not vgg_input:
+            return {s: (x if k is None else antialias_down(x, k, s)) for s, k in self.pyramid_kernels.items()}
+        if self._vgg_affine is None:
+            mean, std = self.vgg.get("mean").reshape(-1), self.vgg.get("std").reshape(-1)
+            self._vgg_affine = ((1.0 / std).contiguous(), (-mean / std).contiguous())
+        return {s: antialias_down(x, k, s, rows4=True, affine=self._vgg_affine) for s, k in self.pyramid_kernels.items()}
 
     def forward(self, x, transform_noise=None):
         src, drv = x["source"], x["driving"]
@@ -349,12 +376,15 @@ class ReconstructionModel:
         gen.update({"source_region_params": source_rp, "driving_region_params": driving_rp})
         losses = {}
         if sum(lw["perceptual"]) != 0:
-            pyr_real, pyr_gen = self.pyramid(drv), self.pyramid(gen["prediction"])
+            fast = drv.shape[1] == 3
+            with torch.no_grad():
+                pyr_real = self.pyramid(drv, vgg_input=fast)
+            pyr_gen = self.pyramid(gen["prediction"], vgg_input=fast)
             total = 0
             for s in self.scales:
-                x_vgg = self.vgg.features(pyr_gen[s])
+                x_vgg = self.vgg.features(pyr_gen[s], prepared=fast)
                 with torch.no_grad():
-                    y_vgg = self.vgg.features(pyr_real[s])
+                    y_vgg = self.vgg.features(pyr_real[s], prepared=fast)
                 for i, wgt in enumerate(lw["perceptual"]):
                     total = total + wgt * torch.abs(x_vgg[i] - y_vgg[i]).mean()
             losses["perceptual"] = total
@@ -371,6 +401,7 @@ class ReconstructionModel:
                     value = value * torch.sign(value[:, :, 0:1, 0:1])
                 eye = torch.eye(2, dtype=value.dtype, device=value.device).view(1, 1, 2, 2)
                 losses["equivariance_affine"] = lw["equivariance_affine"] * torch.abs(eye - value).mean()
+        flush_batches_tracked()
         return losses, gen
 
     __call__ = forward

@@ -602,6 +602,100 @@ int lfdm_depthwise_down_planar_f32(const float* x, const float* wgt, float* out,
 int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int pad,
                               int reflect, int backward, lfdm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LFAE stage-1 training glue (ABI version 10; csrc/train_lfae.hip): what connects the convolutions of
+ * ReconstructionModel.forward (LFAE/modules/model.py:141-217) - replaces the MIOpen BatchNorm, MIOpen / composable_kernel depth-wise
+ * convolution and ATen grid_sampler kernels the reference's nn.Modules dispatch to.
+ */
+#define LFDM_BN_TICKETS 1024
+/* nn.BatchNorm2d in training mode (+ optional ReLU) on channels-last rows: LFAE/modules/util.py:70-150 (ResBlock2d :84-90, UpBlock2d
+ * :108-112, DownBlock2d :128-133, SameBlock2d :146-150).  y = relu(((x - mean) * rstd) * gamma + beta) with the batch mean / BIASED
+ * variance per channel over `rows`; running_mean / running_var (may both be NULL) are updated with `momentum` and the UNBIASED variance like
+ * torch; stat receives [mean (C) | rstd (C)] for the backward.  Two launches (row-chunk reduce folded by tickets in a fixed order - the
+ * result does not depend on workgroup arrival order - and apply).  tickets: LFDM_BN_TICKETS zeroed 32-bit words, left zeroed. */
+size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels);
+int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int ldx, int ldy, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                    float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
+/* Backward of the above from the saved input x and stat: dx, dgamma (C), dbeta (C) (either may be NULL); relu = 1 masks dy by the sign of
+ * the recomputed pre-activation (the same arithmetic as the forward: identical mask). */
+int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int ldx, int lddy, int lddx,
+                                    const float* gamma, const float* beta, const float* stat, int relu, float* dgamma, float* dbeta,
+                                    void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
+
+/* AntiAliasInterpolation2d (LFAE/modules/util.py:217-264) / ImagePyramide (model.py:62-82) with any element strides on both sides:
+ * out[n, c, oy, ox] = scale[c] * sum_k wgt[c, ky, kx] * x[n, c, oy*stride + ky - pad_lo, ox*stride + kx - pad_lo] + bias[c] (zero
+ * padding; only the kept outputs are computed; scale / bias NULL = 1 / 0 - the VGG input normalisation of model.py:52 when given);
+ * channels in [channels, c_store) of the output are written as zeros (the pad channel of 4-channel rows).  _bwd: dx from dy. */
+typedef struct lfdm_blur_params {
+  const float* x;
+  const float* wgt;      /* (channels, k, k) */
+  float* out;
+  const float* dy;       /* backward: gradient of out (out strides) */
+  float* dx;             /* backward: gradient of x (x strides) */
+  int64_t xs_n, xs_c, xs_h, xs_w, os_n, os_c, os_h, os_w;
+  int n_img, channels, c_store, h, w, k, pad_lo, pad_hi, stride;
+  const float* scale;
+  const float* bias;
+} lfdm_blur_params;
+int lfdm_blur_down_fwd_f32(const lfdm_blur_params* p, lfdm_stream_t stream);
+int lfdm_blur_down_bwd_f32(const lfdm_blur_params* p, lfdm_stream_t stream);
+
+/* Backward of Generator.deform_input + apply_optical (LFAE/modules/generator.py:59-88): out = grid_sample(src, resize(flow)) *
+ * resize(occ) + prev * (1 - resize(occ)) per sample n (one source per sample; maps (fh, fw) planes, element (n, y, x) at n*fsn + y*fw + x,
+ * resized bilinearly to (h, w) when the sizes differ - lfdm_warp_cl_f32's forward arithmetic).  Produces
+ *   dprev = dout * (1 - occ)                                     (optional),
+ *   dmaps (n_img, 3, h, w) = [d flow_x, d flow_y, d occ] at OUTPUT resolution (lfdm_resize_adjoint_f32 folds them to (fh, fw)),
+ *   dsrc_fix: 64-bit fixed-point accumulators (n_img*h*w, C), zero on entry, += tap weight * occ * dout * 2^k (channels-last form only),
+ *             k from *amax_bits = max |dout| (lfdm_absmax_f32) so that no sum can overflow; lfdm_fix_finalize_f32 converts to float and
+ *             re-zeroes.  Integer atomics commute: the gradient is identical from run to run (ATen's float atomics are not).
+ * layout_cl = 1: src / dout / prev / dprev are channels-last rows with the ld_* leading dimensions, C / 4 a power of two <= 64;
+ * layout_cl = 0: any element strides (ss_*, ds_*, ps_*, dps_*), few channels, src shared by n_div consecutive samples, no dsrc. */
+typedef struct lfdm_warp_bwd_params {
+  const float* src;
+  const float* dout;
+  const float* prev;       /* NULL: no blend partner (out = warped * occ) */
+  float* dprev;            /* NULL: not wanted */
+  long long* dsrc_fix;     /* NULL: not wanted */
+  unsigned* amax_bits;
+  float* dmaps;
+  const float* flow_x;
+  const float* flow_y;
+  const float* occ;        /* NULL: occ = 1 */
+  int n_img, h, w, c, fh, fw, n_div, layout_cl;
+  int64_t fsn;
+  int ld_src, ld_dout, ld_prev, ld_dprev;
+  int64_t ss_n, ss_c, ss_h, ss_w, ds_n, ds_c, ds_h, ds_w, ps_n, ps_c, ps_h, ps_w, dps_n, dps_c, dps_h, dps_w;
+} lfdm_warp_bwd_params;
+int lfdm_warp_bwd_f32(const lfdm_warp_bwd_params* p, lfdm_stream_t stream);
+/* *out_bits = max(*out_bits, bit pattern of max |x|) over a (rows, channels) matrix with leading dimension ld (integer max). */
+int lfdm_absmax_f32(const float* x, int64_t rows, int channels, int64_t ld, unsigned* out_bits, lfdm_stream_t stream);
+/* out (rows, channels; ld) = acc * 2^-k, acc re-zeroed, *amax_bits cleared by the last workgroup (ticket: one zeroed word, left zeroed);
+ * count = the per-address bound the scatter used (4 * h * w). */
+int lfdm_fix_finalize_f32(long long* acc, float* out, int64_t rows, int channels, int64_t ld, unsigned* amax_bits, int64_t count,
+                          unsigned* ticket, lfdm_stream_t stream);
+/* Adjoint of F.interpolate(mode='bilinear', align_corners=False) from (fh, fw) to (h, w) on `planes` planes (gather form, no atomics). */
+int lfdm_resize_adjoint_f32(const float* dhigh, float* dlow, int planes, int h, int w, int fh, int fw, lfdm_stream_t stream);
+
+/* F.grid_sample(x, grid, mode='bilinear', align_corners=False) with an explicit grid (n_img, ho, wo, 2) on strided tensors of few channels;
+ * x is shared by n_div consecutive samples (pixelwise_flow_predictor.py:95-102 repeats the source K+1 times); pad_mode 0 = zeros, 1 =
+ * reflection (Transform.transform_frame, model.py:118-122).  _bwd: dgrid (n_img, ho, wo, 2) from dout (out strides), zeros padding. */
+typedef struct lfdm_grid_sample_params {
+  const float* x;
+  const float* grid;
+  float* out;
+  const float* dout;
+  float* dgrid;
+  int64_t xs_n, xs_c, xs_h, xs_w, os_n, os_c, os_h, os_w;
+  int n_img, channels, h, w, ho, wo, n_div, pad_mode;
+} lfdm_grid_sample_params;
+int lfdm_grid_sample_fwd_f32(const lfdm_grid_sample_params* p, lfdm_stream_t stream);
+int lfdm_grid_sample_bwd_f32(const lfdm_grid_sample_params* p, lfdm_stream_t stream);
+
+/* Backward of lfdm_svd2x2_sym_f32 / torch.svd on symmetric positive semi-definite 2x2 matrices (region_predictor.py:16-26): ga (n, 2, 2)
+ * from u (n, 2, 2), s (n, 2) and the gradients gu / gs (either may be NULL) - torch's svd_backward with V = U, closed form. */
+int lfdm_svd2x2_sym_bwd_f32(const float* u, const float* s, const float* gu, const float* gs, float* ga, int64_t n, lfdm_stream_t stream);
+
 /* Box calibration, not on the product path (bench.py prints it beside every timing; ABI version 7): `blocks` workgroups of four
  * wavefronts run `iters` x 4 independent v_mfma_f32_32x32x2_f32 (2 * 32 * 32 * 2 FLOP each, pseudo-random operands) and
  * record, per workgroup b, out[2b] = shader cycles and out[2b+1] = 100 MHz real-time ticks of the loop: effective clock (MHz) =
