@@ -114,23 +114,29 @@ class ConvCL(Function):
                 ww = _pack_wino(weight, _c(w4))
             y = _conv(_c(x0.detach()), (w4, 0), w4.shape[0], kh, kw, n_img, hi, wi,
                       src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
-                      weight_wino=ww)
+                      weight_wino=ww, act=ops.ACT_RELU if geom.get("relu") else ops.ACT_NONE)
             hq = (hi + 2 * pad[0] - kh) // stride + 1
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
             assert x1 is None and residual is None and kh == 4 and kw == 4
             y = ops.deconv4x4s2_cl(_c(x0.detach()), ops.pack_conv_weight_dev(w4, 2), w4.shape[1], n_img, hi, wi, bias=b)
             stride, pad, hq, wq = 2, (1, 1), 2 * hi, 2 * wi
-        ctx.save_for_backward(x0, x1, weight)
+        relu_out = None
+        if geom.get("relu"):          # ReLU in the convolution's epilogue (geom relu=True): the backward masks dy by the saved output
+            assert kind == "conv" and residual is None
+            relu_out = y
+        ctx.save_for_backward(x0, x1, weight, relu_out)
         ctx.bias_param = bias
         ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x0, x1, weight = ctx.saved_tensors
+        x0, x1, weight, relu_out = ctx.saved_tensors
         kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, has_bias, has_res = ctx.meta
         dy = _c(dy)
+        if relu_out is not None:
+            dy = train_ops.relu_bwd(relu_out, dy)
         w4 = _c(weight.detach().reshape(weight.shape[0], weight.shape[1], kh, kw))
         need = ctx.needs_input_grad
         dx0 = dx1 = dw = db = None

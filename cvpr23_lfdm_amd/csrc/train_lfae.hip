@@ -93,25 +93,42 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnArgs a) {
     ga = *reinterpret_cast<const float4*>(a.gamma + ch);
     be = *reinterpret_cast<const float4*>(a.beta + ch);
   }
-  if (cvalid) {
-    for (int64_t r = r0 + rl; r < r1; r += lanes) {
-      const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
-      if (MODE == 0) {
-        const float dx_ = v.x - mu.x, dy_ = v.y - mu.y, dz_ = v.z - mu.z, dw_ = v.w - mu.w;
-        s0.x += dx_; s0.y += dy_; s0.z += dz_; s0.w += dw_;
-        s1.x = fmaf(dx_, dx_, s1.x); s1.y = fmaf(dy_, dy_, s1.y); s1.z = fmaf(dz_, dz_, s1.z); s1.w = fmaf(dw_, dw_, s1.w);
-      } else {
-        float4 g = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch);
-        const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z, hw = (v.w - mu.w) * rs.w;
-        if (a.relu) {
-          if (!(fmaf(hx, ga.x, be.x) > 0.f)) g.x = 0.f;
-          if (!(fmaf(hy, ga.y, be.y) > 0.f)) g.y = 0.f;
-          if (!(fmaf(hz, ga.z, be.z) > 0.f)) g.z = 0.f;
-          if (!(fmaf(hw, ga.w, be.w) > 0.f)) g.w = 0.f;
-        }
-        s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
-        s1.x = fmaf(g.x, hx, s1.x); s1.y = fmaf(g.y, hy, s1.y); s1.z = fmaf(g.z, hz, s1.z); s1.w = fmaf(g.w, hw, s1.w);
+  // four rows in flight per thread (one 16-byte load per row and operand): a single dependent load per iteration left the pass
+  // latency-bound at ~1.5 TB/s (profiles/r05_a2_lfae_census.txt)
+  auto accumulate = [&](const float4& v, float4 g) {
+    if (MODE == 0) {
+      const float dx_ = v.x - mu.x, dy_ = v.y - mu.y, dz_ = v.z - mu.z, dw_ = v.w - mu.w;
+      s0.x += dx_; s0.y += dy_; s0.z += dz_; s0.w += dw_;
+      s1.x = fmaf(dx_, dx_, s1.x); s1.y = fmaf(dy_, dy_, s1.y); s1.z = fmaf(dz_, dz_, s1.z); s1.w = fmaf(dw_, dw_, s1.w);
+    } else {
+      const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z, hw = (v.w - mu.w) * rs.w;
+      if (a.relu) {
+        if (!(fmaf(hx, ga.x, be.x) > 0.f)) g.x = 0.f;
+        if (!(fmaf(hy, ga.y, be.y) > 0.f)) g.y = 0.f;
+        if (!(fmaf(hz, ga.z, be.z) > 0.f)) g.z = 0.f;
+        if (!(fmaf(hw, ga.w, be.w) > 0.f)) g.w = 0.f;
       }
+      s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+      s1.x = fmaf(g.x, hx, s1.x); s1.y = fmaf(g.y, hy, s1.y); s1.z = fmaf(g.z, hz, s1.z); s1.w = fmaf(g.w, hw, s1.w);
+    }
+  };
+  if (cvalid) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t r = r0 + rl;
+    for (; r + 3 * lanes < r1; r += 4 * lanes) {
+      float4 v[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(a.x + (r + u * lanes) * a.ldx + ch);
+        g[u] = MODE == 1 ? *reinterpret_cast<const float4*>(a.dy + (r + u * lanes) * a.lddy + ch) : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(v[u], g[u]);
+    }
+    for (; r < r1; r += lanes) {
+      const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
+      const float4 g = MODE == 1 ? *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch) : zero4;
+      accumulate(v, g);
     }
   }
   float* m0 = &sm[0][tid * 4];
@@ -212,8 +229,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
     k1[i] = MODE == 1 ? s_k1[quad * 4 + i] : 0.f;
     k2[i] = MODE == 1 ? s_k2[quad * 4 + i] : 0.f;
   }
-  for (int64_t r = r0 + rl; r < r1; r += lanes) {
-    const float4 v4 = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
+  auto apply_row = [&](int64_t r, const float4& v4, const float4& g4) {
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
     float o[4];
     if (MODE == 0) {
@@ -223,7 +239,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
         o[i] = (a.relu && !(z > 0.f)) ? 0.f : z;
       }
     } else {
-      const float4 g4 = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch);
       const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -234,6 +249,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
       }
     }
     *reinterpret_cast<float4*>(a.out + r * a.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t r = r0 + rl;
+  for (; r + 3 * lanes < r1; r += 4 * lanes) {
+    float4 v[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = *reinterpret_cast<const float4*>(a.x + (r + u * lanes) * a.ldx + ch);
+      g[u] = MODE == 1 ? *reinterpret_cast<const float4*>(a.dy + (r + u * lanes) * a.lddy + ch) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) apply_row(r + u * lanes, v[u], g[u]);
+  }
+  for (; r < r1; r += lanes) {
+    const float4 v4 = *reinterpret_cast<const float4*>(a.x + r * a.ldx + ch);
+    const float4 g4 = MODE == 1 ? *reinterpret_cast<const float4*>(a.dy + r * a.lddy + ch) : zero4;
+    apply_row(r, v4, g4);
   }
 }
 
@@ -694,6 +726,147 @@ __global__ __launch_bounds__(256) void svd2x2_sym_bwd_kernel(const float* __rest
   ga[4 * i + 3] = t10 * u10 + t11 * u11;
 }
 
+// =====================================================================================================================================
+// 2x2 pooling family on channels-last rows, element-wise ReLU mask, mean absolute difference
+// =====================================================================================================================================
+// (h, w) is always the FINE resolution (even).  mode 0: average 2x2 (DownBlock2d, util.py:133) | 1: sum 2x2 (backward of the nearest x2
+// up-sampling) | 2: nearest x2 (UpBlock2d, util.py:109) | 3: nearest x2 times 0.25 (backward of the average) | 4: max 2x2 (VGG-19's
+// MaxPool2d) | 5: backward of the max: aux = dy at the coarse resolution, x = the forward's input, the gradient goes to the FIRST maximum of
+// the window in row-major order (ATen's max_pool2d_with_indices keeps the first).
+template <int MODE>
+__global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ x, const float* __restrict__ aux, float* __restrict__ out,
+                                                    int n_img, int h, int w, int channels) {
+  const int c4n = channels >> 2;
+  const int ho = h >> 1, wo = w >> 1;
+  const int64_t total = (int64_t)n_img * ho * wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t pix = i / c4n;
+    const int ox = (int)(pix % wo);
+    pix /= wo;
+    const int oy = (int)(pix % ho);
+    const int n = (int)(pix / ho);
+    const int64_t fine = (((int64_t)n * h + 2 * oy) * w + 2 * ox) * channels + c;
+    const int64_t coarse = (((int64_t)n * ho + oy) * wo + ox) * channels + c;
+    const int64_t dxs = channels, dys = (int64_t)w * channels;
+    if (MODE == 2 || MODE == 3) {
+      float4 v = *reinterpret_cast<const float4*>(x + coarse);
+      if (MODE == 3) { v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f; }
+      *reinterpret_cast<float4*>(out + fine) = v;
+      *reinterpret_cast<float4*>(out + fine + dxs) = v;
+      *reinterpret_cast<float4*>(out + fine + dys) = v;
+      *reinterpret_cast<float4*>(out + fine + dys + dxs) = v;
+      continue;
+    }
+    const float4 v00 = *reinterpret_cast<const float4*>(x + fine);
+    const float4 v01 = *reinterpret_cast<const float4*>(x + fine + dxs);
+    const float4 v10 = *reinterpret_cast<const float4*>(x + fine + dys);
+    const float4 v11 = *reinterpret_cast<const float4*>(x + fine + dys + dxs);
+    if (MODE == 0 || MODE == 1) {
+      const float k = MODE == 0 ? 0.25f : 1.f;
+      float4 y;
+      y.x = ((v00.x + v01.x) + (v10.x + v11.x)) * k;
+      y.y = ((v00.y + v01.y) + (v10.y + v11.y)) * k;
+      y.z = ((v00.z + v01.z) + (v10.z + v11.z)) * k;
+      y.w = ((v00.w + v01.w) + (v10.w + v11.w)) * k;
+      *reinterpret_cast<float4*>(out + coarse) = y;
+    } else if (MODE == 4) {
+      float4 y;
+      y.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+      y.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+      y.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+      y.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+      *reinterpret_cast<float4*>(out + coarse) = y;
+    } else {
+      const float4 g = *reinterpret_cast<const float4*>(aux + coarse);
+      const float a[4][4] = {{v00.x, v01.x, v10.x, v11.x}, {v00.y, v01.y, v10.y, v11.y}, {v00.z, v01.z, v10.z, v11.z}, {v00.w, v01.w, v10.w, v11.w}};
+      const float gg[4] = {g.x, g.y, g.z, g.w};
+      float o[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int best = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+          if (a[j][t] > a[j][best]) best = t;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t][j] = t == best ? gg[j] : 0.f;
+      }
+      *reinterpret_cast<float4*>(out + fine) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+      *reinterpret_cast<float4*>(out + fine + dxs) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+      *reinterpret_cast<float4*>(out + fine + dys) = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]);
+      *reinterpret_cast<float4*>(out + fine + dys + dxs) = make_float4(o[3][0], o[3][1], o[3][2], o[3][3]);
+    }
+  }
+}
+
+// out = y > 0 ? dy : 0 (the backward of a ReLU fused into the producing convolution's epilogue); n4 float4 items
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ y, const float4* __restrict__ dy, float4* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = y[i];
+    float4 g = dy[i];
+    if (!(v.x > 0.f)) g.x = 0.f;
+    if (!(v.y > 0.f)) g.y = 0.f;
+    if (!(v.z > 0.f)) g.z = 0.f;
+    if (!(v.w > 0.f)) g.w = 0.f;
+    out[i] = g;
+  }
+}
+
+constexpr int L1_BLOCKS = 1024;
+// forward: *out = weight / n * sum |x - y| (per-workgroup partials, folded by the last workgroup in index order: run-to-run identical);
+// backward: dx = sign(x - y) * (*gout) * weight / n
+__global__ __launch_bounds__(256) void l1_mean_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ y, int64_t n4, float scale,
+                                                          float* __restrict__ partial, unsigned* ticket, float* __restrict__ out) {
+  __shared__ float s_p[4];
+  __shared__ int s_last;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = x[i], b = y[i];
+    acc += (fabsf(a.x - b.x) + fabsf(a.y - b.y)) + (fabsf(a.z - b.z) + fabsf(a.w - b.w));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]);
+    LFDM_DRAIN_STORES();
+    LFDM_FENCE_RELEASE_AGENT();
+    const bool last = lfdm_ticket_take(ticket) == gridDim.x - 1;
+    if (last) {
+      lfdm_ticket_reset(ticket);
+      LFDM_FENCE_ACQUIRE_AGENT();
+    }
+    s_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double t = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += (double)partial[i];
+  // fixed order: lane-strided partial sums folded through a wavefront reduction of doubles in LDS
+  __shared__ double s_d[256];
+  s_d[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 256; ++i) tot += s_d[i];
+    *out = (float)(tot * (double)scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void l1_mean_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ y, int64_t n4, float scale,
+                                                          const float* __restrict__ gout, float4* __restrict__ dx) {
+  const float g = *gout * scale;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = x[i], b = y[i];
+    float4 o;
+    o.x = a.x > b.x ? g : (a.x < b.x ? -g : 0.f);
+    o.y = a.y > b.y ? g : (a.y < b.y ? -g : 0.f);
+    o.z = a.z > b.z ? g : (a.z < b.z ? -g : 0.f);
+    o.w = a.w > b.w ? g : (a.w < b.w ? -g : 0.f);
+    dx[i] = o;
+  }
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -910,4 +1083,68 @@ extern "C" int lfdm_svd2x2_sym_bwd_f32(const float* u, const float* s, const flo
   if (!u || !s || !ga || n <= 0 || (!gu && !gs)) { lfdm_set_error("svd2x2_sym_bwd: u, s, ga and at least one of gu / gs are required"); return LFDM_EINVAL; }
   LFDM_LAUNCH(svd2x2_sym_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, s, gu, gs, ga, n);
   return lfdm_check_launch("svd2x2_sym_bwd");
+}
+
+extern "C" int lfdm_pool2_cl_f32(const float* x, const float* aux, float* out, int n_img, int h, int w, int channels, int mode,
+                                 lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !out || n_img <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || channels <= 0 || channels % 4 != 0 || mode < 0 || mode > 5 ||
+      (mode == 5 && !aux) || !aligned16(x) || !aligned16(out) || (aux && !aligned16(aux))) {
+    lfdm_set_error("pool2: even fine resolution (h, w), channels % 4 == 0, mode 0..5 (5 needs aux = dy), 16-byte aligned rows");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)n_img * (h / 2) * (w / 2) * (channels / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65535 * 4) blocks = 65535 * 4;
+  const dim3 grid((unsigned)blocks);
+  switch (mode) {
+    case 0: LFDM_LAUNCH((pool2_kernel<0>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+    case 1: LFDM_LAUNCH((pool2_kernel<1>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+    case 2: LFDM_LAUNCH((pool2_kernel<2>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+    case 3: LFDM_LAUNCH((pool2_kernel<3>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+    case 4: LFDM_LAUNCH((pool2_kernel<4>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+    default: LFDM_LAUNCH((pool2_kernel<5>), grid, dim3(256), 0, stream, x, aux, out, n_img, h, w, channels); break;
+  }
+  return lfdm_check_launch("pool2");
+}
+
+extern "C" int lfdm_relu_bwd_f32(const float* y, const float* dy, float* out, int64_t n, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!y || !dy || !out || n <= 0 || n % 4 != 0 || !aligned16(y) || !aligned16(dy) || !aligned16(out)) {
+    lfdm_set_error("relu_bwd: n % 4 == 0 and 16-byte aligned tensors");
+    return LFDM_EINVAL;
+  }
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 65535 * 4) blocks = 65535 * 4;
+  LFDM_LAUNCH(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dy),
+              reinterpret_cast<float4*>(out), n / 4);
+  return lfdm_check_launch("relu_bwd");
+}
+
+extern "C" int lfdm_l1_mean_fwd_f32(const float* x, const float* y, int64_t n, float weight, float* out, void* ws, size_t ws_bytes,
+                                    unsigned* ticket, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y || !out || !ws || !ticket || n <= 0 || n % 4 != 0 || ws_bytes < L1_BLOCKS * sizeof(float) || !aligned16(x) || !aligned16(y)) {
+    lfdm_set_error("l1_mean_fwd: n % 4 == 0, 16-byte aligned x / y, a 4 KB workspace and one zeroed ticket word");
+    return LFDM_EINVAL;
+  }
+  int64_t blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > L1_BLOCKS) blocks = L1_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  LFDM_LAUNCH(l1_mean_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
+              n / 4, weight / (float)n, reinterpret_cast<float*>(ws), ticket, out);
+  return lfdm_check_launch("l1_mean_fwd");
+}
+
+extern "C" int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight, const float* gout, float* dx, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y || !gout || !dx || n <= 0 || n % 4 != 0 || !aligned16(x) || !aligned16(y) || !aligned16(dx)) {
+    lfdm_set_error("l1_mean_bwd: n % 4 == 0 and 16-byte aligned tensors");
+    return LFDM_EINVAL;
+  }
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 65535 * 4) blocks = 65535 * 4;
+  LFDM_LAUNCH(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
+              n / 4, weight / (float)n, gout, reinterpret_cast<float4*>(dx));
+  return lfdm_check_launch("l1_mean_bwd");
 }

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import ops, train_ops
 from ._native import BN_TICKETS, BlurParams, GridSampleParams, WarpBwdParams
 from .autograd import grad_out_pair
 from .ops import _chk, _lib, _p, _stream
@@ -370,3 +370,84 @@ class Svd2x2Sym(Function):
         ga = torch.empty_like(u)
         lib.check(lib.lfdm_svd2x2_sym_bwd_f32(_p(u), _p(s), _p(gu), _p(gs), _p(ga), u.shape[0], _stream(lib)), "lfdm_svd2x2_sym_bwd_f32")
         return ga
+
+
+# ------------------------------------------------------------------------------------------------ 2x2 pooling family, L1 mean
+class Pool2(Function):
+    """kind 'avg' (F.avg_pool2d(x, 2)), 'max' (F.max_pool2d(x, 2)) or 'up' (F.interpolate(x, scale_factor=2), nearest) on an NCHW tensor
+    in channels-last memory with even height / width; forward and backward are lfdm_pool2_cl_f32 launches."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        n, c, h, w = x.shape
+        xr = _rows(x.detach())
+        if kind == "up":
+            out = train_ops.pool2(xr, n, 2 * h, 2 * w, train_ops.POOL_UP)
+            ctx.meta = (kind, n, 2 * h, 2 * w)
+            return _from_rows(out, n, 2 * h, 2 * w)
+        out = train_ops.pool2(xr, n, h, w, train_ops.POOL_AVG if kind == "avg" else train_ops.POOL_MAX)
+        ctx.meta = (kind, n, h, w)
+        if kind == "max":
+            ctx.save_for_backward(xr)
+        return _from_rows(out, n, h // 2, w // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        kind, n, h, w = ctx.meta                  # (h, w): the fine resolution
+        dr = _rows(dy)
+        if kind == "up":
+            return _from_rows(train_ops.pool2(dr, n, h, w, train_ops.POOL_SUM), n, h // 2, w // 2), None
+        if kind == "avg":
+            return _from_rows(train_ops.pool2(dr, n, h, w, train_ops.POOL_UP_QUARTER), n, h, w), None
+        (xr,) = ctx.saved_tensors
+        return _from_rows(train_ops.pool2(xr, n, h, w, train_ops.POOL_MAX_BWD, aux=dr), n, h, w), None
+
+
+def pool2(x, kind):
+    """Native when the geometry allows (even size, channels % 4 == 0), else the ATen op."""
+    import torch.nn.functional as F
+    n, c, h, w = x.shape
+    if c % 4 == 0 and (kind == "up" or (h % 2 == 0 and w % 2 == 0)):
+        return Pool2.apply(x, kind)
+    return {"avg": lambda: F.avg_pool2d(x, 2), "max": lambda: F.max_pool2d(x, 2), "up": lambda: F.interpolate(x, scale_factor=2)}[kind]()
+
+
+class L1Mean(Function):
+    """weight * |x - y|.mean() as a (1,) tensor (the perceptual loss terms, model.py:189-195); y gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, y, weight):
+        lib = _lib()
+        xd, yd = x.detach(), y.detach()
+        xd = xd if _dense(xd) else xd.contiguous()
+        yd = yd if (_dense(yd) and yd.stride() == xd.stride()) else yd.contiguous(memory_format=_fmt(xd))
+        if yd.stride() != xd.stride():
+            xd, yd = xd.contiguous(), yd.contiguous()
+        _chk(lib, xd, yd)
+        n = xd.numel()
+        assert n % 4 == 0
+        st = _state(xd.device)
+        out = torch.empty(1, dtype=torch.float32, device=xd.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=xd.device)
+        lib.check(lib.lfdm_l1_mean_fwd_f32(_p(xd), _p(yd), n, float(weight), _p(out), _p(ws), 4096, C.c_void_p(st["amax"].data_ptr() + 8),
+                                           _stream(lib)), "lfdm_l1_mean_fwd_f32")
+        ctx.save_for_backward(xd, yd)
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xd, yd = ctx.saved_tensors
+        lib = _lib()
+        dx = torch.empty_like(xd)
+        lib.check(lib.lfdm_l1_mean_bwd_f32(_p(xd), _p(yd), xd.numel(), ctx.weight, _p(gout.contiguous()), _p(dx), _stream(lib)),
+                  "lfdm_l1_mean_bwd_f32")
+        return dx, None, None
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _fmt(t):
+    return torch.contiguous_format if t.is_contiguous() else torch.channels_last

@@ -46,7 +46,7 @@ def flush_batches_tracked():
     torch._foreach_add_([v[0] for v in seen.values()], [v[1] for v in seen.values()])
 
 
-def conv2d(x, weight, bias, padding):
+def conv2d(x, weight, bias, padding, relu=False):
     """nn.Conv2d (stride 1, square kernel) through the native kernels.  x: (N, C, H, W); returns a channels-last (N, O, H', W').
     Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded - the padded
     filter slices receive zero gradient through autograd's own pad / slice backward."""
@@ -61,7 +61,7 @@ def conv2d(x, weight, bias, padding):
     if cp or op:
         weight = F.pad(weight, (0, 0, 0, 0, 0, cp, 0, op))
         bias = F.pad(bias, (0, op)) if bias is not None else None
-    y = A.conv_cl(rows, weight, bias, n_img=n, hi=h, wi=w, pad=(padding, padding))
+    y = A.conv_cl(rows, weight, bias, n_img=n, hi=h, wi=w, pad=(padding, padding), relu=relu)       # relu: in the convolution's epilogue
     ho, wo = h + 2 * padding - k + 1, w + 2 * padding - k + 1
     y = y.view(n, ho, wo, cout + op).permute(0, 3, 1, 2)
     return y[:, :cout] if op else y
@@ -74,8 +74,8 @@ class _Net:
     def __init__(self, tree, training=True):
         self.t, self.training = tree, training
 
-    def conv(self, x, prefix, padding):
-        return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding)
+    def conv(self, x, prefix, padding, relu=False):
+        return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding, relu)
 
     def bn_relu(self, x, prefix):
         """BatchNorm2d -> ReLU (every BatchNorm of the LFAE networks is followed by one: util.py:84-90, 108-112, 128-133, 146-150).  Training:
@@ -92,10 +92,10 @@ class _Net:
         return self.bn_relu(self.conv(x, prefix + "conv.", padding), prefix + "norm.")
 
     def down_block(self, x, prefix):                      # DownBlock2d: conv -> BN -> ReLU -> AvgPool 2x2
-        return F.avg_pool2d(self.conv_bn_relu(x, prefix), 2)
+        return L.pool2(self.conv_bn_relu(x, prefix), "avg")
 
     def up_block(self, x, prefix):                        # UpBlock2d: nearest x2 -> conv -> BN -> ReLU
-        return self.conv_bn_relu(F.interpolate(x, scale_factor=2), prefix)
+        return self.conv_bn_relu(L.pool2(x, "up"), prefix)
 
     def res_block(self, x, prefix):                       # ResBlock2d (util.py:70-92): pre-activation, identity skip
         out = self.conv(self.bn_relu(x, prefix + "norm1."), prefix + "conv1.", 1)
@@ -116,11 +116,19 @@ class _Net:
         return out
 
 
+_CONST = {}
+
+
 def make_coordinate_grid(h, w, like):
-    """util.py:51-67: (h, w, 2) grid of (x, y) in [-1, 1]."""
-    x = 2 * (torch.arange(w, dtype=like.dtype, device=like.device) / (w - 1)) - 1
-    y = 2 * (torch.arange(h, dtype=like.dtype, device=like.device) / (h - 1)) - 1
-    return torch.stack((x.view(1, -1).expand(h, w), y.view(-1, 1).expand(h, w)), dim=2)
+    """util.py:51-67: (h, w, 2) grid of (x, y) in [-1, 1].  A constant per (h, w, device): built once (9 launches per call otherwise, 8 calls
+    per step); callers only read it."""
+    key = ("grid", h, w, str(like.device), like.dtype)
+    g = _CONST.get(key)
+    if g is None:
+        x = 2 * (torch.arange(w, dtype=like.dtype, device=like.device) / (w - 1)) - 1
+        y = 2 * (torch.arange(h, dtype=like.dtype, device=like.device) / (h - 1)) - 1
+        g = _CONST[key] = torch.stack((x.view(1, -1).expand(h, w), y.view(-1, 1).expand(h, w)), dim=2)
+    return g
 
 
 def antialias_down(x, weight, scale, rows4=False, affine=None):
@@ -131,7 +139,10 @@ def antialias_down(x, weight, scale, rows4=False, affine=None):
     if scale == 1 and not rows4 and affine is None:
         return x
     if scale == 1:
-        weight = x.new_ones(x.shape[1], 1, 1)
+        key = ("ones", x.shape[1], str(x.device))
+        weight = _CONST.get(key)
+        if weight is None:
+            weight = _CONST[key] = x.new_ones(x.shape[1], 1, 1)
     sc, bi = affine if affine is not None else (None, None)
     return L.BlurDown.apply(x, weight, int(round(1 / scale)), rows4, sc, bi)
 
@@ -139,18 +150,44 @@ def antialias_down(x, weight, scale, rows4=False, affine=None):
 # The reference writes its per-pixel 2x2 / 3x3 algebra as torch.matmul over (B, K, h, w, 2, 2) operands: hundreds of thousands of
 # 2x2 products per call, which a GEMM library runs as a batched GEMM at ~1 ms each (39 % of a step when this file did the same,
 # profiles/r04_x_lfae_*).  The same sums written out as broadcast multiply-adds are a handful of element-wise launches.
+# Element access goes through ONE unbind per operand (its backward is one stack) instead of four / two indexing ops (each with a zeros + copy
+# backward); 2x2 inverses and products are written out too: torch.inverse / torch.matmul on (B, K, 2, 2) tensors run rocSOLVER / Tensile
+# kernels and torch.inverse synchronises with the host to check for singular inputs.
+def _e4(m):
+    """The four entries (a, b, c, d) of (..., 2, 2) matrices [[a, b], [c, d]]."""
+    return m.reshape(*m.shape[:-2], 4).unbind(-1)
+
+
+def _m22(a, b, c, d):
+    return torch.stack((a, b, c, d), dim=-1).reshape(*a.shape, 2, 2)
+
+
+def _inv2(m):
+    a, b, c, d = _e4(m)
+    det = a * d - b * c
+    return _m22(d, -b, -c, a) / det.unsqueeze(-1).unsqueeze(-1)
+
+
+def _mm2(x, y):
+    a, b, c, d = _e4(x)
+    e, f, g, h = _e4(y)
+    return _m22(a * e + b * g, a * f + b * h, c * e + d * g, c * f + d * h)
+
+
 def _mat2_vec(m, v):
     """(..., 2, 2) @ (..., 2) with broadcasting."""
-    return torch.stack((m[..., 0, 0] * v[..., 0] + m[..., 0, 1] * v[..., 1], m[..., 1, 0] * v[..., 0] + m[..., 1, 1] * v[..., 1]), dim=-1)
+    a, b, c, d = _e4(m)
+    vx, vy = v.unbind(-1)
+    return torch.stack((a * vx + b * vy, c * vx + d * vy), dim=-1)
 
 
 def region2gaussian(center, covar, h, w):
     """util.py:22-48 with a matrix covariance: exp(-0.5 d^T covar^-1 d) on the coordinate grid."""
     grid = make_coordinate_grid(h, w, center).view(1, 1, h, w, 2)
     d = grid - center.view(*center.shape[:2], 1, 1, 2)
-    inv = torch.inverse(covar).view(*covar.shape[:2], 1, 1, 2, 2)
-    dx, dy = d[..., 0], d[..., 1]
-    under = (dx * inv[..., 0, 0] + dy * inv[..., 1, 0]) * dx + (dx * inv[..., 0, 1] + dy * inv[..., 1, 1]) * dy
+    i00, i01, i10, i11 = (t.view(*covar.shape[:2], 1, 1) for t in _e4(_inv2(covar)))
+    dx, dy = d.unbind(-1)
+    under = (dx * i00 + dy * i10) * dx + (dx * i01 + dy * i11) * dy
     return torch.exp(-0.5 * under)
 
 
@@ -171,8 +208,9 @@ def region_predictor_forward(tree, x, cfg, training=True):
     # region_predictor.py:21-25 moves the covariances to the host for torch.svd; here: LAPACK's 2x2 path in closed form on the device,
     # analytic backward (lfae_ops.Svd2x2Sym) - no host round trip in the step
     u, s = L.Svd2x2Sym.apply(covar.reshape(-1, 2, 2))
-    d = torch.diag_embed(s ** 0.5)
-    return {"shift": mean, "covar": covar, "heatmap": region, "affine": torch.matmul(u, d).view(*covar.shape), "u": u, "d": d}
+    sq = s ** 0.5
+    d = torch.diag_embed(sq)
+    return {"shift": mean, "covar": covar, "heatmap": region, "affine": (u * sq.unsqueeze(-2)).view(*covar.shape), "u": u, "d": d}      # U @ diag
 
 
 def bg_predictor_forward(tree, source, driving, cfg, training=True):
@@ -196,16 +234,16 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
     heat = torch.cat([heat.new_zeros(bs, 1, h, w), heat], dim=1).unsqueeze(2)
     ident = make_coordinate_grid(h, w, heat).view(1, 1, h, w, 2)
     cg = ident - driving["shift"].view(bs, k, 1, 1, 2)
-    affine = torch.matmul(source["affine"], torch.inverse(driving["affine"]))
+    affine = _mm2(source["affine"], _inv2(driving["affine"]))
     if revert_axis_swap:
         affine = affine * torch.sign(affine[:, :, 0:1, 0:1])
     cg = _mat2_vec(affine.unsqueeze(-3).unsqueeze(-3), cg)
     d2s = cg + source["shift"].view(bs, k, 1, 1, 2)
     bg = ident.repeat(bs, 1, 1, 1, 1)
     if bg_params is not None:      # homogeneous 3x3 transform of the identity grid
-        m = bg_params.view(bs, 1, 1, 1, 3, 3)
-        gx, gy = bg[..., 0], bg[..., 1]
-        hom = [m[..., i, 0] * gx + m[..., i, 1] * gy + m[..., i, 2] for i in range(3)]
+        m = [t.view(bs, 1, 1, 1) for t in bg_params.reshape(bs, 9).unbind(-1)]
+        gx, gy = bg.unbind(-1)
+        hom = [m[3 * i] * gx + m[3 * i + 1] * gy + m[3 * i + 2] for i in range(3)]
         bg = torch.stack((hom[0] / hom[2], hom[1] / hom[2]), dim=-1)
     sparse = torch.cat([bg, d2s], dim=1)
     # (pixelwise_flow_predictor.py:95-102 repeats the source K+1 times; the native kernel reads one source per K+1 grids)
@@ -283,8 +321,8 @@ class Vgg19(ParamTree):
                 outs.append(x)
                 cur = sl
             if idx in P.VGG19_POOLS_BEFORE:
-                x = F.max_pool2d(x, 2)
-            x = F.relu(net.conv(x, "slice%d.%d." % (sl, idx), 1))
+                x = L.pool2(x, "max")
+            x = net.conv(x, "slice%d.%d." % (sl, idx), 1, relu=True)
         outs.append(x)
         return outs
 
@@ -380,14 +418,17 @@ class ReconstructionModel:
             with torch.no_grad():
                 pyr_real = self.pyramid(drv, vgg_input=fast)
             pyr_gen = self.pyramid(gen["prediction"], vgg_input=fast)
-            total = 0
+            terms = []
             for s in self.scales:
                 x_vgg = self.vgg.features(pyr_gen[s], prepared=fast)
                 with torch.no_grad():
                     y_vgg = self.vgg.features(pyr_real[s], prepared=fast)
                 for i, wgt in enumerate(lw["perceptual"]):
-                    total = total + wgt * torch.abs(x_vgg[i] - y_vgg[i]).mean()
-            losses["perceptual"] = total
+                    if x_vgg[i].numel() % 4 == 0:
+                        terms.append(L.L1Mean.apply(x_vgg[i], y_vgg[i], wgt))           # one launch forward, one backward per term
+                    else:
+                        terms.append((wgt * torch.abs(x_vgg[i] - y_vgg[i]).mean()).reshape(1))
+            losses["perceptual"] = torch.cat(terms).sum()
         if lw["equivariance_shift"] + lw["equivariance_affine"] != 0:
             tr = Transform(drv.shape[0], noise=transform_noise, device=drv.device, **self.tp["transform_params"])
             frame = tr.transform_frame(drv)
@@ -396,7 +437,7 @@ class ReconstructionModel:
             if lw["equivariance_shift"] != 0:
                 losses["equivariance_shift"] = lw["equivariance_shift"] * torch.abs(driving_rp["shift"] - tr.warp_coordinates(trp["shift"])).mean()
             if lw["equivariance_affine"] != 0:
-                value = torch.matmul(torch.inverse(driving_rp["affine"]), torch.matmul(tr.jacobian(trp["shift"]), trp["affine"]))
+                value = _mm2(_inv2(driving_rp["affine"]), _mm2(tr.jacobian(trp["shift"]), trp["affine"]))
                 if mp.get("revert_axis_swap", True):
                     value = value * torch.sign(value[:, :, 0:1, 0:1])
                 eye = torch.eye(2, dtype=value.dtype, device=value.device).view(1, 1, 2, 2)

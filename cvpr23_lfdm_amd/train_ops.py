@@ -229,3 +229,30 @@ def upsample2_pad(x, n_img, h, w, pad, reflect, backward=False):
     lib.check(lib.lfdm_upsample2_pad_cl_f32(_p(x), _p(out), n_img, h, w, c, pad, int(reflect), int(backward), _stream(lib)),
               "lfdm_upsample2_pad_cl_f32")
     return out
+
+
+def relu_bwd(y, dy):
+    """dy masked by y > 0 (lfdm_relu_bwd_f32): the backward of a ReLU fused into the producing convolution's epilogue."""
+    lib = _lib()
+    _chk(lib, y, dy)
+    assert y.is_contiguous() and dy.is_contiguous() and y.shape == dy.shape and y.numel() % 4 == 0
+    out = torch.empty_like(dy)
+    lib.check(lib.lfdm_relu_bwd_f32(_p(y), _p(dy), _p(out), y.numel(), _stream(lib)), "lfdm_relu_bwd_f32")
+    return out
+
+
+POOL_AVG, POOL_SUM, POOL_UP, POOL_UP_QUARTER, POOL_MAX, POOL_MAX_BWD = range(6)
+
+
+def pool2(x, n_img, h, w, mode, aux=None):
+    """lfdm_pool2_cl_f32 on channels-last rows; (h, w) = the FINE resolution.  Modes 0 / 1 / 4: x (n*h*w, C) -> (n*h/2*w/2, C); modes
+    2 / 3: x (n*h/2*w/2, C) -> (n*h*w, C); mode 5: x fine, aux = dy coarse -> dx fine."""
+    lib = _lib()
+    _chk(lib, x, aux)
+    assert x.is_contiguous() and (aux is None or aux.is_contiguous())
+    c = x.shape[1]
+    fine, coarse = n_img * h * w, n_img * (h // 2) * (w // 2)
+    assert x.shape[0] == (coarse if mode in (POOL_UP, POOL_UP_QUARTER) else fine)
+    out = torch.empty(coarse if mode in (POOL_AVG, POOL_SUM, POOL_MAX) else fine, c, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_pool2_cl_f32(_p(x), _p(aux), _p(out), n_img, h, w, c, mode, _stream(lib)), "lfdm_pool2_cl_f32")
+    return out

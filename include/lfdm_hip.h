@@ -696,6 +696,19 @@ int lfdm_grid_sample_bwd_f32(const lfdm_grid_sample_params* p, lfdm_stream_t str
  * from u (n, 2, 2), s (n, 2) and the gradients gu / gs (either may be NULL) - torch's svd_backward with V = U, closed form. */
 int lfdm_svd2x2_sym_bwd_f32(const float* u, const float* s, const float* gu, const float* gs, float* ga, int64_t n, lfdm_stream_t stream);
 
+/* 2x2 pooling family on channels-last rows; (h, w) = the FINE resolution (even).  mode 0: average (DownBlock2d, util.py:133) | 1: sum
+ * (backward of nearest x2) | 2: nearest x2 (UpBlock2d, util.py:109) | 3: nearest x2 * 0.25 (backward of the average) | 4: max (VGG-19's
+ * MaxPool2d(2, 2), model.py:19-47) | 5: backward of the max (aux = dy at the coarse resolution, x = the forward's input; the gradient goes
+ * to the first maximum of the window in row-major order, like ATen).  Modes 0 / 1 / 4 read fine and write coarse rows, 2 / 3 / 5 the reverse. */
+int lfdm_pool2_cl_f32(const float* x, const float* aux, float* out, int n_img, int h, int w, int channels, int mode, lfdm_stream_t stream);
+/* out = y > 0 ? dy : 0 over n floats: backward of a ReLU fused into the producing convolution (lfdm_conv_params.act = 1; VGG-19, model.py:19-59). */
+int lfdm_relu_bwd_f32(const float* y, const float* dy, float* out, int64_t n, lfdm_stream_t stream);
+/* *out = weight * mean |x - y| (the perceptual loss terms, model.py:189-195), partials folded in a fixed order by the last workgroup
+ * (ws: 4 KB, ticket: one zeroed word, left zeroed);  _bwd: dx = sign(x - y) * (*gout) * weight / n. */
+int lfdm_l1_mean_fwd_f32(const float* x, const float* y, int64_t n, float weight, float* out, void* ws, size_t ws_bytes, unsigned* ticket,
+                         lfdm_stream_t stream);
+int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight, const float* gout, float* dx, lfdm_stream_t stream);
+
 /* Box calibration, not on the product path (bench.py prints it beside every timing; ABI version 7): `blocks` workgroups of four
  * wavefronts run `iters` x 4 independent v_mfma_f32_32x32x2_f32 (2 * 32 * 32 * 2 FLOP each, pseudo-random operands) and
  * record, per workgroup b, out[2b] = shader cycles and out[2b+1] = 100 MHz real-time ticks of the loop: effective clock (MHz) =

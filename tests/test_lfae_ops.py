@@ -208,3 +208,46 @@ def test_svd2x2_sym_autograd(backend):
     ok = ((s.detach()[:, 0] - s.detach()[:, 1]) / s.detach()[:, 0]) > 0.05
     sc = float(a.grad[ok].abs().max())
     assert_close(ad.grad.cpu()[ok] / sc, a.grad[ok] / sc, 5e-4, "svd backward")
+
+
+@pytest.mark.parametrize("kind", ["avg", "max", "up"])
+def test_pool2(backend, kind):
+    dev = backend
+    n, c, h, w = (2, 8, 6, 10) if dev == "cpu" else (8, 64, 128, 128)
+    x = rnd(n, c, h, w, seed=1)
+    if kind == "max":
+        x[:, :, ::2, ::2] = x[:, :, 1::2, 1::2]          # ties inside every window: the FIRST maximum takes the gradient
+    x.requires_grad_(True)
+    ref = {"avg": lambda: F.avg_pool2d(x, 2), "max": lambda: F.max_pool2d(x, 2), "up": lambda: F.interpolate(x, scale_factor=2)}[kind]()
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(dy)
+    xd = _cl(x.detach().to(dev)).requires_grad_(True)
+    out = L.pool2(xd, kind)
+    assert isinstance(out.grad_fn, torch.autograd.function.BackwardCFunction)
+    assert_close(out.detach().cpu(), ref.detach(), 1e-6, "pool2 %s" % kind)
+    out.backward(_cl(dy.to(dev)))
+    assert_close(xd.grad.cpu(), x.grad, 1e-6, "pool2 %s backward" % kind)
+
+
+def test_l1_mean_and_conv_relu(backend):
+    from cvpr23_lfdm_amd import lfae_train
+    dev = backend
+    n, c, h, w = (2, 8, 6, 6) if dev == "cpu" else (8, 64, 64, 64)
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    y = rnd(n, c, h, w, seed=2)
+    wgt = (rnd(c, c, 3, 3, seed=3) * 0.2).requires_grad_(True)
+    b = rnd(c, seed=4).requires_grad_(True)
+    ref = 10.0 * torch.abs(F.relu(F.conv2d(x, wgt, b, padding=1)) - y).mean()
+    ref.backward()
+    xd = _cl(x.detach().to(dev)).requires_grad_(True)
+    wd, bd = wgt.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    feat = lfae_train.conv2d(xd, wd, bd, 1, relu=True)
+    loss = L.L1Mean.apply(feat, _cl(y.to(dev)), 10.0)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    loss.sum().backward()
+    for name, got, want in (("dx", xd.grad, x.grad), ("dw", wd.grad, wgt.grad), ("db", bd.grad, b.grad)):
+        s = float(want.abs().max())
+        assert_close(got.cpu() / s, want / s, TOL, "conv+relu+l1 " + name)
+    # run-to-run identical, ticket word left zeroed
+    assert float(L.L1Mean.apply(feat.detach(), _cl(y.to(dev)), 10.0)) == float(loss)
+    assert int(L._state(xd.device)["amax"].abs().max()) == 0
