@@ -93,6 +93,31 @@ def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):
             all(c % 16 == 0 for c in chans))
 
 
+def _thin_wgrad_route(kind, x1, stride, pad, kh, kw, cin, cout, hi, wi, hq, wq):
+    """'in' / 'out' when a k x k convolution (k >= 3, stride 1, square, symmetric padding) has <= 16 input (resp. output) channels: its weight
+    gradient then runs as ONE 1x1 weight-gradient GEMM over an im2col of the thin side (train_ops.im2col_cl) instead of k*k per-tap GEMMs
+    that each pad the thin side to the kernel's 64-wide tile (the generator's 7x7 RGB convolutions: 16x the work)."""
+    if kind != "conv" or x1 is not None or stride != 1 or kh != kw or kh < 3 or pad[0] != pad[1]:
+        return None
+    if cin % 4 == 0 and cin <= 16:
+        return "in"
+    if cout % 4 == 0 and cout <= 16 and 2 * pad[0] == kh - 1:
+        return "out"
+    return None
+
+
+def _thin_wgrad(route, x, dy, n_img, hi, wi, hq, wq, k, pad, cin, cout):
+    """-> dw (cout, cin, k, k).  'in': dW[(tap, ci)][co] = im2col(x)^T dy.  'out': with r' = the INPUT pixel, dW[tap][ci][co] =
+    sum_r' x[r'][ci] dy[r' - tap + pad][co] = x^T im2col(dy, pad' = k - 1 - pad) at the mirrored tap."""
+    if route == "in":
+        col = train_ops.im2col_cl(x, n_img, hi, wi, k, pad)                                   # (n*hq*wq, k*k*cin)
+        dwt = train_ops.conv_wgrad(col, dy, n_img, hq, wq, hq, wq, 1, 1, pad=(0, 0))          # (1, k*k*cin, cout)
+        return dwt.view(k, k, cin, cout).permute(3, 2, 0, 1)
+    col = train_ops.im2col_cl(dy, n_img, hq, wq, k, k - 1 - pad)                              # (n*hi*wi, k*k*cout)
+    dwt = train_ops.conv_wgrad(x, col, n_img, hi, wi, hi, wi, 1, 1, pad=(0, 0))               # (1, cin, k*k*cout)
+    return dwt.view(cin, k, k, cout).flip(1, 2).permute(3, 0, 1, 2)
+
+
 class ConvCL(Function):
     """y = conv(cat(x0, x1), weight) + bias (+ residual).  weight in the reference layout (Cout, Cin, [1,] kh, kw)
     (or ConvTranspose (Cin, Cout, [1,] 4, 4) when geom['kind'] == 'deconv').  geom: n_img, hi, wi, stride, pad."""
@@ -142,7 +167,8 @@ class ConvCL(Function):
         dx0 = dx1 = dw = db = None
         bias_p = ctx.bias_param
         taps_ok = kh * kw <= 16         # lfdm_wgrad_params.dw_layout = 1: the gradient in the weight's own layout, bias sums from the same pass
-        fused_bias = kind == "conv" and need[2] and taps_ok
+        fused_bias = (kind == "conv" and need[2] and taps_ok and
+                      _thin_wgrad_route(kind, x1, stride, pad, kh, kw, x0.shape[1], w4.shape[0], hi, wi, hq, wq) is None)
         if has_bias and need[3]:
             db = grad_out(bias_p)
             if not fused_bias:
@@ -150,7 +176,10 @@ class ConvCL(Function):
         if kind == "conv":
             cout = w4.shape[0]
             c0 = x0.shape[1]
-            if need[2] and taps_ok:
+            thin = _thin_wgrad_route(kind, x1, stride, pad, kh, kw, c0, cout, hi, wi, hq, wq) if need[2] else None
+            if thin is not None:
+                dw = _thin_wgrad(thin, _c(x0), dy, n_img, hi, wi, hq, wq, kh, pad[0], c0, cout).reshape(weight.shape)
+            elif need[2] and taps_ok:
                 dw = grad_out(weight)
                 train_ops.conv_wgrad(_c(x0), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad, out=dw, ci_off=0, dbias=db)
                 if x1 is not None:

@@ -867,6 +867,29 @@ __global__ __launch_bounds__(256) void l1_mean_bwd_kernel(const float4* __restri
   }
 }
 
+// im2col of channels-last rows with FEW channels (c % 4 == 0, c <= 16): out[(n, qy, qx)][tap * c + ch] = x[n, qy + ky - pad, qx + kx - pad][ch]
+// (zero outside), stride 1.  Turns the weight gradient of a k x k convolution whose input (or, with the roles swapped, output) has a
+// handful of channels into ONE 1x1 weight-gradient GEMM over k*k*c columns: the per-tap kernel pads 4 channels to its 64-wide tile
+// (16x the work for the 7x7 RGB convolutions of the generator, LFAE/modules/generator.py:37,56).  One thread per (output row, tap, float4).
+__global__ __launch_bounds__(256) void im2col_cl_kernel(const float* __restrict__ x, float* __restrict__ out, int n_img, int h, int w, int c,
+                                                        int ldx, int k, int pad, int hq, int wq) {
+  const int c4n = c >> 2, per_row = k * k * c4n;
+  const int64_t total = (int64_t)n_img * hq * wq * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e = (int)(i % per_row);
+    int64_t r = i / per_row;
+    const int tap = e / c4n, c4 = e - tap * c4n;
+    const int qx = (int)(r % wq);
+    int64_t t = r / wq;
+    const int qy = (int)(t % hq);
+    const int n = (int)(t / hq);
+    const int iy = qy + tap / k - pad, ix = qx + tap % k - pad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = *reinterpret_cast<const float4*>(x + (((int64_t)n * h + iy) * w + ix) * ldx + 4 * c4);
+    *reinterpret_cast<float4*>(out + r * ((int64_t)k * k * c) + tap * c + 4 * c4) = v;
+  }
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -1147,4 +1170,19 @@ extern "C" int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, f
   LFDM_LAUNCH(l1_mean_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
               n / 4, weight / (float)n, gout, reinterpret_cast<float4*>(dx));
   return lfdm_check_launch("l1_mean_bwd");
+}
+
+extern "C" int lfdm_im2col_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int ldx, int k, int pad, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int hq = h + 2 * pad - k + 1, wq = w + 2 * pad - k + 1;
+  if (!x || !out || n_img <= 0 || h <= 0 || w <= 0 || channels <= 0 || channels % 4 != 0 || channels > 16 || ldx % 4 != 0 || ldx < channels ||
+      k <= 0 || pad < 0 || hq <= 0 || wq <= 0 || !aligned16(x) || !aligned16(out)) {
+    lfdm_set_error("im2col_cl: channels % 4 == 0 and <= 16, 16-byte aligned rows, stride 1");
+    return LFDM_EINVAL;
+  }
+  const int64_t total = (int64_t)n_img * hq * wq * k * k * (channels / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65535 * 8) blocks = 65535 * 8;
+  LFDM_LAUNCH(im2col_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, out, n_img, h, w, channels, ldx, k, pad, hq, wq);
+  return lfdm_check_launch("im2col_cl");
 }

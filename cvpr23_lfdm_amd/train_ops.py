@@ -256,3 +256,15 @@ def pool2(x, n_img, h, w, mode, aux=None):
     out = torch.empty(coarse if mode in (POOL_AVG, POOL_SUM, POOL_MAX) else fine, c, dtype=torch.float32, device=x.device)
     lib.check(lib.lfdm_pool2_cl_f32(_p(x), _p(aux), _p(out), n_img, h, w, c, mode, _stream(lib)), "lfdm_pool2_cl_f32")
     return out
+
+
+def im2col_cl(x, n_img, h, w, k, pad):
+    """lfdm_im2col_cl_f32: x (n*h*w, c <= 16) rows -> (n*hq*wq, k*k*c), column tap*c + ch (stride 1, zero padding)."""
+    lib = _lib()
+    _chk(lib, x)
+    assert x.stride(1) == 1 and x.shape[0] == n_img * h * w
+    c = x.shape[1]
+    hq, wq = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+    out = torch.empty(n_img * hq * wq, k * k * c, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_im2col_cl_f32(_p(x), _p(out), n_img, h, w, c, x.stride(0), k, pad, _stream(lib)), "lfdm_im2col_cl_f32")
+    return out

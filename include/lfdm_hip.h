@@ -709,6 +709,11 @@ int lfdm_l1_mean_fwd_f32(const float* x, const float* y, int64_t n, float weight
                          lfdm_stream_t stream);
 int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight, const float* gout, float* dx, lfdm_stream_t stream);
 
+/* im2col of channels-last rows with few channels (channels % 4 == 0, <= 16; stride 1, zero padding): out (n_img*hq*wq, k*k*channels),
+ * column tap * channels + ch.  Lets the weight gradient of the generator's 7x7 RGB convolutions (LFAE/modules/generator.py:37,56: 3 -> 64
+ * and 64 -> 3 channels) run as ONE 1x1 weight-gradient GEMM instead of 49 per-tap GEMMs that pad 4 channels to a 64-wide tile. */
+int lfdm_im2col_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int ldx, int k, int pad, lfdm_stream_t stream);
+
 /* Box calibration, not on the product path (bench.py prints it beside every timing; ABI version 7): `blocks` workgroups of four
  * wavefronts run `iters` x 4 independent v_mfma_f32_32x32x2_f32 (2 * 32 * 32 * 2 FLOP each, pseudo-random operands) and
  * record, per workgroup b, out[2b] = shader cycles and out[2b+1] = 100 MHz real-time ticks of the loop: effective clock (MHz) =
