@@ -463,8 +463,11 @@ __global__ __launch_bounds__(256) void fix_finalize_kernel(long long* __restrict
 }
 
 // Channels-last backward of out = warp(src; flow) * occ + prev * (1 - occ).  A pixel is served by G = C/4 adjacent lanes (a power of two
-// <= 64).  Per pixel: d_prev = dout * (1 - occ); d_src[tap] += w_tap * occ * dout (fixed point); the three map gradients
-// (d flow_x, d flow_y, d occ) at OUTPUT resolution into dmaps (N, 3, H, W) - lfdm_resize_adjoint folds them to the map resolution.
+// <= 64); lane l owns the channels {l, l + G, l + 2G, l + 3G}, so that every load, store and - what matters - every 64-bit atomic
+// instruction of the pixel's lanes covers ONE contiguous run of G elements (with four consecutive channels per lane an atomic instruction
+// touched 8 of every 32 bytes over a 4x larger span: four times the cache-line operations at the L2's atomic units).  Per pixel:
+// d_prev = dout * (1 - occ); d_src[tap] += w_tap * occ * dout (fixed point); the three map gradients (d flow_x, d flow_y, d occ) at OUTPUT
+// resolution into dmaps (N, 3, H, W) - lfdm_resize_adjoint folds them to the map resolution.
 // grid (blocks over h*w*G lane items, N)
 __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(lfdm_warp_bwd_params p) {
   const int g = p.c >> 2;
@@ -475,32 +478,35 @@ __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(lfdm_warp_bwd_params p
   const int kfix = p.dsrc_fix ? fix_exponent(*p.amax_bits, (int64_t)4 * hw) : 0;
   for (int idx0 = blockIdx.x * 256; idx0 < per_img; idx0 += gridDim.x * 256) {
     const int idx = idx0 + threadIdx.x;
-    const bool live = idx < per_img;          // (per_img is a multiple of 64 whenever hw * g is; keep the shuffles convergent anyway)
+    const bool live = idx < per_img;
     const int pix = live ? (idx >> gshift) : 0;
-    const int c = (idx - ((idx >> gshift) << gshift)) * 4;
+    const int c = idx - ((idx >> gshift) << gshift);                 // first channel of this lane; the others follow at stride g
     const int oy = pix / p.w, ox = pix - oy * p.w;
     const int64_t gp = (int64_t)n * hw + pix;
     float dfx = 0.f, dfy = 0.f, dob = 0.f;
     if (live) {
       const WTaps tp = warp_taps(p, n, oy, ox);
-      const float4 d4 = *reinterpret_cast<const float4*>(p.dout + gp * p.ld_dout + c);
-      const float d[4] = {d4.x, d4.y, d4.z, d4.w};
       const float o = tp.occ, om = 1.f - o;
-      float pv[4] = {0.f, 0.f, 0.f, 0.f};
+      float d[4], pv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = p.dout[gp * p.ld_dout + c + i * g];
       if (p.prev) {
-        const float4 t4 = *reinterpret_cast<const float4*>(p.prev + gp * p.ld_prev + c);
-        pv[0] = t4.x; pv[1] = t4.y; pv[2] = t4.z; pv[3] = t4.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = p.prev[gp * p.ld_prev + c + i * g];
       }
-      if (p.dprev) *reinterpret_cast<float4*>(p.dprev + gp * p.ld_dprev + c) = make_float4(d[0] * om, d[1] * om, d[2] * om, d[3] * om);
+      if (p.dprev) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p.dprev[gp * p.ld_dprev + c + i * g] = d[i] * om;
+      }
       float v[4][4];
       bool in[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
         in[k] = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
-        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in[k]) t4 = *reinterpret_cast<const float4*>(p.src + ((int64_t)n * hw + yy * p.w + xx) * p.ld_src + c);
-        v[k][0] = t4.x; v[k][1] = t4.y; v[k][2] = t4.z; v[k][3] = t4.w;
+        const float* sp = p.src + ((int64_t)n * hw + (in[k] ? yy * p.w + xx : 0)) * p.ld_src + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[k][i] = in[k] ? sp[i * g] : 0.f;
       }
       const float wk[4] = {tp.wx0 * tp.wy0, tp.wx1 * tp.wy0, tp.wx0 * tp.wy1, tp.wx1 * tp.wy1};
 #pragma unroll
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256) void warp_bwd_cl_kernel(lfdm_warp_bwd_params p
           long long* dst = p.dsrc_fix + ((int64_t)n * hw + yy * p.w + xx) * p.c + c;
           const float wo = wk[k] * o;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) fix_add(dst + i, d[i] * wo, kfix);
+          for (int i = 0; i < 4; ++i) fix_add(dst + i * g, d[i] * wo, kfix);
         }
       }
     }
