@@ -167,6 +167,19 @@ __device__ __forceinline__ unsigned lfdm_agent_load_u32(const unsigned* p) { ret
 __device__ __forceinline__ void lfdm_sleep() { __builtin_amdgcn_s_sleep(2); }
 #endif
 
+// Ordering point for LDS traffic that stays INSIDE one wavefront (a wave-private LDS region written by some lanes and read by others): the
+// LDS unit executes a wave's operations in order, so all that is needed is that the compiler keeps them in program order and that every
+// lane has issued its writes - no workgroup barrier, the other waves of the workgroup are not involved.
+#if defined(LFDM_EMU_BUILD)
+static inline void lfdm_wave_lds_sync() { emu::wave_sync(); }
+#else
+__device__ __forceinline__ void lfdm_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

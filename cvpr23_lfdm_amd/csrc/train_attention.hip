@@ -14,6 +14,8 @@
 //        dctx[d][e] = sum_n qs[d,n] dout[e,n];  dqs = ctx dout;  dks = dctx v;  dv = dctx^T ks
 //        dk = ks o (dks - sum_e dctx[d,e] ctx[d,e]);  dq = scale * qs/scale o (dqs - sum_d (qs/scale) dqs)
 //    A per-(frame, head) reduction kernel (k-softmax statistics, ctx, dctx) and a per-token apply kernel.
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -27,22 +29,28 @@ constexpr int SQ = 34;                  // LDS row stride of Q, K
 constexpr int SV = 36;                  // LDS row stride of V, dO
 constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
 
-template <int LP, int WPB>
+// LROWS (>= the sequence length, <= LP): rows of the wave's LDS tiles.  The 40-frame videos use 40 of the 48 padded rows: 30.4 KB instead of
+// 36.5 KB per wave, so FIVE waves fit a CU's 160 KB instead of four.  The five tiles of a wave are private to it - the phases are ordered by
+// lfdm_wave_lds_sync, not by workgroup barriers: the waves of a workgroup run their units at their own pace.
+template <int LP, int WPB, int LROWS = LP>
 __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv, int batch, int frames,
     int hw, int mode, const float* __restrict__ bias, const float* __restrict__ rot_cos,
     const float* __restrict__ rot_sin, float* __restrict__ dbias_part) {
   constexpr int NT = LP / 16;
   constexpr int SP = LP + 2;
-  constexpr int PER_WAVE = LP * (2 * SQ + 2 * SV) + LP * SP;
+  constexpr int PER_WAVE = LROWS * (2 * SQ + 2 * SV) + LROWS * SP;
   __shared__ __attribute__((aligned(16))) float smem[WPB * PER_WAVE];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* Qs = smem + wave * PER_WAVE;
-  float* Ks = Qs + LP * SQ;
-  float* Vs = Ks + LP * SQ;
-  float* Gs = Vs + LP * SV;     // dO
-  float* Ps = Gs + LP * SV;     // P, later dS
+  float* Ks = Qs + LROWS * SQ;
+  float* Vs = Ks + LROWS * SQ;
+  float* Gs = Vs + LROWS * SV;     // dO
+  float* Ps = Gs + LROWS * SV;     // P, later dS
+  // rows >= LROWS do not exist: padded tokens (t >= L) read row LROWS - 1 (finite values whose products are masked / never stored) and are
+  // not written
+  auto rowc = [](int t) { return LROWS < LP ? (t < LROWS ? t : LROWS - 1) : t; };
 
   const int L = mode == 0 ? frames : hw;
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
           kr.z = k.z * c1 - k.w * s1; kr.w = k.w * c1 + k.z * s1;
           q = qr; k = kr;
         }
+        if (LROWS < LP && t >= LROWS) continue;
         float* dq = Qs + t * SQ + 4 * c4;
         dq[0] = q.x; dq[1] = q.y; dq[2] = q.z; dq[3] = q.w;
         float* dk = Ks + t * SQ + 4 * c4;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
       }
     }
     if (PREFETCH && base + (int64_t)gridDim.x * WPB < units) fetch(unit + (int64_t)gridDim.x * WPB);       // in flight under this unit's GEMMs
-    __syncthreads();
+    lfdm_wave_lds_sync();
 
     // ---- S = Q K^T, dP = dO V^T ----
     f32x4 p[NT][NT], dp[NT][NT];
@@ -141,11 +150,11 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < DH / 4; ++s) {
-          const float a = Qs[(ti * 16 + l15) * SQ + 4 * s + lq];
-          const float b = Ks[(tj * 16 + l15) * SQ + 4 * s + lq];
+          const float a = Qs[rowc(ti * 16 + l15) * SQ + 4 * s + lq];
+          const float b = Ks[rowc(tj * 16 + l15) * SQ + 4 * s + lq];
           acc = mfma_16x16x4(a, b, acc);
-          const float a2 = Gs[(ti * 16 + l15) * SV + 4 * s + lq];
-          const float b2 = Vs[(tj * 16 + l15) * SV + 4 * s + lq];
+          const float a2 = Gs[rowc(ti * 16 + l15) * SV + 4 * s + lq];
+          const float b2 = Vs[rowc(tj * 16 + l15) * SV + 4 * s + lq];
           acc2 = mfma_16x16x4(a2, b2, acc2);
         }
         p[ti][tj] = acc;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         for (int tj = 0; tj < NT; ++tj) {
           const float pv = p[ti][tj][r] / sum;
           p[ti][tj][r] = pv;
-          Ps[row * SP + tj * 16 + l15] = pv;
+          if (LROWS == LP || row < LROWS) Ps[row * SP + tj * 16 + l15] = pv;
           dot += pv * dp[ti][tj][r];
         }
 #pragma unroll
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         }
       }
     }
-    __syncthreads();
+    lfdm_wave_lds_sync();
 
     // ---- dV = P^T dO ----
 #pragma unroll
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
       o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       o[1] = o[0];
 #pragma unroll
-      for (int s = 0; s < LP / 4; ++s) {
+      for (int s = 0; s < LROWS / 4; ++s) {      // (tokens >= LROWS do not exist; rows in [L, LROWS) hold zeros)
         const float a = Ps[(4 * s + lq) * SP + tj * 16 + l15];      // A[m = token j][k = token i] = P[i][j]
         const float b0 = Gs[(4 * s + lq) * SV + l15];
         const float b1 = Gs[(4 * s + lq) * SV + 16 + l15];
@@ -224,15 +233,16 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         }
       }
     }
-    __syncthreads();
+    lfdm_wave_lds_sync();
     // ---- dS -> LDS (over P) ----
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int tj = 0; tj < NT; ++tj) Ps[(ti * 16 + lq * 4 + r) * SP + tj * 16 + l15] = dp[ti][tj][r];
-    __syncthreads();
+        for (int tj = 0; tj < NT; ++tj)
+          if (LROWS == LP || ti * 16 + lq * 4 + r < LROWS) Ps[(ti * 16 + lq * 4 + r) * SP + tj * 16 + l15] = dp[ti][tj][r];
+    lfdm_wave_lds_sync();
 
     // ---- dQr = dS K ; dKr = dS^T Q ; undo rotary ; store ----
 #pragma unroll
@@ -240,8 +250,8 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
       f32x4 oq[2], ok[2];
       oq[0] = oq[1] = ok[0] = ok[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < LP / 4; ++s) {
-        const float aq = Ps[(ti * 16 + l15) * SP + 4 * s + lq];      // dS[i][j = 4s+lq]
+      for (int s = 0; s < LROWS / 4; ++s) {      // (tokens >= LROWS do not exist; rows in [L, LROWS) hold zeros)
+        const float aq = Ps[rowc(ti * 16 + l15) * SP + 4 * s + lq];      // dS[i][j = 4s+lq]
         const float ak = Ps[(4 * s + lq) * SP + ti * 16 + l15];      // dS[i = 4s+lq][j]
         const float bk0 = Ks[(4 * s + lq) * SQ + l15], bk1 = Ks[(4 * s + lq) * SQ + 16 + l15];
         const float bq0 = Qs[(4 * s + lq) * SQ + l15], bq1 = Qs[(4 * s + lq) * SQ + 16 + l15];
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         }
       }
     }
-    __syncthreads();
+    lfdm_wave_lds_sync();
   }
 
   if (dbias_part) {
@@ -295,9 +305,16 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
   }
 }
 
+bool attn_bwd_rows40_enabled() {          // experiment knob (tools/bench_attn_bwd.py): LFDM_ATTN_BWD_ROWS40=0 -> the 48-row / four-wave form
+  const char* e = getenv("LFDM_ATTN_BWD_ROWS40");
+  return !(e && e[0] == '0');
+}
+
 int attn_bwd_blocks(int64_t units, int wpb) {
   int64_t nb = (units + wpb - 1) / wpb;
-  const int cap = 2048 / wpb;            // 2048 wavefronts in flight; a multiple of 8 per grid stride
+  // 2048 wavefronts in flight (two rounds of one-workgroup-per-CU for the 4-wave form); the 5-wave form runs ONE workgroup per CU, 256 of
+  // them, so that the persistent loop's rounds stay balanced over the 256 CUs
+  const int cap = wpb == 5 ? 256 : 2048 / wpb;
   if (nb > cap) nb = cap;
   // grid*wpb must be a multiple of 8 so that a wavefront keeps its head
   while ((nb * wpb) % 8 != 0) ++nb;
@@ -480,7 +497,8 @@ __global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __r
 
 extern "C" size_t lfdm_attention_bwd_ws_bytes(int batch, int frames, int hw, int mode) {
   const int L = mode == 0 ? frames : hw;
-  const int wpb = L > 48 ? 2 : 4;
+  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles, five waves per CU
+  const int wpb = L > 48 ? 2 : (rows40 ? 5 : 4);
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
   const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
   return (size_t)nb * wpb * L * L * sizeof(float);
@@ -497,7 +515,8 @@ extern "C" int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, fl
     lfdm_set_error("attention_bwd: unsupported arguments (sequence length must be <= 64; dbias iff bias)");
     return LFDM_EINVAL;
   }
-  const int wpb = L > 48 ? 2 : 4;
+  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles, five waves per CU
+  const int wpb = L > 48 ? 2 : (rows40 ? 5 : 4);
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
   const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
   float* part = nullptr;
@@ -511,6 +530,7 @@ extern "C" int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, fl
   const dim3 grid(nb), block(64 * wpb);
   if (L <= 16) LFDM_LAUNCH((attention_bwd_kernel<16, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else if (L <= 32) LFDM_LAUNCH((attention_bwd_kernel<32, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  else if (rows40) LFDM_LAUNCH((attention_bwd_kernel<48, 5, 40>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else if (L <= 48) LFDM_LAUNCH((attention_bwd_kernel<48, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else LFDM_LAUNCH((attention_bwd_kernel<64, 2>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   int rc = lfdm_check_launch("attention_bwd");

@@ -8,13 +8,14 @@ LFDM_PARITY_LOG=$O/parity.jsonl timeout 900 python -m pytest tests -m gpu -x -q 
 timeout 60 python tools/parity_margins.py $O/parity.jsonl $O/parity_margins.json | tail -n 3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
 # (the CPU baseline leg is left to the driver's own bench run: ~2 minutes of host time that the evidence run does not need)
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err      # the driver's own command line (minus the CPU baseline leg); echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err      # the driver's own command line (minus the CPU baseline leg); echo "bench rc=$?"; grep "\[bench" $O/bench.err | tail -n 4
 timeout 300 bash tools/prof_sequence.sh $TAG > $O/prof.txt 2>&1; tail -n 1 $O/step_sequence.txt
 timeout 400 bash tools/prof_step_pmc.sh $TAG > $O/pmc.txt 2>&1; head -n 3 $O/step_pmc.txt
 # the N = 2 code path of bench.py on ONE GPU: plain `python bench.py --gpus 2` re-executes itself under torch.distributed.run (both ranks on
 # cuda:0, gloo because fewer GPUs than ranks): barrier / max-over-ranks protocol, rank-0-only extras, the training step with the gradient
 # all-reduce across two ranks and its exposed-communication figure
-timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 --no-cpu-baseline --no-roofline > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 700 $O/bench_n2_one_gpu.json; echo
+timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 --lfae-train-steps 2 --no-cpu-baseline --no-roofline --no-gpu-eager-baseline > $O/bench_n2_one_gpu.json 2> $O/bench_n2_one_gpu.err; echo "bench n2 rc=$?"; tail -c 700 $O/bench_n2_one_gpu.json; echo
 timeout 300 bash tools/prof_train.sh > $O/train_prof.txt 2>&1; cp gpurun_out/p3/train_kernel_stats.txt gpurun_out/p3/train_top_launches.txt $O/; grep -a value gpurun_out/p3/kt.err | tail -n 1 | cut -c1-200
-# LFAE stage-1 training (lfae_train.py): one line of frame pairs / s at the per-GPU batch where the step is GPU-bound
-timeout 200 python tools/train_lfae.py --batch 32 --steps 8 --warmup 3 --bench > $O/lfae_train_bench.json 2> $O/lfae_train_bench.err; tail -c 400 $O/lfae_train_bench.json
+# LFAE stage-1 training (lfae_train.py; also a leg of bench.py): launches per step / native share from torch.profiler, then the rocprofv3 kernel table
+timeout 200 python tools/lfae_census.py --batch 32 --top 30 > $O/lfae_census.txt 2> $O/lfae_census.err; head -n 6 $O/lfae_census.txt
+timeout 300 bash tools/prof_lfae.sh $TAG > $O/lfae_prof.txt 2>&1; tail -n 3 $O/lfae_prof.txt
