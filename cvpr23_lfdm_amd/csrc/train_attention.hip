@@ -29,9 +29,11 @@ constexpr int SQ = 34;                  // LDS row stride of Q, K
 constexpr int SV = 36;                  // LDS row stride of V, dO
 constexpr float ATT_SCALE = 0.17677669529663687f;  // 32^-0.5
 
-// LROWS (>= the sequence length, <= LP): rows of the wave's LDS tiles.  The 40-frame videos use 40 of the 48 padded rows: 30.4 KB instead of
-// 36.5 KB per wave, so FIVE waves fit a CU's 160 KB instead of four.  The five tiles of a wave are private to it - the phases are ordered by
-// lfdm_wave_lds_sync, not by workgroup barriers: the waves of a workgroup run their units at their own pace.
+// LROWS (>= the sequence length, <= LP): rows of the wave's LDS tiles.  The 40-frame videos use 40 of the 48 padded rows: the three GEMMs that
+// contract over tokens run 10 instead of 12 k-steps.  (Five waves per CU would fit the 160 KB with 30.4 KB tiles, but the kernel lives on the
+// 512 registers a lone wave per SIMD may use: at two waves per SIMD it spills 336 VGPRs and runs 2.1x slower - measured,
+// profiles/r05_b_attn_bwd_ab.txt.)  The five tiles of a wave are private to it - the phases are ordered by lfdm_wave_lds_sync, not by
+// workgroup barriers: the waves of a workgroup run their units at their own pace.
 template <int LP, int WPB, int LROWS = LP>
 __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv, int batch, int frames,
@@ -312,9 +314,7 @@ bool attn_bwd_rows40_enabled() {          // experiment knob (tools/bench_attn_b
 
 int attn_bwd_blocks(int64_t units, int wpb) {
   int64_t nb = (units + wpb - 1) / wpb;
-  // 2048 wavefronts in flight (two rounds of one-workgroup-per-CU for the 4-wave form); the 5-wave form runs ONE workgroup per CU, 256 of
-  // them, so that the persistent loop's rounds stay balanced over the 256 CUs
-  const int cap = wpb == 5 ? 256 : 2048 / wpb;
+  const int cap = 2048 / wpb;            // 2048 wavefronts in flight; a multiple of 8 per grid stride
   if (nb > cap) nb = cap;
   // grid*wpb must be a multiple of 8 so that a wavefront keeps its head
   while ((nb * wpb) % 8 != 0) ++nb;
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __r
 
 extern "C" size_t lfdm_attention_bwd_ws_bytes(int batch, int frames, int hw, int mode) {
   const int L = mode == 0 ? frames : hw;
-  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles, five waves per CU
-  const int wpb = L > 48 ? 2 : (rows40 ? 5 : 4);
+  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles (10 instead of 12 k-steps in the token-contraction GEMMs)
+  const int wpb = L > 48 ? 2 : 4;
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
   const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
   return (size_t)nb * wpb * L * L * sizeof(float);
@@ -515,8 +515,8 @@ extern "C" int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, fl
     lfdm_set_error("attention_bwd: unsupported arguments (sequence length must be <= 64; dbias iff bias)");
     return LFDM_EINVAL;
   }
-  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles, five waves per CU
-  const int wpb = L > 48 ? 2 : (rows40 ? 5 : 4);
+  const bool rows40 = L > 32 && L <= 40 && attn_bwd_rows40_enabled();      // the 40-frame videos: 40-row tiles (10 instead of 12 k-steps in the token-contraction GEMMs)
+  const int wpb = L > 48 ? 2 : 4;
   const int64_t nseq = mode == 0 ? (int64_t)batch * hw : (int64_t)batch * frames;
   const int nb = attn_bwd_blocks(nseq * HEADS, wpb);
   float* part = nullptr;
@@ -530,7 +530,7 @@ extern "C" int lfdm_attention_bwd_cl_f32(const float* qkv, const float* dout, fl
   const dim3 grid(nb), block(64 * wpb);
   if (L <= 16) LFDM_LAUNCH((attention_bwd_kernel<16, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else if (L <= 32) LFDM_LAUNCH((attention_bwd_kernel<32, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
-  else if (rows40) LFDM_LAUNCH((attention_bwd_kernel<48, 5, 40>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
+  else if (rows40) LFDM_LAUNCH((attention_bwd_kernel<48, 4, 40>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else if (L <= 48) LFDM_LAUNCH((attention_bwd_kernel<48, 4>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   else LFDM_LAUNCH((attention_bwd_kernel<64, 2>), grid, block, 0, stream, qkv, dout, dqkv, batch, frames, hw, mode, bias, rot_cos, rot_sin, part);
   int rc = lfdm_check_launch("attention_bwd");

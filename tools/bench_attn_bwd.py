@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """attention_bwd_kernel at the DM training step's shapes (B = 8 videos of 40 frames; temporal attention at 32x32 / 16x16 / 8x8), event-timed:
-the 40-row / five-wave form against the 48-row / four-wave form (LFDM_ATTN_BWD_ROWS40=0).  Usage: bench_attn_bwd.py"""
+the 40-row form against the 48-row form (LFDM_ATTN_BWD_ROWS40=0).  Usage: bench_attn_bwd.py"""
 import os
 import subprocess
 import sys
@@ -33,5 +33,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 
 for knob in ("1", "0"):
     env = dict(os.environ, LFDM_ATTN_BWD_ROWS40=knob)
-    print("# LFDM_ATTN_BWD_ROWS40=%s (%s)" % (knob, "40-row tiles, 5 waves / CU" if knob == "1" else "48-row tiles, 4 waves / CU"), flush=True)
+    print("# LFDM_ATTN_BWD_ROWS40=%s (%s)" % (knob, "40-row tiles, wave-level LDS ordering" if knob == "1" else "48-row tiles, workgroup barriers"), flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
