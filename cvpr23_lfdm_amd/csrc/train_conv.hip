@@ -16,6 +16,8 @@
 // and B[r = l>>5][co = l&31].  One workgroup owns one filter tap x (64*WM input channels) x
 // (64*WN output channels) and a slice of the rows (grid.z); slices land in `partial` and are summed in
 // a fixed order by lfdm_sum_leading_f32 (deterministic - no float atomics).
+#include <stdlib.h>
+
 #include "lfdm_device.h"
 #include "../../include/lfdm_hip.h"
 
@@ -51,8 +53,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
   // slice exactly once on its way into LDS - each thread's float4 column position is the same for all its loads (256 % (TCO/4) == 0).
   const bool do_bias = bias_partial != nullptr && blockIdx.x == 0;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra[A_F4], rb[B_F4];
-  auto fetch = [&](int chunk) {
+  // Two register sets: the global loads of chunk c + 2 and c + 3 are in flight while chunk c is multiplied (one set - loads issued one chunk =
+  // ~1.7 us of MFMA work ahead of their LDS store - left the kernel waiting for HBM at 0.39-0.53 of the MFMA peak, profiles/r05_c_bench_wgrad.txt).
+  // Chunks past the slice's end are fetched as zeros (rows >= row_end take the out-of-range offset), so the loop needs no tail handling
+  // and runs an even number of trips.
+  const int row_end = c_end * BR < M ? c_end * BR : M;
+  float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];
+  auto fetch = [&](int chunk, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
     const int r0 = chunk * BR;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
       const int row = f / (TCI / 4), c4 = f - row * (TCI / 4);
       const int r = r0 + row;
       uint32_t off = LFDM_BUF_OOB;
-      if (r < M && ci0 + 4 * c4 < p.cin) {
+      if (r < row_end && ci0 + 4 * c4 < p.cin) {
         const int img = r / hqwq;
         const int rem = r - img * hqwq;
         const int qy = rem / p.wq, qx = rem - qy * p.wq;
@@ -75,19 +82,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
       const int f = tid + 256 * i;
       const int row = f / (TCO / 4), c4 = f - row * (TCO / 4);
       const int r = r0 + row;
-      const uint32_t off = (r < M && co0 + 4 * c4 < p.cout) ? (uint32_t)(((int64_t)r * p.lddy + co0 + 4 * c4) * 4)
-                                                           : LFDM_BUF_OOB;
+      const uint32_t off = (r < row_end && co0 + 4 * c4 < p.cout) ? (uint32_t)(((int64_t)r * p.lddy + co0 + 4 * c4) * 4)
+                                                                 : LFDM_BUF_OOB;
       rb[i] = lfdm_buf_load_f4(bufy, off);
     }
   };
-  auto stage = [&](int buf, bool fresh) {      // fresh: the registers hold a chunk that has not been staged before (the tail re-fetches the last one)
+  auto stage = [&](int buf, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
     float* const As = smem + buf * STAGE;
     float* const Bs = As + BR * TCI;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(As + 4 * (tid + 256 * i)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(Bs + 4 * (tid + 256 * i)) = rb[i];
-    if (do_bias && fresh) {
+    if (do_bias) {            // (every chunk is staged exactly once; chunks past the slice are zeros)
 #pragma unroll
       for (int i = 0; i < B_F4; ++i) { bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w; }
     }
@@ -101,33 +108,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  auto multiply = [&](int cur) {
+    const float* const As = smem + cur * STAGE + wm * (32 * WM) + l31;
+    const float* const Bs = smem + cur * STAGE + BR * TCI + wn * (32 * WN) + l31;
+#pragma unroll
+    for (int s = 0; s < BR / 2; ++s) {
+      const int r = 2 * s + kk;
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[r * TCI + 32 * i];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[r * TCO + 32 * j];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = mfma_32x32x2(a[i], b[j], acc[i][j]);
+    }
+  };
+
   if (nk > 0) {
-    fetch(c_begin);
-    stage(0, true);
+    fetch(c_begin, ra0, rb0);
+    stage(0, ra0, rb0);
     __syncthreads();
-    fetch(c_begin + (nk > 1 ? 1 : 0));
-    for (int c = 0; c < nk; ++c) {
-      const int cur = c & 1;
-      stage(cur ^ 1, c + 1 < nk);
-      {
-        const int nxt = c + 2 < nk ? c + 2 : nk - 1;
-        fetch(c_begin + nxt);
-      }
-      const float* const As = smem + cur * STAGE + wm * (32 * WM) + l31;
-      const float* const Bs = smem + cur * STAGE + BR * TCI + wn * (32 * WN) + l31;
-#pragma unroll
-      for (int s = 0; s < BR / 2; ++s) {
-        const int r = 2 * s + kk;
-        float a[WM], b[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a[i] = As[r * TCI + 32 * i];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) b[j] = Bs[r * TCO + 32 * j];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = mfma_32x32x2(a[i], b[j], acc[i][j]);
-      }
+    fetch(c_begin + 1, ra0, rb0);
+    fetch(c_begin + 2, ra1, rb1);
+    const int nk2 = (nk + 1) & ~1;
+    for (int c = 0; c < nk2; c += 2) {
+      stage(1, ra0, rb0);                       // chunk c + 1 -> buffer 1
+      fetch(c_begin + c + 3, ra0, rb0);
+      multiply(0);                              // chunk c
+      __syncthreads();
+      stage(0, ra1, rb1);                       // chunk c + 2 -> buffer 0
+      fetch(c_begin + c + 4, ra1, rb1);
+      multiply(1);                              // chunk c + 1 (zeros when nk is odd and this is the last trip)
       __syncthreads();
     }
   }
@@ -152,6 +165,137 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(lfdm_wgrad_params p, in
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < RL; ++k) sum += smem[k * TCO + tid];
+      bias_partial[(int64_t)blockIdx.z * p.cout + co0 + tid] = sum;
+    }
+  }
+}
+
+// 3x3 / stride 1 / pad 1 (every ResnetBlock, ResBlock2d, hourglass and VGG convolution): ONE workgroup owns ALL NINE taps of a 64 ci x 64 co
+// block.  The per-tap kernel above streams X and dY once per tap and (ci, co) tile pair - 1.5 GB for the 64 -> 64 convolution of a B = 8
+// training step, 3.8-4.7 TB/s of re-reads at 0.39-0.53 of the matrix-pipe peak (profiles/r05_c_bench_wgrad.txt).  Here a chunk is a TW x 4
+// pixel tile (x 2 images at TW = 4): its dY rows (32) and its X window with a one-pixel halo ((TW+2) x 6 rows per image, out-of-image pixels
+// = out-of-range offsets = zeros, so the taps need no masks) are staged once, and each k-step feeds nine MFMAs - one per tap - from window rows at
+// compile-time offsets.  Nine accumulator tiles per wave (144 registers), 2 x 26.6 KB of LDS, two workgroups per CU.
+template <int TW>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(lfdm_wgrad_params p, int splits, float* dst_base, float* bias_partial) {
+  constexpr int TH = 4, TI = 32 / (TW * TH), WW = TW + 2, WH = TH + 2, WROWS = TI * WW * WH;      // window rows: 60 (TW = 8) / 72 (TW = 4)
+  constexpr int XF4 = (WROWS * 16 + 255) / 256;
+  constexpr int STAGE = WROWS * 64 + 32 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kk = lane >> 5;
+  const int ci_tiles = (p.cin + 63) / 64;
+  const int ci_tile = blockIdx.x % ci_tiles;
+  const int ci0 = ci_tile * 64, co0 = (blockIdx.x / ci_tiles) * 64;
+  const int tiles_x = p.wi / TW, per_img = tiles_x * (p.hi / TH);
+  const int n_tiles = (p.n_img / TI) * per_img;
+  const int t_begin = (int)((int64_t)n_tiles * blockIdx.z / splits);
+  const int t_end = (int)((int64_t)n_tiles * (blockIdx.z + 1) / splits);
+  const int nk = t_end - t_begin;
+
+  const int64_t rows = (int64_t)p.n_img * p.hi * p.wi;
+  const lfdm_buf bufx = lfdm_make_buf(p.x, (uint32_t)(((rows - 1) * p.ldx + p.cin) * 4));
+  const lfdm_buf bufy = lfdm_make_buf(p.dy, (uint32_t)(((rows - 1) * p.lddy + p.cout) * 4));
+  const bool do_bias = bias_partial != nullptr && ci_tile == 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rx[XF4], ry[2];
+  const int c4 = tid & 15;                                   // this thread's float4 column in both operands
+  auto fetch = [&](int tile) {
+    const bool live = tile < t_end;
+    const int g = tile / per_img, rem = tile - g * per_img;
+    const int tyi = rem / tiles_x;
+    const int ty0 = tyi * TH, tx0 = (rem - tyi * tiles_x) * TW, img0 = g * TI;
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) {
+      const int w = (tid >> 4) + 16 * i;                     // window row
+      uint32_t off = LFDM_BUF_OOB;
+      if (live && w < WROWS && ci0 + 4 * c4 < p.cin) {
+        const int ti = w / (WW * WH), wr = w - ti * (WW * WH);
+        const int wy = wr / WW, wx = wr - wy * WW;
+        const int iy = ty0 + wy - 1, ix = tx0 + wx - 1;
+        if (iy >= 0 && iy < p.hi && ix >= 0 && ix < p.wi)
+          off = (uint32_t)((((int64_t)((img0 + ti) * p.hi + iy) * p.wi + ix) * p.ldx + ci0 + 4 * c4) * 4);
+      }
+      rx[i] = lfdm_buf_load_f4(bufx, off);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 4) + 16 * i;                     // pixel of the tile
+      const int ti = r / (TW * TH), pr = r - ti * (TW * TH);
+      const int py = pr / TW, px = pr - py * TW;
+      const uint32_t off = (live && co0 + 4 * c4 < p.cout)
+                               ? (uint32_t)((((int64_t)((img0 + ti) * p.hi + ty0 + py) * p.wi + tx0 + px) * p.lddy + co0 + 4 * c4) * 4)
+                               : LFDM_BUF_OOB;
+      ry[i] = lfdm_buf_load_f4(bufy, off);
+    }
+  };
+  auto stage = [&](int buf) {
+    float* const Xs = smem + buf * STAGE;
+    float* const Ys = Xs + WROWS * 64;
+#pragma unroll
+    for (int i = 0; i < XF4; ++i)
+      if ((tid >> 4) + 16 * i < WROWS) *reinterpret_cast<float4*>(Xs + 4 * (tid + 256 * i)) = rx[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Ys + 4 * (tid + 256 * i)) = ry[i];
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { bsum.x += ry[i].x; bsum.y += ry[i].y; bsum.z += ry[i].z; bsum.w += ry[i].w; }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto multiply = [&](int buf) {
+    const float* const Xb = smem + buf * STAGE + kk * 64 + wm * 32 + l31;      // k-slot kk = the second pixel of the pair: one window row on
+    const float* const Yb = smem + buf * STAGE + WROWS * 64 + kk * 64 + wn * 32 + l31;
+    lfdm_static_for<0, 16>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      constexpr int ti = (2 * s) / (TW * TH), pr = (2 * s) % (TW * TH), py = pr / TW, px = pr % TW;
+      const float b = Yb[(2 * s) * 64];
+      lfdm_static_for<0, 9>([&](auto T) {
+        constexpr int tap = decltype(T)::value;
+        constexpr int wrow = ti * (WW * WH) + (py + tap / 3) * WW + px + tap % 3;
+        acc[tap] = mfma_32x32x2(Xb[wrow * 64], b, acc[tap]);
+      });
+    });
+  };
+
+  if (nk > 0) {
+    fetch(t_begin);
+    stage(0);
+    __syncthreads();
+    fetch(t_begin + 1);
+    for (int c = 0; c < nk; ++c) {
+      const int cur = c & 1;
+      stage(cur ^ 1);                           // tile c + 1 (zeros past the slice)
+      fetch(t_begin + c + 2);
+      multiply(cur);
+      __syncthreads();
+    }
+  }
+
+  float* const dst = dst_base + (int64_t)blockIdx.z * ((int64_t)9 * p.cin * p.cout);
+  const int co = co0 + wn * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (ci < p.cin && co < p.cout) dst[((int64_t)t * p.cin + ci) * p.cout + co] = acc[t][r];
+    }
+  if (do_bias) {      // (uniform per workgroup; the loop ended with a barrier, the staging buffers are free)
+    *reinterpret_cast<float4*>(smem + (tid >> 4) * 64 + 4 * c4) = bsum;
+    __syncthreads();
+    if (tid < 64 && co0 + tid < p.cout) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += smem[k * 64 + tid];
       bias_partial[(int64_t)blockIdx.z * p.cout + co0 + tid] = sum;
     }
   }
@@ -333,10 +477,40 @@ __global__ __launch_bounds__(256) void upsample_pad_bwd_kernel(const float* __re
 
 struct WgradPlan {
   int wm, wn, splits;
+  int tile_w;       // 0: one workgroup per tap (conv_wgrad_kernel); 8 / 4: all nine taps of a TW x 4 pixel tile (conv_wgrad3_kernel)
 };
 
 WgradPlan wgrad_plan(const lfdm_wgrad_params& p) {
   WgradPlan pl;
+  pl.tile_w = 0;
+  {
+    const char* e = getenv("LFDM_WGRAD3");        // experiment knob (tools/bench_wgrad.py): 0 = the per-tap kernel everywhere
+    const bool on = !(e && e[0] == '0');
+    if (on && p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && p.hq == p.hi && p.wq == p.wi && p.hi % 4 == 0 &&
+        p.cin >= 32 && p.cout >= 32) {
+      const int tw = p.wi % 8 == 0 ? 8 : ((p.wi % 4 == 0 && p.n_img % 2 == 0) ? 4 : 0);
+      if (tw) {
+        const int64_t n_tiles = (int64_t)(p.n_img / (32 / (tw * 4))) * (p.hi / 4) * (p.wi / tw);
+        const int64_t blocks = (int64_t)((p.cin + 63) / 64) * ((p.cout + 63) / 64);
+        if (n_tiles >= 32) {
+          // two workgroups per CU and no more: every further split is another 9 * cin * cout slab to write and re-read (sweep in
+          // profiles/r05_d_bench_wgrad3.txt: 1024 / 2048 workgroups lose 10-25 % on the 128 ... 512-channel shapes)
+          const char* ew = getenv("LFDM_WGRAD3_WGS");      // experiment knob: workgroups aimed at
+          const int64_t want = ew ? atol(ew) : 512;
+          const char* ec = getenv("LFDM_WGRAD3_MAXSPLIT");
+          const int64_t cap = ec ? atol(ec) : 256;
+          int64_t s = (want + blocks - 1) / blocks;
+          if (s > n_tiles / 8) s = n_tiles / 8;
+          if (s > cap) s = cap;
+          if (s < 1) s = 1;
+          pl.tile_w = tw;
+          pl.wm = pl.wn = 1;
+          pl.splits = (int)s;
+          return pl;
+        }
+      }
+    }
+  }
   pl.wm = p.cin >= 96 ? 2 : 1;
   pl.wn = p.cout >= 96 ? 2 : 1;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
@@ -416,7 +590,11 @@ extern "C" int lfdm_conv2d_wgrad_cl_f32(const lfdm_wgrad_params* pp, void* ws, s
   float* bias_partial = p.dbias ? (float*)ws + (slabs ? (int64_t)pl.splits * n_dw : 0) : nullptr;
   const dim3 grid((unsigned)(taps * ((p.cin + 64 * pl.wm - 1) / (64 * pl.wm))), (unsigned)((p.cout + 64 * pl.wn - 1) / (64 * pl.wn)),
                   (unsigned)pl.splits);
-  if (pl.wm == 2 && pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+  if (pl.tile_w) {
+    const dim3 grid3((unsigned)(((p.cin + 63) / 64) * ((p.cout + 63) / 64)), 1, (unsigned)pl.splits);
+    if (pl.tile_w == 8) LFDM_LAUNCH((conv_wgrad3_kernel<8>), grid3, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+    else LFDM_LAUNCH((conv_wgrad3_kernel<4>), grid3, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
+  } else if (pl.wm == 2 && pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
   else if (pl.wm == 2) LFDM_LAUNCH((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
   else if (pl.wn == 2) LFDM_LAUNCH((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);
   else LFDM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, p, pl.splits, dst, bias_partial);

@@ -235,3 +235,38 @@ def test_multi_linear(backend, rows, k, ns, act):
             assert_close(bd[j].grad.cpu() / sc, bs[j].grad / sc, TOL, "multi_linear dbias[%d]" % j)
     if len(ns) > 3 and ws[3].requires_grad:        # the unused block: zero gradients, like autograd's
         assert float(wd[3].grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,cout,n,res", [(64, 64, 16, 8), (96, 40, 64, 4), (32, 128, 4, 16), (160, 64, 2, 12)])
+def test_conv_wgrad_nine_tap_tiles(backend, cin, cout, n, res):
+    """conv_wgrad3_kernel (3x3 / stride 1 / pad 1: all nine taps of a pixel tile per workgroup; TW = 8 and the TW = 4 two-image form, partial
+    channel tiles, ragged split counts) against autograd, in both output layouts, with the fused bias sums - and bit-identical to the per-tap
+    kernel's summation order is NOT required (different tiling): tolerance as for the other weight-gradient tests."""
+    import os
+    dev = backend
+    if big(dev):
+        n, res = n * 4, res * 2
+    x = rnd(n, cin, res, res, seed=1)
+    w = (rnd(cout, cin, 3, 3, seed=2) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    y.backward(dy)
+    scale = float(w.grad.abs().max())
+    ref_db = dy.sum(dim=(0, 2, 3))
+    xd, dyd = to_cl(x).to(dev), to_cl(dy).to(dev)
+    dw = train_ops.conv_wgrad(xd, dyd, n, res, res, res, res, 3, 3, stride=1, pad=(1, 1))
+    got = dw.cpu().view(3, 3, cin, cout).permute(3, 2, 0, 1)
+    assert_close(got / scale, w.grad / scale, TOL, "nine-tap wgrad, tap-major")
+    out = torch.full((cout, cin, 3, 3), float("nan"), device=dev)
+    db = torch.full((cout,), float("nan"), device=dev)
+    c0 = (cin // 8) * 4
+    train_ops.conv_wgrad(xd[:, :c0], dyd, n, res, res, res, res, 3, 3, stride=1, pad=(1, 1), out=out, ci_off=0, dbias=db)
+    train_ops.conv_wgrad(xd[:, c0:], dyd, n, res, res, res, res, 3, 3, stride=1, pad=(1, 1), out=out, ci_off=c0)
+    assert_close(out.cpu() / scale, w.grad / scale, TOL, "nine-tap wgrad, reference layout in two channel halves")
+    assert_close(db.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias sums from the nine-tap pass")
+    os.environ["LFDM_WGRAD3"] = "0"
+    try:
+        old = train_ops.conv_wgrad(xd, dyd, n, res, res, res, res, 3, 3, stride=1, pad=(1, 1))
+    finally:
+        del os.environ["LFDM_WGRAD3"]
+    assert_close(old.cpu() / scale, dw.cpu() / scale, TOL, "per-tap kernel vs nine-tap kernel")
