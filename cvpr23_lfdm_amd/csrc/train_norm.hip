@@ -151,29 +151,52 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnArgs a, float* __r
   }
 }
 
-// pass 2: grid (B).  sums[b][c] = (S1, S2);  dss[b] = [dscale | dshift];  dgb_part[b] = [dgamma part | dbeta part]
+// pass 2: grid (ceil(C / 64), B).  sums[b][c] = (S1, S2);  dss[b] = [dscale | dshift];  dgb_part[b] = [dgamma part | dbeta part].
+// 256 threads = 64 channels x 4 interleaved chunk ranges (part q sums chunks q, q+4, ...; four independent 8-byte loads in flight), folded in
+// the fixed order 0..3 through LDS.  (Round 4: one workgroup per sample, every thread walking all chunks serially - 8 workgroups and a
+// dependent load chain per launch: 39 us on average, 1.6 ms of a B = 8 training step for 40 launches.)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs a, const float* __restrict__ part2, int nchunk2,
                                                               float* __restrict__ sums, float* __restrict__ dss, int dss_ld,
                                                               float* __restrict__ dgb_part) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < a.channels; c += 256) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunk2; ++k) {
-      const float* src = part2 + (((int64_t)b * nchunk2 + k) * a.channels + c) * 2;
-      s1 += src[0];
-      s2 += src[1];
+  __shared__ float s_p[4][64][2];
+  const int b = blockIdx.y;
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < a.channels) {
+    const float* base = part2 + ((int64_t)b * nchunk2 * a.channels + c) * 2;
+    int k = q;
+    for (; k + 12 < nchunk2; k += 16) {
+      const float2 v0 = *reinterpret_cast<const float2*>(base + (int64_t)k * a.channels * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(base + (int64_t)(k + 4) * a.channels * 2);
+      const float2 v2 = *reinterpret_cast<const float2*>(base + (int64_t)(k + 8) * a.channels * 2);
+      const float2 v3 = *reinterpret_cast<const float2*>(base + (int64_t)(k + 12) * a.channels * 2);
+      s1 += v0.x; s2 += v0.y;
+      s1 += v1.x; s2 += v1.y;
+      s1 += v2.x; s2 += v2.y;
+      s1 += v3.x; s2 += v3.y;
     }
-    sums[((int64_t)b * a.channels + c) * 2 + 0] = s1;
-    sums[((int64_t)b * a.channels + c) * 2 + 1] = s2;
-    float sc = 1.f;
-    if (a.scale_shift) {
-      sc = a.scale_shift[(int64_t)b * a.ss_ld + c] + 1.0f;
-      dss[(int64_t)b * dss_ld + c] = a.gamma[c] * s2 + a.beta[c] * s1;
-      dss[(int64_t)b * dss_ld + a.channels + c] = s1;
+    for (; k < nchunk2; k += 4) {
+      const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)k * a.channels * 2);
+      s1 += v.x; s2 += v.y;
     }
-    dgb_part[(int64_t)b * 2 * a.channels + c] = sc * s2;
-    dgb_part[(int64_t)b * 2 * a.channels + a.channels + c] = sc * s1;
   }
+  s_p[q][cl][0] = s1;
+  s_p[q][cl][1] = s2;
+  __syncthreads();
+  if (q != 0 || c >= a.channels) return;
+  s1 = ((s_p[0][cl][0] + s_p[1][cl][0]) + s_p[2][cl][0]) + s_p[3][cl][0];
+  s2 = ((s_p[0][cl][1] + s_p[1][cl][1]) + s_p[2][cl][1]) + s_p[3][cl][1];
+  sums[((int64_t)b * a.channels + c) * 2 + 0] = s1;
+  sums[((int64_t)b * a.channels + c) * 2 + 1] = s2;
+  float sc = 1.f;
+  if (a.scale_shift) {
+    sc = a.scale_shift[(int64_t)b * a.ss_ld + c] + 1.0f;
+    dss[(int64_t)b * dss_ld + c] = a.gamma[c] * s2 + a.beta[c] * s1;
+    dss[(int64_t)b * dss_ld + a.channels + c] = s1;
+  }
+  dgb_part[(int64_t)b * 2 * a.channels + c] = sc * s2;
+  dgb_part[(int64_t)b * 2 * a.channels + a.channels + c] = sc * s1;
 }
 
 // pass 3: grid (blocks, B).  dx = dz*K1[c] - (C0[g] + x*C1[g])
@@ -309,6 +332,71 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     part[(int64_t)blockIdx.x * channels + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// The same for C = 64 / 128 (the two finest levels: 16 / 32 float4 per row): a wavefront serves 64 / C4N rows at once - lane = (row of the group,
+// float4 column), the row reductions are xor-shuffles inside C4N adjacent lanes - and two row groups are in flight per trip.  One row per
+// wavefront left 48 of 64 lanes idle at C = 64 and walked 327 680 rows of 256 bytes behind four full-wave reductions each: 343 us for 252 MB
+// (0.73 TB/s) in the B = 8 training step (profiles/r05_m_train_kernel_stats.txt).
+template <int C4N>
+__global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, int64_t rows, const float* __restrict__ gamma, float eps,
+                                                                  float* __restrict__ part) {
+  constexpr int RPW = 64 / C4N, C = 4 * C4N;            // rows per wavefront and trip, channels
+  __shared__ __attribute__((aligned(16))) float red[4 * RPW][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / C4N, f = lane % C4N;
+  const float4 gm = reinterpret_cast<const float4*>(gamma)[f];
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto group_sum = [&](float v) {
+#pragma unroll
+    for (int m = 1; m < C4N; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+  };
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW * 2;
+  for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW * 2; row0 < rows; row0 += stride) {
+    float4 v[2], g[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = row0 + u * RPW + sub;
+      live[u] = row < rows;
+      v[u] = g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live[u]) {
+        v[u] = reinterpret_cast<const float4*>(x + row * C)[f];
+        g[u] = reinterpret_cast<const float4*>(dy + row * C)[f];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float mean = group_sum((v[u].x + v[u].y) + (v[u].z + v[u].w)) / (float)C;
+      const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+      const float var = group_sum((a * a + b * b) + (c * c + d * d)) / (float)C;
+      const float inv = 1.0f / sqrtf(var + eps);
+      float4 nh = make_float4(a * inv, b * inv, c * inv, d * inv);
+      float4 dn = g[u];
+      dg.x += dn.x * nh.x; dg.y += dn.y * nh.y; dg.z += dn.z * nh.z; dg.w += dn.w * nh.w;      // (rows past the end: dy = 0)
+      dn.x *= gm.x; dn.y *= gm.y; dn.z *= gm.z; dn.w *= gm.w;
+      const float m1 = group_sum((dn.x + dn.y) + (dn.z + dn.w)) / (float)C;
+      const float m2 = group_sum((dn.x * nh.x + dn.y * nh.y) + (dn.z * nh.z + dn.w * nh.w)) / (float)C;
+      if (live[u]) {
+        float4 o;
+        o.x = (dn.x - m1 - nh.x * m2) * inv;
+        o.y = (dn.y - m1 - nh.y * m2) * inv;
+        o.z = (dn.z - m1 - nh.z * m2) * inv;
+        o.w = (dn.w - m1 - nh.w * m2) * inv;
+        reinterpret_cast<float4*>(dx + (row0 + u * RPW + sub) * C)[f] = o;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(&red[wave * RPW + sub][4 * f]) = dg;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 * RPW; ++k) sum += red[k][c];        // fixed order
+    part[(int64_t)blockIdx.x * C + c] = sum;
+  }
+}
+
 int ln_bwd_blocks(int64_t rows) {
   int64_t nb = (rows + 3) / 4;
   if (nb > 512) nb = 512;
@@ -351,8 +439,8 @@ extern "C" int lfdm_groupnorm_silu_bwd_cl_f32(const float* x, const float* dy, f
   a.nchunk = nchunk; a.gamma = gamma; a.beta = beta; a.scale_shift = scale_shift; a.ss_ld = ss_ld; a.eps = eps;
   a.silu = apply_silu;
   LFDM_LAUNCH(gn_bwd_reduce_kernel, dim3(nchunk2, batch), dim3(256), 0, stream, a, part2);
-  LFDM_LAUNCH(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, a, (const float*)part2, nchunk2, sums,
-              dscale_shift, dss_ld, dgb);
+  LFDM_LAUNCH(gn_bwd_finalize_kernel, dim3((unsigned)((channels + 63) / 64), (unsigned)batch), dim3(256), 0, stream, a, (const float*)part2,
+              nchunk2, sums, dscale_shift, dss_ld, dgb);
   int rc = lfdm_sum_leading_f32(dgb, dgamma_dbeta, 2 * (int64_t)channels, batch, stream_);
   if (rc) return rc;
   const int64_t per_b = (int64_t)pixels * (channels / 4);
@@ -380,7 +468,10 @@ extern "C" int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float*
     return LFDM_EWORKSPACE;
   }
   const int nb = ln_bwd_blocks(rows);
-  LFDM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, channels, gamma, eps, (float*)ws);
+  const bool al16 = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
+  if (channels == 64 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<16>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws);
+  else if (channels == 128 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<32>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws);
+  else LFDM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, channels, gamma, eps, (float*)ws);
   int rc = lfdm_check_launch("layernorm_bwd");
   if (rc) return rc;
   return lfdm_sum_leading_f32((const float*)ws, dgamma, channels, nb, stream_);

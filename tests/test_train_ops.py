@@ -92,12 +92,12 @@ def test_groupnorm_bwd(backend, c, with_ss, silu):
         assert_close(dss.cpu() / sc, ss.grad / sc, TOL, "gn dscale_shift")
 
 
-@pytest.mark.parametrize("c", [32, 72, 1024])
+@pytest.mark.parametrize("c", [32, 72, 1024, 64, 128])        # 64 / 128: the several-rows-per-wavefront form (ragged last group)
 def test_layernorm_bwd(backend, c):
     dev = backend
     rows = 37 if c != 1024 else 5
     if big(dev):
-        rows, c = 40 * 1024 + 3, {32: 64, 72: 512, 1024: 1024}[c]
+        rows, c = 40 * 1024 + 3, {32: 64, 72: 512, 1024: 1024, 64: 64, 128: 128}[c]
     x = rnd(rows, c, seed=1).requires_grad_(True)
     gamma = (1 + 0.2 * rnd(c, seed=2)).requires_grad_(True)
     mean = x.mean(dim=1, keepdim=True)
