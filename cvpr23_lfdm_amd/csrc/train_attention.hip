@@ -430,66 +430,93 @@ __global__ __launch_bounds__(256) void linattn_bwd_context_kernel(const float* _
   }
 }
 
-// grid (ceil(hw/32), n_frames*8); 256 threads = 8 tokens x 32 features per iteration, 4 iterations
+// grid (ceil(hw / LA_TOK), n_frames); 256 threads = 8 heads x 32 features: a workgroup walks LA_TOK tokens of one frame and reads / writes
+// whole 3 KB qkv rows (1 KB contiguous per operand and token - round 4's grid gave every (frame, head) its own workgroups, i.e. 128-byte pieces
+// 3 KB apart: 2.1 TB/s).  Thread (head, feature j) keeps row j of ctx, row j of dctx and column j of dctx of its head in REGISTERS (96 floats,
+// loaded once per workgroup; round 4 read them from LDS inside the loop, six ds_read_b32 per three FMAs); a token's dout / v / softmax(k)
+// vectors are exchanged through a wave-private LDS row (the 32 lanes of a head are half a wavefront: a wave-level fence orders them) and read
+// back as broadcast float4s.  Four tokens per trip keep 16 loads in flight per thread.
+constexpr int LA_TOK = 64;
 __global__ __launch_bounds__(256) void linattn_bwd_apply_kernel(const float* __restrict__ qkv,
                                                                 const float* __restrict__ dout,
                                                                 const float* __restrict__ ws, int hw,
                                                                 float* __restrict__ dqkv) {
-  __shared__ float ctx[DH][DH + 1], dctx[DH][DH + 1];
-  __shared__ float kmax[DH], ksum[DH], rowdot[DH];
-  __shared__ float t_go[8][DH], t_v[8][DH], t_ks[8][DH];
+  __shared__ __attribute__((aligned(16))) float t_go[8][4][DH], t_v[8][4][DH], t_ks[8][4][DH];
   const int tid = threadIdx.x;
-  const int fh = blockIdx.y, f = fh >> 3, h = fh & 7;
-  const float* w = ws + (int64_t)fh * LA_WS;
-  for (int i = tid; i < DH * DH; i += 256) {
-    ctx[i >> 5][i & 31] = w[i];
-    dctx[i >> 5][i & 31] = w[DH * DH + i];
+  const int f = blockIdx.y;
+  const int h = tid >> 5, j = tid & 31;
+  const float* w = ws + ((int64_t)f * HEADS + h) * LA_WS;
+  float cj[DH], dj[DH], dtj[DH];
+#pragma unroll
+  for (int e4 = 0; e4 < DH / 4; ++e4) {
+    const float4 a = *reinterpret_cast<const float4*>(w + j * DH + 4 * e4);
+    const float4 b = *reinterpret_cast<const float4*>(w + DH * DH + j * DH + 4 * e4);
+    cj[4 * e4] = a.x; cj[4 * e4 + 1] = a.y; cj[4 * e4 + 2] = a.z; cj[4 * e4 + 3] = a.w;
+    dj[4 * e4] = b.x; dj[4 * e4 + 1] = b.y; dj[4 * e4 + 2] = b.z; dj[4 * e4 + 3] = b.w;
   }
-  if (tid < DH) {
-    kmax[tid] = w[2 * DH * DH + tid];
-    ksum[tid] = w[2 * DH * DH + DH + tid];
-    rowdot[tid] = w[2 * DH * DH + 2 * DH + tid];
-  }
-  __syncthreads();
-  const int tl = tid >> 5, j = tid & 31;
-  for (int it = 0; it < 4; ++it) {
-    const int n = blockIdx.x * 32 + it * 8 + tl;
-    const bool ok = n < hw;
-    const int64_t row = (int64_t)f * hw + (ok ? n : 0);
-    const float* src = qkv + row * QKV_LD + h * DH + j;
-    const float q = ok ? src[0] : 0.f, k = ok ? src[OUT_LD] : 0.f, v = ok ? src[2 * OUT_LD] : 0.f;
-    const float g = ok ? dout[row * OUT_LD + h * DH + j] : 0.f;
-    float m = q;
 #pragma unroll
-    for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
-    const float eq = expf(q - m);
-    float sm = eq;
+  for (int e = 0; e < DH; ++e) dtj[e] = w[DH * DH + e * DH + j];
+  const float kmax_j = w[2 * DH * DH + j], ksum_j = w[2 * DH * DH + DH + j], rowdot_j = w[2 * DH * DH + 2 * DH + j];
+  const int n0 = blockIdx.x * LA_TOK;
+  for (int it = 0; it < LA_TOK / 4; ++it) {
+    float q[4], k[4], v[4], g[4];
+    bool ok[4];
+    int64_t row[4];
 #pragma unroll
-    for (int x = 1; x < 32; x <<= 1) sm += __shfl_xor(sm, x);
-    const float s = eq / sm;                                  // softmax_d(q)
-    const float ks = expf(k - kmax[j]) / ksum[j];             // softmax_n(k)
-    t_go[tl][j] = g;
-    t_v[tl][j] = v;
-    t_ks[tl][j] = ks;
-    __syncthreads();
-    float dqs = 0.f, dks = 0.f, dv = 0.f;
-#pragma unroll 8
-    for (int e = 0; e < DH; ++e) {
-      dqs = fmaf(ctx[j][e], t_go[tl][e], dqs);
-      dks = fmaf(dctx[j][e], t_v[tl][e], dks);
-      dv = fmaf(dctx[e][j], t_ks[tl][e], dv);
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + 4 * it + u;
+      ok[u] = n < hw;
+      row[u] = (int64_t)f * hw + (ok[u] ? n : 0);
+      const float* src = qkv + row[u] * QKV_LD + h * DH + j;
+      q[u] = ok[u] ? src[0] : 0.f;
+      k[u] = ok[u] ? src[OUT_LD] : 0.f;
+      v[u] = ok[u] ? src[2 * OUT_LD] : 0.f;
+      g[u] = ok[u] ? dout[row[u] * OUT_LD + h * DH + j] : 0.f;
     }
-    const float dl = dqs * ATT_SCALE;
-    float dot = s * dl;
+    float s[4], ks[4];
 #pragma unroll
-    for (int x = 1; x < 32; x <<= 1) dot += __shfl_xor(dot, x);
-    if (ok) {
-      float* dst = dqkv + row * QKV_LD + h * DH + j;
-      dst[0] = s * (dl - dot);
-      dst[OUT_LD] = ks * (dks - rowdot[j]);
-      dst[2 * OUT_LD] = dv;
+    for (int u = 0; u < 4; ++u) {
+      float m = q[u];
+#pragma unroll
+      for (int x = 1; x < 32; x <<= 1) m = fmaxf(m, __shfl_xor(m, x));
+      const float eq = expf(q[u] - m);
+      float sm = eq;
+#pragma unroll
+      for (int x = 1; x < 32; x <<= 1) sm += __shfl_xor(sm, x);
+      s[u] = eq / sm;                                         // softmax_d(q)
+      ks[u] = expf(k[u] - kmax_j) / ksum_j;                   // softmax_n(k)
     }
-    __syncthreads();
+    lfdm_wave_lds_sync();                                     // (the previous trip's reads of these rows are done)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t_go[h][u][j] = g[u];
+      t_v[h][u][j] = v[u];
+      t_ks[h][u][j] = ks[u];
+    }
+    lfdm_wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float dqs = 0.f, dks = 0.f, dv = 0.f;
+#pragma unroll
+      for (int e4 = 0; e4 < DH / 4; ++e4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(&t_go[h][u][4 * e4]);
+        const float4 v4 = *reinterpret_cast<const float4*>(&t_v[h][u][4 * e4]);
+        const float4 k4 = *reinterpret_cast<const float4*>(&t_ks[h][u][4 * e4]);
+        dqs = fmaf(cj[4 * e4], g4.x, dqs); dqs = fmaf(cj[4 * e4 + 1], g4.y, dqs); dqs = fmaf(cj[4 * e4 + 2], g4.z, dqs); dqs = fmaf(cj[4 * e4 + 3], g4.w, dqs);
+        dks = fmaf(dj[4 * e4], v4.x, dks); dks = fmaf(dj[4 * e4 + 1], v4.y, dks); dks = fmaf(dj[4 * e4 + 2], v4.z, dks); dks = fmaf(dj[4 * e4 + 3], v4.w, dks);
+        dv = fmaf(dtj[4 * e4], k4.x, dv); dv = fmaf(dtj[4 * e4 + 1], k4.y, dv); dv = fmaf(dtj[4 * e4 + 2], k4.z, dv); dv = fmaf(dtj[4 * e4 + 3], k4.w, dv);
+      }
+      const float dl = dqs * ATT_SCALE;
+      float dot = s[u] * dl;
+#pragma unroll
+      for (int x = 1; x < 32; x <<= 1) dot += __shfl_xor(dot, x);
+      if (ok[u]) {
+        float* dst = dqkv + row[u] * QKV_LD + h * DH + j;
+        dst[0] = s[u] * (dl - dot);
+        dst[OUT_LD] = ks[u] * (dks - rowdot_j);
+        dst[2 * OUT_LD] = dv;
+      }
+    }
   }
 }
 
@@ -558,7 +585,7 @@ extern "C" int lfdm_linear_attention_bwd_cl_f32(const float* qkv, const float* d
     return LFDM_EWORKSPACE;
   }
   LFDM_LAUNCH(linattn_bwd_context_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, qkv, dout, hw, (float*)ws);
-  LFDM_LAUNCH(linattn_bwd_apply_kernel, dim3((hw + 31) / 32, n_frames * HEADS), dim3(256), 0, stream, qkv, dout,
+  LFDM_LAUNCH(linattn_bwd_apply_kernel, dim3((hw + LA_TOK - 1) / LA_TOK, n_frames), dim3(256), 0, stream, qkv, dout,
               (const float*)ws, hw, dqkv);
   return lfdm_check_launch("linear_attention_bwd");
 }
