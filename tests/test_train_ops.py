@@ -53,7 +53,8 @@ def test_conv_wgrad(backend, cin, cout, k, stride, res):
         assert_close(out.cpu() / scale, w.grad / scale, TOL, "conv wgrad, reference layout")
         assert_close(db2.cpu() / float(ref_db.abs().max()), ref_db / float(ref_db.abs().max()), TOL, "bias grad from the wgrad pass")
         if c0 == cin:
-            assert torch.equal(out.cpu(), got.contiguous()), "layout 1 must be a pure permutation of layout 0"
+            # (the two layouts fold their row-slice slabs in different - each fixed - orders since round 5: equal up to fp32 summation order)
+            assert_close(out.cpu() / scale, got.contiguous() / scale, 1e-5, "layout 1 vs layout 0")
 
 
 @pytest.mark.parametrize("c,with_ss,silu", [(32, True, True), (64, False, True), (32, False, False), (512, True, True)])
@@ -237,10 +238,10 @@ def test_multi_linear(backend, rows, k, ns, act):
         assert float(wd[3].grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cin,cout,n,res", [(64, 64, 16, 8), (96, 40, 64, 4), (32, 128, 4, 16), (160, 64, 2, 12)])
+@pytest.mark.parametrize("cin,cout,n,res", [(64, 64, 16, 8), (96, 40, 64, 4), (32, 128, 4, 16), (160, 64, 2, 12), (128, 136, 16, 8), (192, 64, 64, 4)])
 def test_conv_wgrad_nine_tap_tiles(backend, cin, cout, n, res):
-    """conv_wgrad3_kernel (3x3 / stride 1 / pad 1: all nine taps of a pixel tile per workgroup; TW = 8 and the TW = 4 two-image form, partial
-    channel tiles, ragged split counts) against autograd, in both output layouts, with the fused bias sums - and bit-identical to the per-tap
+    """conv_wgrad3_kernel (3x3 / stride 1 / pad 1: all nine taps of a pixel tile per workgroup - or one filter row per workgroup where a
+    convolution has one or two channel blocks; TW = 8 and the TW = 4 two-image form, partial channel tiles, ragged split counts) against autograd, in both output layouts, with the fused bias sums - and bit-identical to the per-tap
     kernel's summation order is NOT required (different tiling): tolerance as for the other weight-gradient tests."""
     import os
     dev = backend
