@@ -26,12 +26,18 @@ class RegionPredictor(ParamTree):
 
     def __init__(self, num_regions, num_channels, estimate_affine=True, **params):
         super().__init__()
-        build_tree(self, region_predictor_spec(num_regions=num_regions, num_channels=num_channels, **params))
+        pca_based = params.get("pca_based", False)       # (region_predictor.py:36 default; every LFDM yaml sets pca_based: true)
+        build_tree(self, region_predictor_spec(num_regions=num_regions, num_channels=num_channels, estimate_affine=estimate_affine,
+                                               **dict(params, pca_based=pca_based)))
+        if self.has("jacobian.weight"):                  # region_predictor.py:46-47: the regression head starts at the identity
+            with torch.no_grad():
+                self.get("jacobian.weight").zero_()
+                self.get("jacobian.bias").copy_(torch.tensor([1, 0, 0, 1], dtype=torch.float))
         from .lfae_predictors import RegionPredictorExec
         self._exec = RegionPredictorExec(self, num_blocks=params.get("num_blocks", 5),
                                          temperature=params.get("temperature", 0.1),
                                          scale_factor=params.get("scale_factor", 0.25),
-                                         pca_based=params.get("pca_based", True), pad=params.get("pad", 3))
+                                         pca_based=pca_based, pad=params.get("pad", 3), estimate_affine=estimate_affine)
 
     def forward(self, x):
         return self._exec(x)
@@ -43,8 +49,11 @@ class BGMotionPredictor(ParamTree):
     def __init__(self, num_channels, **params):
         super().__init__()
         build_tree(self, bg_predictor_spec(num_channels=num_channels, **params))
-        with torch.no_grad():   # reference initialises fc to the identity affine (bg_motion_predictor.py:33-39)
-            self.get("fc.bias").copy_(torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float))
+        self.bg_type = params.get("bg_type", "affine")
+        if self.bg_type != "zero":
+            from .params import BG_FC_BIAS
+            with torch.no_grad():   # reference initialises fc to the identity transform (bg_motion_predictor.py:27-40)
+                self.get("fc.bias").copy_(torch.tensor(BG_FC_BIAS[self.bg_type], dtype=torch.float))
 
         from .lfae_predictors import BGMotionPredictorExec
         self._exec = BGMotionPredictorExec(self, num_blocks=params.get("num_blocks", 5),

@@ -228,8 +228,9 @@ def svd2x2_sym_lapack(a, b, c):
 
 
 class RegionPredictorExec:
-    def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3):
+    def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3, estimate_affine=True):
         self.tree, self.temperature, self.scale_factor, self.pca_based, self.pad = tree, temperature, scale_factor, pca_based, pad
+        self.regression = bool(estimate_affine) and not pca_based          # FOMM-like `jacobian` head (region_predictor.py:43-49, 98-108)
         self.hg = HourglassExec(tree, "predictor.", num_blocks, in_pad_to=32)      # 3-channel image in a 32-wide buffer (the
         #                                                     head's fast schedules want both concatenated sources in 32s)
 
@@ -243,7 +244,21 @@ class RegionPredictorExec:
         k_regions = self.tree.get("regions.weight").shape[0]
         ho, wo = h + 2 * self.pad - 6, w + 2 * self.pad - 6                    # 7x7 head
         if not self.pca_based:
-            raise NotImplementedError("regression-based affine (estimate_affine and not pca_based): no LFDM config uses it")
+            # No LFDM yaml selects these two modes (all set pca_based: true); the reference accepts them.  The 7x7 heads run on the native
+            # convolution (region and jacobian logits as ONE launch); the spatial softmax and the heat-map weighted sums over the few-KB
+            # (N, K, h, w) maps are torch ops on the device.
+            heads = _head_conv(self.tree, ("regions.", "jacobian.") if self.regression else "regions.", out, skip, n, h, w, self.pad)
+            logits = heads[:, :k_regions]
+            region = torch.softmax(logits.reshape(n, k_regions, -1) / self.temperature, dim=2).view(n, k_regions, ho, wo)
+            ys, xs = torch.meshgrid(torch.linspace(-1, 1, ho, device=x.device), torch.linspace(-1, 1, wo, device=x.device), indexing="ij")
+            grid = torch.stack((xs, ys), dim=-1).view(1, 1, ho, wo, 2)
+            res = {"shift": (region.unsqueeze(-1) * grid).sum(dim=(2, 3)), "heatmap": region}
+            if self.regression:
+                jac = heads[:, k_regions:k_regions + 4].reshape(n, 1, 4, ho * wo)
+                jac = (region.reshape(n, k_regions, 1, ho * wo) * jac).sum(dim=-1).view(n, k_regions, 2, 2)
+                res["affine"] = jac
+                res["covar"] = torch.matmul(jac, jac.transpose(-1, -2))
+            return res
         if n > 65535 or ho * wo > 4096:
             raise ValueError("RegionPredictor: %d frames with %dx%d heat-maps per call (the fused launch takes at most 65535 frames "
                              "of at most 4096 pixels; split the batch)" % (n, ho, wo))
@@ -255,23 +270,25 @@ class RegionPredictorExec:
 
 class BGMotionPredictorExec:
     def __init__(self, tree, num_blocks=5, bg_type="affine"):
-        if bg_type != "affine":
-            raise NotImplementedError("bg_type %r: the LFDM configs use 'affine'" % bg_type)
-        self.tree = tree
-        self.enc = HourglassExec(tree, "", num_blocks, decoder=False, in_pad_to=16)         # cat(source, driving): 6 channels
+        if bg_type not in ("zero", "shift", "affine", "perspective"):
+            raise ValueError("bg_type %r (the reference accepts 'zero', 'shift', 'affine', 'perspective')" % (bg_type,))
+        self.tree, self.bg_type = tree, bg_type
+        self.enc = None if bg_type == "zero" else HourglassExec(tree, "", num_blocks, decoder=False, in_pad_to=16)   # cat(source, driving): 6 channels
 
     @torch.no_grad()
     def __call__(self, source, driving):
-        """(N,3,H,W) x2 -> (N,3,3) background affine (bg_motion_predictor.py:42-57)."""
+        """(N,3,H,W) x2 -> (N,3,3) background transform (bg_motion_predictor.py:42-57): identity ('zero'), translation ('shift'), affine or
+        perspective."""
         n, _, h, w = source.shape
+        if self.bg_type == "zero":
+            return torch.eye(3, device=source.device).unsqueeze(0).repeat(n, 1, 1)
         x = torch.cat((source, driving), dim=1).float()
         feats = self.enc.encode(_image_rows(x, pad_to=16, full=True), n, h, w)
         last, hh, ww = feats[-1]
         pooled = last.view(n, hh * ww, -1).mean(dim=1)
         pred = F.linear(pooled, self.tree.get("fc.weight"), self.tree.get("fc.bias"))
-        out = torch.eye(3, device=x.device).unsqueeze(0).repeat(n, 1, 1)
-        out[:, :2, :] = pred.view(n, 2, 3)
-        return out
+        from .params import bg_matrix
+        return bg_matrix(pred, n, self.bg_type)
 
 
 class PixelwiseFlowPredictorExec:

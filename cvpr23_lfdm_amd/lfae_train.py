@@ -203,6 +203,14 @@ def region_predictor_forward(tree, x, cfg, training=True):
     grid = make_coordinate_grid(shp[2], shp[3], region).view(1, 1, shp[2], shp[3], 2)
     r = region.unsqueeze(-1)
     mean = (r * grid).sum(dim=(2, 3))
+    if not cfg.get("pca_based", False):           # region_predictor.py:98-108: the regression head, or centres + heat-maps only
+        out = {"shift": mean, "heatmap": region}
+        if cfg.get("estimate_affine", True):
+            jmap = net.conv(fmap, "jacobian.", cfg.get("pad", 3)).reshape(shp[0], 1, 4, shp[2] * shp[3])
+            jac = (region.reshape(shp[0], shp[1], 1, -1) * jmap).sum(dim=-1).view(shp[0], shp[1], 2, 2)
+            out["affine"] = jac
+            out["covar"] = _mm2(jac, jac.transpose(-1, -2))
+        return out
     mean_sub = grid - mean.unsqueeze(-2).unsqueeze(-2)
     covar = ((mean_sub.unsqueeze(-1) * mean_sub.unsqueeze(-2)) * r.unsqueeze(-1)).sum(dim=(2, 3))       # outer product per pixel
     # region_predictor.py:21-25 moves the covariances to the host for torch.svd; here: LAPACK's 2x2 path in closed form on the device,
@@ -214,13 +222,15 @@ def region_predictor_forward(tree, x, cfg, training=True):
 
 
 def bg_predictor_forward(tree, source, driving, cfg, training=True):
-    """BGMotionPredictor.forward, bg_type 'affine' (bg_motion_predictor.py:42-57) -> (B, 3, 3)."""
+    """BGMotionPredictor.forward (bg_motion_predictor.py:42-57) -> (B, 3, 3): identity ('zero'), translation, affine or perspective."""
+    bg_type = cfg.get("bg_type", "affine")
+    bs = source.shape[0]
+    if bg_type == "zero":
+        return torch.eye(3, dtype=source.dtype, device=source.device).unsqueeze(0).repeat(bs, 1, 1)
     net = _Net(tree, training)
     feats = net.hourglass(_cl(torch.cat([source, driving], dim=1)), "", cfg["num_blocks"], decoder=False)
     pred = F.linear(feats[-1].mean(dim=(2, 3)), tree.get("fc.weight"), tree.get("fc.bias"))
-    out = torch.eye(3, dtype=pred.dtype, device=pred.device).unsqueeze(0).repeat(source.shape[0], 1, 1)
-    out[:, :2, :] = pred.view(-1, 2, 3)
-    return out
+    return P.bg_matrix(pred, bs, bg_type)
 
 
 def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, num_regions, revert_axis_swap=True, training=True):
@@ -230,14 +240,21 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
     img = antialias_down(source_image, tree.get(p + "down.weight"), cfg["scale_factor"]) if cfg["scale_factor"] != 1 else source_image
     bs, _, h, w = img.shape
     k = num_regions
-    heat = region2gaussian(driving["shift"], driving["covar"], h, w) - region2gaussian(source["shift"], source["covar"], h, w)
+    if cfg.get("use_covar_heatmap", False):        # pixelwise_flow_predictor.py:53-56 (every LFDM yaml: true); else an isotropic variance
+        heat = region2gaussian(driving["shift"], driving["covar"], h, w) - region2gaussian(source["shift"], source["covar"], h, w)
+    else:
+        var = float(cfg.get("region_var", 0.01))
+        gd = make_coordinate_grid(h, w, driving["shift"]).view(1, 1, h, w, 2)
+        iso = lambda c: torch.exp(-0.5 * ((gd - c.view(*c.shape[:2], 1, 1, 2)) ** 2).sum(-1) / var)
+        heat = iso(driving["shift"]) - iso(source["shift"])
     heat = torch.cat([heat.new_zeros(bs, 1, h, w), heat], dim=1).unsqueeze(2)
     ident = make_coordinate_grid(h, w, heat).view(1, 1, h, w, 2)
     cg = ident - driving["shift"].view(bs, k, 1, 1, 2)
-    affine = _mm2(source["affine"], _inv2(driving["affine"]))
-    if revert_axis_swap:
-        affine = affine * torch.sign(affine[:, :, 0:1, 0:1])
-    cg = _mat2_vec(affine.unsqueeze(-3).unsqueeze(-3), cg)
+    if "affine" in driving:                        # pixelwise_flow_predictor.py:71-78
+        affine = _mm2(source["affine"], _inv2(driving["affine"]))
+        if revert_axis_swap:
+            affine = affine * torch.sign(affine[:, :, 0:1, 0:1])
+        cg = _mat2_vec(affine.unsqueeze(-3).unsqueeze(-3), cg)
     d2s = cg + source["shift"].view(bs, k, 1, 1, 2)
     bg = ident.repeat(bs, 1, 1, 1, 1)
     if bg_params is not None:      # homogeneous 3x3 transform of the identity grid
@@ -391,7 +408,8 @@ class ReconstructionModel:
         return self
 
     def _regions(self, x):
-        return region_predictor_forward(self.region_predictor, x, self.mp["region_predictor_params"], self.training)
+        cfg = dict(self.mp["region_predictor_params"], estimate_affine=self.mp.get("estimate_affine", False))
+        return region_predictor_forward(self.region_predictor, x, cfg, self.training)
 
     def pyramid(self, x, vgg_input=False):
         """ImagePyramide (model.py:62-82).  vgg_input: every level leaves its launch as the perceptual network's input - normalised

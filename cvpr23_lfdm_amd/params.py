@@ -284,21 +284,49 @@ def _hourglass_entries(prefix, block_expansion, in_features, num_blocks, max_fea
 
 
 def region_predictor_spec(num_regions=10, num_channels=3, block_expansion=32, max_features=1024,
-                          num_blocks=5, scale_factor=0.25, **_):
-    """RegionPredictor state-dict layout (LFAE/modules/region_predictor.py:28-50)."""
+                          num_blocks=5, scale_factor=0.25, estimate_affine=True, pca_based=True, **_):
+    """RegionPredictor state-dict layout (LFAE/modules/region_predictor.py:28-50); the FOMM-like regression head `jacobian` exists when
+    estimate_affine and not pca_based (:43-49)."""
     spec = _hourglass_entries("predictor.", block_expansion, num_channels, num_blocks, max_features)
     spec += _conv_entries("regions.", num_regions, block_expansion + num_channels, 7, 7)
+    if estimate_affine and not pca_based:
+        spec += _conv_entries("jacobian.", 4, block_expansion + num_channels, 7, 7)
     if scale_factor != 1:
         spec.append(("down.weight", (num_channels, 1, 13, 13), ("const", antialias_kernel(num_channels, scale_factor)), True))
     return spec
 
 
-def bg_predictor_spec(num_channels=3, block_expansion=32, max_features=1024, num_blocks=5, **_):
-    """BGMotionPredictor state-dict layout (LFAE/modules/bg_motion_predictor.py:15-40)."""
+BG_FC_OUT = {"shift": 2, "affine": 6, "perspective": 8}        # bg_motion_predictor.py:27-40; bg_type 'zero' has no parameters at all
+BG_FC_BIAS = {"shift": (0, 0), "affine": (1, 0, 0, 0, 1, 0), "perspective": (1, 0, 0, 0, 1, 0, 0, 0)}
+
+
+def bg_predictor_spec(num_channels=3, block_expansion=32, max_features=1024, num_blocks=5, bg_type="affine", **_):
+    """BGMotionPredictor state-dict layout (LFAE/modules/bg_motion_predictor.py:15-40) for every bg_type the reference accepts."""
+    if bg_type == "zero":
+        return []
+    if bg_type not in BG_FC_OUT:
+        raise ValueError("bg_type %r (the reference accepts 'zero', 'shift', 'affine', 'perspective')" % (bg_type,))
     spec = _hourglass_entries("", block_expansion, num_channels * 2, num_blocks, max_features, decoder=False)
     co = min(max_features, block_expansion * (2 ** num_blocks))
-    spec += [("fc.weight", (6, co), ("zeros",), False), ("fc.bias", (6,), ("zeros",), False)]
+    n = BG_FC_OUT[bg_type]
+    spec += [("fc.weight", (n, co), ("zeros",), False), ("fc.bias", (n,), ("zeros",), False)]
     return spec
+
+
+def bg_matrix(pred, bs, bg_type):
+    """(bs, 3, 3) background transform from the fc output (bg_motion_predictor.py:44-57); pred is None for bg_type 'zero'."""
+    import torch
+    if bg_type == "zero":
+        return None
+    dev, dt = pred.device, pred.dtype
+    one, zero = torch.ones(bs, 1, device=dev, dtype=dt), torch.zeros(bs, 1, device=dev, dtype=dt)
+    if bg_type == "shift":
+        rows = torch.cat((one, zero, pred[:, 0:1], zero, one, pred[:, 1:2], zero, zero, one), dim=1)
+    elif bg_type == "affine":
+        rows = torch.cat((pred, zero, zero, one), dim=1)
+    else:
+        rows = torch.cat((pred, one), dim=1)
+    return rows.view(bs, 3, 3)
 
 
 VGG19_CONVS = ((1, 0, 3, 64), (2, 2, 64, 64), (2, 5, 64, 128), (3, 7, 128, 128), (3, 10, 128, 256), (4, 12, 256, 256), (4, 14, 256, 256),

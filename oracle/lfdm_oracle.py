@@ -607,16 +607,25 @@ def hourglass(x, sd, prefix, num_blocks=5, decoder=True):
     return out
 
 
-def region_predictor(rsd, x, temperature=0.1, scale=0.25, pad=3):
-    """RegionPredictor.forward, pca_based (region_predictor.py:52-117)."""
-    x = anti_alias_down(x, rsd["down.weight"], scale)
-    fmap = hourglass(x, rsd, "predictor.")
+def region_predictor(rsd, x, temperature=0.1, scale=0.25, pad=3, pca_based=True, num_blocks=5):
+    """RegionPredictor.forward (region_predictor.py:52-117): pca_based (:109-116, what every LFDM yaml selects), the FOMM-like regression head
+    when the state dict has `jacobian.*` (:98-108), or centres + heat-maps only."""
+    x = anti_alias_down(x, rsd["down.weight"], scale) if scale != 1 else x
+    fmap = hourglass(x, rsd, "predictor.", num_blocks=num_blocks)
     pred = F.conv2d(fmap, rsd["regions.weight"], rsd["regions.bias"], padding=pad)
     shp = pred.shape
     region = F.softmax(pred.view(shp[0], shp[1], -1) / temperature, dim=2).view(*shp)
     grid = make_coordinate_grid(shp[2], shp[3]).unsqueeze(0).unsqueeze(0)
     r = region.unsqueeze(-1)
     mean = (r * grid).sum(dim=(2, 3))
+    if not pca_based:
+        out = {"shift": mean, "heatmap": region}
+        if "jacobian.weight" in rsd:
+            jmap = F.conv2d(fmap, rsd["jacobian.weight"], rsd["jacobian.bias"], padding=pad).reshape(shp[0], 1, 4, shp[2], shp[3])
+            jac = (region.unsqueeze(2) * jmap).view(shp[0], shp[1], 4, -1).sum(dim=-1).view(shp[0], shp[1], 2, 2)
+            out["affine"] = jac
+            out["covar"] = torch.matmul(jac, jac.permute(0, 1, 3, 2))
+        return out
     mean_sub = grid - mean.unsqueeze(-2).unsqueeze(-2)
     covar = torch.matmul(mean_sub.unsqueeze(-1), mean_sub.unsqueeze(-2)) * r.unsqueeze(-1)
     covar = covar.sum(dim=(2, 3))
@@ -625,12 +634,24 @@ def region_predictor(rsd, x, temperature=0.1, scale=0.25, pad=3):
     return {"shift": mean, "covar": covar, "affine": affine, "heatmap": region}
 
 
-def bg_predictor(bsd, source, driving):
-    """BGMotionPredictor.forward, bg_type 'affine' (bg_motion_predictor.py:42-57)."""
-    feats = hourglass(torch.cat([source, driving], dim=1), bsd, "", decoder=False)
+def bg_predictor(bsd, source, driving, bg_type="affine", num_blocks=5):
+    """BGMotionPredictor.forward (bg_motion_predictor.py:42-57) for every bg_type of :19: 'zero' (identity, no network), 'shift'
+    (fc -> translation column), 'affine' (fc -> upper 2x3), 'perspective' (fc -> upper 2x3 and the first two entries of the last row)."""
+    bs = source.shape[0]
+    out = torch.eye(3).unsqueeze(0).repeat(bs, 1, 1)
+    if bg_type == "zero":
+        return out
+    feats = hourglass(torch.cat([source, driving], dim=1), bsd, "", num_blocks=num_blocks, decoder=False)
     pred = F.linear(feats[-1].mean(dim=(2, 3)), bsd["fc.weight"], bsd["fc.bias"])
-    out = torch.eye(3).unsqueeze(0).repeat(source.shape[0], 1, 1)
-    out[:, :2, :] = pred.view(-1, 2, 3)
+    if bg_type == "shift":
+        out[:, :2, 2] = pred
+    elif bg_type == "affine":
+        out[:, :2, :] = pred.view(-1, 2, 3)
+    elif bg_type == "perspective":
+        out[:, :2, :] = pred[:, :6].view(bs, 2, 3)
+        out[:, 2, :2] = pred[:, 6:].view(bs, 2)
+    else:
+        raise ValueError(bg_type)
     return out
 
 

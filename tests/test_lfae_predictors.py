@@ -92,3 +92,53 @@ def test_pixelwise_flow_predictor(backend):
         a = ex(src[:1].to(dev), to(d_par), one(s_par), bg.to(dev), frames=2)
         b = ex(src[:1].repeat(2, 1, 1, 1).to(dev), to(d_par), rep2(s_par), bg.to(dev))
     assert torch.equal(a["optical_flow"], b["optical_flow"]) and torch.equal(a["occlusion_map"], b["occlusion_map"])
+
+
+@pytest.mark.parametrize("bg_type", ["zero", "shift", "perspective"])
+def test_bg_motion_predictor_other_types(backend, bg_type):
+    """The bg_type values no LFDM yaml selects but the reference accepts (bg_motion_predictor.py:19, 27-57): identity, translation and
+    perspective - the holder class and its executor against the oracle's restatement (itself checked against the live reference in
+    tests/test_oracle_vs_reference.py), on a small encoder."""
+    from cvpr23_lfdm_amd import params as P
+    from cvpr23_lfdm_amd.flow_diffusion import BGMotionPredictor
+    dev = backend
+    kw = dict(block_expansion=8, max_features=32, num_blocks=2, bg_type=bg_type)
+    net = BGMotionPredictor(num_channels=3, **kw)
+    sd = P.synthetic_state_dict(P.bg_predictor_spec(num_channels=3, **kw), 6262)
+    if bg_type != "zero":
+        sd["fc.weight"] = sd["fc.weight"] * 0.05
+        sd["fc.bias"] = torch.tensor(P.BG_FC_BIAS[bg_type], dtype=torch.float32) + 0.2 * sd["fc.bias"]
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(79)
+    n = 2
+    src, drv = torch.rand(n, 3, 32, 32, generator=g), torch.rand(n, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        ref = O.bg_predictor({k: v.float() for k, v in sd.items()}, src, drv, bg_type=bg_type, num_blocks=2)
+        got = net(src.to(dev), drv.to(dev))
+    assert got.shape == (n, 3, 3)
+    assert_close(got.cpu(), ref, 1e-3, "background transform, bg_type %s" % bg_type)
+    if bg_type != "zero":
+        assert float((ref - torch.eye(3)).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("estimate_affine", [True, False], ids=["regression", "centres_only"])
+def test_region_predictor_without_pca(backend, estimate_affine):
+    """pca_based: false (region_predictor.py:43-49, 98-108): the FOMM-like `jacobian` regression head, or centres + heat-maps only -
+    holder + executor against the oracle (which tests/test_oracle_vs_reference.py checks against the reference module), small hourglass."""
+    from cvpr23_lfdm_amd import params as P
+    from cvpr23_lfdm_amd.flow_diffusion import RegionPredictor
+    dev = backend
+    kw = dict(block_expansion=8, max_features=32, num_blocks=2, temperature=0.1, scale_factor=0.25, pca_based=False, pad=3)
+    net = RegionPredictor(num_regions=4, num_channels=3, estimate_affine=estimate_affine, **kw)
+    assert net.has("jacobian.weight") == estimate_affine
+    sd = P.synthetic_state_dict(P.region_predictor_spec(num_regions=4, num_channels=3, estimate_affine=estimate_affine, **kw), 7171)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(80))
+    with torch.no_grad():
+        ref = O.region_predictor({k: v.float() for k, v in sd.items()}, x, pca_based=False, num_blocks=2)
+        got = net(x.to(dev))
+    assert set(got) == set(ref)
+    for key in ref:
+        assert_close(got[key].cpu(), ref[key], 1e-3, "region predictor (no pca) " + key)
