@@ -237,6 +237,9 @@ class RegionPredictorExec:
     @torch.no_grad()
     def __call__(self, x):
         """x (N, 3, H, W) -> dict(shift (N,K,2), covar, affine (N,K,2,2), heatmap (N,K,h,w), u, d)."""
+        if x.shape[0] > 65535 and self.pca_based:       # (grid limit of the fused statistics launch: more frames than any LFDM batch - slices)
+            parts = [self(x_part) for x_part in x.split(32768)]
+            return {key: torch.cat([q[key] for q in parts], dim=0) for key in parts[0]}
         if self.scale_factor != 1:
             x = antialias_down(x.float(), self.tree.get("down.weight"), self.scale_factor)
         n, _, h, w = x.shape
@@ -259,9 +262,8 @@ class RegionPredictorExec:
                 res["affine"] = jac
                 res["covar"] = torch.matmul(jac, jac.transpose(-1, -2))
             return res
-        if n > 65535 or ho * wo > 4096:
-            raise ValueError("RegionPredictor: %d frames with %dx%d heat-maps per call (the fused launch takes at most 65535 frames "
-                             "of at most 4096 pixels; split the batch)" % (n, ho, wo))
+        if ho * wo > 4096:
+            raise ValueError("RegionPredictor: %dx%d heat-maps (the fused statistics launch takes at most 4096 pixels per map)" % (ho, wo))
         # one launch: spatial softmax, centre, covariance, U sqrt(S) with LAPACK's sign convention (region_predictor.py:16-25 does
         # torch.svd(covar.cpu()) per frame; svd2x2_sym_lapack above is the same closed form in tensor ops, kept for tests/test_svd2x2.py)
         rows = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad, planar=False)
