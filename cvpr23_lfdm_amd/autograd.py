@@ -137,9 +137,17 @@ class ConvCL(Function):
             ww = None
             if _wino_ok(kh, kw, stride, pad, hi, wi, x0.shape[1], 0 if x1 is None else x1.shape[1]):
                 ww = _pack_wino(weight, _c(w4))
-            y = _conv(_c(x0.detach()), (w4, 0), w4.shape[0], kh, kw, n_img, hi, wi,
-                      src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
-                      weight_wino=ww, act=ops.ACT_RELU if geom.get("relu") else ops.ACT_NONE)
+            if (w4.shape[0] <= 4 and x1 is None and res is None and stride == 1 and kh == kw and kh % 2 == 1 and 3 <= kh <= 7 and
+                    tuple(pad) == (kh // 2, kh // 2) and x0.shape[1] % 16 == 0 and not geom.get("relu")):
+                # <= 4 output channels (the generator's 7x7 RGB projection, generator.py:56): the 4x4x1-MFMA kernel of the decode path -
+                # every multiply useful - instead of a 32-column tile that is 7/8 padding (0.98 -> 0.25 ms at 32 frames of 128x128)
+                wsm, bsm = ops.pack_smalln_weight(w4, b)
+                y = ops.conv2d_smalln_cl(_c(x0.detach()), wsm, bsm, 4, kh, n_img, hi, wi)
+                y = y if w4.shape[0] == 4 else y[:, :w4.shape[0]].contiguous()
+            else:
+                y = _conv(_c(x0.detach()), (w4, 0), w4.shape[0], kh, kw, n_img, hi, wi,
+                          src1=None if x1 is None else _c(x1.detach()), bias=b, residual=res, stride=stride, pad=pad,
+                          weight_wino=ww, act=ops.ACT_RELU if geom.get("relu") else ops.ACT_NONE)
             hq = (hi + 2 * pad[0] - kh) // stride + 1
             wq = (wi + 2 * pad[1] - kw) // stride + 1
         else:
