@@ -221,6 +221,7 @@ _SIGNATURES = {
     "lfdm_grid_sample_fwd_f32": (i32, [C.POINTER(GridSampleParams), stream_t]),
     "lfdm_grid_sample_bwd_f32": (i32, [C.POINTER(GridSampleParams), stream_t]),
     "lfdm_svd2x2_sym_bwd_f32": (i32, [f32p, f32p, f32p, f32p, f32p, i64, stream_t]),
+    "lfdm_pack_wino_weights_multi_f32": (i32, [C.c_void_p, i32, i32, stream_t]),
     "lfdm_im2col_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, i32, i32, i32, stream_t]),
     "lfdm_pool2_cl_f32": (i32, [f32p, f32p, f32p, i32, i32, i32, i32, i32, stream_t]),
     "lfdm_relu_bwd_f32": (i32, [f32p, f32p, f32p, i64, stream_t]),

@@ -83,8 +83,32 @@ def _pack_wino(weight, w4, dgrad=False, part=None):
         for k in [k for k, v in _PACKS.items() if v[0]() is None]:
             del _PACKS[k]
     packed = ops.pack_wino_weight(w4, dgrad=dgrad)
-    _PACKS[key] = (weakref.ref(weight), tag, packed)
+    _PACKS[key] = (weakref.ref(weight), tag, packed, w4)
     return packed
+
+
+def repack_stale():
+    """Re-pack every cached Winograd filter of a TRAINABLE weight whose pack is older than the last optimizer step - forward and data-gradient
+    forms, all in ONE launch into their existing tensors (ops.pack_wino_weights_multi).  Call at the start of a training step's forward:
+    the packs a step needs are the packs the previous step used, so after the first step the ~100 (DM) / ~80 (LFAE) per-filter pack launches
+    of a step become one.  Entries whose weight torch itself has rewritten (load_state_dict, .to()) are left to the per-call path."""
+    from .params import weights_epoch
+    epoch = weights_epoch()
+    jobs, keys = [], []
+    for key, (ref, tag, packed, w4) in _PACKS.items():
+        weight = ref()
+        if (weight is None or not weight.requires_grad or tag[1] == epoch or tag[0] != weight._version or
+                w4.data_ptr() != tag[2]):
+            continue
+        jobs.append((w4, packed, key[1]))
+        keys.append(key)
+    if not jobs:
+        return 0
+    ops.pack_wino_weights_multi(jobs)
+    for key in keys:
+        ref, tag, packed, w4 = _PACKS[key]
+        _PACKS[key] = (ref, (tag[0], epoch, tag[2], tag[3]), packed, w4)
+    return len(jobs)
 
 
 def _wino_ok(kh, kw, stride, pad, hi, wi, *chans):

@@ -472,11 +472,10 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
 }
 
 // U = G g G^T, one thread per (reduction channel k, output channel n) pair of the convolution the result is used for
-__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
-                                                        int dgrad, float* __restrict__ out) {
+__device__ __forceinline__ void pack_wino_item(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp, int dgrad,
+                                               float* __restrict__ out, int64_t idx) {
   const int K = dgrad ? cout : cin;                     // reduction channels of the target convolution
   const int N = dgrad ? cin : cout;                     // its output channels
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)K * coutp) return;
   const int n = (int)(idx % coutp), k = (int)(idx / coutp);
   float g[9];
@@ -509,6 +508,29 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
+                                                        int dgrad, float* __restrict__ out) {
+  pack_wino_item(w, ld_o, cout, cin, coutp, dgrad, out, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Many filters in ONE launch (training re-packs every 3x3 filter - forward and data-gradient form - after each optimizer step: ~100 launches of
+// 5-130 us per DM step, ~80 per LFAE step).  jobs: n_jobs records in device memory, sorted by block0 (the first workgroup of the job).
+__global__ __launch_bounds__(256) void pack_wino_multi_kernel(const lfdm_pack_wino_job* __restrict__ jobs, int n_jobs) {
+  __shared__ int s_job;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_jobs - 1;                        // last job with block0 <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    s_job = lo;
+  }
+  __syncthreads();
+  const lfdm_pack_wino_job j = jobs[s_job];
+  pack_wino_item(j.w, j.ld_o, j.cout, j.cin, j.coutp, j.dgrad, j.out, (int64_t)((int)blockIdx.x - j.block0) * 256 + threadIdx.x);
+}
+
 }  // namespace
 
 extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int cin, int coutp, int dgrad, float* out,
@@ -522,6 +544,13 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
   const int64_t total = (int64_t)K * coutp;
   LFDM_LAUNCH(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, ld_o, cout, cin, coutp, dgrad, out);
   return lfdm_check_launch("pack_wino_weight");
+}
+
+extern "C" int lfdm_pack_wino_weights_multi_f32(const lfdm_pack_wino_job* jobs, int n_jobs, int total_blocks, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!jobs || n_jobs <= 0 || total_blocks <= 0) { lfdm_set_error("pack_wino_weights_multi: needs a device job table and its workgroup count"); return LFDM_EINVAL; }
+  LFDM_LAUNCH(pack_wino_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, jobs, n_jobs);
+  return lfdm_check_launch("pack_wino_weights_multi");
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).  kgroups = G (1, 2, 3; 32-column tiles only).

@@ -503,6 +503,7 @@ class LFAETrainer:
         self.optimizer.zero_grad()
         if self._dp is not None:
             self._dp.prepare()
+        A.repack_stale()          # the Winograd filters of the three trained networks, forward + data-gradient forms: one launch
         losses, generated = self.model(x, transform_noise=transform_noise)
         loss = sum(v.mean() for v in losses.values())
         loss.backward()

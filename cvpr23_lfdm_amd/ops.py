@@ -219,6 +219,37 @@ def pack_wino_weight(w, coutp=None, dgrad=False):
     return out
 
 
+_PACK_JOB_TABLES = {}
+
+
+def pack_wino_weights_multi(jobs):
+    """lfdm_pack_wino_weights_multi_f32: jobs = [(w view (Cout, Cin, 3, 3) or an input-channel slice of one, packed output tensor, dgrad)]
+    - every filter re-packed into its EXISTING output tensor by one launch.  The device job table is cached per job list (pointers)."""
+    import numpy as np
+    lib = _lib()
+    key, recs, block0 = [], [], 0
+    for w, out, dgrad in jobs:
+        cout, cin = w.shape[0], w.shape[1]
+        k, n = (cout, cin) if dgrad else (cin, cout)
+        coutp = out.shape[2]
+        assert out.shape == (16, k // 16, coutp, 16) and out.is_contiguous() and w.stride(3) == 1 and w.stride(2) == 3 and w.stride(1) == 9
+        _chk(lib, w, out)
+        recs.append((w.data_ptr(), out.data_ptr(), w.stride(0), cout, cin, coutp, int(bool(dgrad)), block0))
+        key.append(recs[-1][:7])
+        block0 += (k * coutp + 255) // 256
+    key = (tuple(key), str(jobs[0][1].device))
+    table = _PACK_JOB_TABLES.get(key)
+    if table is None:
+        if len(_PACK_JOB_TABLES) > 16:
+            _PACK_JOB_TABLES.clear()
+        dt = np.dtype([("w", "<u8"), ("out", "<u8"), ("ld_o", "<i4"), ("cout", "<i4"), ("cin", "<i4"), ("coutp", "<i4"), ("dgrad", "<i4"),
+                       ("block0", "<i4")])
+        arr = np.array(recs, dtype=dt)
+        assert arr.dtype.itemsize == 40
+        table = _PACK_JOB_TABLES[key] = torch.from_numpy(arr.view(np.uint8).copy()).to(jobs[0][1].device)
+    lib.check(lib.lfdm_pack_wino_weights_multi_f32(C.c_void_p(table.data_ptr()), len(recs), block0, _stream(lib)), "lfdm_pack_wino_weights_multi_f32")
+
+
 def pack_wino4_weight(w, coutp=None):
     """(Cout, Cin, 3, 3) -> Winograd F(4x4,3x3) filters U = G g G^T as [36][Cin/8][coutp][8] (lfdm_conv_params.weight_wino4, the
     batched-shape schedule of conv_wino4.hip).  lfdm_pack_wino4_weight_f32."""

@@ -110,6 +110,7 @@ def unet_train_forward(unet, x_dyn, fea, time, cond, null_cond_prob=0., none_con
     time (B,) long, cond (B, 768)  ->  eps_hat (B, 3, T, S, S) with grad to every UNet parameter."""
     g = unet.get
     c = _Ctx()
+    A.repack_stale()          # every Winograd filter the previous step used (forward + data-gradient forms): one launch
     b, n_dyn, t, s, _ = x_dyn.shape
     c.batch, c.frames = b, t
     dev = x_dyn.device

@@ -714,6 +714,16 @@ int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight
  * and 64 -> 3 channels) run as ONE 1x1 weight-gradient GEMM instead of 49 per-tap GEMMs that pad 4 channels to a 64-wide tile. */
 int lfdm_im2col_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int ldx, int k, int pad, lfdm_stream_t stream);
 
+/* lfdm_pack_wino_weight_f32 for MANY filters in one launch: `jobs` is a table of n_jobs records IN DEVICE MEMORY, sorted by block0 = the first
+ * workgroup of the job (job i covers ceil(K_i * coutp_i / 256) workgroups; total_blocks = their sum).  Same arguments per record as the single
+ * call.  Training re-packs every 3x3 filter after each optimizer step (video_flow_diffusion_model.py:181-188; LFAE/train.py:96-104). */
+typedef struct lfdm_pack_wino_job {
+  const float* w;
+  float* out;
+  int ld_o, cout, cin, coutp, dgrad, block0;
+} lfdm_pack_wino_job;
+int lfdm_pack_wino_weights_multi_f32(const lfdm_pack_wino_job* jobs, int n_jobs, int total_blocks, lfdm_stream_t stream);
+
 /* Box calibration, not on the product path (bench.py prints it beside every timing; ABI version 7): `blocks` workgroups of four
  * wavefronts run `iters` x 4 independent v_mfma_f32_32x32x2_f32 (2 * 32 * 32 * 2 FLOP each, pseudo-random operands) and
  * record, per workgroup b, out[2b] = shader cycles and out[2b+1] = 100 MHz real-time ticks of the loop: effective clock (MHz) =

@@ -129,3 +129,52 @@ def test_filter_pack_cache_follows_the_weights(backend):
         assert_close(from_cl(run(wn), n, h, h), ref, TOL, "fresh parameter %d" % seed)
         del wn
     assert not torch.equal(y1, y2)
+
+
+def test_repack_stale_batches_the_winograd_packs(backend):
+    """autograd.repack_stale: after an optimizer step every cached Winograd pack of a trainable weight (forward and data-gradient forms, incl. the
+    input-channel slices of a convolution over cat(x, skip)) is rebuilt by ONE multi-filter launch into its existing tensor - the results equal
+    fresh single packs, and a step that follows needs no per-filter pack launch."""
+    import torch
+    from cvpr23_lfdm_amd import autograd as A
+    from cvpr23_lfdm_amd import ops, params as P
+    from util import rnd, to_cl
+    dev = backend
+    A._PACKS.clear()
+    w1 = (rnd(32, 48, 3, 3, seed=1) * 0.1).to(dev).requires_grad_(True)          # conv over cat(x0 (32 ch), x1 (16 ch))
+    w2 = (rnd(16, 32, 3, 3, seed=2) * 0.1).to(dev).requires_grad_(True)
+    x0, x1 = to_cl(rnd(2, 32, 8, 8, seed=3)).to(dev).requires_grad_(True), to_cl(rnd(2, 16, 8, 8, seed=4)).to(dev).requires_grad_(True)
+
+    def step():
+        h = A.conv_cl(x0, w1, None, x1=x1, n_img=2, hi=8, wi=8)
+        y = A.conv_cl(h, w2, None, n_img=2, hi=8, wi=8)
+        for t in (w1, w2, x0, x1):
+            t.grad = None
+        y.sum().backward()
+        return y.detach().clone(), w1.grad.clone(), x0.grad.clone(), x1.grad.clone()
+
+    ref = step()
+    n_entries = len(A._PACKS)
+    assert n_entries == 5                                   # w1 fwd, w1 dgrad x 2 parts, w2 fwd, w2 dgrad
+    with torch.no_grad():                                    # what FlatAdam.step does: raw writes + an epoch bump
+        w1.data.mul_(1.5)
+        w2.data.add_(0.01)
+    w1._version, w2._version                                 # (data writes do not touch the version counters)
+    P.bump_weights_epoch()
+    packs_before = {k: v[2].data_ptr() for k, v in A._PACKS.items()}
+    assert A.repack_stale() == 5
+    assert {k: v[2].data_ptr() for k, v in A._PACKS.items()} == packs_before       # rebuilt in place
+    calls = []
+    orig = ops.pack_wino_weight
+    ops.pack_wino_weight = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    try:
+        got = step()
+    finally:
+        ops.pack_wino_weight = orig
+    assert not calls, "a step after repack_stale() still packed %d filters one by one" % len(calls)
+    A._PACKS.clear()
+    want = step()                                            # the same step on fresh single packs
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[0], ref[0])
+    assert A.repack_stale() == 0
