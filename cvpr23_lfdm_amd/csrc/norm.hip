@@ -196,6 +196,49 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
   }
 }
 
+// C = 64 / 128 (the two finest levels of the training forward): a wavefront serves 64 / C4N rows at once - lane = (row of the group, float4
+// column), the row reductions are xor-shuffles inside C4N adjacent lanes - and two row groups are in flight per trip (one row per wavefront
+// leaves 48 of 64 lanes idle at C = 64: train_norm.hip, layernorm_bwd_small_kernel).  Same arithmetic as the kernel below.
+template <int C4N>
+__global__ __launch_bounds__(256) void layernorm_small_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                              const float* __restrict__ gamma, float eps) {
+  constexpr int RPW = 64 / C4N, C = 4 * C4N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / C4N, f = lane % C4N;
+  const float4 g = reinterpret_cast<const float4*>(gamma)[f];
+  auto group_sum = [&](float v) {
+#pragma unroll
+    for (int m = 1; m < C4N; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+  };
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW * 2;
+  for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW * 2; row0 < rows; row0 += stride) {
+    float4 v[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = row0 + u * RPW + sub;
+      live[u] = row < rows;
+      v[u] = live[u] ? reinterpret_cast<const float4*>(x + row * C)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float mean = group_sum((v[u].x + v[u].y) + (v[u].z + v[u].w)) / (float)C;
+      const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+      const float var = group_sum((a * a + b * b) + (c * c + d * d)) / (float)C;
+      const float denom = sqrtf(var + eps);
+      if (live[u]) {
+        float4 y;
+        y.x = a / denom * g.x;
+        y.y = b / denom * g.y;
+        y.z = c / denom * g.z;
+        y.w = d / denom * g.w;
+        reinterpret_cast<float4*>(out + (row0 + u * RPW + sub) * C)[f] = y;
+      }
+    }
+  }
+}
+
 // one wavefront per row, 4 rows per workgroup; C % 4 == 0, C <= 1024
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         float* __restrict__ out, int64_t rows,
@@ -763,6 +806,15 @@ extern "C" int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, i
   }
   int64_t nb = (rows + 3) / 4;
   if (nb > 16384) nb = 16384;
+  const bool al16 = ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)gamma)) & 15) == 0;
+  if ((channels == 64 || channels == 128) && al16 && rows >= 4096) {
+    int64_t nbs = (rows + 4 * (256 / channels) * 2 * 4 - 1) / (4 * (256 / channels) * 2 * 4);      // ~4 trips per wavefront
+    if (nbs > 8192) nbs = 8192;
+    if (nbs < 1) nbs = 1;
+    if (channels == 64) LFDM_LAUNCH((layernorm_small_kernel<16>), dim3((unsigned)nbs), dim3(256), 0, stream, x, out, rows, gamma, eps);
+    else LFDM_LAUNCH((layernorm_small_kernel<32>), dim3((unsigned)nbs), dim3(256), 0, stream, x, out, rows, gamma, eps);
+    return lfdm_check_launch("layernorm");
+  }
   LFDM_LAUNCH(layernorm_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, out, rows, channels,
               gamma, eps);
   return lfdm_check_launch("layernorm");

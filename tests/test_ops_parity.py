@@ -554,6 +554,11 @@ def test_layernorm(backend, c):
     ref = O.channel_layernorm(x, gamma)
     out = ops.layernorm_cl(unet_to_cl(x).to(dev), gamma.reshape(-1).contiguous().to(dev))
     assert_close(unet_from_cl(out.cpu(), 2, 2, 4, 4), ref, TOL, "layernorm")
+    if c in (64, 128):      # >= 4096 rows: the several-rows-per-wavefront form (ragged last group)
+        xb = rnd(1, c, 3, 37, 37, seed=3) * 2 - 0.5
+        refb = O.channel_layernorm(xb, gamma)
+        outb = ops.layernorm_cl(unet_to_cl(xb).to(dev), gamma.reshape(-1).contiguous().to(dev))
+        assert_close(unet_from_cl(outb.cpu(), 1, 3, 37, 37), refb, TOL, "layernorm, many rows")
 
 
 # ------------------------------------------------------------------------------------------
