@@ -354,7 +354,8 @@ class Transform:
             tps_noise = torch.normal(mean=0, std=sigma_tps * torch.ones([bs, 1, points_tps ** 2])) if sigma_tps is not None else None
         else:
             theta_noise, tps_noise = noise
-        self.theta = (theta_noise + torch.eye(2, 3).view(1, 2, 3)).to(device)
+        # (noise already on the device - the graphed step hands its static buffers over - is used where it lies)
+        self.theta = (theta_noise + torch.eye(2, 3, device=theta_noise.device).view(1, 2, 3)).to(device)
         self.bs = bs
         self.tps = tps_noise is not None
         if self.tps:
@@ -483,6 +484,7 @@ class LFAETrainer:
         self.base_lr = train_params["lr"]
         self.epoch, self.examples = 0, 0
         self._dp = None
+        self._graphs = {}
 
     def to(self, device):
         for net in (self.generator, self.region_predictor, self.bg_predictor):
@@ -497,6 +499,72 @@ class LFAETrainer:
             self._dp = GradAllReduce(self.optimizer, bucket_bytes=bucket_bytes)
             self._dp.sync_replicas()
         return self
+
+    def draw_transform_noise(self, bs):
+        """(theta noise (B, 2, 3), tps noise (B, 1, points^2) or None) drawn like Transform.__init__ draws them (model.py:90-100)."""
+        tp = self.train_params["transform_params"]
+        theta = torch.normal(mean=0, std=tp["sigma_affine"] * torch.ones([bs, 2, 3]))
+        tps = (torch.normal(mean=0, std=tp["sigma_tps"] * torch.ones([bs, 1, tp["points_tps"] ** 2]))
+               if tp.get("sigma_tps") is not None else None)
+        return theta, tps
+
+    def step_graphed(self, x, transform_noise=None):
+        """The same step with forward + backward replayed as ONE hipGraph (opt-in; single process).  A step is ~2 200 launches: below ~32 pairs
+        per GPU the host cannot issue them as fast as the GPU retires them (45 ms per step at 8 pairs for 30 ms of kernels) - and the
+        reference's batch_size 100 over 8 GPUs is 12 pairs per GPU.  The first call for a batch shape runs two eager steps (filter packs,
+        job tables, workspaces, constant grids come into being), captures the third into a graph on static input / noise buffers, and every later
+        call copies its inputs and the step's transform noise (drawn on the host exactly as the eager step draws it) into those buffers and replays;
+        the optimizer step (its bias correction changes per step) stays outside.  Returns the loss terms; `generated` tensors are the graph's
+        static outputs (overwritten by the next replay)."""
+        if self._dp is not None:
+            raise RuntimeError("step_graphed is single-process (the gradient all-reduce is launched from autograd hooks)")
+        bs = x["source"].shape[0]
+        dev = x["source"].device
+        key = (tuple(x["source"].shape), str(dev))
+        g = self._graphs.get(key)
+        noise = transform_noise if transform_noise is not None else self.draw_transform_noise(bs)
+        if g is None:
+            g = self._graphs[key] = {"warm": 0}
+        if "graph" not in g:
+            if g["warm"] < 2:                          # eager warm-up steps (they are real training steps) - on a SIDE stream, as torch's
+                g["warm"] += 1                         # whole-network capture recipe asks: the AccumulateGrad nodes must not be born on the default stream
+                side = g.setdefault("side", torch.cuda.Stream())
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    res = self.step(x, transform_noise=noise)
+                torch.cuda.current_stream().wait_stream(side)
+                return res
+            g["src"], g["drv"] = x["source"].clone(), x["driving"].clone()
+            g["theta"] = noise[0].to(dev)
+            g["tps"] = None if noise[1] is None else noise[1].to(dev)
+            self.optimizer.zero_grad()
+            A.repack_stale()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                losses, generated = self.model({"source": g["src"], "driving": g["drv"]}, transform_noise=(g["theta"], g["tps"]))
+                loss = sum(v.mean() for v in losses.values())
+                loss.backward()
+            g["graph"], g["losses"], g["generated"], g["loss"] = graph, losses, generated, loss
+            g["grads"] = [p.grad for grp in self.optimizer.param_groups for p in grp["params"]]      # the capture's gradient tensors
+            graph.replay()                              # (capturing records the launches, it does not run them)
+        else:
+            g["src"].copy_(x["source"])
+            g["drv"].copy_(x["driving"])
+            g["theta"].copy_(noise[0])
+            if g["tps"] is not None:
+                g["tps"].copy_(noise[1])
+            A.repack_stale()
+            # autograd does not run on a replay: hand every parameter the gradient tensor the captured backward writes
+            for p, gr in zip((p for grp in self.optimizer.param_groups for p in grp["params"]), g["grads"]):
+                p.grad = gr
+            self.optimizer._staged = False
+            g["graph"].replay()
+        self.optimizer.step()
+        self.examples += bs
+        out = {k: v.detach() for k, v in g["losses"].items()}
+        out["total"] = g["loss"].detach()
+        return out, g["generated"]
 
     def step(self, x, transform_noise=None):
         """x: {'source': (B, 3, H, W), 'driving': (B, 3, H, W)} in [0, 1].  -> (loss terms (detached), generated)."""

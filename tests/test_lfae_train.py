@@ -186,3 +186,27 @@ def test_lfae_trainer_two_ranks_gloo(tmp_path):
     assert a["spread"] == 0.0 and b["spread"] == 0.0
     assert a["grad_sum"] == b["grad_sum"] and a["final_bias"] == b["final_bias"]
     assert a["loss"] != b["loss"] and np.isfinite(a["loss"]) and np.isfinite(b["loss"])
+
+
+@pytest.mark.gpu
+def test_graphed_step_equals_eager_step():
+    """LFAETrainer.step_graphed (forward + backward as one replayed hipGraph, optimizer outside) against the eager step on the same inputs and
+    transform noise, eight steps in a row: loss terms and parameters must agree (the ROCm 7.2 graph memset bug of DESIGN.md would show up here
+    as a drift after a few replays)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = "cuda"
+    ta, (mp, tp, hw, b) = _build("tiny", dev)
+    tb, _ = _build("tiny", dev)
+    g = torch.Generator().manual_seed(5)
+    for it in range(8):
+        src, drv = torch.rand(b, 3, hw, hw, generator=g).to(dev), torch.rand(b, 3, hw, hw, generator=g).to(dev)
+        noise = ta.draw_transform_noise(b)
+        la, _ = ta.step({"source": src, "driving": drv}, transform_noise=noise)
+        lb, _ = tb.step_graphed({"source": src, "driving": drv}, transform_noise=noise)
+        for k in la:
+            assert abs(float(la[k]) - float(lb[k])) <= 1e-5 * max(1.0, abs(float(la[k]))), (it, k, float(la[k]), float(lb[k]))
+    assert "graph" in next(iter(tb._graphs.values()))
+    pa = torch.cat([p.detach().reshape(-1) for p in ta.optimizer.param_groups[0]["params"]])
+    pb = torch.cat([p.detach().reshape(-1) for p in tb.optimizer.param_groups[0]["params"]])
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())

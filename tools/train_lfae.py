@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--vgg")
     ap.add_argument("--checkpoint")
     ap.add_argument("--bench", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="forward + backward of a step as one replayed hipGraph (single process)")
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
@@ -84,7 +85,7 @@ def main():
             x = {k: v.to(dev) for k, v in x.items() if k in ("source", "driving")}
         else:
             x = synthetic_pairs(args.batch, args.frame_shape, dev, seed=1000 * rank + it)
-        losses, _ = trainer.step(x)
+        losses, _ = (trainer.step_graphed(x) if args.graph and world == 1 else trainer.step(x))
         if it >= args.warmup:
             timed += 1
         if rank == 0 and not args.bench and it % cfg["train_params"].get("print_freq", 10) == 0:
@@ -99,7 +100,7 @@ def main():
             torch.save(trainer.state_dict(), os.path.join(args.log_dir, "RegionMM.pth"))
         print(json.dumps({"metric": "LFAE stage-1 training frame pairs / s", "value": round(timed * args.batch * world / dt, 2),
                           "ms_per_step": round(1e3 * dt / timed, 1), "batch_per_gpu": args.batch, "n_gpus": world, "frame": args.frame_shape,
-                          "steps": timed, "loss_last": round(float(losses["total"]), 4), "data": "synthetic" if loader is None else args.data_dir,
+                          "graphed": bool(args.graph and world == 1), "steps": timed, "loss_last": round(float(losses["total"]), 4), "data": "synthetic" if loader is None else args.data_dir,
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
