@@ -144,7 +144,11 @@ def _thin_wgrad(route, x, dy, n_img, hi, wi, hq, wq, k, pad, cin, cout):
 
 class ConvCL(Function):
     """y = conv(cat(x0, x1), weight) + bias (+ residual).  weight in the reference layout (Cout, Cin, [1,] kh, kw)
-    (or ConvTranspose (Cin, Cout, [1,] 4, 4) when geom['kind'] == 'deconv').  geom: n_img, hi, wi, stride, pad."""
+    (or ConvTranspose (Cin, Cout, [1,] 4, 4) when geom['kind'] == 'deconv').  geom: n_img, hi, wi, stride, pad.
+    geom['fork'] (stride-1 convolutions): -> (y, x0[, x1]) - the inputs themselves as further outputs, for the second consumer of the same
+    tensors (ResnetBlock: block1 and the skip / res_conv read the same x, :214-238).  The gradients of both consumers then arrive at this
+    node together and the data-gradient convolution adds the other one in its epilogue (the `residual` operand of the forward kernels)
+    instead of the autograd engine launching an add per block."""
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, geom):
@@ -185,12 +189,18 @@ class ConvCL(Function):
         ctx.save_for_backward(x0, x1, weight, relu_out)
         ctx.bias_param = bias
         ctx.meta = (kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, bias is not None, residual is not None)
+        ctx.fork = bool(geom.get("fork"))
+        if ctx.fork:
+            assert kind == "conv" and stride == 1
+            return (y, x0) if x1 is None else (y, x0, x1)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *dpass):
         x0, x1, weight, relu_out = ctx.saved_tensors
         kind, n_img, hi, wi, hq, wq, kh, kw, stride, pad, has_bias, has_res = ctx.meta
+        dpass = [None if d is None else _c(d) for d in dpass] + [None, None]
+        assert dy is not None, "ConvCL(fork): the convolution's own output must be used"
         dy = _c(dy)
         if relu_out is not None:
             dy = train_ops.relu_bwd(relu_out, dy)
@@ -222,16 +232,16 @@ class ConvCL(Function):
                     parts.append(train_ops.conv_wgrad(_c(x1), dy, n_img, hi, wi, hq, wq, kh, kw, stride=stride, pad=pad))
                 dwt = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)            # (taps, cin, cout)
                 dw = dwt.view(kh, kw, -1, cout).permute(3, 2, 0, 1).reshape(weight.shape)
-            srcs = [(x0, 0, c0, need[0])] + ([(x1, c0, c0 + x1.shape[1], need[1])] if x1 is not None else [])
+            srcs = [(x0, 0, c0, need[0], dpass[0])] + ([(x1, c0, c0 + x1.shape[1], need[1], dpass[1])] if x1 is not None else [])
             grads = []
-            for xs, lo, hi_c, wanted in srcs:
+            for xs, lo, hi_c, wanted, other in srcs:
                 if not wanted:
                     grads.append(None)
                     continue
                 ws = w4[:, lo:hi_c]
                 if stride == 1:
                     ww = _pack_wino(weight, ws, dgrad=True, part=(lo, hi_c)) if _wino_ok(kh, kw, stride, pad, hq, wq, cout) else None
-                    g = _conv(dy, (ws, 1), hi_c - lo, kh, kw, n_img, hq, wq,
+                    g = _conv(dy, (ws, 1), hi_c - lo, kh, kw, n_img, hq, wq, residual=other,
                               pad=(kh - 1 - pad[0], kw - 1 - pad[1]), weight_wino=ww)                # filter (cin, cout, kh, kw)
                 else:
                     assert stride == 2 and kh == 4 and kw == 4 and pad == (1, 1)
@@ -277,22 +287,29 @@ class GroupNormSiLU(Function):
 
 
 class LayerNormCL(Function):
-    """Channel LayerNorm (gamma only), :170-179."""
+    """Channel LayerNorm (gamma only), :170-179.  fork=True -> (normed, x): the second output is x itself for the residual path around the
+    normalised branch (Residual(PreNorm(fn)): fn(norm(x)) + x, :118-125 / :181-188).  Both consumers' gradients then arrive at THIS node
+    together and the backward kernel stores their sum - the autograd engine's separate add per block (19 per DM step) is gone."""
 
     @staticmethod
-    def forward(ctx, x, gamma):
+    def forward(ctx, x, gamma, fork=False):
         xs = _c(x.detach())
         g = _c(gamma.detach().reshape(-1))
         ctx.save_for_backward(xs, g)
         ctx.gamma_param = gamma
-        return ops.layernorm_cl(xs, g)
+        ctx.fork = fork
+        y = ops.layernorm_cl(xs, g)
+        return (y, x) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, g = ctx.saved_tensors
         dg = grad_out(ctx.gamma_param)
-        dx, _ = train_ops.layernorm_bwd(x, _c(dy), g, dgamma=dg)
-        return dx, dg
+        if dy is None:              # only the residual path was used downstream
+            dg.zero_()
+            return dpass, dg, None
+        dx, _ = train_ops.layernorm_bwd(x, _c(dy), g, dgamma=dg, dx_add=None if dpass is None else _c(dpass))
+        return dx, dg, None
 
 
 class AttentionCL(Function):

@@ -64,9 +64,15 @@ struct BnArgs {
   float momentum, eps;
   int relu;
   int q, chunk_rows, nchunk, ngroups;
-  float* part1;             // [ctile][chunk][2][tw] float
-  double* part2;            // [ctile][group][2][tw] double
-  unsigned* tickets;        // [ctile][group], zero between launches
+  float* part1;             // [segment][ctile][chunk][2][tw] float
+  double* part2;            // [segment][ctile][group][2][tw] double
+  unsigned* tickets;        // [segment][ctile][group], zero between launches
+  // segments: `segments` independent batches of `rows` rows stacked along the row axis, each normalised with its own statistics
+  // (blockIdx.z); stat is [segment][2][c]; the running statistics take the segments' updates one after the other, and dgamma / dbeta
+  // are the sums over the segments.  This is N module calls on N batches as one launch pair.
+  int segments;
+  int64_t seg_p1, seg_p2;   // strides of part1 / part2 per segment (elements)
+  int seg_tk;
   float* dgamma;            // backward
   float* dbeta;
 };
@@ -79,7 +85,15 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnArgs a) {
   __shared__ int s_last;
   const int tid = threadIdx.x, q = a.q, lanes = 256 / q, tw = 4 * q;
   const int quad = tid & (q - 1), rl = tid / q;
-  const int chunk = blockIdx.x, ct = blockIdx.y;
+  const int chunk = blockIdx.x, ct = blockIdx.y, seg = blockIdx.z;
+  a.x += seg * a.rows * a.ldx;
+  if (MODE == 1) {
+    a.dy += seg * a.rows * a.lddy;
+    a.stat += (int64_t)seg * 2 * a.c;
+  }
+  a.part1 += seg * a.seg_p1;
+  a.part2 += seg * a.seg_p2;
+  a.tickets += seg * a.seg_tk;
   const int ch = ct * tw + quad * 4;
   const bool cvalid = ch < a.c;
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
@@ -175,15 +189,27 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
   __shared__ float s_mu[64], s_rs[64], s_ga[64], s_be[64], s_k1[64], s_k2[64];
   const int tid = threadIdx.x, q = a.q, lanes = 256 / q, tw = 4 * q;
-  const int chunk = blockIdx.x, ct = blockIdx.y;
+  const int chunk = blockIdx.x, ct = blockIdx.y, seg = blockIdx.z;
+  const float* x_all = a.x;
+  const double* part2_all = a.part2;
+  a.x += seg * a.rows * a.ldx;
+  if (MODE == 1) a.dy += seg * a.rows * a.lddy;
+  a.out += seg * a.rows * a.ldo;
+  a.stat += (int64_t)seg * 2 * a.c;
+  a.part2 += seg * a.seg_p2;
   if (tid < tw) {
     const int channel = ct * tw + tid;
     if (channel < a.c) {
-      double S0 = 0.0, S1 = 0.0;
-      for (int g = 0; g < a.ngroups; ++g) {
-        S0 += a.part2[(((int64_t)ct * a.ngroups + g) * 2 + 0) * tw + tid];
-        S1 += a.part2[(((int64_t)ct * a.ngroups + g) * 2 + 1) * tw + tid];
-      }
+      // the (sum, sum) pair of one segment, level-2 fold in fixed order
+      auto fold = [&](const double* p2, double& S0, double& S1) {
+        S0 = 0.0; S1 = 0.0;
+        for (int g = 0; g < a.ngroups; ++g) {
+          S0 += p2[(((int64_t)ct * a.ngroups + g) * 2 + 0) * tw + tid];
+          S1 += p2[(((int64_t)ct * a.ngroups + g) * 2 + 1) * tw + tid];
+        }
+      };
+      double S0, S1;
+      fold(a.part2, S0, S1);
       const double m = (double)a.rows;
       if (MODE == 0) {
         const double shifted = S0 / m;                 // mean of (x - pivot), pivot = row 0 (bn_reduce_kernel)
@@ -196,20 +222,38 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
         if (chunk == 0) {
           a.stat[channel] = (float)mean;
           a.stat[a.c + channel] = rstd;
-          if (a.running_mean) {
-            const double unbiased = a.rows > 1 ? var * m / (m - 1.0) : var;
-            a.running_mean[channel] = (float)((1.0 - a.momentum) * (double)a.running_mean[channel] + a.momentum * mean);
-            a.running_var[channel] = (float)((1.0 - a.momentum) * (double)a.running_var[channel] + a.momentum * unbiased);
+        }
+        if (chunk == 0 && seg == 0 && a.running_mean) {
+          // one momentum update per segment, in segment order (= the order of the separate module calls)
+          float rm = a.running_mean[channel], rv = a.running_var[channel];
+          for (int sg = 0; sg < a.segments; ++sg) {
+            double T0, T1;
+            fold(part2_all + sg * a.seg_p2, T0, T1);
+            const double sh = T0 / m;
+            const double mean_s = (double)x_all[sg * a.rows * a.ldx + channel] + sh;
+            double var_s = T1 / m - sh * sh;
+            if (var_s < 0.0) var_s = 0.0;
+            const double unbiased = a.rows > 1 ? var_s * m / (m - 1.0) : var_s;
+            rm = (float)((1.0 - a.momentum) * (double)rm + a.momentum * mean_s);
+            rv = (float)((1.0 - a.momentum) * (double)rv + a.momentum * unbiased);
           }
+          a.running_mean[channel] = rm;
+          a.running_var[channel] = rv;
         }
       } else {
         s_mu[tid] = a.stat[channel];
         s_rs[tid] = a.stat[a.c + channel];
         s_k1[tid] = (float)(S0 / m);
         s_k2[tid] = (float)(S1 / m);
-        if (chunk == 0) {
-          if (a.dbeta) a.dbeta[channel] = (float)S0;
-          if (a.dgamma) a.dgamma[channel] = (float)S1;
+        if (chunk == 0 && seg == 0) {
+          double D0 = S0, D1 = S1;
+          for (int sg = 1; sg < a.segments; ++sg) {
+            double T0, T1;
+            fold(part2_all + sg * a.seg_p2, T0, T1);
+            D0 += T0; D1 += T1;
+          }
+          if (a.dbeta) a.dbeta[channel] = (float)D0;
+          if (a.dgamma) a.dgamma[channel] = (float)D1;
         }
       }
       s_ga[tid] = a.gamma[channel];
@@ -903,60 +947,71 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // =====================================================================================================================================
 // C ABI
 // =====================================================================================================================================
-extern "C" size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels) {
-  if (rows <= 0 || channels <= 0) return 0;
+extern "C" size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels, int segments) {
+  if (rows <= 0 || channels <= 0 || segments <= 0) return 0;
   const BnGeom g = bn_geom(rows, channels);
-  return (size_t)g.ctiles * g.nchunk * 2 * g.tw * sizeof(float) + (size_t)g.ctiles * g.ngroups * 2 * g.tw * sizeof(double) + 16;
+  return (size_t)segments * ((size_t)g.ctiles * g.nchunk * 2 * g.tw * sizeof(float) + (size_t)g.ctiles * g.ngroups * 2 * g.tw * sizeof(double)) +
+         16;
 }
 
 namespace {
-int bn_fill(BnArgs& a, const float* x, int64_t rows, int channels, int ldx, const float* gamma, const float* beta, void* ws, size_t ws_bytes,
-            unsigned* tickets, const char* who) {
+int bn_fill(BnArgs& a, const float* x, int64_t rows, int channels, int segments, int ldx, const float* gamma, const float* beta, void* ws,
+            size_t ws_bytes, unsigned* tickets, const char* who) {
   if (!x || !gamma || !beta || !ws || !tickets || rows <= 0 || channels <= 0 || channels % 4 != 0 || channels > 64 * 32 || ldx % 4 != 0 ||
-      ldx < channels || !aligned16(x) || !aligned16(gamma) || !aligned16(beta) || ws_bytes < lfdm_batchnorm_train_ws_bytes(rows, channels)) {
+      segments <= 0 || segments > 64 || ldx < channels || !aligned16(x) || !aligned16(gamma) || !aligned16(beta) ||
+      ws_bytes < lfdm_batchnorm_train_ws_bytes(rows, channels, segments)) {
     (void)who;
-    lfdm_set_error("batchnorm_train: rows > 0, channels % 4 == 0 (<= 2048), 16-byte aligned x / gamma / beta, workspace of "
-                   "lfdm_batchnorm_train_ws_bytes and a zeroed ticket array of LFDM_BN_TICKETS words");
+    lfdm_set_error("batchnorm_train: rows > 0 (per segment), 1..64 segments, channels % 4 == 0 (<= 2048), 16-byte aligned x / gamma / beta, "
+                   "workspace of lfdm_batchnorm_train_ws_bytes and a zeroed ticket array of LFDM_BN_TICKETS words");
     return LFDM_EINVAL;
   }
   const BnGeom g = bn_geom(rows, channels);
+  if ((int64_t)segments * g.ctiles * g.ngroups > LFDM_BN_TICKETS) {
+    lfdm_set_error("batchnorm_train: segments x channel tiles x chunk groups exceeds LFDM_BN_TICKETS");
+    return LFDM_EINVAL;
+  }
+  a.segments = segments;
+  a.seg_p1 = (int64_t)g.ctiles * g.nchunk * 2 * g.tw;
+  a.seg_p2 = (int64_t)g.ctiles * g.ngroups * 2 * g.tw;
+  a.seg_tk = g.ctiles * g.ngroups;
   a.x = x; a.rows = rows; a.c = channels; a.ldx = ldx; a.gamma = gamma; a.beta = beta;
   a.q = g.q; a.chunk_rows = g.chunk_rows; a.nchunk = g.nchunk; a.ngroups = g.ngroups;
   // doubles first (alignment), then the float partials
   a.part2 = reinterpret_cast<double*>((((uintptr_t)ws) + 15) & ~(uintptr_t)15);
-  a.part1 = reinterpret_cast<float*>(a.part2 + (size_t)g.ctiles * g.ngroups * 2 * g.tw);
+  a.part1 = reinterpret_cast<float*>(a.part2 + (size_t)segments * a.seg_p2);
   a.tickets = tickets;
   return LFDM_OK;
 }
 }  // namespace
 
-extern "C" int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int ldx, int ldy, const float* gamma,
+extern "C" int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int segments, int ldx, int ldy,
+                                               const float* gamma,
                                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                                int relu, float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BnArgs a = {};
-  const int rc = bn_fill(a, x, rows, channels, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_fwd");
+  const int rc = bn_fill(a, x, rows, channels, segments, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_fwd");
   if (rc) return rc;
   if (!y || !stat || ldy % 4 != 0 || ldy < channels || !aligned16(y) || ((running_mean == nullptr) != (running_var == nullptr))) {
-    lfdm_set_error("batchnorm_train_fwd: y (16-byte aligned, ldy % 4 == 0) and stat (2 * channels floats) are required; running_mean and "
+    lfdm_set_error("batchnorm_train_fwd: y (16-byte aligned, ldy % 4 == 0) and stat (segments * 2 * channels floats) are required; running_mean and "
                    "running_var come together");
     return LFDM_EINVAL;
   }
   a.out = y; a.ldo = ldy; a.stat = stat; a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
   a.relu = relu;
   const BnGeom g = bn_geom(rows, channels);
-  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles);
+  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles, (unsigned)segments);
   LFDM_LAUNCH((bn_reduce_kernel<0>), grid, dim3(256), 0, stream, a);
   LFDM_LAUNCH((bn_apply_kernel<0>), grid, dim3(256), 0, stream, a);
   return lfdm_check_launch("batchnorm_train_fwd");
 }
 
-extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int ldx, int lddy,
-                                               int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma,
+extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int segments, int ldx,
+                                               int lddy, int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma,
                                                float* dbeta, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BnArgs a = {};
-  const int rc = bn_fill(a, x, rows, channels, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_bwd");
+  const int rc = bn_fill(a, x, rows, channels, segments, ldx, gamma, beta, ws, ws_bytes, tickets, "batchnorm_train_bwd");
   if (rc) return rc;
   if (!dy || !dx || !stat || lddy % 4 != 0 || lddx % 4 != 0 || lddy < channels || lddx < channels || !aligned16(dy) || !aligned16(dx) ||
       !aligned16(stat)) {
@@ -965,7 +1020,7 @@ extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, 
   }
   a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.stat = const_cast<float*>(stat); a.relu = relu; a.dgamma = dgamma; a.dbeta = dbeta;
   const BnGeom g = bn_geom(rows, channels);
-  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles);
+  const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles, (unsigned)segments);
   LFDM_LAUNCH((bn_reduce_kernel<1>), grid, dim3(256), 0, stream, a);
   LFDM_LAUNCH((bn_apply_kernel<1>), grid, dim3(256), 0, stream, a);
   return lfdm_check_launch("batchnorm_train_bwd");

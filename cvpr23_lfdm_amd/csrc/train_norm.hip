@@ -253,10 +253,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs a, const float
 // ---------------- channel LayerNorm backward: one wavefront per row ----------------
 // y = (x - mean)/sqrt(var + eps) * gamma ;  dn = dy*gamma ;  dx = (dn - mean(dn) - nh*mean(dn*nh)) / denom
 // dgamma partial per workgroup: part[blk][c] = sum over the workgroup's rows of dy*nh
+// dx_add (may be null): a second gradient of x (the residual path around the normalised branch) summed into dx here instead of by an ATen add.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dx, int64_t rows, int channels,
                                                             const float* __restrict__ gamma, float eps,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, const float* __restrict__ dx_add) {
   __shared__ __attribute__((aligned(16))) float red[4][GNB_MAX_C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c4n = channels >> 2;
@@ -318,6 +319,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.y = (g[i].y - m1 - v[i].y * m2) * inv;
         o.z = (g[i].z - m1 - v[i].z * m2) * inv;
         o.w = (g[i].w - m1 - v[i].w * m2) * inv;
+        if (dx_add) {
+          const float4 r = reinterpret_cast<const float4*>(dx_add + row * channels)[f];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         orow[f] = o;
       }
     }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 template <int C4N>
 __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ dx, int64_t rows, const float* __restrict__ gamma, float eps,
-                                                                  float* __restrict__ part) {
+                                                                  float* __restrict__ part, const float* __restrict__ dx_add) {
   constexpr int RPW = 64 / C4N, C = 4 * C4N;            // rows per wavefront and trip, channels
   __shared__ __attribute__((aligned(16))) float red[4 * RPW][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -383,6 +388,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const float* _
         o.y = (dn.y - m1 - nh.y * m2) * inv;
         o.z = (dn.z - m1 - nh.z * m2) * inv;
         o.w = (dn.w - m1 - nh.w * m2) * inv;
+        if (dx_add) {
+          const float4 r = reinterpret_cast<const float4*>(dx_add + (row0 + u * RPW + sub) * C)[f];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         reinterpret_cast<float4*>(dx + (row0 + u * RPW + sub) * C)[f] = o;
       }
     }
@@ -458,6 +467,12 @@ extern "C" size_t lfdm_layernorm_bwd_ws_bytes(int64_t rows, int channels) {
 extern "C" int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels,
                                          const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes,
                                          lfdm_stream_t stream_) {
+  return lfdm_layernorm_bwd_add_cl_f32(x, dy, nullptr, dx, rows, channels, gamma, eps, dgamma, ws, ws_bytes, stream_);
+}
+
+extern "C" int lfdm_layernorm_bwd_add_cl_f32(const float* x, const float* dy, const float* dx_add, float* dx, int64_t rows, int channels,
+                                             const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes,
+                                             lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !dy || !dx || !gamma || !dgamma || rows <= 0 || channels <= 0 || channels % 4 != 0 || channels > GNB_MAX_C) {
     lfdm_set_error("layernorm_bwd: unsupported shape (C%4==0, C<=1024)");
@@ -468,10 +483,10 @@ extern "C" int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float*
     return LFDM_EWORKSPACE;
   }
   const int nb = ln_bwd_blocks(rows);
-  const bool al16 = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma)) & 15) == 0;
-  if (channels == 64 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<16>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws);
-  else if (channels == 128 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<32>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws);
-  else LFDM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, channels, gamma, eps, (float*)ws);
+  const bool al16 = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma) | ((uintptr_t)dx_add)) & 15) == 0;
+  if (channels == 64 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<16>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws, dx_add);
+  else if (channels == 128 && al16) LFDM_LAUNCH((layernorm_bwd_small_kernel<32>), dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, gamma, eps, (float*)ws, dx_add);
+  else LFDM_LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, x, dy, dx, rows, channels, gamma, eps, (float*)ws, dx_add);
   int rc = lfdm_check_launch("layernorm_bwd");
   if (rc) return rc;
   return lfdm_sum_leading_f32((const float*)ws, dgamma, channels, nb, stream_);

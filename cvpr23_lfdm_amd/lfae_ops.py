@@ -50,17 +50,19 @@ def _from_rows(rows, n, h, w):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm (batch statistics) + ReLU
-def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
-    """x: (rows, C) rows (stride(1) == 1).  -> (y (rows, C), stat (2, C) = [mean | rstd])."""
+def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, segments=1):
+    """x: (rows, C) rows (stride(1) == 1), `segments` equal batches stacked along the rows, each with its own statistics.
+    -> (y (rows, C), stat (segments, 2, C) = [mean | rstd] per segment)."""
     lib = _lib()
     _chk(lib, x, gamma, beta, running_mean, running_var)
     rows, c = x.shape
-    assert x.stride(1) == 1
+    assert x.stride(1) == 1 and rows % segments == 0
+    seg_rows = rows // segments
     y = torch.empty(rows, c, dtype=torch.float32, device=x.device)
-    stat = torch.empty(2, c, dtype=torch.float32, device=x.device)
-    nbytes = lib.lfdm_batchnorm_train_ws_bytes(rows, c)
+    stat = torch.empty(segments, 2, c, dtype=torch.float32, device=x.device)
+    nbytes = lib.lfdm_batchnorm_train_ws_bytes(seg_rows, c, segments)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    lib.check(lib.lfdm_batchnorm_train_fwd_cl_f32(_p(x), _p(y), rows, c, x.stride(0), c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+    lib.check(lib.lfdm_batchnorm_train_fwd_cl_f32(_p(x), _p(y), seg_rows, c, segments, x.stride(0), c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                                   float(momentum), float(eps), int(relu), _p(stat), _p(ws), nbytes, _p(_state(x.device)["tickets"]),
                                                   _stream(lib)), "lfdm_batchnorm_train_fwd_cl_f32")
     return y, stat
@@ -70,11 +72,13 @@ def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None)
     lib = _lib()
     _chk(lib, x, dy, gamma, beta, stat, dgamma, dbeta)
     rows, c = x.shape
-    assert x.stride(1) == 1 and dy.stride(1) == 1 and dy.shape == x.shape
+    segments = stat.shape[0] if stat.dim() == 3 else 1
+    assert x.stride(1) == 1 and dy.stride(1) == 1 and dy.shape == x.shape and rows % segments == 0
+    seg_rows = rows // segments
     dx = torch.empty(rows, c, dtype=torch.float32, device=x.device)
-    nbytes = lib.lfdm_batchnorm_train_ws_bytes(rows, c)
+    nbytes = lib.lfdm_batchnorm_train_ws_bytes(seg_rows, c, segments)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    lib.check(lib.lfdm_batchnorm_train_bwd_cl_f32(_p(x), _p(dy), _p(dx), rows, c, x.stride(0), dy.stride(0), c, _p(gamma), _p(beta), _p(stat),
+    lib.check(lib.lfdm_batchnorm_train_bwd_cl_f32(_p(x), _p(dy), _p(dx), seg_rows, c, segments, x.stride(0), dy.stride(0), c, _p(gamma), _p(beta), _p(stat),
                                                   int(relu), _p(dgamma), _p(dbeta), _p(ws), nbytes, _p(_state(x.device)["tickets"]), _stream(lib)),
               "lfdm_batchnorm_train_bwd_cl_f32")
     return dx
@@ -82,14 +86,16 @@ def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None)
 
 class BatchNormReLU(Function):
     """nn.BatchNorm2d (training mode: batch statistics, running statistics updated in place) followed by ReLU when relu=True, on an NCHW
-    tensor in channels-last memory (LFAE/modules/util.py:84-90, 108-112, 128-133, 146-150)."""
+    tensor in channels-last memory (LFAE/modules/util.py:84-90, 108-112, 128-133, 146-150).  segments = S: the batch is S equal
+    sub-batches, each normalised with its own statistics, the running statistics updated S times in order - S module calls as one."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, segments=1):
         n, c, h, w = x.shape
+        assert n % segments == 0, "BatchNormReLU: the batch must split evenly into the segments"
         xr = _rows(x.detach())
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        y, stat = batchnorm_train_fwd(xr, g, b, running_mean, running_var, momentum, eps, relu)
+        y, stat = batchnorm_train_fwd(xr, g, b, running_mean, running_var, momentum, eps, relu, segments)
         ctx.save_for_backward(xr, gamma, beta, stat)
         ctx.meta = (n, h, w, relu)
         return _from_rows(y, n, h, w)
@@ -103,7 +109,7 @@ class BatchNormReLU(Function):
         if need[1] or need[2]:
             _, dg, db = grad_out_pair(gamma, beta)
         dx = batchnorm_train_bwd(xr, _rows(dy), gamma.detach().contiguous(), beta.detach().contiguous(), stat, relu, dg, db)
-        return _from_rows(dx, n, h, w), dg, db, None, None, None, None, None
+        return _from_rows(dx, n, h, w), dg, db, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ blur + subsample

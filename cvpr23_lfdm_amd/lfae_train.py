@@ -71,8 +71,8 @@ class _Net:
     """Forward helpers over one ParamTree (reference state-dict keys); `training` selects batch statistics (and updates the running
     ones, momentum 0.1 like nn.BatchNorm2d) or the stored statistics."""
 
-    def __init__(self, tree, training=True):
-        self.t, self.training = tree, training
+    def __init__(self, tree, training=True, segments=1):
+        self.t, self.training, self.segments = tree, training, segments
 
     def conv(self, x, prefix, padding, relu=False):
         return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding, relu)
@@ -82,9 +82,9 @@ class _Net:
         one native forward (batch statistics, running statistics updated in place), one native backward (lfae_ops.BatchNormReLU)."""
         g = self.t.get
         if self.training:
-            _NBT_PENDING.append(g(prefix + "num_batches_tracked"))
+            _NBT_PENDING.extend([g(prefix + "num_batches_tracked")] * self.segments)
             return L.BatchNormReLU.apply(x, g(prefix + "weight"), g(prefix + "bias"), g(prefix + "running_mean"), g(prefix + "running_var"),
-                                         0.1, 1e-5, True)
+                                         0.1, 1e-5, True, self.segments)
         return F.relu(F.batch_norm(x, g(prefix + "running_mean"), g(prefix + "running_var"), g(prefix + "weight"), g(prefix + "bias"),
                                    False, 0.1, 1e-5))
 
@@ -150,51 +150,49 @@ def antialias_down(x, weight, scale, rows4=False, affine=None):
 # The reference writes its per-pixel 2x2 / 3x3 algebra as torch.matmul over (B, K, h, w, 2, 2) operands: hundreds of thousands of
 # 2x2 products per call, which a GEMM library runs as a batched GEMM at ~1 ms each (39 % of a step when this file did the same,
 # profiles/r04_x_lfae_*).  The same sums written out as broadcast multiply-adds are a handful of element-wise launches.
-# Element access goes through ONE unbind per operand (its backward is one stack) instead of four / two indexing ops (each with a zeros + copy
-# backward); 2x2 inverses and products are written out too: torch.inverse / torch.matmul on (B, K, 2, 2) tensors run rocSOLVER / Tensile
-# kernels and torch.inverse synchronises with the host to check for singular inputs.
-def _e4(m):
-    """The four entries (a, b, c, d) of (..., 2, 2) matrices [[a, b], [c, d]]."""
-    return m.reshape(*m.shape[:-2], 4).unbind(-1)
+# 2x2 inverses and products are written out too: torch.inverse / torch.matmul on (B, K, 2, 2) tensors run rocSOLVER / Tensile kernels and
+# torch.inverse synchronises with the host to check for singular inputs.
+def _sign22(like):
+    key = ("sign22", like.device)
+    if key not in _CONST:
+        _CONST[key] = (torch.tensor([[1.0, -1.0], [-1.0, 1.0]], device=like.device), torch.tensor([1.0, -1.0], device=like.device))
+    return _CONST[key]
 
 
-def _m22(a, b, c, d):
-    return torch.stack((a, b, c, d), dim=-1).reshape(*a.shape, 2, 2)
-
-
+# The 2x2 algebra as a few broadcast launches each (torch.inverse / matmul would bring rocSOLVER, a host sync and Tensile kernels into the
+# step; one launch per scalar product made ~25 launches per call).  Same arithmetic: every entry is the two-term sum of products.
 def _inv2(m):
-    a, b, c, d = _e4(m)
-    det = a * d - b * c
-    return _m22(d, -b, -c, a) / det.unsqueeze(-1).unsqueeze(-1)
+    sign, pm = _sign22(m)
+    rev = m.flip(-1, -2)                                   # [[d, c], [b, a]]
+    det = ((m * rev)[..., 0, :] * pm).sum(-1)              # a d - b c
+    return rev.transpose(-1, -2) * sign / det.unsqueeze(-1).unsqueeze(-1)
 
 
 def _mm2(x, y):
-    a, b, c, d = _e4(x)
-    e, f, g, h = _e4(y)
-    return _m22(a * e + b * g, a * f + b * h, c * e + d * g, c * f + d * h)
+    return (x.unsqueeze(-1) * y.unsqueeze(-3)).sum(-2)
 
 
 def _mat2_vec(m, v):
     """(..., 2, 2) @ (..., 2) with broadcasting."""
-    a, b, c, d = _e4(m)
-    vx, vy = v.unbind(-1)
-    return torch.stack((a * vx + b * vy, c * vx + d * vy), dim=-1)
+    return (m * v.unsqueeze(-2)).sum(-1)
 
 
 def region2gaussian(center, covar, h, w):
     """util.py:22-48 with a matrix covariance: exp(-0.5 d^T covar^-1 d) on the coordinate grid."""
     grid = make_coordinate_grid(h, w, center).view(1, 1, h, w, 2)
     d = grid - center.view(*center.shape[:2], 1, 1, 2)
-    i00, i01, i10, i11 = (t.view(*covar.shape[:2], 1, 1) for t in _e4(_inv2(covar)))
-    dx, dy = d.unbind(-1)
-    under = (dx * i00 + dy * i10) * dx + (dx * i01 + dy * i11) * dy
+    inv_t = _inv2(covar).transpose(-1, -2).unsqueeze(-3).unsqueeze(-3)
+    under = (_mat2_vec(inv_t, d) * d).sum(-1)
     return torch.exp(-0.5 * under)
 
 
 # ------------------------------------------------------------------------------------------------ the three networks
-def region_predictor_forward(tree, x, cfg, training=True):
-    """RegionPredictor.forward, pca_based (region_predictor.py:52-117) -> shift, covar, affine, heatmap, u, d."""
-    net = _Net(tree, training)
+def region_predictor_forward(tree, x, cfg, training=True, segments=1):
+    """RegionPredictor.forward, pca_based (region_predictor.py:52-117) -> shift, covar, affine, heatmap, u, d.
+    segments = S: x is S equal batches stacked along dim 0 that the reference sends through S separate calls (source, driving,
+    transformed driving frames: model.py:157-160, :190-191); every BatchNorm keeps per-call statistics (lfae_ops.BatchNormReLU), the
+    rest of the network is per-sample, so the result is the concatenation of the S calls' results."""
+    net = _Net(tree, training, segments)
     x = antialias_down(x, tree.get("down.weight") if cfg["scale_factor"] != 1 else None, cfg["scale_factor"], rows4=x.shape[1] == 3)
     fmap = net.hourglass(_cl(x), "predictor.", cfg["num_blocks"])
     pred = net.conv(fmap, "regions.", cfg.get("pad", 3))
@@ -258,10 +256,9 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
     d2s = cg + source["shift"].view(bs, k, 1, 1, 2)
     bg = ident.repeat(bs, 1, 1, 1, 1)
     if bg_params is not None:      # homogeneous 3x3 transform of the identity grid
-        m = [t.view(bs, 1, 1, 1) for t in bg_params.reshape(bs, 9).unbind(-1)]
-        gx, gy = bg.unbind(-1)
-        hom = [m[3 * i] * gx + m[3 * i + 1] * gy + m[3 * i + 2] for i in range(3)]
-        bg = torch.stack((hom[0] / hom[2], hom[1] / hom[2]), dim=-1)
+        m = bg_params.reshape(bs, 1, 1, 1, 3, 3)
+        hom = (m[..., :2] * ident.unsqueeze(-2)).sum(-1) + m[..., 2]
+        bg = hom[..., :2] / hom[..., 2:]
     sparse = torch.cat([bg, d2s], dim=1)
     # (pixelwise_flow_predictor.py:95-102 repeats the source K+1 times; the native kernel reads one source per K+1 grids)
     deformed = L.GridSample.apply(img, sparse.reshape(bs * (k + 1), h, w, 2), k + 1, False).view(bs, k + 1, -1, h, w)
@@ -408,9 +405,15 @@ class ReconstructionModel:
             self.vgg.to(device)
         return self
 
-    def _regions(self, x):
+    def _regions(self, *frames):
+        """The region predictor on each batch of frames -> one dict per batch.  All the batches go through the network together (one
+        launch sequence instead of len(frames), BatchNorm statistics per batch like the separate calls of model.py:157-160, :190-191)."""
         cfg = dict(self.mp["region_predictor_params"], estimate_affine=self.mp.get("estimate_affine", False))
-        return region_predictor_forward(self.region_predictor, x, cfg, self.training)
+        if len(frames) == 1 or not self.training or any(f.shape != frames[0].shape for f in frames):
+            return [region_predictor_forward(self.region_predictor, f, cfg, self.training) for f in frames]
+        b = frames[0].shape[0]
+        out = region_predictor_forward(self.region_predictor, torch.cat(frames), cfg, True, segments=len(frames))
+        return [{k: v[i * b:(i + 1) * b] for k, v in out.items()} for i in range(len(frames))]
 
     def pyramid(self, x, vgg_input=False):
         """ImagePyramide (model.py:62-82).  vgg_input: every level leaves its launch as the perceptual network's input - normalised
@@ -425,8 +428,14 @@ class ReconstructionModel:
     def forward(self, x, transform_noise=None):
         src, drv = x["source"], x["driving"]
         mp, lw = self.mp, self.loss_weights
-        source_rp = self._regions(src)
-        driving_rp = self._regions(drv)
+        equivariance = lw["equivariance_shift"] + lw["equivariance_affine"] != 0
+        if equivariance:
+            # (the transform's draws are the forward's only random numbers: building it before the generator changes nothing)
+            tr = Transform(drv.shape[0], noise=transform_noise, device=drv.device, **self.tp["transform_params"])
+            frame = tr.transform_frame(drv)
+            source_rp, driving_rp, trp = self._regions(src, drv, frame)
+        else:
+            source_rp, driving_rp = self._regions(src, drv)
         bg = bg_predictor_forward(self.bg_predictor, src, drv, mp["bg_predictor_params"], self.training)
         gen = generator_forward(self.generator, src, driving_rp, source_rp, bg, mp["generator_params"], mp["num_regions"],
                                 mp.get("revert_axis_swap", True), self.training)
@@ -448,10 +457,7 @@ class ReconstructionModel:
                     else:
                         terms.append((wgt * torch.abs(x_vgg[i] - y_vgg[i]).mean()).reshape(1))
             losses["perceptual"] = torch.cat(terms).sum()
-        if lw["equivariance_shift"] + lw["equivariance_affine"] != 0:
-            tr = Transform(drv.shape[0], noise=transform_noise, device=drv.device, **self.tp["transform_params"])
-            frame = tr.transform_frame(drv)
-            trp = self._regions(frame)
+        if equivariance:
             gen["transformed_frame"], gen["transformed_region_params"] = frame, trp
             if lw["equivariance_shift"] != 0:
                 losses["equivariance_shift"] = lw["equivariance_shift"] * torch.abs(driving_rp["shift"] - tr.warp_coordinates(trp["shift"])).mean()

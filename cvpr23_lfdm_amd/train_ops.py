@@ -114,20 +114,21 @@ def groupnorm_silu_bwd(x, dy, batch, gamma, beta, partial, nchunk, scale_shift=N
     return dx, dgb[0], dgb[1], dss
 
 
-def layernorm_bwd(x, dy, gamma, eps=1e-5, dgamma=None):
-    """-> (dx, dgamma).  dgamma: optional contiguous tensor of C elements that receives the gamma gradient."""
+def layernorm_bwd(x, dy, gamma, eps=1e-5, dgamma=None, dx_add=None):
+    """-> (dx, dgamma).  dgamma: optional contiguous tensor of C elements that receives the gamma gradient; dx_add: optional second
+    gradient of x (same shape) summed into dx by the kernel."""
     lib = _lib()
-    _chk(lib, x, dy, gamma, dgamma)
+    _chk(lib, x, dy, gamma, dgamma, dx_add)
     rows, c = x.shape
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert x.is_contiguous() and dy.is_contiguous() and (dx_add is None or (dx_add.is_contiguous() and dx_add.shape == x.shape))
     dx = torch.empty_like(x)
     if dgamma is None:
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     assert dgamma.is_contiguous() and dgamma.numel() == c
     nbytes = lib.lfdm_layernorm_bwd_ws_bytes(rows, c)
     ws = _ws(nbytes, x)
-    lib.check(lib.lfdm_layernorm_bwd_cl_f32(_p(x), _p(dy), _p(dx), rows, c, _p(gamma), eps, _p(dgamma), _p(ws), nbytes,
-                                            _stream(lib)), "lfdm_layernorm_bwd_cl_f32")
+    lib.check(lib.lfdm_layernorm_bwd_add_cl_f32(_p(x), _p(dy), _p(dx_add), _p(dx), rows, c, _p(gamma), eps, _p(dgamma), _p(ws), nbytes,
+                                                _stream(lib)), "lfdm_layernorm_bwd_add_cl_f32")
     return dx, dgamma
 
 

@@ -57,8 +57,12 @@ class _Ctx:
 def _resblock(unet, c, prefix, x, skip, res, cout, ss_of):
     g = unet.get
     n_img = c.batch * c.frames
-    h = A.conv_cl(x, g(prefix + "block1.proj.weight"), g(prefix + "block1.proj.bias"), x1=skip,
-                  n_img=n_img, hi=res, wi=res)
+    # fork: x (and skip) come back as outputs for the block's second reader (res_conv / the identity skip), so that both gradients meet
+    # in block1's data-gradient convolution (autograd.ConvCL)
+    forked = A.conv_cl(x, g(prefix + "block1.proj.weight"), g(prefix + "block1.proj.bias"), x1=skip,
+                       n_img=n_img, hi=res, wi=res, fork=True)
+    h, x = forked[0], forked[1]
+    skip = forked[2] if skip is not None else None
     ss = None if ss_of is None else ss_of.get(prefix)                                                  # (B, 2*cout)
     h = A.GroupNormSiLU.apply(h, g(prefix + "block1.norm.weight"), g(prefix + "block1.norm.bias"), ss, None, c.batch, True)
     h = A.conv_cl(h, g(prefix + "block2.proj.weight"), g(prefix + "block2.proj.bias"), n_img=n_img, hi=res, wi=res)
@@ -73,7 +77,7 @@ def _resblock(unet, c, prefix, x, skip, res, cout, ss_of):
 def _temporal_attn(unet, c, prefix, x, res, focus=None):
     g = unet.get
     n_img = c.batch * c.frames
-    normed = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"))
+    normed, x = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"), True)       # x again: the residual path's gradient meets the norm's
     qkv = A.conv_cl(normed, g(prefix + "fn.fn.fn.to_qkv.weight"), None, n_img=n_img, hi=res, wi=res)
     if focus is not None and all(focus):          # Attention.forward :313-317: the values pass straight through to_out
         att = qkv[:, 512:768].contiguous()
@@ -88,7 +92,7 @@ def _temporal_attn(unet, c, prefix, x, res, focus=None):
 def _mid_spatial_attn(unet, c, prefix, x, res):
     g = unet.get
     n_img = c.batch * c.frames
-    normed = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"))
+    normed, x = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"), True)       # x again: the residual path's gradient meets the norm's
     qkv = A.conv_cl(normed, g(prefix + "fn.fn.fn.to_qkv.weight"), None, n_img=n_img, hi=res, wi=res)
     att = A.AttentionCL.apply(qkv, None, None, None, c.batch, c.frames, res * res, 1)
     return A.conv_cl(att, g(prefix + "fn.fn.fn.to_out.weight"), None, residual=x, n_img=n_img, hi=res, wi=res)
@@ -97,7 +101,7 @@ def _mid_spatial_attn(unet, c, prefix, x, res):
 def _linear_attn(unet, c, prefix, x, res):
     g = unet.get
     n_img = c.batch * c.frames
-    normed = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"))
+    normed, x = A.LayerNormCL.apply(x, g(prefix + "fn.norm.gamma"), True)       # x again: the residual path's gradient meets the norm's
     qkv = A.conv_cl(normed, g(prefix + "fn.fn.to_qkv.weight"), None, n_img=n_img, hi=res, wi=res)
     att = A.LinearAttentionCL.apply(qkv, n_img, res * res)
     return A.conv_cl(att, g(prefix + "fn.fn.to_out.weight"), g(prefix + "fn.fn.to_out.bias"), residual=x,

@@ -539,6 +539,10 @@ size_t lfdm_layernorm_bwd_ws_bytes(int64_t rows, int channels);
 int lfdm_layernorm_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels,
                               const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes,
                               lfdm_stream_t stream);
+/* The same with dx = (LayerNorm gradient) + dx_add (ABI 11; dx_add rows x C, may be NULL): the residual path's gradient of the pre-norm
+ * blocks (Residual(PreNorm(...)), video_flow_diffusion.py:118-125, :181-188) summed in the kernel's store instead of by an ATen add. */
+int lfdm_layernorm_bwd_add_cl_f32(const float* x, const float* dy, const float* dx_add, float* dx, int64_t rows, int channels,
+                                  const float* gamma, float eps, float* dgamma, void* ws, size_t ws_bytes, lfdm_stream_t stream);
 
 /* Backward of lfdm_attention_cl_f32 (Attention.forward, video_flow_diffusion.py:303-363): dqkv rows
  * (768 = [dq | dk | dv], same order as qkv) from the saved qkv rows and dout (rows of 256).  Scores and
@@ -603,7 +607,7 @@ int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int 
                               int reflect, int backward, lfdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * LFAE stage-1 training glue (ABI version 10; csrc/train_lfae.hip): what connects the convolutions of
+ * LFAE stage-1 training glue (ABI version 10, BatchNorm segments 11; csrc/train_lfae.hip): what connects the convolutions of
  * ReconstructionModel.forward (LFAE/modules/model.py:141-217) - replaces the MIOpen BatchNorm, MIOpen / composable_kernel depth-wise
  * convolution and ATen grid_sampler kernels the reference's nn.Modules dispatch to.
  */
@@ -613,14 +617,18 @@ int lfdm_upsample2_pad_cl_f32(const float* x, float* out, int n_img, int h, int 
  * variance per channel over `rows`; running_mean / running_var (may both be NULL) are updated with `momentum` and the UNBIASED variance like
  * torch; stat receives [mean (C) | rstd (C)] for the backward.  Two launches (row-chunk reduce folded by tickets in a fixed order - the
  * result does not depend on workgroup arrival order - and apply).  tickets: LFDM_BN_TICKETS zeroed 32-bit words, left zeroed. */
-size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels);
-int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int ldx, int ldy, const float* gamma,
-                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
-                                    float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
+/* segments (ABI 11, 1..64): x / y hold `segments` batches of `rows` rows each, one after the other; every segment is normalised with
+ * its own batch statistics (stat = [segment][mean (C) | rstd (C)]), the running statistics take the segments' momentum updates in segment
+ * order and dgamma / dbeta are summed over the segments - exactly `segments` calls of the module on the separate batches (the region
+ * predictor on source, driving and transformed frames, model.py:157-160, :190-191), as one launch pair. */
+size_t lfdm_batchnorm_train_ws_bytes(int64_t rows, int channels, int segments);
+int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int channels, int segments, int ldx, int ldy,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, int relu, float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
 /* Backward of the above from the saved input x and stat: dx, dgamma (C), dbeta (C) (either may be NULL); relu = 1 masks dy by the sign of
  * the recomputed pre-activation (the same arithmetic as the forward: identical mask). */
-int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int ldx, int lddy, int lddx,
-                                    const float* gamma, const float* beta, const float* stat, int relu, float* dgamma, float* dbeta,
+int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int segments, int ldx, int lddy,
+                                    int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma, float* dbeta,
                                     void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
 
 /* AntiAliasInterpolation2d (LFAE/modules/util.py:217-264) / ImagePyramide (model.py:62-82) with any element strides on both sides:

@@ -178,3 +178,55 @@ def test_repack_stale_batches_the_winograd_packs(backend):
         assert torch.equal(a, b)
     assert not torch.equal(got[0], ref[0])
     assert A.repack_stale() == 0
+
+
+@pytest.mark.parametrize("two_sources,wino", [(False, False), (True, False), (False, True), (True, True)])
+def test_conv_fork_sums_both_gradients_in_the_dgrad(backend, two_sources, wino):
+    """geom fork=True: the inputs come back as outputs for their second reader; the gradient equals the unforked graph's (where the
+    autograd engine adds the two contributions)."""
+    dev = backend
+    n, h = 2, 8
+    c0, c1, co = (16, 16, 32) if wino else (8, 12, 12)
+    mk = lambda *s, seed: rnd(*s, seed=seed).to(dev)
+    w = (mk(co, c0 + (c1 if two_sources else 0), 1, 3, 3, seed=3) * 0.1).requires_grad_(True)
+    wr = (mk(co, c0 + (c1 if two_sources else 0), seed=4) * 0.1).requires_grad_(True)        # the block's 1x1 res_conv
+    b = mk(co, seed=5).requires_grad_(True)
+    dy = to_cl(mk(n, co, h, h, seed=9))
+    grads = []
+    for fork in (False, True):
+        x0 = to_cl(mk(n, c0, h, h, seed=1)).requires_grad_(True)
+        x1 = to_cl(mk(n, c1, h, h, seed=2)).requires_grad_(True) if two_sources else None
+        for p in (w, wr, b):
+            p.grad = None
+        if fork:
+            out = A.conv_cl(x0, w, b, x1=x1, n_img=n, hi=h, wi=h, fork=True)
+            hmid, xa, xb = out[0], out[1], (out[2] if two_sources else None)
+        else:
+            hmid, xa, xb = A.conv_cl(x0, w, b, x1=x1, n_img=n, hi=h, wi=h), x0, x1
+        y = A.conv_cl(xa, wr, None, x1=xb, residual=hmid, n_img=n, hi=h, wi=h)
+        y.backward(dy)
+        grads.append([x0.grad.clone(), None if x1 is None else x1.grad.clone(), w.grad.clone(), wr.grad.clone(), b.grad.clone()])
+    for a, f, what in zip(grads[0], grads[1], ("dx0", "dx1", "dw", "dw_res", "db")):
+        if a is not None:
+            _cmp(f, a.cpu(), "fork " + what)
+
+
+@pytest.mark.parametrize("c", [64, 128, 96])
+def test_layernorm_fork_sums_the_residual_gradient(backend, c):
+    dev = backend
+    rows = 70
+    gamma = (rnd(c, seed=2).to(dev) * 0.2 + 1.0).requires_grad_(True)
+    dy = rnd(rows, c, seed=9).to(dev)
+    grads = []
+    for fork in (False, True):
+        x = rnd(rows, c, seed=1).to(dev).requires_grad_(True)
+        gamma.grad = None
+        if fork:
+            normed, xa = A.LayerNormCL.apply(x, gamma, True)
+        else:
+            normed, xa = A.LayerNormCL.apply(x, gamma), x
+        y = normed * 0.7 + xa * 1.3
+        y.backward(dy)
+        grads.append((x.grad.clone(), gamma.grad.clone()))
+    _cmp(grads[1][0], grads[0][0].cpu(), "fork dx")
+    _cmp(grads[1][1], grads[0][1].cpu(), "fork dgamma")

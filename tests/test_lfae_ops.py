@@ -53,6 +53,41 @@ def test_batchnorm_relu(backend, n, c, h, w, relu):
     assert int(L._state(xd.device)["tickets"].abs().max()) == 0
 
 
+@pytest.mark.parametrize("segments,n,c,h,w", [(3, 2, 32, 6, 5), (2, 3, 12, 9, 9), (3, 1, 256, 2, 2), (4, 2, 64, 16, 16)])
+def test_batchnorm_relu_segments(backend, segments, n, c, h, w):
+    """segments = S is S calls of the module on the S sub-batches: own batch statistics each, the running statistics updated S times in
+    order, the parameter gradients summed (the region predictor on source / driving / transformed frames, model.py:157-160, :190-191)."""
+    dev = backend
+    if dev == "cuda" and c == 64:
+        n, h, w = 16, 64, 64                      # 65536 rows per segment
+    x = (rnd(segments * n, c, h, w, seed=1) * 1.7 + 0.3)
+    x = (x + torch.arange(segments).repeat_interleave(n).view(-1, 1, 1, 1).float()).requires_grad_(True)      # different means per segment
+    g = (rnd(c, seed=2) * 0.3 + 1.0).requires_grad_(True)
+    b = (rnd(c, seed=3) * 0.2).requires_grad_(True)
+    rm, rv = rnd(c, seed=4) * 0.1, rnd(c, seed=5).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = torch.cat([F.relu(F.batch_norm(xs, rm_ref, rv_ref, g, b, True, 0.1, 1e-5)) for xs in x.chunk(segments)])
+    dy = rnd(*y.shape, seed=6)
+    y.backward(dy)
+    xd = _cl(x.detach().to(dev)).requires_grad_(True)
+    gd, bd = g.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    yd = L.BatchNormReLU.apply(xd, gd, bd, rmd, rvd, 0.1, 1e-5, True, segments)
+    assert_close(yd.detach().cpu(), y.detach(), TOL, "bn y")
+    assert_close(rmd.cpu(), rm_ref, TOL, "running_mean")
+    assert_close(rvd.cpu(), rv_ref, TOL, "running_var")
+    yd.backward(_cl(dy.to(dev)))
+    for name, got, want in (("dx", xd.grad, x.grad), ("dgamma", gd.grad, g.grad), ("dbeta", bd.grad, b.grad)):
+        sc = float(want.abs().max())
+        assert_close(got.cpu() / sc, want / sc, TOL, "bn " + name)
+    # bit-identical to the separate calls
+    rm1, rv1 = rm.to(dev), rv.to(dev)
+    parts = [L.BatchNormReLU.apply(_cl(xs), gd.detach(), bd.detach(), rm1, rv1, 0.1, 1e-5, True) for xs in xd.detach().chunk(segments)]
+    assert torch.equal(torch.cat(parts), yd.detach())
+    assert torch.equal(rm1, rmd) and torch.equal(rv1, rvd)
+    assert int(L._state(xd.device)["tickets"].abs().max()) == 0
+
+
 def _antialias_ref(x, weight, scale):
     ks = weight.shape[-1]
     ka = ks // 2
