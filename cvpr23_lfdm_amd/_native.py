@@ -211,7 +211,7 @@ _SIGNATURES = {
     "lfdm_batchnorm_train_ws_bytes": (sz, [i64, i32, i32]),
     "lfdm_batchnorm_train_fwd_cl_f32": (i32, [f32p, f32p, i64, i32, i32, i32, i32, f32p, f32p, f32p, f32p, f32, f32, i32, f32p, C.c_void_p, sz,
                                             C.c_void_p, stream_t]),
-    "lfdm_batchnorm_train_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32p, C.c_void_p, sz,
+    "lfdm_batchnorm_train_bwd_cl_f32": (i32, [f32p, f32p, f32p, i64, i32, i32, i32, i32, i32, f32p, i32, f32p, f32p, f32p, i32, f32p, f32p, C.c_void_p, sz,
                                             C.c_void_p, stream_t]),
     "lfdm_blur_down_fwd_f32": (i32, [C.POINTER(BlurParams), stream_t]),
     "lfdm_blur_down_bwd_f32": (i32, [C.POINTER(BlurParams), stream_t]),

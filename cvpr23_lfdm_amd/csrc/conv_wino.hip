@@ -471,41 +471,54 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   }
 }
 
-// U = G g G^T, one thread per (reduction channel k, output channel n) pair of the convolution the result is used for
+// U = G g G^T.  One thread per (16-channel chunk, half, output channel n, kh): the FOUR reduction channels k = 16 chunk + 8 kh + 4 half + e
+// whose 16 transformed values lie side by side in the packed layout [pos][chunk][half][n][kh][e] - one 16-byte store per position, and
+// adjacent threads (kh, then n) store adjacent 16 bytes: a wavefront writes 1 KB contiguous per position.  (One thread per (k, n) pair wrote
+// 4 bytes at a 32-byte stride, 16 times: the multi-filter re-pack of a training step ran at 0.58 TB/s, profiles/r05_n_lfae_census.txt.)
 __device__ __forceinline__ void pack_wino_item(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp, int dgrad,
                                                float* __restrict__ out, int64_t idx) {
   const int K = dgrad ? cout : cin;                     // reduction channels of the target convolution
   const int N = dgrad ? cin : cout;                     // its output channels
-  if (idx >= (int64_t)K * coutp) return;
-  const int n = (int)(idx % coutp), k = (int)(idx / coutp);
-  float g[9];
-  if (n < N) {
-    const float* src = dgrad ? w + (int64_t)k * ld_o + (int64_t)n * 9 : w + (int64_t)n * ld_o + (int64_t)k * 9;
+  if (idx >= (int64_t)(K / 4) * coutp) return;
+  const int kh2 = (int)(idx & 1);
+  const int n = (int)((idx >> 1) % coutp);
+  const int rest = (int)((idx >> 1) / coutp);           // chunk * 2 + half
+  const int half = rest & 1, chunk = rest >> 1;
+  const int k0 = chunk * WKC + 8 * kh2 + 4 * half;
+  float u[16][4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = dgrad ? src[8 - t] : src[t];
-  } else {
+  for (int e = 0; e < 4; ++e) {
+    float g[9];
+    if (n < N) {
+      const int k = k0 + e;
+      const float* src = dgrad ? w + (int64_t)k * ld_o + (int64_t)n * 9 : w + (int64_t)n * ld_o + (int64_t)k * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = 0.f;
-  }
-  float r[4][3];                                        // G g
+      for (int t = 0; t < 9; ++t) g[t] = dgrad ? src[8 - t] : src[t];
+    } else {
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    r[0][b] = g[b];
-    r[1][b] = 0.5f * (g[b] + g[3 + b] + g[6 + b]);
-    r[2][b] = 0.5f * (g[b] - g[3 + b] + g[6 + b]);
-    r[3][b] = g[6 + b];
+      for (int t = 0; t < 9; ++t) g[t] = 0.f;
+    }
+    float r[4][3];                                      // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      r[0][b] = g[b];
+      r[1][b] = 0.5f * (g[b] + g[3 + b] + g[6 + b]);
+      r[2][b] = 0.5f * (g[b] - g[3 + b] + g[6 + b]);
+      r[3][b] = g[6 + b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[4 * i + 0][e] = r[i][0];
+      u[4 * i + 1][e] = 0.5f * (r[i][0] + r[i][1] + r[i][2]);
+      u[4 * i + 2][e] = 0.5f * (r[i][0] - r[i][1] + r[i][2]);
+      u[4 * i + 3][e] = r[i][2];
+    }
   }
   const int nch = K / WKC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float u[4] = {r[i][0], 0.5f * (r[i][0] + r[i][1] + r[i][2]), 0.5f * (r[i][0] - r[i][1] + r[i][2]), r[i][2]};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      {      // k % 16 = 8 * kh + 4 * half + e  ->  [pos][chunk][half][n][kh][e]
-        const int kk = k % WKC, kh2 = kk >> 3, half = (kk >> 2) & 1, e = kk & 3;
-        out[((((((int64_t)(4 * i + j)) * nch + k / WKC) * 2 + half) * coutp + n) * 2 + kh2) * 4 + e] = u[j];
-      }
-  }
+  for (int pos = 0; pos < 16; ++pos)
+    *reinterpret_cast<float4*>(out + ((((((int64_t)pos) * nch + chunk) * 2 + half) * coutp + n) * 2 + kh2) * 4) =
+        make_float4(u[pos][0], u[pos][1], u[pos][2], u[pos][3]);
 }
 
 __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, int ld_o, int cout, int cin, int coutp,
@@ -541,7 +554,7 @@ extern "C" int lfdm_pack_wino_weight_f32(const float* w, int ld_o, int cout, int
     lfdm_set_error("pack_wino_weight: reduction channels must be a multiple of 16 and coutp a multiple of 32 >= the output channels");
     return LFDM_EINVAL;
   }
-  const int64_t total = (int64_t)K * coutp;
+  const int64_t total = (int64_t)(K / 4) * coutp;
   LFDM_LAUNCH(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, ld_o, cout, cin, coutp, dgrad, out);
   return lfdm_check_launch("pack_wino_weight");
 }

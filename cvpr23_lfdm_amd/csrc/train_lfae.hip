@@ -53,6 +53,8 @@ BnGeom bn_geom(int64_t rows, int c) {
 struct BnArgs {
   const float* x;
   const float* dy;          // backward only
+  const float* add;         // backward, may be null: a second gradient of x (the block's skip path), summed into dx; row stride ldadd
+  int ldadd;
   float* out;               // y (forward) / dx (backward)
   int64_t rows;
   int c, ldx, lddy, ldo;
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
   const double* part2_all = a.part2;
   a.x += seg * a.rows * a.ldx;
   if (MODE == 1) a.dy += seg * a.rows * a.lddy;
+  if (MODE == 1 && a.add) a.add += seg * a.rows * a.ldadd;
   a.out += seg * a.rows * a.ldo;
   a.stat += (int64_t)seg * 2 * a.c;
   a.part2 += seg * a.seg_p2;
@@ -290,6 +293,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
         float gi = g[i];
         if (a.relu && !(fmaf(h, ga[i], be[i]) > 0.f)) gi = 0.f;
         o[i] = ga[i] * rs[i] * (gi - k1[i] - h * k2[i]);
+      }
+      if (a.add) {
+        const float4 e = *reinterpret_cast<const float4*>(a.add + r * a.ldadd + ch);
+        o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
       }
     }
     *reinterpret_cast<float4*>(a.out + r * a.ldo + ch) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1007,7 +1014,7 @@ extern "C" int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t
 }
 
 extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int segments, int ldx,
-                                               int lddy, int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma,
+                                               int lddy, int lddx, const float* dx_add, int ldadd, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma,
                                                float* dbeta, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BnArgs a = {};
@@ -1018,6 +1025,11 @@ extern "C" int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, 
     lfdm_set_error("batchnorm_train_bwd: dy, dx (16-byte aligned, leading dimensions % 4 == 0) and the forward's stat are required");
     return LFDM_EINVAL;
   }
+  if (dx_add && (ldadd % 4 != 0 || ldadd < channels || !aligned16(dx_add))) {
+    lfdm_set_error("batchnorm_train_bwd: dx_add must be 16-byte aligned with a leading dimension % 4 == 0");
+    return LFDM_EINVAL;
+  }
+  a.add = dx_add; a.ldadd = ldadd;
   a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.stat = const_cast<float*>(stat); a.relu = relu; a.dgamma = dgamma; a.dbeta = dbeta;
   const BnGeom g = bn_geom(rows, channels);
   const dim3 grid((unsigned)g.nchunk, (unsigned)g.ctiles, (unsigned)segments);

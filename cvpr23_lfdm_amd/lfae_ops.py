@@ -45,6 +45,16 @@ def _rows(x):
     return r.reshape(n * h * w, c)
 
 
+def _rows_ld(x):
+    """Like _rows for kernels that take a row stride: a channel slice of a wider channels-last tensor (the halves of a torch.cat's
+    gradient) is used where it lies - (N*H*W, C) with stride (ld, 1) - instead of being copied."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if sc == 1 and sw % 4 == 0 and sw >= c and sh == w * sw and sn == h * sh and x.storage_offset() % 4 == 0:
+        return x.as_strided((n * h * w, c), (sw, 1), x.storage_offset())
+    return _rows(x)
+
+
 def _from_rows(rows, n, h, w):
     return rows.view(n, h, w, rows.shape[1]).permute(0, 3, 1, 2)
 
@@ -68,9 +78,9 @@ def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps
     return y, stat
 
 
-def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None):
+def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None, dx_add=None):
     lib = _lib()
-    _chk(lib, x, dy, gamma, beta, stat, dgamma, dbeta)
+    _chk(lib, x, dy, gamma, beta, stat, dgamma, dbeta, dx_add)
     rows, c = x.shape
     segments = stat.shape[0] if stat.dim() == 3 else 1
     assert x.stride(1) == 1 and dy.stride(1) == 1 and dy.shape == x.shape and rows % segments == 0
@@ -78,7 +88,8 @@ def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None)
     dx = torch.empty(rows, c, dtype=torch.float32, device=x.device)
     nbytes = lib.lfdm_batchnorm_train_ws_bytes(seg_rows, c, segments)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    lib.check(lib.lfdm_batchnorm_train_bwd_cl_f32(_p(x), _p(dy), _p(dx), seg_rows, c, segments, x.stride(0), dy.stride(0), c, _p(gamma), _p(beta), _p(stat),
+    lib.check(lib.lfdm_batchnorm_train_bwd_cl_f32(_p(x), _p(dy), _p(dx), seg_rows, c, segments, x.stride(0), dy.stride(0), c, _p(dx_add),
+                                                  0 if dx_add is None else dx_add.stride(0), _p(gamma), _p(beta), _p(stat),
                                                   int(relu), _p(dgamma), _p(dbeta), _p(ws), nbytes, _p(_state(x.device)["tickets"]), _stream(lib)),
               "lfdm_batchnorm_train_bwd_cl_f32")
     return dx
@@ -87,29 +98,32 @@ def batchnorm_train_bwd(x, dy, gamma, beta, stat, relu, dgamma=None, dbeta=None)
 class BatchNormReLU(Function):
     """nn.BatchNorm2d (training mode: batch statistics, running statistics updated in place) followed by ReLU when relu=True, on an NCHW
     tensor in channels-last memory (LFAE/modules/util.py:84-90, 108-112, 128-133, 146-150).  segments = S: the batch is S equal
-    sub-batches, each normalised with its own statistics, the running statistics updated S times in order - S module calls as one."""
+    sub-batches, each normalised with its own statistics, the running statistics updated S times in order - S module calls as one.
+    fork=True -> (y, x): x itself as a second output for the block's skip path (ResBlock2d: out += x, util.py:84-92); the skip's gradient
+    then arrives here together with y's and the backward kernel stores the sum (like autograd.LayerNormCL / ConvCL)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, segments=1):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, segments=1, fork=False):
         n, c, h, w = x.shape
         assert n % segments == 0, "BatchNormReLU: the batch must split evenly into the segments"
-        xr = _rows(x.detach())
+        xr = _rows_ld(x.detach())
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         y, stat = batchnorm_train_fwd(xr, g, b, running_mean, running_var, momentum, eps, relu, segments)
         ctx.save_for_backward(xr, gamma, beta, stat)
         ctx.meta = (n, h, w, relu)
-        return _from_rows(y, n, h, w)
+        return (_from_rows(y, n, h, w), x) if fork else _from_rows(y, n, h, w)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         xr, gamma, beta, stat = ctx.saved_tensors
         n, h, w, relu = ctx.meta
         need = ctx.needs_input_grad
         dg = db = None
         if need[1] or need[2]:
             _, dg, db = grad_out_pair(gamma, beta)
-        dx = batchnorm_train_bwd(xr, _rows(dy), gamma.detach().contiguous(), beta.detach().contiguous(), stat, relu, dg, db)
-        return _from_rows(dx, n, h, w), dg, db, None, None, None, None, None, None
+        dx = batchnorm_train_bwd(xr, _rows_ld(dy), gamma.detach().contiguous(), beta.detach().contiguous(), stat, relu, dg, db,
+                                 None if dpass is None else _rows_ld(dpass))
+        return _from_rows(dx, n, h, w), dg, db, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ blur + subsample

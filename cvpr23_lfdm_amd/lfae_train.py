@@ -18,6 +18,7 @@ Only the pca_based / affine-background / RGB configuration the LFDM yaml files u
 """
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
 
 from . import autograd as A
 from . import lfae_ops as L
@@ -46,10 +47,39 @@ def flush_batches_tracked():
     torch._foreach_add_([v[0] for v in seen.values()], [v[1] for v in seen.values()])
 
 
-def conv2d(x, weight, bias, padding, relu=False):
+class _PadParam(Function):
+    """A parameter zero-padded to the channel multiples the kernels take (RGB inputs, the 10 / 11 / 1 / 3-channel heads), into a
+    persistent buffer whose pad region stays zero: one copy per use instead of F.pad's fill + copy, the gradient is the slice back."""
+
+    @staticmethod
+    def forward(ctx, p, shape):
+        key = (id(p), shape)
+        hit = _PAD_BUFFERS.get(key)
+        if hit is None or hit[0]() is not p or hit[1].device != p.device:
+            import weakref
+            hit = [weakref.ref(p), torch.zeros(shape, dtype=p.dtype, device=p.device), None]
+            _PAD_BUFFERS[key] = hit
+        ctx.sl = tuple(slice(0, n) for n in p.shape)
+        # (valid while neither torch nor a raw-pointer optimizer step has written p - the tag of autograd._pack_wino; a second use in the
+        # same step - the frozen VGG filters, eight times - must not write the buffer again: earlier uses have saved it for their backward)
+        tag = (p._version, P.weights_epoch() if p.requires_grad else -1, p.data_ptr())
+        if hit[2] != tag:
+            hit[1][ctx.sl].copy_(p)
+            hit[2] = tag
+        return hit[1].detach()
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[ctx.sl], None
+
+
+_PAD_BUFFERS = {}
+
+
+def conv2d(x, weight, bias, padding, relu=False, residual=None):
     """nn.Conv2d (stride 1, square kernel) through the native kernels.  x: (N, C, H, W); returns a channels-last (N, O, H', W').
-    Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded - the padded
-    filter slices receive zero gradient through autograd's own pad / slice backward."""
+    Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded (_PadParam).
+    residual: an (N, O, H', W') tensor added in the convolution's epilogue."""
     n, c, h, w = x.shape
     cout, k = weight.shape[0], weight.shape[-1]
     rows = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
@@ -59,9 +89,13 @@ def conv2d(x, weight, bias, padding, relu=False):
         rows = F.pad(rows, (0, cp))
     assert rows.shape[1] == cin + cp
     if cp or op:
-        weight = F.pad(weight, (0, 0, 0, 0, 0, cp, 0, op))
-        bias = F.pad(bias, (0, op)) if bias is not None else None
-    y = A.conv_cl(rows, weight, bias, n_img=n, hi=h, wi=w, pad=(padding, padding), relu=relu)       # relu: in the convolution's epilogue
+        weight = _PadParam.apply(weight, (cout + op, cin + cp) + tuple(weight.shape[2:]))
+        bias = _PadParam.apply(bias, (cout + op,)) if bias is not None and op else bias
+    res_rows = None
+    if residual is not None:
+        assert not op
+        res_rows = residual.permute(0, 2, 3, 1).reshape(-1, cout)
+    y = A.conv_cl(rows, weight, bias, residual=res_rows, n_img=n, hi=h, wi=w, pad=(padding, padding), relu=relu)   # relu: in the epilogue
     ho, wo = h + 2 * padding - k + 1, w + 2 * padding - k + 1
     y = y.view(n, ho, wo, cout + op).permute(0, 3, 1, 2)
     return y[:, :cout] if op else y
@@ -74,17 +108,19 @@ class _Net:
     def __init__(self, tree, training=True, segments=1):
         self.t, self.training, self.segments = tree, training, segments
 
-    def conv(self, x, prefix, padding, relu=False):
-        return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding, relu)
+    def conv(self, x, prefix, padding, relu=False, residual=None):
+        return conv2d(x, self.t.get(prefix + "weight"), self.t.get(prefix + "bias") if self.t.has(prefix + "bias") else None, padding, relu,
+                      residual)
 
-    def bn_relu(self, x, prefix):
+    def bn_relu(self, x, prefix, fork=False):
         """BatchNorm2d -> ReLU (every BatchNorm of the LFAE networks is followed by one: util.py:84-90, 108-112, 128-133, 146-150).  Training:
         one native forward (batch statistics, running statistics updated in place), one native backward (lfae_ops.BatchNormReLU)."""
         g = self.t.get
         if self.training:
             _NBT_PENDING.extend([g(prefix + "num_batches_tracked")] * self.segments)
             return L.BatchNormReLU.apply(x, g(prefix + "weight"), g(prefix + "bias"), g(prefix + "running_mean"), g(prefix + "running_var"),
-                                         0.1, 1e-5, True, self.segments)
+                                         0.1, 1e-5, True, self.segments, fork)
+        assert not fork
         return F.relu(F.batch_norm(x, g(prefix + "running_mean"), g(prefix + "running_var"), g(prefix + "weight"), g(prefix + "bias"),
                                    False, 0.1, 1e-5))
 
@@ -98,9 +134,13 @@ class _Net:
         return self.conv_bn_relu(L.pool2(x, "up"), prefix)
 
     def res_block(self, x, prefix):                       # ResBlock2d (util.py:70-92): pre-activation, identity skip
-        out = self.conv(self.bn_relu(x, prefix + "norm1."), prefix + "conv1.", 1)
-        out = self.conv(self.bn_relu(out, prefix + "norm2."), prefix + "conv2.", 1)
-        return out + x
+        if not self.training:
+            out = self.conv(self.bn_relu(x, prefix + "norm1."), prefix + "conv1.", 1)
+            return self.conv(self.bn_relu(out, prefix + "norm2."), prefix + "conv2.", 1) + x
+        # training: the skip is conv2's residual operand and its gradient is summed inside norm1's backward kernel - no add launches
+        out, x = self.bn_relu(x, prefix + "norm1.", fork=True)
+        out = self.conv(out, prefix + "conv1.", 1)
+        return self.conv(self.bn_relu(out, prefix + "norm2."), prefix + "conv2.", 1, residual=x)
 
     def hourglass(self, x, prefix, num_blocks, decoder=True):
         """Encoder / Decoder of util.py:153-214.  decoder=False returns the encoder's feature list."""

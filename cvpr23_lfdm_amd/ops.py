@@ -236,7 +236,7 @@ def pack_wino_weights_multi(jobs):
         _chk(lib, w, out)
         recs.append((w.data_ptr(), out.data_ptr(), w.stride(0), cout, cin, coutp, int(bool(dgrad)), block0))
         key.append(recs[-1][:7])
-        block0 += (k * coutp + 255) // 256
+        block0 += (k // 4 * coutp + 255) // 256          # one thread per four reduction channels (conv_wino.hip pack_wino_item)
     key = (tuple(key), str(jobs[0][1].device))
     table = _PACK_JOB_TABLES.get(key)
     if table is None:

@@ -626,9 +626,11 @@ int lfdm_batchnorm_train_fwd_cl_f32(const float* x, float* y, int64_t rows, int 
                                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                     float eps, int relu, float* stat, void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
 /* Backward of the above from the saved input x and stat: dx, dgamma (C), dbeta (C) (either may be NULL); relu = 1 masks dy by the sign of
- * the recomputed pre-activation (the same arithmetic as the forward: identical mask). */
+ * the recomputed pre-activation (the same arithmetic as the forward: identical mask).  dx_add (may be NULL, row stride ldadd): a second
+ * gradient of x - the identity skip of ResBlock2d (util.py:84-92) - summed into dx by the kernel. */
 int lfdm_batchnorm_train_bwd_cl_f32(const float* x, const float* dy, float* dx, int64_t rows, int channels, int segments, int ldx, int lddy,
-                                    int lddx, const float* gamma, const float* beta, const float* stat, int relu, float* dgamma, float* dbeta,
+                                    int lddx, const float* dx_add, int ldadd, const float* gamma, const float* beta, const float* stat, int relu,
+                                    float* dgamma, float* dbeta,
                                     void* ws, size_t ws_bytes, unsigned* tickets, lfdm_stream_t stream);
 
 /* AntiAliasInterpolation2d (LFAE/modules/util.py:217-264) / ImagePyramide (model.py:62-82) with any element strides on both sides:
@@ -723,7 +725,7 @@ int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight
 int lfdm_im2col_cl_f32(const float* x, float* out, int n_img, int h, int w, int channels, int ldx, int k, int pad, lfdm_stream_t stream);
 
 /* lfdm_pack_wino_weight_f32 for MANY filters in one launch: `jobs` is a table of n_jobs records IN DEVICE MEMORY, sorted by block0 = the first
- * workgroup of the job (job i covers ceil(K_i * coutp_i / 256) workgroups; total_blocks = their sum).  Same arguments per record as the single
+ * workgroup of the job (job i covers ceil(K_i / 4 * coutp_i / 256) workgroups - a thread packs four reduction channels; total_blocks = their sum).  Same arguments per record as the single
  * call.  Training re-packs every 3x3 filter after each optimizer step (video_flow_diffusion_model.py:181-188; LFAE/train.py:96-104). */
 typedef struct lfdm_pack_wino_job {
   const float* w;

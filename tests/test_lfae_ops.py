@@ -88,6 +88,36 @@ def test_batchnorm_relu_segments(backend, segments, n, c, h, w):
     assert int(L._state(xd.device)["tickets"].abs().max()) == 0
 
 
+def test_batchnorm_fork_and_channel_slices(backend):
+    """fork=True: x comes back for the block's skip path and the skip's gradient is summed inside the backward kernel; inputs / gradients that
+    are channel slices of a wider channels-last tensor (the halves of a torch.cat) are read where they lie (row stride > C)."""
+    dev = backend
+    n, c, h, w = 3, 16, 6, 5
+    wide = _cl(rnd(n, c + 8, h, w, seed=1).to(dev))
+    g = (rnd(c, seed=2) * 0.3 + 1.0).to(dev).requires_grad_(True)
+    b = (rnd(c, seed=3) * 0.2).to(dev).requires_grad_(True)
+    dyw = _cl(rnd(n, c + 8, h, w, seed=6).to(dev))
+    grads = []
+    for fork in (False, True):
+        x = wide.clone().requires_grad_(True)
+        g.grad = b.grad = None
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        xs = x[:, 8:]                                   # a channel slice: row stride c + 8
+        assert L._rows_ld(xs.detach()).stride(0) == c + 8
+        if fork:
+            y, xa = L.BatchNormReLU.apply(xs, g, b, rm, rv, 0.1, 1e-5, True, 1, True)
+        else:
+            y, xa = L.BatchNormReLU.apply(xs, g, b, rm, rv, 0.1, 1e-5, True), xs
+        out = y * 0.7 + xa * 1.3
+        out.backward(dyw[:, 8:])
+        grads.append((x.grad.clone(), g.grad.clone(), b.grad.clone(), y.detach().clone()))
+    ref = F.relu(F.batch_norm(wide[:, 8:].cpu(), None, None, g.detach().cpu(), b.detach().cpu(), True, 0.1, 1e-5))
+    assert_close(grads[0][3].cpu(), ref, TOL, "bn y of a channel slice")
+    for a, f, what in zip(grads[0], grads[1], ("dx", "dgamma", "dbeta", "y")):
+        sc = float(a.abs().max())
+        assert_close(f.cpu() / sc, a.cpu() / sc, TOL, "bn fork " + what)
+
+
 def _antialias_ref(x, weight, scale):
     ks = weight.shape[-1]
     ka = ks // 2
