@@ -143,7 +143,19 @@ def dist_setup(n_gpus):
         # "nccl" = RCCL over xGMI on the GPU box; LFDM_DIST_BACKEND=gloo lets the N>1 path be exercised with several
         # ranks sharing ONE GPU (RCCL refuses duplicate devices) - a test hook, never used by the driver
         backend = os.environ.get("LFDM_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend)
+        # stdout carries exactly one line - rank 0's JSON: whatever a backend's C++ side prints while connecting (gloo's
+        # "[Gloo] Rank 0 is connected to ..." goes to fd 1) is sent to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend=backend)
+            if backend == "gloo":
+                dist.barrier()      # (gloo connects its pairs lazily: do it while fd 1 is diverted)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, world, local
 
 

@@ -108,8 +108,8 @@ def test_bench_self_launch_gpus2():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout       # stdout = the JSON line and nothing else (no backend chatter)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["elapsed"] >= 0.018      # rank 1 sleeps 2 x 10 ms
 
