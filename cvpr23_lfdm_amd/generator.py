@@ -28,7 +28,7 @@ class Generator(ParamTree):
             num_down_blocks=num_down_blocks, num_bottleneck_blocks=num_bottleneck_blocks,
             num_regions=num_regions, with_flow_predictor=pixelwise_flow_predictor_params is not None,
             fp_block_expansion=fp.get("block_expansion", 64), fp_max_features=fp.get("max_features", 1024),
-            fp_num_blocks=fp.get("num_blocks", 5)))
+            fp_num_blocks=fp.get("num_blocks", 5), use_deformed_source=fp.get("use_deformed_source", True)))
         self.num_channels = num_channels
         self.num_down_blocks = num_down_blocks
         self.num_bottleneck_blocks = num_bottleneck_blocks

@@ -263,7 +263,21 @@ class RegionPredictorExec:
                 res["covar"] = torch.matmul(jac, jac.transpose(-1, -2))
             return res
         if ho * wo > 4096:
-            raise ValueError("RegionPredictor: %dx%d heat-maps (the fused statistics launch takes at most 4096 pixels per map)" % (ho, wo))
+            # frames above 256x256 at scale 0.25 (no LFDM yaml): the fused statistics launch holds one map per workgroup in LDS and stops at
+            # 4096 pixels.  Head on the native convolution, softmax / centre / covariance as torch ops on the device (region_predictor.py:
+            # 77-97), the 2x2 SVD with LAPACK's sign convention on the native kernel (:16-25 runs torch.svd on the host).
+            logits = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad)
+            region = torch.softmax(logits.reshape(n, k_regions, -1) / self.temperature, dim=2).view(n, k_regions, ho, wo)
+            ys, xs = torch.meshgrid(torch.linspace(-1, 1, ho, device=x.device), torch.linspace(-1, 1, wo, device=x.device), indexing="ij")
+            grid = torch.stack((xs, ys), dim=-1).view(1, 1, ho, wo, 2)
+            r = region.unsqueeze(-1)
+            mean = (r * grid).sum(dim=(2, 3))
+            sub = grid - mean.view(n, k_regions, 1, 1, 2)
+            covar = ((sub.unsqueeze(-1) * sub.unsqueeze(-2)) * r.unsqueeze(-1)).sum(dim=(2, 3))
+            cv = covar.reshape(-1, 4)
+            u, sv = ops.svd2x2_sym(cv[:, 0], cv[:, 1], cv[:, 3])
+            d = torch.diag_embed(sv ** 0.5)
+            return {"shift": mean, "heatmap": region, "covar": covar, "affine": torch.matmul(u, d).view(n, k_regions, 2, 2), "u": u, "d": d}
         # one launch: spatial softmax, centre, covariance, U sqrt(S) with LAPACK's sign convention (region_predictor.py:16-25 does
         # torch.svd(covar.cpu()) per frame; svd2x2_sym_lapack above is the same closed form in tensor ops, kept for tests/test_svd2x2.py)
         rows = _head_conv(self.tree, "regions.", out, skip, n, h, w, self.pad, planar=False)
@@ -295,6 +309,7 @@ class BGMotionPredictorExec:
 
 class PixelwiseFlowPredictorExec:
     """`tree` is the Generator (keys pixelwise_flow_predictor.*)."""
+    MAX_FRAMES = 65535          # frames per library launch (grid limit); larger calls run in slices of whole videos
 
     def __init__(self, tree, num_regions, num_blocks=5, scale_factor=0.25, use_covar_heatmap=True,
                  use_deformed_source=True, revert_axis_swap=True, region_var=0.01):
@@ -309,19 +324,35 @@ class PixelwiseFlowPredictorExec:
         frames=T: source_image (B, ...) and source params (B, K, ...) are per VIDEO, the driving params / bg_params per frame
         (N = B*T, n = b*T + t): nothing is repeated T times (the down-sampled source image in particular)."""
         p = "pixelwise_flow_predictor."
+        t_ = 1 if frames is None else frames
+        if source_image.shape[0] * t_ > self.MAX_FRAMES and t_ <= self.MAX_FRAMES:
+            # more frames than the library launches' grid limit (no LFDM batch comes close): slices of whole videos
+            step = self.MAX_FRAMES // t_
+            parts = []
+            for lo in range(0, source_image.shape[0], step):
+                vid, frm = slice(lo, lo + step), slice(lo * t_, (lo + step) * t_)
+                parts.append(self(source_image[vid], {key: v[frm] for key, v in driving.items()}, {key: v[vid] for key, v in source.items()},
+                                  None if bg_params is None else bg_params[frm], frames))
+            return {key: torch.cat([q[key] for q in parts], dim=0) for key in parts[0]}
         if self.scale_factor != 1:
             source_image = antialias_down(source_image.float(), self.tree.get(p + "down.weight"), self.scale_factor)
         k = self.k
-        if source_image.shape[1] == 3 and self.use_deformed_source and k <= 32:
+        if source_image.shape[1] == 3 and k <= 32:
             # two library launches around the hourglass instead of ~120 element-wise ATen launches over (N, K+1, h, w[, 2])
             t = 1 if frames is None else frames
             b, c, h, w = source_image.shape
             n = b * t
             if n > 65535 or h * w > 4096:
-                raise ValueError("PixelwiseFlowPredictor: %d frames of %dx%d per call (the library launches take at most 65535 frames of "
-                                 "at most 4096 pixels; split the batch)" % (n, h, w))
+                raise ValueError("PixelwiseFlowPredictor: %d frames per video / %dx%d maps per call (the library launches take at most 65535 "
+                                 "frames of at most 4096 pixels)" % (n, h, w))
             rows, sparse = ops.lfae_motion_inputs(source_image, driving, source, bg_params, t, region_var=self.region_var,
                                                   revert_axis_swap=self.revert_axis_swap, use_covar=self.use_covar_heatmap)
+            if not self.use_deformed_source:
+                # pixelwise_flow_predictor.py:116-119: the hourglass sees the K+1 heat-maps only (channels 0, 4, 8, ... of the launch's
+                # [heat | deformed RGB] groups), in a zero-padded buffer of the width its first filter was padded to
+                heat = rows.new_zeros(rows.shape[0], (k + 1 + 31) // 32 * 32)
+                heat[:, :k + 1] = rows[:, 0:4 * (k + 1):4]
+                rows = heat
             out, skip = self.hg.forward(rows, n, h, w)
             has_occ = self.tree.has(p + "occlusion.weight")
             heads = _head_conv(self.tree, (p + "mask.", p + "occlusion.") if has_occ else (p + "mask.",), out, skip, n, h, w, 3,
@@ -333,6 +364,5 @@ class PixelwiseFlowPredictorExec:
             return res
         # (a pure-ATen formulation of this head / tail - F.grid_sample and element-wise tensors over (N, K+1, h, w[, 2]) - used to stand
         #  here for other configurations: a silent non-native route on the product path.  No LFDM configuration reaches it.)
-        raise NotImplementedError("PixelwiseFlowPredictor: only the LFDM configurations are built (RGB source, use_deformed_source=True, "
-                                  "num_regions <= 32); got %d channels, use_deformed_source=%s, %d regions"
-                                  % (source_image.shape[1], self.use_deformed_source, k))
+        raise NotImplementedError("PixelwiseFlowPredictor: RGB sources and num_regions <= 32 are built; got %d channels, %d regions"
+                                  % (source_image.shape[1], k))

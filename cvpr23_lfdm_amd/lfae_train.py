@@ -302,7 +302,8 @@ def pixelwise_flow_forward(tree, source_image, driving, source, bg_params, cfg, 
     sparse = torch.cat([bg, d2s], dim=1)
     # (pixelwise_flow_predictor.py:95-102 repeats the source K+1 times; the native kernel reads one source per K+1 grids)
     deformed = L.GridSample.apply(img, sparse.reshape(bs * (k + 1), h, w, 2), k + 1, False).view(bs, k + 1, -1, h, w)
-    inp = torch.cat([heat, deformed], dim=2).view(bs, -1, h, w)
+    # pixelwise_flow_predictor.py:116-119 (the deformed sources are computed either way, like the reference does)
+    inp = (torch.cat([heat, deformed], dim=2) if cfg.get("use_deformed_source", True) else heat).reshape(bs, -1, h, w)
     pred = net.hourglass(_cl(inp), p + "hourglass.", cfg["num_blocks"])
     mask = F.softmax(net.conv(pred, p + "mask.", 3), dim=1).unsqueeze(2)
     out = {"optical_flow": (sparse.permute(0, 1, 4, 2, 3) * mask).sum(dim=1).permute(0, 2, 3, 1)}

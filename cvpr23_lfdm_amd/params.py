@@ -163,13 +163,13 @@ def unet_spec(dim=64, dim_mults=(1, 2, 4, 8), channels=259, out_grid_dim=2, out_
 
 def generator_spec(num_channels=3, block_expansion=64, max_features=512, num_down_blocks=2,
                    num_bottleneck_blocks=6, num_regions=10, with_flow_predictor=True,
-                   fp_block_expansion=64, fp_max_features=1024, fp_num_blocks=5):
+                   fp_block_expansion=64, fp_max_features=1024, fp_num_blocks=5, use_deformed_source=True):
     """State-dict layout of LFAE Generator (LFAE/modules/generator.py:23-56, util.py).  The
     pixelwise_flow_predictor entries are held for checkpoint compatibility (training pseudo-GT path)."""
     spec = []
     if with_flow_predictor:
         hp = "pixelwise_flow_predictor.hourglass."
-        in_f = (num_regions + 1) * (num_channels + 1)
+        in_f = (num_regions + 1) * (num_channels * int(bool(use_deformed_source)) + 1)      # pixelwise_flow_predictor.py:28
         for i in range(fp_num_blocks):
             ci = in_f if i == 0 else min(fp_max_features, fp_block_expansion * (2 ** i))
             co = min(fp_max_features, fp_block_expansion * (2 ** (i + 1)))

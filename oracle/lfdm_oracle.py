@@ -664,7 +664,8 @@ def region2gaussian(center, covar, h, w):
     return torch.exp(-0.5 * under.sum(dim=(-1, -2)))
 
 
-def pixelwise_flow_predictor(gsd, source_image, driving, source, bg_params, num_regions=10, scale=0.25):
+def pixelwise_flow_predictor(gsd, source_image, driving, source, bg_params, num_regions=10, scale=0.25, use_deformed_source=True,
+                             num_blocks=5):
     """PixelwiseFlowPredictor.forward with use_covar_heatmap, use_deformed_source, revert_axis_swap, occlusion
     (pixelwise_flow_predictor.py:48-137)."""
     p = "pixelwise_flow_predictor."
@@ -687,8 +688,8 @@ def pixelwise_flow_predictor(gsd, source_image, driving, source, bg_params, num_
     sparse = torch.cat([bg, d2s], dim=1)
     rep = img.unsqueeze(1).unsqueeze(1).repeat(1, k + 1, 1, 1, 1, 1).view(bs * (k + 1), -1, h, w)
     deformed = F.grid_sample(rep, sparse.view(bs * (k + 1), h, w, -1), align_corners=False).view(bs, k + 1, -1, h, w)
-    inp = torch.cat([heat, deformed], dim=2).view(bs, -1, h, w)
-    pred = hourglass(inp, gsd, p + "hourglass.")
+    inp = (torch.cat([heat, deformed], dim=2) if use_deformed_source else heat).reshape(bs, -1, h, w)      # :116-119
+    pred = hourglass(inp, gsd, p + "hourglass.", num_blocks)
     mask = F.softmax(F.conv2d(pred, gsd[p + "mask.weight"], gsd[p + "mask.bias"], padding=3), dim=1).unsqueeze(2)
     deformation = (sparse.permute(0, 1, 4, 2, 3) * mask).sum(dim=1).permute(0, 2, 3, 1)
     occ = torch.sigmoid(F.conv2d(pred, gsd[p + "occlusion.weight"], gsd[p + "occlusion.bias"], padding=3))

@@ -142,3 +142,76 @@ def test_region_predictor_without_pca(backend, estimate_affine):
     assert set(got) == set(ref)
     for key in ref:
         assert_close(got[key].cpu(), ref[key], 1e-3, "region predictor (no pca) " + key)
+
+
+def _small_generator(use_deformed_source, k=4):
+    from cvpr23_lfdm_amd import params as P
+    from cvpr23_lfdm_amd.generator import Generator
+    fp = dict(block_expansion=8, max_features=32, num_blocks=2, scale_factor=0.25, use_covar_heatmap=True,
+              use_deformed_source=use_deformed_source, estimate_occlusion_map=True)
+    gen = Generator(num_channels=3, num_regions=k, block_expansion=8, max_features=32, num_down_blocks=1, num_bottleneck_blocks=1,
+                    pixelwise_flow_predictor_params=fp)
+    spec = P.generator_spec(num_channels=3, block_expansion=8, max_features=32, num_down_blocks=1, num_bottleneck_blocks=1, num_regions=k,
+                            fp_block_expansion=8, fp_max_features=32, fp_num_blocks=2, use_deformed_source=use_deformed_source)
+    gsd = P.synthetic_state_dict(spec, 4242)
+    gen.load_state_dict(gsd)
+    return gen, gsd, fp
+
+
+def _region_params(n, k, g):
+    mk = lambda: {"shift": torch.rand(n, k, 2, generator=g) * 1.2 - 0.6,
+                  "covar": torch.eye(2).view(1, 1, 2, 2) * 0.02 + 0.004 * torch.rand(n, k, 1, 1, generator=g),
+                  "affine": torch.eye(2).view(1, 1, 2, 2) * 0.15 + 0.03 * torch.rand(n, k, 2, 2, generator=g)}
+    return mk(), mk()
+
+
+@pytest.mark.parametrize("use_deformed_source", [False, True])
+def test_pixelwise_flow_predictor_heatmaps_only(backend, use_deformed_source):
+    """use_deformed_source=False (pixelwise_flow_predictor.py:28, :116-119; no LFDM yaml): the hourglass reads the K+1 heat-maps only - the
+    frozen executor and the trainer's forward (eval statistics) against the oracle (pinned on the live reference in test_oracle_vs_reference)."""
+    dev = backend
+    from cvpr23_lfdm_amd import lfae_train
+    from cvpr23_lfdm_amd.lfae_predictors import PixelwiseFlowPredictorExec
+    k, n = 4, 2
+    gen, gsd, fp = _small_generator(use_deformed_source, k)
+    gen = gen.to(dev).eval()
+    g = torch.Generator().manual_seed(81)
+    src = torch.rand(n, 3, 64, 64, generator=g)
+    drv, sr = _region_params(n, k, g)
+    bg = torch.eye(3).view(1, 3, 3).repeat(n, 1, 1) + 0.05 * torch.rand(n, 3, 3, generator=g)
+    to = lambda d: {key: v.to(dev) for key, v in d.items()}
+    with torch.no_grad():
+        ref = O.pixelwise_flow_predictor({key: v.float() for key, v in gsd.items()}, src, drv, sr, bg, num_regions=k,
+                                         use_deformed_source=use_deformed_source, num_blocks=2)
+        ex = PixelwiseFlowPredictorExec(gen, num_regions=k, num_blocks=2, scale_factor=0.25, use_covar_heatmap=True,
+                                        use_deformed_source=use_deformed_source)
+        got = ex(src.to(dev), to(drv), to(sr), bg.to(dev))
+        trn = lfae_train.pixelwise_flow_forward(gen, src.to(dev), to(drv), to(sr), bg.to(dev), fp, k, True, training=False)
+    for name, out in (("executor", got), ("trainer forward", trn)):
+        assert_close(out["optical_flow"].cpu(), ref["optical_flow"], 1e-3, name + ": pixelwise flow")
+        assert_close(out["occlusion_map"].cpu(), ref["occlusion_map"], 1e-3, name + ": occlusion map")
+    # calls above the launches' frame limit run in slices of whole videos: same result (limit lowered to one frame per slice here)
+    ex.MAX_FRAMES = 1
+    with torch.no_grad():
+        sliced = ex(src.to(dev), to(drv), to(sr), bg.to(dev))
+    assert torch.equal(sliced["optical_flow"], got["optical_flow"]) and torch.equal(sliced["occlusion_map"], got["occlusion_map"])
+
+
+def test_region_predictor_large_heatmaps(backend):
+    """Heat-maps above 4096 pixels (frames above 256x256 at scale 0.25): the fused statistics launch does not take them; the executor computes
+    the statistics in tensor ops and the 2x2 SVD on the native kernel - against the oracle."""
+    dev = backend
+    from cvpr23_lfdm_amd import params as P
+    from cvpr23_lfdm_amd.flow_diffusion import RegionPredictor
+    kw = dict(block_expansion=8, max_features=32, num_blocks=2, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3)
+    net = RegionPredictor(num_regions=4, num_channels=3, estimate_affine=True, **kw)
+    sd = P.synthetic_state_dict(P.region_predictor_spec(num_regions=4, num_channels=3, estimate_affine=True, **kw), 7171)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = torch.rand(1, 3, 272, 288, generator=torch.Generator().manual_seed(80))            # 68 x 72 = 4896-pixel maps
+    with torch.no_grad():
+        ref = O.region_predictor({key: v.float() for key, v in sd.items()}, x, num_blocks=2)
+        got = net(x.to(dev))
+    assert got["heatmap"].shape[-2:] == (68, 72)
+    for key in ("shift", "covar", "affine", "heatmap"):
+        assert_close(got[key].cpu(), ref[key], 1e-3, "large-map region predictor: " + key)
