@@ -701,7 +701,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStream_t stream);  // conv_wino.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, bool fuse_reduce, hipStream_t stream);  // conv_wino.hip
 int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
 int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream);         // conv_wino4.hip
 
@@ -906,8 +906,19 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
 
 // in-launch slab reduction: KSW schedule with enough zeroed tile counters
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
-  if (pl.kind != 1 || pl.ksplit <= 1 || !p.tile_counters || p.deconv4) return false;
+  if (pl.ksplit <= 1 || !p.tile_counters || p.deconv4 || p.defer_reduce) return false;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  if (pl.kind == 2) {
+    // Winograd F(2x2): the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
+    static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B knob)
+    if (!on || pl.bn != 32 || pl.kgroups != 1 || p.groups > 1 || p.pool2 || p.gn_in_partial || p.cout != p.coutp || p.ldo % 4 != 0 ||
+        (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.partial) & 15) != 0 || (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
+        (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
+      return false;
+    const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+    return (int64_t)p.tile_counters_len >= ((ntiles + 31) / 32) * (p.coutp / 32);
+  }
+  if (pl.kind != 1) return false;
   const int64_t tiles = ((M + 159) / 160) * ((p.coutp + pl.bn - 1) / pl.bn);
   return (int64_t)p.tile_counters_len >= tiles;
 }
@@ -969,9 +980,9 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
                    "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
   }
-  if (p.defer_reduce && (p.ln_wsum || p.deconv4 || p.residual || p.act != LFDM_ACT_NONE || p.gn_partial || p.tile_counters)) {
+  if (p.defer_reduce && (p.ln_wsum || p.deconv4 || p.residual || p.act != LFDM_ACT_NONE || p.gn_partial)) {
     lfdm_set_error("conv2d: defer_reduce leaves the raw split-K slabs for lfdm_groupnorm_splitk_apply_cl_f32: no LayerNorm fold, deconv4, "
-                   "residual, activation, fused statistics or in-launch reduction");
+                   "residual, activation or fused statistics");
     return LFDM_EINVAL;
   }
   if (p.gn_in_partial) {
@@ -985,6 +996,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     }
   }
   p.ksplit = pl.ksplit;
+  if (p.defer_reduce) { p.tile_counters = nullptr; p.tile_counters_len = 0; }      // raw slabs wanted: nobody reduces in the launch
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (p.gn_partial) {
@@ -994,7 +1006,8 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     const bool ok = p.gn_groups > 0 && p.cout % p.gn_groups == 0 && cg % 4 == 0 && p.gn_pixels > 0 &&
                     p.gn_pixels % rows == 0 && p.cout % 4 == 0 && p.ldo % 4 == 0 &&
                     (((uintptr_t)p.out) & 15) == 0 &&
-                    ((p.ksplit > 1 && !fused) ? (256 % (p.coutp / 4) == 0 && p.cout == p.coutp) : (pl.bn % cg == 0));
+                    ((p.ksplit > 1 && !fused) ? (256 % (p.coutp / 4) == 0 && p.cout == p.coutp)
+                                              : (pl.bn % cg == 0 || (pl.kind == 2 && cg % pl.bn == 0)));      // (Winograd: a group may span column tiles)
     if (!ok) {
       lfdm_set_error("conv2d: fused GroupNorm statistics need pixels % tile_rows == 0 and a group size dividing "
                      "the column tile (see lfdm_conv2d_plan)");
@@ -1012,7 +1025,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
-    rc = lfdm_conv_wino_launch(p, pl.bn, pl.kgroups, stream);
+    rc = lfdm_conv_wino_launch(p, pl.bn, pl.kgroups, splitk_fused(pl, p), stream);
   } else if (pl.kind == 3) {
     rc = lfdm_conv_pw_launch(p, stream);
   } else if (pl.kind == 4) {

@@ -60,8 +60,15 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // the patches on their way into the transform (block1's norm inside block2's convolution: one launch less per ResnetBlock).  The
 // workgroup merges the statistics partials of its sample (double, fixed order - the arithmetic of gn_apply_kernel) while its first
 // patch / filter loads are in flight and keeps A[c], B[c] of its K slice in LDS.
-template <bool ACT, int NT, bool POOL = false, int G = 1, bool GNIN = false>
+// FUSE (round 5, lfdm_conv_params.tile_counters): split-K without a reduce launch.  Every slice's workgroup stores its 128 x 32 slab tile as
+// 8-byte agent-scope words (written through to memory: no cache-wide release), takes a ticket of its output tile, and the workgroup that draws
+// the tile's last ticket reads the ksplit slabs back past the non-coherent L2s (agent-scope loads: no acquire / invalidate), sums them in
+// slice order - bit-identical to conv_splitk_reduce_vec_kernel, whoever arrives last - and runs the epilogue (bias, GroupNorm partial sums,
+// residual, activation) itself.  The fence-based form of this hand-off (round 2, KSW schedule) measured neutral: its release wrote back the
+// XCD's whole L2 from every workgroup's tail - the cost found in the BatchNorm reduce (profiles/r05_p_bench_bn.txt, r05_q_*).
+template <bool ACT, int NT, bool POOL = false, int G = 1, bool GNIN = false, bool FUSE = false>
 __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_wino_kernel(lfdm_conv_params p) {
+  static_assert(!FUSE || (NT == 1 && G == 1 && !POOL && !GNIN), "in-launch split-K reduction: the plain 32-column workgroup only");
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
@@ -413,7 +420,14 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       for (int q = 0; q < 4; ++q) {
         const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
         if (ksplit > 1) {
-          *reinterpret_cast<float4*>(p.partial + ((int64_t)bz * M + orow) * p.coutp + co) = y[q];
+          float* dst = p.partial + ((int64_t)bz * M + orow) * p.coutp + co;
+          if (FUSE) {
+            unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+            lfdm_agent_store_u64(d8, (unsigned long long)__float_as_uint(y[q].x) | ((unsigned long long)__float_as_uint(y[q].y) << 32));
+            lfdm_agent_store_u64(d8 + 1, (unsigned long long)__float_as_uint(y[q].z) | ((unsigned long long)__float_as_uint(y[q].w) << 32));
+          } else {
+            *reinterpret_cast<float4*>(dst) = y[q];
+          }
         } else if (co < p.cout) {
           float4 v = make_float4(y[q].x + bb.x, y[q].y + bb.y, y[q].z + bb.z, y[q].w + bb.w);
           gs[ct][0] += v.x; gs[ct][1] += v.y; gs[ct][2] += v.z; gs[ct][3] += v.w;
@@ -437,7 +451,79 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
     for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
   }
 #endif
-  if (p.gn_partial && ksplit == 1) {
+  bool reduced_here = false;
+  if (FUSE && ksplit > 1) {
+    __shared__ int s_last;
+    LFDM_DRAIN_STORES();                                   // every storing wave: its slab words have left for memory
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* cnt = p.tile_counters + ((int64_t)by * gridDim.x + bx);
+      const bool last = lfdm_ticket_take(cnt) == (unsigned)(ksplit - 1);
+      if (last) lfdm_ticket_reset(cnt);                   // ready for the next launch
+      s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    reduced_here = true;
+    const int co = n0 + 4 * e_c4;
+    const int n = my_n;
+    const bool live = n >= 0 && co < p.cout;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gs[0][e] = gq[0][e] = 0.f;
+    if (live) {
+      const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + co);
+      float4 res[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        res[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual) res[q] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.ldr + co);
+      }
+      const int64_t zs2 = (M * p.coutp) / 2;                // slab stride in 8-byte words
+      const unsigned long long* src[4];
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        src[q] = reinterpret_cast<const unsigned long long*>(p.partial + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.coutp + co);
+      // four slabs x the thread's four pixels in flight per round (32 loads: one memory round trip for ksplit <= 4, two up to 8);
+      // summed z = 0, 1, ... per pixel (fixed order)
+      for (int z0 = 0; z0 < ksplit; z0 += 4) {
+        unsigned long long w[4][4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool in = z0 + u < ksplit;
+            w[u][q][0] = in ? lfdm_agent_load_u64(src[q] + (int64_t)(z0 + u) * zs2) : 0ull;
+            w[u][q][1] = in ? lfdm_agent_load_u64(src[q] + (int64_t)(z0 + u) * zs2 + 1) : 0ull;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (z0 + u < ksplit) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float ux = __uint_as_float((unsigned)(w[u][q][0] & 0xffffffffull)), uy = __uint_as_float((unsigned)(w[u][q][0] >> 32));
+              const float uz = __uint_as_float((unsigned)(w[u][q][1] & 0xffffffffull)), uw = __uint_as_float((unsigned)(w[u][q][1] >> 32));
+              if (z0 + u == 0) v[q] = make_float4(ux, uy, uz, uw);
+              else { v[q].x += ux; v[q].y += uy; v[q].z += uz; v[q].w += uw; }
+            }
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
+        float4 t = v[q];
+        t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w;
+        gs[0][0] += t.x; gs[0][1] += t.y; gs[0][2] += t.z; gs[0][3] += t.w;
+        gq[0][0] += t.x * t.x; gq[0][1] += t.y * t.y; gq[0][2] += t.z * t.z; gq[0][3] += t.w * t.w;
+        t.x = apply_act(t.x + res[q].x, p.act); t.y = apply_act(t.y + res[q].y, p.act);
+        t.z = apply_act(t.z + res[q].z, p.act); t.w = apply_act(t.w + res[q].w, p.act);
+        *reinterpret_cast<float4*>(p.out + orow * p.ldo + co) = t;
+      }
+    }
+  }
+  if (p.gn_partial && (ksplit == 1 || reduced_here)) {
     // per-channel sums over the workgroup's 32 tiles: lanes with equal e_c4 (stride 8) inside the wave, then the four waves
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
@@ -456,7 +542,25 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       }
     __syncthreads();
     const int cg = p.cout / p.gn_groups;
-    const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32: host check)
+    if (cg > WNB) {
+      // a group wider than the workgroup's columns (512 channels / 8 groups at the 4x4 level): the workgroup's sums are ONE of the
+      // cg / WNB column parts of its group and go to their own chunk slot - chunk = tile block * parts + part; the consumer merges
+      // (pixels / tile rows) * parts chunks per sample (host: lfdm_conv2d_plan's tile_rows, unet.py)
+      if (kgrp == 0 && tid == 0) {
+        float sv = 0.f, qv = 0.f;
+        for (int c = 0; c < WNB; ++c)
+          for (int w4 = 0; w4 < 4; ++w4) {
+            sv += s_gn[0][w4][c];
+            qv += s_gn[1][w4][c];
+          }
+        const int parts = cg / WNB;
+        float* dst = p.gn_partial + (((int64_t)bx * parts + (n0 % cg) / WNB) * p.gn_groups + n0 / cg) * 2;
+        dst[0] = sv;
+        dst[1] = qv;
+      }
+      return;
+    }
+    const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32 or is a multiple of it: host check)
     if (kgrp == 0 && tid < gpt && n0 + tid * cg < p.cout) {
       float sv = 0.f, qv = 0.f;
       for (int c = 0; c < cg; ++c)
@@ -567,11 +671,15 @@ extern "C" int lfdm_pack_wino_weights_multi_f32(const lfdm_pack_wino_job* jobs, 
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).  kgroups = G (1, 2, 3; 32-column tiles only).
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, hipStream_t stream) {
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, bool fuse_reduce, hipStream_t stream) {
   if (getenv("LFDM_WINO_TRACE") != nullptr) fprintf(stderr, "conv_wino: bn=%d ksplit=%d groups=%d kgroups=%d\n", bn, p.ksplit, p.groups, kgroups);   // which schedule ran: sweeps and tests
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
+  if (fuse_reduce) {                      // (splitk_fused, conv_igemm.hip: 32-column tiles, one K group, split-K; any activation at run time)
+    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 1, false, true>), grid, dim3(256), 0, stream, p);
+    return lfdm_check_launch("conv_wino");
+  }
   if (p.gn_in_partial) {                  // (lfdm_conv2d_cl_f32 has checked: 32-column tiles, one K group, no output activation, no pool)
     LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 1, true>), grid, dim3(256), 0, stream, p);
     return lfdm_check_launch("conv_wino");

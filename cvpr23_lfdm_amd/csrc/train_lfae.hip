@@ -66,7 +66,7 @@ struct BnArgs {
   float momentum, eps;
   int relu;
   int q, chunk_rows, nchunk, ngroups;
-  float* part1;             // [segment][ctile][chunk][2][tw] float
+  float* part1;             // [segment][ctile][chunk][tw] pairs (sum, sum) as 8-byte words
   double* part2;            // [segment][ctile][group][2][tw] double
   unsigned* tickets;        // [segment][ctile][group], zero between launches
   // segments: `segments` independent batches of `rows` rows stacked along the row axis, each normalised with its own statistics
@@ -152,36 +152,48 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnArgs a) {
   m0[0] = s0.x; m0[1] = s0.y; m0[2] = s0.z; m0[3] = s0.w;
   m1[0] = s1.x; m1[1] = s1.y; m1[2] = s1.z; m1[3] = s1.w;
   __syncthreads();
-  const int which = tid / tw, chn = tid - which * tw;        // tid < 2 * tw: one (sum, channel) each
-  float* p1 = a.part1 + (((int64_t)ct * a.nchunk + chunk) * 2) * tw;
-  if (tid < 2 * tw) {
-    const int qd = chn >> 2, comp = chn & 3;
-    float acc = 0.f;
-    for (int l = 0; l < lanes; ++l) acc += sm[which][(l * q + qd) * 4 + comp];      // fixed order
-    p1[which * tw + chn] = acc;
+  // The chunk's (sum, sum) pair of a channel travels as ONE 8-byte agent-scope word: written through to memory by its store, read past the
+  // (per-XCD, mutually non-coherent) L2s by the finalizer's load - no cache-wide release / acquire around the ticket (lfdm_device.h,
+  // guide section 6 guideline 16).  The release fence this replaces wrote back every dirty line of the XCD's L2 - the producing
+  // convolution's output - from inside each of the 1 024+ workgroup tails: the pass ran at 0.6-1.5 TB/s (profiles/r05_p_bench_bn.txt).
+  unsigned long long* p1 = reinterpret_cast<unsigned long long*>(a.part1) + ((int64_t)ct * a.nchunk + chunk) * tw;
+  if (tid < tw) {
+    const int qd = tid >> 2, comp = tid & 3;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int l = 0; l < lanes; ++l) {                     // fixed order
+      acc0 += sm[0][(l * q + qd) * 4 + comp];
+      acc1 += sm[1][(l * q + qd) * 4 + comp];
+    }
+    lfdm_agent_store_u64(p1 + tid, (unsigned long long)__float_as_uint(acc0) | ((unsigned long long)__float_as_uint(acc1) << 32));
   }
-  // level-1 fold by the workgroup that completes its group of BN_GROUP chunks (lfdm_device.h: ticket hand-off)
+  // level-1 fold by the workgroup that completes its group of BN_GROUP chunks
   LFDM_DRAIN_STORES();
   __syncthreads();
   const int grp = chunk / BN_GROUP;
   const int c0 = grp * BN_GROUP, c1 = c0 + BN_GROUP < a.nchunk ? c0 + BN_GROUP : a.nchunk;
   if (tid == 0) {
-    LFDM_FENCE_RELEASE_AGENT();
-    LFDM_DRAIN_STORES();
     unsigned* cnt = a.tickets + ct * a.ngroups + grp;
     const bool last = lfdm_ticket_take(cnt) == (unsigned)(c1 - c0 - 1);
-    if (last) {
-      lfdm_ticket_reset(cnt);
-      LFDM_FENCE_ACQUIRE_AGENT();
-    }
+    if (last) lfdm_ticket_reset(cnt);
     s_last = last ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
-  if (tid < 2 * tw) {
-    double acc = 0.0;
-    for (int k = c0; k < c1; ++k) acc += (double)a.part1[(((int64_t)ct * a.nchunk + k) * 2 + which) * tw + chn];
-    a.part2[(((int64_t)ct * a.ngroups + grp) * 2 + which) * tw + chn] = acc;
+  if (tid < tw) {
+    double acc0 = 0.0, acc1 = 0.0;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(a.part1) + (int64_t)ct * a.nchunk * tw + tid;
+    for (int k = c0; k < c1; k += 8) {                     // eight loads in flight, folded in index order
+      unsigned long long w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = k + u < c1 ? lfdm_agent_load_u64(base + (int64_t)(k + u) * tw) : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc0 += (double)__uint_as_float((unsigned)(w[u] & 0xffffffffull));
+        acc1 += (double)__uint_as_float((unsigned)(w[u] >> 32));
+      }
+    }
+    a.part2[(((int64_t)ct * a.ngroups + grp) * 2 + 0) * tw + tid] = acc0;
+    a.part2[(((int64_t)ct * a.ngroups + grp) * 2 + 1) * tw + tid] = acc1;
   }
 }
 
@@ -477,11 +489,33 @@ __device__ __forceinline__ void fix_add(long long* acc, float v, int k) {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int c, int64_t ld, unsigned* out) {
   __shared__ float s_m[4];
   float m = 0.f;
-  const int64_t total = rows * c;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / c;
-    const float v = fabsf(x[r * ld + (i - r * c)]);
-    if (v > m) m = v;                   // NaN never wins: a NaN gradient stays a NaN through the float paths of the caller
+  // NaN never wins a comparison: a NaN gradient stays a NaN through the float paths of the caller
+  if ((c & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0) {       // 16-byte loads, two in flight (a scalar loop read 2.5 TB/s)
+    const int c4 = c >> 2;
+    const int64_t total = rows * c4, step = (int64_t)gridDim.x * 256;
+    auto at = [&](int64_t i) {
+      const int64_t r = i / c4;
+      return *reinterpret_cast<const float4*>(x + r * ld + 4 * (i - r * c4));
+    };
+    auto fold = [&](const float4& v) {
+      const float a = fmaxf(fabsf(v.x), fabsf(v.y)), b = fmaxf(fabsf(v.z), fabsf(v.w));
+      if (a > m) m = a;
+      if (b > m) m = b;
+    };
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + step < total; i += 2 * step) {
+      const float4 v0 = at(i), v1 = at(i + step);
+      fold(v0);
+      fold(v1);
+    }
+    if (i < total) fold(at(i));
+  } else {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / c;
+      const float v = fabsf(x[r * ld + (i - r * c)]);
+      if (v > m) m = v;
+    }
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
@@ -884,21 +918,19 @@ __global__ __launch_bounds__(256) void l1_mean_fwd_kernel(const float4* __restri
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
   __syncthreads();
+  // (partials as 8-byte agent-scope words: written through / read past the non-coherent L2s - no cache-wide fence, see bn_reduce_kernel)
+  unsigned long long* part = reinterpret_cast<unsigned long long*>(partial);
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]);
+    lfdm_agent_store_u64(part + blockIdx.x, (unsigned long long)__float_as_uint((s_p[0] + s_p[1]) + (s_p[2] + s_p[3])));
     LFDM_DRAIN_STORES();
-    LFDM_FENCE_RELEASE_AGENT();
     const bool last = lfdm_ticket_take(ticket) == gridDim.x - 1;
-    if (last) {
-      lfdm_ticket_reset(ticket);
-      LFDM_FENCE_ACQUIRE_AGENT();
-    }
+    if (last) lfdm_ticket_reset(ticket);
     s_last = last ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
   double t = 0.0;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += (double)partial[i];
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += (double)__uint_as_float((unsigned)lfdm_agent_load_u64(part + i));
   // fixed order: lane-strided partial sums folded through a wavefront reduction of doubles in LDS
   __shared__ double s_d[256];
   s_d[threadIdx.x] = t;
@@ -1220,8 +1252,8 @@ extern "C" int lfdm_relu_bwd_f32(const float* y, const float* dy, float* out, in
 extern "C" int lfdm_l1_mean_fwd_f32(const float* x, const float* y, int64_t n, float weight, float* out, void* ws, size_t ws_bytes,
                                     unsigned* ticket, lfdm_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !y || !out || !ws || !ticket || n <= 0 || n % 4 != 0 || ws_bytes < L1_BLOCKS * sizeof(float) || !aligned16(x) || !aligned16(y)) {
-    lfdm_set_error("l1_mean_fwd: n % 4 == 0, 16-byte aligned x / y, a 4 KB workspace and one zeroed ticket word");
+  if (!x || !y || !out || !ws || !ticket || n <= 0 || n % 4 != 0 || ws_bytes < L1_BLOCKS * sizeof(unsigned long long) || (((uintptr_t)ws) & 7) || !aligned16(x) || !aligned16(y)) {
+    lfdm_set_error("l1_mean_fwd: n % 4 == 0, 16-byte aligned x / y, an 8 KB workspace (8-byte aligned) and one zeroed ticket word");
     return LFDM_EINVAL;
   }
   int64_t blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);

@@ -448,8 +448,8 @@ class L1Mean(Function):
         assert n % 4 == 0
         st = _state(xd.device)
         out = torch.empty(1, dtype=torch.float32, device=xd.device)
-        ws = torch.empty(1024, dtype=torch.float32, device=xd.device)
-        lib.check(lib.lfdm_l1_mean_fwd_f32(_p(xd), _p(yd), n, float(weight), _p(out), _p(ws), 4096, C.c_void_p(st["amax"].data_ptr() + 8),
+        ws = torch.empty(2048, dtype=torch.float32, device=xd.device)
+        lib.check(lib.lfdm_l1_mean_fwd_f32(_p(xd), _p(yd), n, float(weight), _p(out), _p(ws), 8192, C.c_void_p(st["amax"].data_ptr() + 8),
                                            _stream(lib)), "lfdm_l1_mean_fwd_f32")
         ctx.save_for_backward(xd, yd)
         ctx.weight = float(weight)

@@ -385,6 +385,11 @@ def conv_plan(p):
     return rows.value, ks.value
 
 
+def conv_schedule(p):
+    """lfdm_conv2d_schedule: 0 = implicit GEMM, 1 = K-split across waves, 2 = Winograd F(2x2), 3 = pointwise, 4 = Winograd F(4x4)."""
+    return _lib().lfdm_conv2d_schedule(C.byref(p))
+
+
 def conv_launch(p):
     lib = _lib()
     lib.check(lib.lfdm_conv2d_cl_f32(C.byref(p), _stream(lib)), "lfdm_conv2d_cl_f32")

@@ -28,6 +28,9 @@ _GN_SPLITK = os.environ.get("LFDM_GN_SPLITK", "0") == "1"      # conv (split-K) 
 # ~19 us where the reduce launch + apply launch cost 12.6 - a counter barrier is 7 us on this chip (MI355X_MICROARCH.md "barrier-counter"),
 # a kernel boundary 2.  Off by default; LFDM_GN_COOP=1 turns it on.
 _GN_COOP = os.environ.get("LFDM_GN_COOP", "0") == "1"
+# Split-K Winograd convolutions reduce their slabs inside the launch (lfdm_conv_params.tile_counters: fence-free hand-off, conv_wino.hip FUSE):
+# no conv_splitk_reduce launch behind the 8x8 / 4x4 convolutions of a B = 1 step.  LFDM_WINO_FUSE_REDUCE=0: the separate reduce pass.
+_WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
 _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 # block1's GroupNorm + scale/shift + SiLU inside block2's Winograd convolution (lfdm_conv_params.gn_in_*): one launch less per ResnetBlock.
 # MEASURED SLOWER (round 4, profiles/r04_d_*): 146 instead of 165 launches per step, but every fused convolution takes ~10 us longer (the
@@ -308,8 +311,8 @@ class Unet3D(ParamTree):
     # ------------------------------------------------------------------ building blocks
     def _conv(self, src0, w, cout, k, n_img, s, *, src1=None, bias=None, residual=None, out=None, gn=None,
               scratch="splitk", ww=None, **kw):
-        # (measured and removed: split-K slabs reduced inside the launch by the last-arriving workgroup - neutral to slower -
-        #  and res_conv on a second stream - slower; DESIGN.md "negative results")
+        # (measured and removed: res_conv on a second stream - slower; split-K slabs reduced inside the launch with a release / acquire
+        #  fence pair, KSW schedule - neutral; the fence-free form on the Winograd schedule is `_WINO_FUSE_REDUCE` below)
         """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
         if k == 1 and self._pk is not None and w.dim() == 3 and w.shape[1] % 32 == 0 and not kw.get("deconv4"):
@@ -322,6 +325,9 @@ class Unet3D(ParamTree):
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         coutp = p.coutp
+        if _WINO_FUSE_REDUCE and ww is not None and p.weight_wino and ops.conv_schedule(p) == 2:
+            counters = self._tile_counters(src0.device)
+            p.tile_counters, p.tile_counters_len = counters.data_ptr(), counters.numel()
         if gn is not None:
             p.gn_partial = 1      # (placeholder: "fused statistics wanted" changes the plan - schedules 3 / 4 have none; include/lfdm_hip.h)
         tile_rows, ksplit = ops.conv_plan(p)
@@ -349,17 +355,28 @@ class Unet3D(ParamTree):
             batch, groups = gn[0], (gn[1] if len(gn) > 1 else 8)
             pixels = m // batch
             cg = cout // groups
-            fused = ksplit > 1 and tile_rows == 160
-            in_tile = (ksplit == 1 or fused) and 32 % cg == 0             # statistics from the conv epilogue (group inside a 32-column tile)
+            fused = ksplit > 1 and tile_rows != 16                        # slabs reduced inside the launch (KSW: 160-row tiles, Winograd: 128)
+            # the fused Winograd form always runs 32-column workgroups: a group wider than that (512 channels / 8) gets one chunk slot per
+            # column part (conv_wino.hip)
+            parts = cg // 32 if (fused and tile_rows == 128 and cg > 32 and cg % 32 == 0) else 1
+            in_tile = (ksplit == 1 or fused) and (32 % cg == 0 or parts > 1)   # statistics from the conv epilogue
             in_reduce = ksplit > 1 and not fused and 256 % (coutp // 4) == 0 and coutp == cout    # ... from the split-K reduce pass (any group width)
             if pixels % tile_rows == 0 and cg % 4 == 0 and (in_tile or in_reduce):
-                nchunk = pixels // tile_rows
+                nchunk = pixels // tile_rows * (parts if in_tile else 1)
                 # (a convolution that READS the previous statistics through gn_in writes its own into the other arena: its workgroups finish
                 #  - and store their partial sums - while others are still merging the input's)
                 stats = (self._buf("gn.partial2" if kw.get("gn_in") is not None else "gn.partial", batch * nchunk, 2 * groups), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), groups, pixels
         ops.conv_launch(p)
         return (y, stats) if gn is not None else y
+
+    def _tile_counters(self, dev):
+        """Ticket words of the in-launch split-K reduction: zeroed once, every launch leaves them zeroed (launches of a step are serialised)."""
+        cur = getattr(self, "_tile_cnt", None)
+        if cur is None or cur.device != torch.device(dev):
+            cur = self._tile_cnt = torch.zeros(8192, dtype=torch.int32, device=dev)
+            self._buf_gen += 1          # (a captured graph holds this pointer)
+        return cur
 
     def _gn(self, x, batch, gamma, beta, stats, groups=8, **kw):
         if stats is not None and stats[0] == "coop":

@@ -714,7 +714,7 @@ int lfdm_pool2_cl_f32(const float* x, const float* aux, float* out, int n_img, i
 /* out = y > 0 ? dy : 0 over n floats: backward of a ReLU fused into the producing convolution (lfdm_conv_params.act = 1; VGG-19, model.py:19-59). */
 int lfdm_relu_bwd_f32(const float* y, const float* dy, float* out, int64_t n, lfdm_stream_t stream);
 /* *out = weight * mean |x - y| (the perceptual loss terms, model.py:189-195), partials folded in a fixed order by the last workgroup
- * (ws: 4 KB, ticket: one zeroed word, left zeroed);  _bwd: dx = sign(x - y) * (*gout) * weight / n. */
+ * (ws: 8 KB, 8-byte aligned; ticket: one zeroed word, left zeroed);  _bwd: dx = sign(x - y) * (*gout) * weight / n. */
 int lfdm_l1_mean_fwd_f32(const float* x, const float* y, int64_t n, float weight, float* out, void* ws, size_t ws_bytes, unsigned* ticket,
                          lfdm_stream_t stream);
 int lfdm_l1_mean_bwd_f32(const float* x, const float* y, int64_t n, float weight, const float* gout, float* dx, lfdm_stream_t stream);

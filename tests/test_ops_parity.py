@@ -1250,3 +1250,58 @@ def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
         out = ops.conv2d_cl(src0, wd, cout, 3, 3, n, h, w, **kw)
         assert_close(from_cl(out.cpu(), n, ref.shape[2], ref.shape[3]), ref, TOL,
                      "winograd cin=%d cout=%d n=%d h=%d w=%d up=%s ks=%d split=%d" % (cin, cout, n, h, w, up, ks, split))
+
+
+@pytest.mark.parametrize("case", [
+    dict(b=2, t=8, s=4, cin=64, cout=64, ksplit=2),                      # 4x4 images, 8-channel groups inside a column tile
+    dict(b=1, t=8, s=4, cin=96, cout=512, ksplit=3, residual=True),      # 64-channel groups: two column tiles per group (sub-chunks)
+    dict(b=2, t=2, s=8, cin=128, cout=256, ksplit=4, residual=True, c1=64),
+    dict(b=1, t=40, s=4, cin=512, cout=512, ksplit=6, gpu_only=True),    # the sampler's 4x4 level
+    dict(b=1, t=40, s=8, cin=256, cout=256, ksplit=3, residual=True, gpu_only=True),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_winograd_splitk_reduced_in_launch(backend, case):
+    """lfdm_conv_params.tile_counters on the Winograd schedule: the workgroup that draws a tile's last ticket sums the split-K slabs and runs
+    the epilogue (bias, GroupNorm partial sums, residual) - no reduce launch.  Equal to the separate reduce pass bit for bit (same summation
+    order, whoever arrives last), counters left at zero, and conv -> GroupNorm through its statistics equals torch."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    b, t, s, cin, cout, ks = (case[k] for k in ("b", "t", "s", "cin", "cout", "ksplit"))
+    c1 = case.get("c1", 0)
+    n = b * t
+    x = rnd(n, cin, s, s, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * cin))
+    bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
+    res = rnd(n, cout, s, s, seed=7) if case.get("residual") else None
+    conv = F.conv2d(x, wt, bias, padding=1)
+    xs = to_cl(x).to(dev)
+    src0, src1 = (xs, None) if not c1 else (xs[:, :cin - c1].contiguous(), xs[:, cin - c1:].contiguous())
+    w, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
+    pixels = t * s * s
+    groups = 8
+    cg = cout // groups
+    outs = []
+    for fused in (False, True):
+        counters = torch.zeros(256, dtype=torch.int32, device=dev) if fused else None
+        kw = dict(src1=src1, bias=bias.to(dev), weight_wino=ww, ksplit=ks, tile_counters=counters)
+        pp, _ = ops.conv_params(src0, w, cout, 3, 3, n, s, s, **kw)
+        assert ops.conv_schedule(pp) == 2
+        pp.gn_partial = 1
+        rows_per_tile, got_ks = ops.conv_plan(pp)
+        assert got_ks == ks and rows_per_tile == (128 if fused else 16) and pixels % rows_per_tile == 0
+        parts = max(1, cg // 32) if fused else 1
+        nchunk = pixels // rows_per_tile * parts
+        for rep in range(2):                                   # second launch: the counters were left at zero
+            partial = torch.zeros(b * nchunk, 2 * groups, device=dev)
+            y = ops.conv2d_cl(src0, w, cout, 3, 3, n, s, s, residual=None if res is None else to_cl(res).to(dev),
+                              gn_partial=partial, gn_groups=groups, gn_pixels=pixels, **kw)
+        if fused:
+            assert int(counters.abs().sum()) == 0
+        assert_close(from_cl(y.cpu(), n, s, s), conv + (0 if res is None else res), TOL, "winograd split-K, fused=%s" % fused)
+        outs.append(y.clone())
+        # the statistics describe conv + bias (before the residual): normalise a copy of exactly that
+        h = ops.conv2d_cl(src0, w, cout, 3, 3, n, s, s, **kw) if res is not None else y
+        gn = ops.groupnorm_apply_cl(h.clone(), b, gamma.to(dev), beta.to(dev), partial, nchunk, groups=groups, silu=False)
+        ref = F.group_norm(conv.view(b, t, cout, s, s).permute(0, 2, 1, 3, 4), groups, gamma, beta, eps=1e-5)
+        assert_close(gn.cpu().view(b, t, s, s, cout).permute(0, 4, 1, 2, 3), ref, TOL, "group norm from the partial sums, fused=%s" % fused)
+    assert torch.equal(outs[0], outs[1]), "in-launch reduction must equal the reduce pass bit for bit"
