@@ -263,8 +263,16 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
       const int colbase = n0 + 32 * j + 4 * c4;
       if (img >= 0) {
         if (ksplit > 1) {
-          if (colbase < p.coutp)
-            *reinterpret_cast<float4*>(p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp + colbase) = v;
+          if (colbase < p.coutp) {
+            float* dst = p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp + colbase;
+            if (fuse) {      // 8-byte agent-scope words: written through to memory - no cache-wide release before the ticket (conv_wino.hip FUSE)
+              unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+              lfdm_agent_store_u64(d8, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32));
+              lfdm_agent_store_u64(d8 + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32));
+            } else {
+              *reinterpret_cast<float4*>(dst) = v;
+            }
+          }
         } else if (colbase < p.cout) {
           const int64_t orow = out_row(i);
           v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
@@ -294,14 +302,9 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     __syncthreads();
     int* const s_last = reinterpret_cast<int*>(smem);
     if (tid == 0) {
-      LFDM_FENCE_RELEASE_AGENT();
-      LFDM_DRAIN_STORES();
       unsigned* cnt = p.tile_counters + (blockIdx.y * gridDim.x + blockIdx.x);
       const bool last = lfdm_ticket_take(cnt) == (unsigned)(ksplit - 1);
-      if (last) {
-        lfdm_ticket_reset(cnt);                       // ready for the next launch
-        LFDM_FENCE_ACQUIRE_AGENT();
-      }
+      if (last) lfdm_ticket_reset(cnt);               // ready for the next launch
       s_last[0] = last ? 1 : 0;
     }
     __syncthreads();
@@ -319,12 +322,24 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
         const int row = 32 * i + trow;
         const int colbase = n0 + 32 * j + 4 * c4;
         if (s_img[row] >= 0 && colbase < p.cout) {
-          const float* src = p.partial + ((int64_t)(m0 + row)) * p.coutp + colbase;
+          // slabs read past the non-coherent L2s (agent-scope loads, four slabs in flight); fixed order z = 0, 1, ...: bit-reproducible
+          const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.partial + ((int64_t)(m0 + row)) * p.coutp + colbase);
+          const int64_t zs2 = (M * p.coutp) / 2;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-          for (int z = 0; z < ksplit; ++z) {          // fixed order: bit-reproducible
-            const float4 u = *reinterpret_cast<const float4*>(src + (int64_t)z * M * p.coutp);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          for (int z0 = 0; z0 < ksplit; z0 += 4) {
+            unsigned long long w[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const bool in = z0 + u < ksplit;
+              w[u][0] = in ? lfdm_agent_load_u64(src + (int64_t)(z0 + u) * zs2) : 0ull;
+              w[u][1] = in ? lfdm_agent_load_u64(src + (int64_t)(z0 + u) * zs2 + 1) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (z0 + u < ksplit) {
+                v.x += __uint_as_float((unsigned)(w[u][0] & 0xffffffffull)); v.y += __uint_as_float((unsigned)(w[u][0] >> 32));
+                v.z += __uint_as_float((unsigned)(w[u][1] & 0xffffffffull)); v.w += __uint_as_float((unsigned)(w[u][1] >> 32));
+              }
           }
           const int64_t orow = out_row(i);
           v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;

@@ -31,6 +31,9 @@ _GN_COOP = os.environ.get("LFDM_GN_COOP", "0") == "1"
 # Split-K Winograd convolutions reduce their slabs inside the launch (lfdm_conv_params.tile_counters: fence-free hand-off, conv_wino.hip FUSE):
 # no conv_splitk_reduce launch behind the 8x8 / 4x4 convolutions of a B = 1 step.  LFDM_WINO_FUSE_REDUCE=0: the separate reduce pass.
 _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
+# ... the same for the K-split-across-waves schedule: measured SLOWER (its four split-K launches per step have 4-40 workgroups whose last
+# arriver walks up to ten 32x32 tiles one after the other: 280.5 vs 279.6 ms per video, profiles/r05_s_fuse_reduce_ab.txt) - off
+_KSW_FUSE_REDUCE = os.environ.get("LFDM_KSW_FUSE_REDUCE", "0") == "1"
 _RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
 # block1's GroupNorm + scale/shift + SiLU inside block2's Winograd convolution (lfdm_conv_params.gn_in_*): one launch less per ResnetBlock.
 # MEASURED SLOWER (round 4, profiles/r04_d_*): 146 instead of 165 launches per step, but every fused convolution takes ~10 us longer (the
@@ -325,7 +328,9 @@ class Unet3D(ParamTree):
         p, y = ops.conv_params(src0, w, cout, k, k, n_img, s, s, src1=src1, bias=bias, residual=residual,
                                out=out, weight_wino=ww if (src1 is None or src0.shape[1] % 16 == 0) else None, **kw)
         coutp = p.coutp
-        if _WINO_FUSE_REDUCE and ww is not None and p.weight_wino and ops.conv_schedule(p) == 2:
+        sched = ops.conv_schedule(p) if (_WINO_FUSE_REDUCE and kw.get("deconv4") is None) else -1
+        # (KSW: fused statistics need the group inside a 32-column tile - wider groups keep the reduce pass, whose statistics take any width)
+        if sched == 2 or (sched == 1 and _KSW_FUSE_REDUCE and (gn is None or 32 % (cout // (gn[1] if len(gn) > 1 else 8)) == 0)):
             counters = self._tile_counters(src0.device)
             p.tile_counters, p.tile_counters_len = counters.data_ptr(), counters.numel()
         if gn is not None:
