@@ -374,14 +374,20 @@ def conv_roofline(model, ms_per_sampler_step):
     n_split = sum(1 for p in fam["winograd"] if ops.conv_plan(p)[1] > 1)
     rocprof = None
     if prof["kernel_stats"]:
+        # all conv_wino_kernel<false, ...> rows of the table: the plain instantiation and - since round 5 - the one that reduces its split-K
+        # slabs inside the launch (..., true>): calls / total_us are the 6th / 5th fields from the end
+        calls, total = 0, 0.0
         for ln in open(os.path.join(REPO_ROOT, prof["kernel_stats"])):
-            if ln.startswith("conv_wino_kernel<false"):
-                avg = float(ln.split()[-4])
-                rocprof = {"file": prof["kernel_stats"], "avg_us_per_launch": avg,
-                           "tflops_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3, 2),
-                           "frac_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                           "what": "KERNEL ONLY: the conv_wino_kernel rows of the table, without the split-K reduce launches"}
-                break
+            f = ln.split()
+            if ln.startswith("conv_wino_kernel<false") and len(f) >= 7:
+                calls, total = calls + int(f[-6]), total + float(f[-5])
+        if calls:
+            avg = total / calls
+            rocprof = {"file": prof["kernel_stats"], "avg_us_per_launch": round(avg, 2),
+                       "tflops_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3, 2),
+                       "frac_from_avg": round(w["gflop_per_step"] / (avg * w["launches"]) * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                       "what": "the conv_wino_kernel<false, ...> rows of the table (call-weighted): the kernel as launched - with the split-K "
+                               "slabs reduced inside the launch where the sequence below shows no conv_splitk_reduce behind it"}
     if rocprof and prof["step_sequence"]:
         red_us, red_n, prev = 0.0, 0, ""
         for ln in open(os.path.join(REPO_ROOT, prof["step_sequence"])):
@@ -404,10 +410,11 @@ def conv_roofline(model, ms_per_sampler_step):
         rows["direct"]["traffic"] = direct_traffic
         rows["direct"]["traffic_over_algorithmic"] = round(direct_traffic / max(1, rows["direct"]["algorithmic_bytes_per_step"]), 2)
     return {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) - the %d launches of one "
-                                       "sampler step TOGETHER WITH the %d conv_splitk_reduce_kernel passes that finish the split-K ones" % (w["launches"], n_split),
+                                       "sampler step; %d of them split K - their slabs are reduced inside the launch by the workgroup that draws a tile's last "
+                                       "ticket (conv_wino.hip FUSE), or by a conv_splitk_reduce_kernel pass where LFDM_WINO_FUSE_REDUCE=0" % (w["launches"], n_split),
             "achieved": w["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": w["frac"],
-            "frac_definition": "direct-form FLOPs of the family / in-situ time of (kernel + its split-K reduce passes) / peak; `rocprofv3` carries the "
-                               "kernel-only figure from the committed kernel table and the reduce passes that make up the difference",
+            "frac_definition": "direct-form FLOPs of the family / in-situ time of the launches incl. their split-K reduction (in-launch, or the reduce "
+                               "passes where there are any) / peak; `rocprofv3` carries the figure from the committed kernel table",
             "traffic": traffic, "traffic_unit": "HBM-side bytes per sampler step over the same launches incl. their reduce passes (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes, not live)",
             "traffic_source": traffic_src, "traffic_build": traffic_build,
             "traffic_is_of_this_build": bool(traffic_build) and traffic_build == __import__("cvpr23_lfdm_amd._build", fromlist=["x"]).source_fingerprint(),

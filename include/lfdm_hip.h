@@ -93,10 +93,14 @@ typedef struct lfdm_conv_params {
      the row and writes rstd*(x.W' - mean*ln_wsum) - algebraically LayerNorm(x)*gamma followed by W. */
   const float* ln_wsum;
   float ln_eps;
-  /* Optional in-launch split-K reduction (KSW schedule only): tile_counters_len zero-initialised words, at least one per
-     output tile (lfdm_conv2d_plan's tile_rows x 32/64 columns).  When given, the workgroup that finishes a tile's last
-     K slice sums the slabs in `partial` (fixed order) and runs the epilogue itself - no reduce launch; the counters
-     are left at zero again.  NULL / too short = separate reduce pass. */
+  /* Optional in-launch split-K reduction (Winograd F(2x2) schedule with 32-column workgroups, and the KSW schedule): tile_counters_len
+     zero-initialised words, at least one per output tile (lfdm_conv2d_plan's tile_rows - 128 / 160 - x 32/64 columns).  When given, the
+     workgroup that finishes a tile's last K slice sums the slabs in `partial` (slice order: bit-identical to the reduce pass) and runs the
+     epilogue itself - no reduce launch; the counters are left at zero again.  NULL / too short / an unsupported geometry = separate reduce
+     pass (lfdm_conv2d_plan's tile_rows says which: 16 = reduce pass).  The slabs cross workgroups as 8-byte agent-scope words (written
+     through, read past the per-XCD L2s): no scope fence.  With tile_counters the Winograd plan also splits 8..15-chunk reductions.
+     GroupNorm partial sums of a fused Winograd launch whose groups are wider than 32 channels occupy cg/32 chunk slots per tile block:
+     chunk = tile block * (cg / 32) + column part. */
   unsigned int* tile_counters;
   int tile_counters_len;
   /* Optional Winograd F(2x2,3x3) form of the SAME filter (3x3, stride 1, zero pad 1, even H and W, C0 % 16 == C1 % 16 == 0;
