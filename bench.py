@@ -389,15 +389,26 @@ def conv_roofline(model, ms_per_sampler_step):
                        "what": "the conv_wino_kernel<false, ...> rows of the table (call-weighted): the kernel as launched - with the split-K "
                                "slabs reduced inside the launch where the sequence below shows no conv_splitk_reduce behind it"}
     if rocprof and prof["step_sequence"]:
-        red_us, red_n, prev = 0.0, 0, ""
+        # the dispatch sequence of ONE sampler step from the same rocprofv3 trace: exactly the step's launches (the table's rows also hold the
+        # LFAE encoder / decoder launches of the same instantiation, which are larger) - the figure that must agree with the live in-situ one
+        red_us, red_n, prev, wn, wus = 0.0, 0, "", 0, 0.0
         for ln in open(os.path.join(REPO_ROOT, prof["step_sequence"])):
             f = ln.split()
             if len(f) < 5 or not f[0].isdigit():
                 continue
+            if f[1].startswith("conv_wino_kernel"):
+                wn, wus = wn + 1, wus + float(f[-2])
             if f[1].startswith("conv_splitk_reduce") and prev.startswith("conv_wino_kernel"):      # (incl. conv_splitk_reduce_vec_kernel<KS>)
                 red_us, red_n = red_us + float(f[-2]), red_n + 1
             prev = f[1]
-        with_red = avg * w["launches"] + red_us
+        if wn:
+            rocprof.update(table_avg_us_per_launch=rocprof["avg_us_per_launch"], avg_us_per_launch=round(wus / wn, 2), launches_in_sequence=wn,
+                           tflops_from_avg=round(w["gflop_per_step"] / wus * 1e3, 2),
+                           frac_from_avg=round(w["gflop_per_step"] / wus * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           what="avg_us_per_launch = the conv_wino_kernel launches of ONE sampler step in the committed dispatch sequence "
+                                "(rocprofv3 --kernel-trace); table_avg_us_per_launch = the call-weighted conv_wino_kernel<false, ...> rows of the "
+                                "kernel table, which also hold the larger LFAE encoder / decoder launches")
+        with_red = (wus if wn else avg * w["launches"]) + red_us
         rocprof.update(split_k_reduce_launches=red_n, split_k_reduce_us_per_step=round(red_us, 1), sequence_file=prof["step_sequence"],
                        frac_with_reduce_passes=round(w["gflop_per_step"] / with_red * 1e3 / FP32_MFMA_PEAK_TFLOPS, 4))
     try:
