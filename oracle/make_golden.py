@@ -247,6 +247,41 @@ def c3_steps_case(name, b=16, t=40, s=32, steps=(999, 500, 0)):
     save(name, b=b, t=t, s=s, steps=np.array(steps), input_seed=31, **out)
 
 
+def c3_full_schedule_case(name, b=2, t=40, s=32, hw=128, timesteps=1000, every=50, keep=(750, 500, 250)):
+    """BASELINE.json configs[2] END TO END: the reference's p_sample_loop (:748-759) over ALL 1000 timesteps (MHAD shape class,
+    40 frames, 32x32 latent, B = 2) on a recorded noise tape, then the per-frame LFAE decode of sample_one_video.  Besides the
+    final tensors the fixture keeps the state x_t ENTERING the steps t in `keep` (strided sub-tensor) and statistics / random
+    projections of x_t every `every` steps, so that a parity miss shows where the drift enters (~1 h on 8 cores)."""
+    m = reference_model(s, t, timesteps, timesteps)
+    assert not m.diffusion.is_ddim_sampling
+    img, cond = synth.inputs(b, hw)
+    m.set_sample_input(sample_img=img, sample_text=cond)
+    inner = m.diffusion.p_sample
+    trace = {}
+
+    def p_sample(x, tt, *a, **k):
+        step = int(tt[0])
+        if step % every == 0 or step in keep:
+            st, pr = probes(x)
+            trace["xt_stats_%d" % step], trace["xt_probes_%d" % step] = st, pr
+            if step in keep:
+                trace["xt_%d" % step] = x[:, :, ::8, ::4, ::4].clone()
+            print("c3 full schedule: entering t=%d  mean|x| %.4f" % (step, float(x.abs().mean())), flush=True)
+        return inner(x, tt, *a, **k)
+
+    m.diffusion.p_sample = p_sample
+    with patched_noise(synth.NoiseTape(11)), torch.no_grad():
+        m.sample_one_video(cond_scale=1.0)
+    vf = np.array([0, 20, 39])
+    pred = torch.cat((m.sample_vid_grid, m.sample_vid_conf * 2 - 1), dim=1)
+    st, pr = probes(pred)
+    so, po = probes(m.sample_out_vid)
+    save(name, b=b, t=t, s=s, hw=hw, steps=timesteps, timesteps=timesteps, noise_seed=11, video_frames=vf, every=every, keep=np.array(keep),
+         sample_vid_grid=m.sample_vid_grid[:, :, :, ::2, ::2], sample_vid_conf=m.sample_vid_conf[:, :, :, ::2, ::2],
+         sample_out_vid=m.sample_out_vid[:, :, vf][..., ::2, ::2], sample_warped_vid=m.sample_warped_vid[:, :, vf][..., ::2, ::2],
+         pred_stats=st, pred_probes=pr, out_stats=so, out_probes=po, **trace)
+
+
 def train_full_case(name, b=4, t=40, hw=128):
     """BASELINE.json configs[3] per-GPU shape class at full T: one reference training step (B=4, T=40, 128x128)."""
     labels = (["label a", "None", "label c", "label d"] * 2)[:b]
@@ -360,11 +395,12 @@ def main():
     ap.add_argument("--focus", action="store_true", help="only the fixtures of the branches no LFDM script takes: focus_present_mask (unet_tiny_focus), Generator(skips=False)")
     ap.add_argument("--lfae-train", choices=["tiny", "mug128", "both"], help="only the LFAE stage-1 training-step fixtures (lfae_train.py)")
     ap.add_argument("--train-flops", action="store_true", help="count the FLOPs of one reference training step (B=1, T=40, 128x128); writes nothing")
-    ap.add_argument("--full", choices=["c3", "c4", "c4b8", "c5", "c5d50", "c5b4"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
+    ap.add_argument("--full", choices=["c3", "c3full", "c4", "c4b8", "c5", "c5d50", "c5b4"], help="one full-size fixture of the other BASELINE.json configurations (minutes each)")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.full:
-        {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"), "c4": lambda: train_full_case("train_step_c4_b4_t40"),
+        {"c3": lambda: c3_steps_case("c3_ddpm_steps_b16"),
+         "c3full": lambda: c3_full_schedule_case("sample_ddpm1000_c3_b2"),      # configs[2]'s whole 1000-step schedule, ~1 h here "c4": lambda: train_full_case("train_step_c4_b4_t40"),
          "c4b8": lambda: train_full_case("train_step_c4_b8_t40", b=8),
          "c5": lambda: c5_case("sample_ddim10_c5_256"),
          "c5b4": lambda: c5_case("sample_ddim50_c5_256_b4", b=4, steps=50, stride=4),      # configs[4] at its per-GPU batch (32 videos over 8 GPUs), ~35 min here

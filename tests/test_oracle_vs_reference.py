@@ -145,3 +145,40 @@ def test_pixelwise_flow_predictor_matches_live_reference(use_deformed_source):
                                          use_deformed_source=use_deformed_source, num_blocks=2)
     for key in ("optical_flow", "occlusion_map"):
         assert float((got[key] - want[key]).abs().max()) < 2e-5, key
+
+
+def test_p_losses_tensor_cond_quirk_is_stated(monkeypatch):
+    """Bug-compatibility note (reference DM/modules/video_flow_diffusion.py:856-869): the single-GPU
+    `GaussianDiffusion.p_losses` binds `none_cond_mask` only when `cond` is a list of strings, so a TENSOR condition raises
+    UnboundLocalError in the reference (every reference script passes list[str]).  The drop-in is deliberately MORE permissive:
+    a tensor condition trains with `none_cond_mask = None` (cvpr23_lfdm_amd/diffusion.py p_losses) - what the reference's own
+    multi-GPU flavour does with a tensor (video_flow_diffusion_multiGPU.py, mask passed by the caller)."""
+    import synth
+    ref = reference_loader.load_reference()
+    b, t, s = 1, 2, 8
+    rm = ref.vfdm.FlowDiffusion(img_size=s, num_frames=t, sampling_timesteps=3, is_train=True, config_pth=synth.CONFIG, pretrained_pth="")
+    x0 = torch.zeros(b, 3, t, s, s)
+    fea = torch.zeros(b, 256, t, s, s)
+    tt = torch.zeros(b, dtype=torch.long)
+    cond = torch.zeros(b, 768)
+    with pytest.raises(UnboundLocalError):
+        rm.diffusion.p_losses(x0, tt, fea, cond=cond)
+
+    from cvpr23_lfdm_amd import FlowDiffusion
+    import cvpr23_lfdm_amd.unet_train as ut
+    om = FlowDiffusion(img_size=s, num_frames=t, sampling_timesteps=3, is_train=True, config_pth=synth.CONFIG, pretrained_pth="")
+    seen = {}
+
+    def fake_forward(unet, x_noisy, fea2d, tsteps, c, **kw):       # (no kernels here: the test states the host-side contract only)
+        seen.update(kw, cond=c)
+        return torch.zeros_like(x_noisy, requires_grad=True)
+
+    monkeypatch.setattr(ut, "unet_train_forward", fake_forward)
+    om.diffusion.use_dynamic_thres = False
+    om.unet.train()
+    loss = om.diffusion.p_losses(x0, tt, fea[:, :, 0], cond=cond, clip_denoised=False)
+    assert loss.dim() == 0 and seen["none_cond_mask"] is None and seen["cond"] is not None
+    seen.clear()
+    om.diffusion.text_encoder = lambda texts: cond
+    om.diffusion.p_losses(x0, tt, fea[:, :, 0], cond=["None"], clip_denoised=False)
+    assert seen["none_cond_mask"] == [True]
