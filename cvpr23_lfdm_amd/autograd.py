@@ -63,27 +63,60 @@ def _conv(x0, w4_direct, cout, kh, kw, n_img, hi, wi, *, weight_wino=None, **kw_
 _PACKS = {}
 
 
+def _view_geometry(weight, w4):
+    """(storage offset, shape, strides) of w4 inside weight's storage, or the view itself when it is a copy (a non-contiguous parameter):
+    the cache must not pin a deleted model's parameter storage through a strong reference to a view of it."""
+    if w4.untyped_storage().data_ptr() == weight.untyped_storage().data_ptr():
+        return (w4.storage_offset(), tuple(w4.shape), tuple(w4.stride()))
+    return w4
+
+
+def _live_view(weight, geo):
+    return geo if torch.is_tensor(geo) else weight.detach().as_strided(geo[1], geo[2], geo[0])
+
+
+def _purge_dead_packs():
+    for k in [k for k, v in _PACKS.items() if v[0]() is None]:
+        del _PACKS[k]
+
+
 def _pack_wino(weight, w4, dgrad=False, part=None):
     """ops.pack_wino_weight(w4) with a cache over the life of the weights: the frozen VGG-19 of LFAE stage-1 training convolves with the
     same 13 filters 8 times forward and 4 times backward per step, the region predictor runs three times per step - each use re-packed
     (1 290 pack launches per 5 steps, 4 % of a step).  Only leaf tensors (parameters) are cached, by object identity (a weak reference:
     an address can be re-used by another tensor); an entry is valid while neither torch (`_version`) nor a raw-pointer optimizer step
-    (params.weights_epoch) has written the tensor.  weight: the tensor the caller passed to the Function; w4: the view of it to pack."""
-    if not weight.is_leaf:
-        return ops.pack_wino_weight(w4, dgrad=dgrad)
+    (params.weights_epoch) has written the tensor.  weight: the tensor the caller passed to the Function; w4: the view of it to pack.
+    A stale entry of the same geometry is refilled IN PLACE and its tensor is never rebound: a captured hipGraph (LFAETrainer.step_graphed)
+    holds the pack's raw address, and an eager / eval forward, a load_state_dict or a second batch shape between two replays must not free
+    the memory it reads.  A pack that has to be allocated anew bumps params.buffers_epoch (captured graphs then re-capture)."""
+    # A cache entry belongs to a PERSISTENT tensor object: a parameter, or the zero-padded buffer a frozen parameter was copied into
+    # (lfae_train._PadParam hands out a fresh alias of that buffer per call and names the buffer in `_lfdm_pack_owner`).  Anything else
+    # (a non-leaf, a transient alias) is packed per call.
+    owner = getattr(weight, "_lfdm_pack_owner", None)
+    if owner is not None and weight.is_leaf and owner.data_ptr() == weight.data_ptr():
+        weight = owner
+    elif not weight.is_leaf or not (weight.requires_grad or isinstance(weight, torch.nn.Parameter)):
+        return ops.pack_wino_weight(w4, dgrad=dgrad)          # (a frozen non-parameter leaf: somebody's detached alias, a new object per call)
     import weakref
-    from .params import weights_epoch
+    from .params import bump_buffers_epoch, weights_epoch
     key = (id(weight), dgrad, part)
     # (a frozen tensor is in no optimizer: only torch writes - load_state_dict, .to() - can change it)
     tag = (weight._version, weights_epoch() if weight.requires_grad else -1, w4.data_ptr(), tuple(w4.shape))
     hit = _PACKS.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == tag:
-        return hit[2]
+    if hit is not None and hit[0]() is weight:
+        if hit[1] == tag:
+            return hit[2]
+        k, n = (w4.shape[0], w4.shape[1]) if dgrad else (w4.shape[1], w4.shape[0])
+        packed = hit[2]
+        if packed.device == w4.device and tuple(packed.shape) == (16, k // 16, (n + 31) // 32 * 32, 16):
+            ops.pack_wino_weight(w4, dgrad=dgrad, out=packed)
+            _PACKS[key] = (hit[0], tag, packed, _view_geometry(weight, w4))
+            return packed
     if len(_PACKS) > 2048:
-        for k in [k for k, v in _PACKS.items() if v[0]() is None]:
-            del _PACKS[k]
+        _purge_dead_packs()
     packed = ops.pack_wino_weight(w4, dgrad=dgrad)
-    _PACKS[key] = (weakref.ref(weight), tag, packed, w4)
+    _PACKS[key] = (weakref.ref(weight), tag, packed, _view_geometry(weight, w4))
+    bump_buffers_epoch()
     return packed
 
 
@@ -91,23 +124,31 @@ def repack_stale():
     """Re-pack every cached Winograd filter of a TRAINABLE weight whose pack is older than the last optimizer step - forward and data-gradient
     forms, all in ONE launch into their existing tensors (ops.pack_wino_weights_multi).  Call at the start of a training step's forward:
     the packs a step needs are the packs the previous step used, so after the first step the ~100 (DM) / ~80 (LFAE) per-filter pack launches
-    of a step become one.  Entries whose weight torch itself has rewritten (load_state_dict, .to()) are left to the per-call path."""
+    of a step become one.  Entries whose weight torch itself has rewritten (load_state_dict, .to()) are left to the per-call path (which
+    refills them in place); entries of deleted weights are dropped."""
     from .params import weights_epoch
     epoch = weights_epoch()
-    jobs, keys = [], []
-    for key, (ref, tag, packed, w4) in _PACKS.items():
+    jobs, keys, dead = [], [], False
+    for key, (ref, tag, packed, geo) in _PACKS.items():
         weight = ref()
-        if (weight is None or not weight.requires_grad or tag[1] == epoch or tag[0] != weight._version or
-                w4.data_ptr() != tag[2]):
+        if weight is None:
+            dead = True
+            continue
+        if not weight.requires_grad or tag[1] == epoch or tag[0] != weight._version:
+            continue
+        w4 = _live_view(weight, geo)
+        if w4.data_ptr() != tag[2]:
             continue
         jobs.append((w4, packed, key[1]))
         keys.append(key)
+    if dead:
+        _purge_dead_packs()
     if not jobs:
         return 0
     ops.pack_wino_weights_multi(jobs)
     for key in keys:
-        ref, tag, packed, w4 = _PACKS[key]
-        _PACKS[key] = (ref, (tag[0], epoch, tag[2], tag[3]), packed, w4)
+        ref, tag, packed, geo = _PACKS[key]
+        _PACKS[key] = (ref, (tag[0], epoch, tag[2], tag[3]), packed, geo)
     return len(jobs)
 
 

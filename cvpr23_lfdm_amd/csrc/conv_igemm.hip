@@ -920,7 +920,8 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
     // Winograd F(2x2): the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
     static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B knob)
     if (!on || pl.bn != 32 || pl.kgroups != 1 || p.groups > 1 || p.pool2 || p.gn_in_partial || p.cout != p.coutp || p.ldo % 4 != 0 ||
-        (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.partial) & 15) != 0 || (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
+        (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.partial) & 127) != 0 ||      // (slab rows of a column tile = whole 128-byte lines: lfdm_device.h)
+        (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
         (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
       return false;
     const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);

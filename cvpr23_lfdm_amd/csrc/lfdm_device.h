@@ -151,6 +151,17 @@ __device__ __forceinline__ void lfdm_ticket_reset(unsigned* c) {
 // Agent-scope words shared by the workgroups of ONE launch without a fence (cdna_hip_programming.md section 6 Guideline 16, the "8-byte agent
 // atomics on both sides" form: write-through sc1 stores, L1-bypassing loads): payload granules and arrival counters of the cooperative
 // split-K reduce + GroupNorm kernel (norm.hip).
+// WHAT THIS RESTS ON.  Relaxed agent-scope stores -> `s_waitcnt vmcnt(0)` -> relaxed ticket RMW -> relaxed agent-scope loads carry no
+// release / acquire, so the HIP / LLVM memory model promises no happens-before between payload and ticket.  The hand-off is correct on
+// gfx950 because of how that target lowers and executes it (MI355X_MICROARCH.md, "inter-workgroup visibility": sc1 stores are written
+// through and acknowledged at memory before vmcnt drops; sc1 loads and atomics are served past the per-XCD L2s; observed untorn for 8-byte
+// granules) - hardware behaviour validated on gfx950 / ROCm 7.2, not an architectural guarantee.  Hence the compile-time guard below (the
+// library is built for gfx950 only, _build.py), the 128-byte alignment the launchers demand of slab buffers (two column tiles on different
+// XCDs never share a cache line), and tests/test_ops_parity.py::test_wino_fused_reduce_stress (bit-equal to the separate reduce pass over
+// many launches under load).  A ticket array belongs to ONE stream: launches that share it must be ordered.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(LFDM_EMU_BUILD)
+#error "fence-free hand-off (lfdm_agent_store_u64 / lfdm_agent_load_u64 / lfdm_ticket_take) validated on gfx950 only: re-validate, or use LFDM_FENCE_RELEASE_AGENT / LFDM_FENCE_ACQUIRE_AGENT, before building for another target"
+#endif
 #if defined(LFDM_EMU_BUILD)
 static inline void lfdm_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned long long lfdm_agent_load_u64(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

@@ -121,7 +121,10 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
     double s = 0.0, q = 0.0;
     if (g < groups) {
       // four chunk loads in flight per lane (round 4: the one-load-per-trip walk paid an L2 round trip per chunk - 2.4 us of the launch
-      // at 320 chunks, tools/ubench/launch_floor.py); same summation order as before: k ascending per lane
+      // at 320 chunks, tools/ubench/launch_floor.py); same summation order as before: k ascending per lane.
+      // Round 6, measured and NOT kept: all of a lane's loads in flight at once (sixteen 64-bit-addressed loads: 56 -> 135 VGPRs = three
+      // waves per SIMD, +3.6 ms per video, profiles/r06_b_gn_merge_ab.txt) and eight per trip through a buffer descriptor with no single-
+      // load tail (64 VGPRs, still +1.4 ms per video, profiles/r06_c_gn_merge8_ab.txt): in situ the walk is not what the launch waits for.
       const float2* src = reinterpret_cast<const float2*>(partial) + ((int64_t)b * nchunk) * groups + g;
       int k = sub;
       for (; k + 3 * lpg < nchunk; k += 4 * lpg) {

@@ -24,7 +24,7 @@ class RegionPredictor(ParamTree):
     """LFAE/modules/region_predictor.py: same state-dict keys; forward = lfae_predictors.RegionPredictorExec
     (any number of frames per call)."""
 
-    def __init__(self, num_regions, num_channels, estimate_affine=True, **params):
+    def __init__(self, num_regions, num_channels, estimate_affine=False, **params):      # (region_predictor.py:34 default)
         super().__init__()
         pca_based = params.get("pca_based", False)       # (region_predictor.py:36 default; every LFDM yaml sets pca_based: true)
         build_tree(self, region_predictor_spec(num_regions=num_regions, num_channels=num_channels, estimate_affine=estimate_affine,
@@ -49,7 +49,7 @@ class BGMotionPredictor(ParamTree):
     def __init__(self, num_channels, **params):
         super().__init__()
         build_tree(self, bg_predictor_spec(num_channels=num_channels, **params))
-        self.bg_type = params.get("bg_type", "affine")
+        self.bg_type = params.get("bg_type", "zero")          # (bg_motion_predictor.py:20 default)
         if self.bg_type != "zero":
             from .params import BG_FC_BIAS
             with torch.no_grad():   # reference initialises fc to the identity transform (bg_motion_predictor.py:27-40)
@@ -57,7 +57,7 @@ class BGMotionPredictor(ParamTree):
 
         from .lfae_predictors import BGMotionPredictorExec
         self._exec = BGMotionPredictorExec(self, num_blocks=params.get("num_blocks", 5),
-                                           bg_type=params.get("bg_type", "affine"))
+                                           bg_type=self.bg_type)
 
     def forward(self, source_image, driving_image):
         return self._exec(source_image, driving_image)

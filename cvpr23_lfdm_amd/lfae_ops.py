@@ -30,9 +30,14 @@ def _state(dev):
 
 
 def _fix_acc(dev, n):
+    """The 64-bit scatter accumulator, grown on demand.  Growing it frees the old one, whose address a captured graph may hold
+    (LFAETrainer.step_graphed): params.buffers_epoch is bumped so that such graphs are captured again instead of scatter-adding into - and
+    zeroing - freed memory."""
     st = _state(dev)
     if st["fix"] is None or st["fix"].numel() < n:
+        from .params import bump_buffers_epoch
         st["fix"] = torch.zeros(n, dtype=torch.int64, device=dev)
+        bump_buffers_epoch()
     return st["fix"]
 
 

@@ -228,7 +228,7 @@ def svd2x2_sym_lapack(a, b, c):
 
 
 class RegionPredictorExec:
-    def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=True, pad=3, estimate_affine=True):
+    def __init__(self, tree, num_blocks=5, temperature=0.1, scale_factor=0.25, pca_based=False, pad=3, estimate_affine=False):      # (the reference constructor's defaults, region_predictor.py:33-35)
         self.tree, self.temperature, self.scale_factor, self.pca_based, self.pad = tree, temperature, scale_factor, pca_based, pad
         self.regression = bool(estimate_affine) and not pca_based          # FOMM-like `jacobian` head (region_predictor.py:43-49, 98-108)
         self.hg = HourglassExec(tree, "predictor.", num_blocks, in_pad_to=32)      # 3-channel image in a 32-wide buffer (the
@@ -285,7 +285,7 @@ class RegionPredictorExec:
 
 
 class BGMotionPredictorExec:
-    def __init__(self, tree, num_blocks=5, bg_type="affine"):
+    def __init__(self, tree, num_blocks=5, bg_type="zero"):
         if bg_type not in ("zero", "shift", "affine", "perspective"):
             raise ValueError("bg_type %r (the reference accepts 'zero', 'shift', 'affine', 'perspective')" % (bg_type,))
         self.tree, self.bg_type = tree, bg_type

@@ -9,12 +9,14 @@ through `autograd.ConvCL` (channels-last rows, Winograd where the channel counts
 slots), the same `torch.autograd.Function`s the DM training step uses.  What connects the convolutions stays on tensors in
 channels-last memory format, so entering / leaving a convolution is a view: BatchNorm with batch statistics (per rank, as the
 reference's nn.DataParallel replicas compute them with `use_sync_bn: False`), ReLU, 2x2 pooling, nearest up-sampling, softmax
-heat-maps, `grid_sample` warps and the 2x2 SVD (on the host, exactly as region_predictor.py:16-26 does it).  Parameters live in the
+heat-maps, `grid_sample` warps and the 2x2 SVD (on the device: `lfdm_svd2x2_sym_f32` with LAPACK's sign conventions and an analytic
+backward - region_predictor.py:16-26 round-trips through the host).  Parameters live in the
 same `ParamTree`s as on the sampling path (reference state-dict keys: a reference checkpoint loads, a checkpoint written here loads
 into the reference).  The optimizer is the flat fused Adam (betas (0.5, 0.999), LFAE/train.py:38-40) with the DM path's bucketed
 gradient all-reduce for one-process-per-GPU data parallelism.
 
-Only the pca_based / affine-background / RGB configuration the LFDM yaml files use is covered (like lfae_predictors.py).
+Covered: the RGB configurations of the LFDM yaml files and their switches - pca_based / estimate_affine (Jacobian head) region
+parameters, bg_type zero / shift / affine / perspective, use_deformed_source on or off (lfae_predictors.py); the AVD network is not.
 """
 import torch
 import torch.nn.functional as F
@@ -57,8 +59,12 @@ class _PadParam(Function):
         hit = _PAD_BUFFERS.get(key)
         if hit is None or hit[0]() is not p or hit[1].device != p.device:
             import weakref
+            if len(_PAD_BUFFERS) > 256:            # entries of deleted parameters (ids are re-used)
+                for k in [k for k, v in _PAD_BUFFERS.items() if v[0]() is None]:
+                    del _PAD_BUFFERS[k]
             hit = [weakref.ref(p), torch.zeros(shape, dtype=p.dtype, device=p.device), None]
             _PAD_BUFFERS[key] = hit
+            P.bump_buffers_epoch()
         ctx.sl = tuple(slice(0, n) for n in p.shape)
         # (valid while neither torch nor a raw-pointer optimizer step has written p - the tag of autograd._pack_wino; a second use in the
         # same step - the frozen VGG filters, eight times - must not write the buffer again: earlier uses have saved it for their backward)
@@ -66,7 +72,9 @@ class _PadParam(Function):
         if hit[2] != tag:
             hit[1][ctx.sl].copy_(p)
             hit[2] = tag
-        return hit[1].detach()
+        out = hit[1].detach()
+        out._lfdm_pack_owner = hit[1]        # autograd._pack_wino: the persistent tensor a cached Winograd pack of this alias belongs to
+        return out
 
     @staticmethod
     def backward(ctx, d):
@@ -243,7 +251,7 @@ def region_predictor_forward(tree, x, cfg, training=True, segments=1):
     mean = (r * grid).sum(dim=(2, 3))
     if not cfg.get("pca_based", False):           # region_predictor.py:98-108: the regression head, or centres + heat-maps only
         out = {"shift": mean, "heatmap": region}
-        if cfg.get("estimate_affine", True):
+        if cfg.get("estimate_affine", False):
             jmap = net.conv(fmap, "jacobian.", cfg.get("pad", 3)).reshape(shp[0], 1, 4, shp[2] * shp[3])
             jac = (region.reshape(shp[0], shp[1], 1, -1) * jmap).sum(dim=-1).view(shp[0], shp[1], 2, 2)
             out["affine"] = jac
@@ -261,7 +269,7 @@ def region_predictor_forward(tree, x, cfg, training=True, segments=1):
 
 def bg_predictor_forward(tree, source, driving, cfg, training=True):
     """BGMotionPredictor.forward (bg_motion_predictor.py:42-57) -> (B, 3, 3): identity ('zero'), translation, affine or perspective."""
-    bg_type = cfg.get("bg_type", "affine")
+    bg_type = cfg.get("bg_type", "zero")
     bs = source.shape[0]
     if bg_type == "zero":
         return torch.eye(3, dtype=source.dtype, device=source.device).unsqueeze(0).repeat(bs, 1, 1)
@@ -572,6 +580,12 @@ class LFAETrainer:
         noise = transform_noise if transform_noise is not None else self.draw_transform_noise(bs)
         if g is None:
             g = self._graphs[key] = {"warm": 0}
+        if "graph" in g and g["buffers_epoch"] != P.buffers_epoch():
+            # a filter pack or the scatter accumulator was (re)allocated since the capture (an eager / eval forward of another shape, a
+            # new model, a larger batch): the graph holds raw addresses of the old buffers - capture again on the live ones
+            for k in ("graph", "losses", "generated", "loss", "grads"):
+                g.pop(k, None)
+            g["warm"] = 1
         if "graph" not in g:
             if g["warm"] < 2:                          # eager warm-up steps (they are real training steps) - on a SIDE stream, as torch's
                 g["warm"] += 1                         # whole-network capture recipe asks: the AccumulateGrad nodes must not be born on the default stream
@@ -593,6 +607,9 @@ class LFAETrainer:
                 loss = sum(v.mean() for v in losses.values())
                 loss.backward()
             g["graph"], g["losses"], g["generated"], g["loss"] = graph, losses, generated, loss
+            g["buffers_epoch"] = P.buffers_epoch()
+            # the graph reads these through raw addresses: keep them alive for as long as it can be replayed
+            g["held"] = ([v[2] for v in A._PACKS.values()], [v[1] for v in _PAD_BUFFERS.values()], dict(L._state(dev)))
             g["grads"] = [p.grad for grp in self.optimizer.param_groups for p in grp["params"]]      # the capture's gradient tensors
             graph.replay()                              # (capturing records the launches, it does not run them)
         else:
@@ -725,7 +742,7 @@ def build_from_config(config):
     mp = config["model_params"]
     gen = Generator(num_regions=mp["num_regions"], num_channels=mp["num_channels"], revert_axis_swap=mp.get("revert_axis_swap", True),
                     **mp["generator_params"])
-    reg = RegionPredictor(num_regions=mp["num_regions"], num_channels=mp["num_channels"], estimate_affine=mp.get("estimate_affine", True),
+    reg = RegionPredictor(num_regions=mp["num_regions"], num_channels=mp["num_channels"], estimate_affine=mp["estimate_affine"],      # (LFAE/run_mug.py:100 reads the key unconditionally)
                           **mp["region_predictor_params"])
     bgp = BGMotionPredictor(num_channels=mp["num_channels"], **mp["bg_predictor_params"])
     return gen, reg, bgp

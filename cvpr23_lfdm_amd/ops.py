@@ -198,11 +198,12 @@ def pack_ln_conv_weight(w, gamma):
     return packed, wsum
 
 
-def pack_wino_weight(w, coutp=None, dgrad=False):
+def pack_wino_weight(w, coutp=None, dgrad=False, out=None):
     """(Cout, Cin, 3, 3) -> Winograd F(2x2,3x3) filters U = G g G^T as [16][K/16][coutp][16] (position, reduction-channel
     chunk, output channel, channel in chunk) - the operand order conv_wino.hip loads (lfdm_conv_params.weight_wino).
     dgrad=True: the filters of the data-gradient convolution dY -> dX (channel roles exchanged, taps flipped);
-    `w` may be a slice w[:, lo:hi] of the input-channel axis (no copy).  lfdm_pack_wino_weight_f32."""
+    `w` may be a slice w[:, lo:hi] of the input-channel axis (no copy).  out: an existing pack of this geometry to refill IN PLACE
+    (its address may be held by a captured graph).  lfdm_pack_wino_weight_f32."""
     lib = _lib()
     if w.dim() == 5:
         w = w[:, :, 0]
@@ -212,8 +213,10 @@ def pack_wino_weight(w, coutp=None, dgrad=False):
     _chk(lib, w)
     k, n = (cout, cin) if dgrad else (cin, cout)
     assert k % 16 == 0
-    coutp = coutp or (n + 31) // 32 * 32
-    out = torch.empty(16, k // 16, coutp, 16, dtype=torch.float32, device=w.device)
+    coutp = coutp or (out.shape[2] if out is not None else (n + 31) // 32 * 32)
+    if out is None:
+        out = torch.empty(16, k // 16, coutp, 16, dtype=torch.float32, device=w.device)
+    assert tuple(out.shape) == (16, k // 16, coutp, 16) and out.is_contiguous() and out.device == w.device
     lib.check(lib.lfdm_pack_wino_weight_f32(_p(w), w.stride(0), cout, cin, coutp, int(dgrad), _p(out), _stream(lib)),
               "lfdm_pack_wino_weight_f32")
     return out

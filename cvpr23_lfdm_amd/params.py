@@ -25,6 +25,20 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
+_BUFFERS_EPOCH = [0]
+
+
+def buffers_epoch():
+    """Counts (re)allocations of persistent device buffers whose RAW POINTERS a captured hipGraph may hold without owning them (cached
+    Winograd filter packs of autograd._pack_wino, the fixed-point scatter accumulator of lfae_ops): a graph captured at another epoch must
+    be captured again (LFAETrainer.step_graphed)."""
+    return _BUFFERS_EPOCH[0]
+
+
+def bump_buffers_epoch():
+    _BUFFERS_EPOCH[0] += 1
+
+
 class ParamTree(nn.Module):
     def _walk(self, parts, create):
         node = self
@@ -284,9 +298,10 @@ def _hourglass_entries(prefix, block_expansion, in_features, num_blocks, max_fea
 
 
 def region_predictor_spec(num_regions=10, num_channels=3, block_expansion=32, max_features=1024,
-                          num_blocks=5, scale_factor=0.25, estimate_affine=True, pca_based=True, **_):
+                          num_blocks=5, scale_factor=0.25, estimate_affine=False, pca_based=False, **_):
     """RegionPredictor state-dict layout (LFAE/modules/region_predictor.py:28-50); the FOMM-like regression head `jacobian` exists when
-    estimate_affine and not pca_based (:43-49)."""
+    estimate_affine and not pca_based (:43-49).  estimate_affine / pca_based default as the reference constructor does (:34-35): a tree
+    built from a yaml without those keys has the reference's keys."""
     spec = _hourglass_entries("predictor.", block_expansion, num_channels, num_blocks, max_features)
     spec += _conv_entries("regions.", num_regions, block_expansion + num_channels, 7, 7)
     if estimate_affine and not pca_based:
@@ -300,8 +315,8 @@ BG_FC_OUT = {"shift": 2, "affine": 6, "perspective": 8}        # bg_motion_predi
 BG_FC_BIAS = {"shift": (0, 0), "affine": (1, 0, 0, 0, 1, 0), "perspective": (1, 0, 0, 0, 1, 0, 0, 0)}
 
 
-def bg_predictor_spec(num_channels=3, block_expansion=32, max_features=1024, num_blocks=5, bg_type="affine", **_):
-    """BGMotionPredictor state-dict layout (LFAE/modules/bg_motion_predictor.py:15-40) for every bg_type the reference accepts."""
+def bg_predictor_spec(num_channels=3, block_expansion=32, max_features=1024, num_blocks=5, bg_type="zero", **_):
+    """BGMotionPredictor state-dict layout (LFAE/modules/bg_motion_predictor.py:15-40) for every bg_type the reference accepts (default 'zero', :20)."""
     if bg_type == "zero":
         return []
     if bg_type not in BG_FC_OUT:

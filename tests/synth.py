@@ -19,13 +19,13 @@ def generator_state(seed=4321):
 
 
 def region_state(seed=5151):
-    return P.synthetic_state_dict(P.region_predictor_spec(), seed)
+    return P.synthetic_state_dict(P.region_predictor_spec(pca_based=True), seed)      # (configs/lfae_128.yaml)
 
 
 def bg_state(seed=6161):
     """fc near the reference's identity-affine initialisation (bg_motion_predictor.py:33-39) so the background
     transform is a small perturbation of the identity rather than a degenerate random matrix."""
-    sd = P.synthetic_state_dict(P.bg_predictor_spec(), seed)
+    sd = P.synthetic_state_dict(P.bg_predictor_spec(bg_type="affine"), seed)
     sd["fc.weight"] = sd["fc.weight"] * 0.02
     sd["fc.bias"] = torch.tensor([1, 0, 0, 0, 1, 0], dtype=torch.float32) + 0.2 * sd["fc.bias"]
     return sd

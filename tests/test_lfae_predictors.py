@@ -215,3 +215,18 @@ def test_region_predictor_large_heatmaps(backend):
     assert got["heatmap"].shape[-2:] == (68, 72)
     for key in ("shift", "covar", "affine", "heatmap"):
         assert_close(got[key].cpu(), ref[key], 1e-3, "large-map region predictor: " + key)
+
+
+def test_constructor_defaults_are_the_reference_ones():
+    """A yaml without estimate_affine / pca_based / bg_type builds the reference's module tree (region_predictor.py:33-35: estimate_affine
+    False, pca_based False; bg_motion_predictor.py:20: bg_type 'zero' = no parameters), the same in every place that reads the keys - the
+    state dict then loads into a reference model built from the same yaml."""
+    from cvpr23_lfdm_amd import params as P
+    from cvpr23_lfdm_amd.flow_diffusion import BGMotionPredictor, RegionPredictor
+    kw = dict(block_expansion=8, max_features=32, num_blocks=2, temperature=0.1, scale_factor=0.25)
+    net = RegionPredictor(num_regions=4, num_channels=3, **kw)
+    assert not net.has("jacobian.weight") and not net._exec.regression and not net._exec.pca_based
+    assert [k for k, *_ in P.region_predictor_spec(num_regions=4, num_channels=3, **kw)] == list(net.state_dict().keys())
+    bg = BGMotionPredictor(num_channels=3, block_expansion=8, max_features=32, num_blocks=2)
+    assert bg.bg_type == "zero" and bg._exec.bg_type == "zero" and len(bg.state_dict()) == 0
+    assert P.bg_predictor_spec(num_channels=3) == []

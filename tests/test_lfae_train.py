@@ -210,3 +210,54 @@ def test_graphed_step_equals_eager_step():
     pa = torch.cat([p.detach().reshape(-1) for p in ta.optimizer.param_groups[0]["params"]])
     pb = torch.cat([p.detach().reshape(-1) for p in tb.optimizer.param_groups[0]["params"]])
     assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())
+
+
+@pytest.mark.gpu
+def test_graphed_step_survives_foreign_work_between_replays():
+    """The captured graph holds raw addresses of buffers it does not own (cached Winograd filter packs, the fixed-point scatter accumulator,
+    the padded-parameter buffers).  Between two replays: an eval forward, a load_state_dict (torch rewrites every weight: the per-call path
+    must refill the packs IN PLACE), an eager step of a LARGER batch (the accumulator grows: the graph must be captured again, not replayed
+    on freed memory) - and the graphed trainer must still equal the eager one that saw the same sequence."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cvpr23_lfdm_amd import autograd as A
+    dev = "cuda"
+    ta, (mp, tp, hw, b) = _build("tiny", dev)
+    tb, _ = _build("tiny", dev)
+    g = torch.Generator().manual_seed(6)
+    draw = lambda n: (torch.rand(n, 3, hw, hw, generator=g).to(dev), torch.rand(n, 3, hw, hw, generator=g).to(dev))
+
+    def both(n, graphed=True):
+        src, drv = draw(n)
+        noise = ta.draw_transform_noise(n)
+        la, _ = ta.step({"source": src, "driving": drv}, transform_noise=noise)
+        lb, _ = (tb.step_graphed if graphed else tb.step)({"source": src, "driving": drv}, transform_noise=noise)
+        for k in la:
+            assert abs(float(la[k]) - float(lb[k])) <= 1e-5 * max(1.0, abs(float(la[k]))), (k, float(la[k]), float(lb[k]))
+
+    for _ in range(4):
+        both(b)
+    key = next(iter(tb._graphs))
+    assert "graph" in tb._graphs[key]
+    packs_before = {k: v[2].data_ptr() for k, v in A._PACKS.items()}
+    # (1) eval forward in between
+    for t in (ta, tb):
+        t.model.training = False                 # (ReconstructionModel is a plain object: `training` selects BatchNorm's running statistics)
+        with torch.no_grad():
+            src, drv = draw(b)
+            t.model({"source": src, "driving": drv}, transform_noise=ta.draw_transform_noise(b))
+        t.model.training = True
+    both(b)
+    # (2) load_state_dict: same values, but torch bumps every _version -> every cached pack is stale by tag
+    for t in (ta, tb):
+        for net in (t.generator, t.region_predictor, t.bg_predictor):
+            net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    both(b)
+    assert all(A._PACKS[k][2].data_ptr() == p for k, p in packs_before.items() if k in A._PACKS), "a cached pack was rebound, not refilled"
+    # (3) an eager step of twice the batch (grows the scatter accumulator), then graphed steps of the captured shape again
+    both(2 * b, graphed=False)
+    both(b)
+    both(b)
+    pa = torch.cat([p.detach().reshape(-1) for p in ta.optimizer.param_groups[0]["params"]])
+    pb = torch.cat([p.detach().reshape(-1) for p in tb.optimizer.param_groups[0]["params"]])
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())

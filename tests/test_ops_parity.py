@@ -9,6 +9,8 @@ import ctypes
 import math
 import os
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1305,3 +1307,60 @@ def test_conv_winograd_splitk_reduced_in_launch(backend, case):
         ref = F.group_norm(conv.view(b, t, cout, s, s).permute(0, 2, 1, 3, 4), groups, gamma, beta, eps=1e-5)
         assert_close(gn.cpu().view(b, t, s, s, cout).permute(0, 4, 1, 2, 3), ref, TOL, "group norm from the partial sums, fused=%s" % fused)
     assert torch.equal(outs[0], outs[1]), "in-launch reduction must equal the reduce pass bit for bit"
+
+
+@pytest.mark.gpu
+def test_wino_fused_reduce_stress():
+    """The fence-free in-launch split-K hand-off (conv_wino.hip FUSE; csrc/lfdm_device.h states what it rests on) under UNEVEN load: 60 launches
+    of seeded random geometry (4x4 / 8x8 / 16x16 images, 128-512 reduction channels, ksplit 2-8, with and without residual) while a second
+    stream keeps the memory system busy with large copies, each compared BIT FOR BIT with the separate reduce pass (same summation order);
+    the ticket words must be back at zero after every launch, and a slab buffer that is not 128-byte aligned must fall back to the reduce
+    launch (two column tiles on different XCDs must never share a cache line)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cvpr23_lfdm_amd import _native
+    _native._set_library_for_tests(None)
+    dev = "cuda"
+    rng = np.random.Generator(np.random.PCG64(2025))
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(64 << 20, device=dev), torch.empty(64 << 20, device=dev)       # 256 MB each
+    counters = torch.zeros(1024, dtype=torch.int32, device=dev)
+    worst = 0
+    for it in range(60):
+        s = int(rng.choice([4, 8, 16]))
+        cin = int(rng.choice([128, 256, 384, 512]))
+        cout = int(rng.choice([64, 128, 256]))
+        n = int(rng.integers(3, 41))
+        ks = int(rng.integers(2, 9))
+        x = torch.from_numpy(rng.standard_normal((n * s * s, cin)).astype(np.float32)).to(dev)
+        wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(9 * cin)).astype(np.float32)).to(dev)
+        bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
+        res = torch.from_numpy(rng.standard_normal((n * s * s, cout)).astype(np.float32)).to(dev) if it % 2 else None
+        w, ww = ops.pack_conv_weight(wt.cpu()).to(dev), ops.pack_wino_weight(wt)
+        kw = dict(bias=bias, weight_wino=ww, ksplit=ks, residual=res, act=3 if it % 3 == 0 else 0)
+        pp, _ = ops.conv_params(x, w, cout, 3, 3, n, s, s, tile_counters=counters, **kw)
+        if ops.conv_schedule(pp) != 2 or ops.conv_plan(pp)[1] != ks:
+            continue
+        plain = ops.conv2d_cl(x, w, cout, 3, 3, n, s, s, **kw).clone()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # uneven load on the memory system while the fused launches run
+            for _ in range(3):
+                big_b.copy_(big_a)
+        for rep in range(3):
+            fused = ops.conv2d_cl(x, w, cout, 3, 3, n, s, s, tile_counters=counters, **kw)
+            diff = int((fused.view(torch.int32) != plain.view(torch.int32)).sum())
+            worst = max(worst, diff)
+            assert diff == 0, "launch %d rep %d: %d words differ from the reduce pass (s=%d cin=%d cout=%d n=%d ksplit=%d)" % (it, rep, diff, s, cin, cout, n, ks)
+        torch.cuda.current_stream().wait_stream(side)
+        assert int(counters.abs().sum()) == 0
+    # a misaligned slab buffer: the planner must not take the in-launch path (tile rows fall back to the reduce pass's 16)
+    x = torch.randn(16 * 16, 256, device=dev)
+    wt = torch.randn(64, 256, 3, 3, device=dev) / 48
+    w, ww = ops.pack_conv_weight(wt.cpu()).to(dev), ops.pack_wino_weight(wt)
+    pp, keep = ops.conv_params(x, w, 64, 3, 3, 16, 4, 4, weight_wino=ww, ksplit=4, tile_counters=counters)
+    pp.gn_partial = 1
+    slab = torch.empty(4 * 256 * 64 + 64, device=dev)
+    pp.partial = slab.data_ptr()
+    assert slab.data_ptr() % 128 == 0 and ops.conv_plan(pp)[0] == 128
+    pp.partial = slab.data_ptr() + 16
+    assert ops.conv_plan(pp)[0] == 16
