@@ -676,7 +676,17 @@ def cpu_baseline():
             O.generator_forward_with_flow(gsd, img, flow, occ)
         t_dec = (time.perf_counter() - t0) / n_dec
     per_video = WORKLOAD["sampling_timesteps"] * t_unet + t_fea + t * t_dec
+    calib = None                 # the port timed beside the reference itself on the same cores (tests/test_oracle_vs_reference.py, build container)
+    try:
+        with open(os.path.join(REPO_ROOT, "profiles", "port_vs_reference_cpu.json")) as f:
+            calib = json.load(f)
+    except (OSError, ValueError):
+        pass
     return {"value": round(b / per_video, 6), "unit": "videos/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "port_over_reference": calib["port_over_reference"] if calib else None,
+            "port_over_reference_note": ("one UNet forward at this shape, port / unmodified reference, best of 3 each, interleaved on the same %d torch threads of "
+                                         "the %d-CPU build container (profiles/port_vs_reference_cpu.json): the port's videos/s times this ratio is what the "
+                                         "reference itself would give on these cores" % (calib["threads"], calib["host_cpus"])) if calib else None,
             "thread_sweep_s_per_8_frame_unet_forward": {str(k): round(v, 3) for k, v in sweep.items()},
             "reference_figure": "SURVEY.md 6: the reference itself (its own code, torch CPU) takes 1.56 s per UNet forward of this shape on the 8 cores of "
                                 "the build container (0.0053-0.0061 videos/s); /root/reference does not travel to the GPU box, so what is timed here is the PORT (kind = 'port')",

@@ -124,8 +124,8 @@ def repack_stale():
     """Re-pack every cached Winograd filter of a TRAINABLE weight whose pack is older than the last optimizer step - forward and data-gradient
     forms, all in ONE launch into their existing tensors (ops.pack_wino_weights_multi).  Call at the start of a training step's forward:
     the packs a step needs are the packs the previous step used, so after the first step the ~100 (DM) / ~80 (LFAE) per-filter pack launches
-    of a step become one.  Entries whose weight torch itself has rewritten (load_state_dict, .to()) are left to the per-call path (which
-    refills them in place); entries of deleted weights are dropped."""
+    of a step become one.  Entries whose weight torch itself has rewritten in place (load_state_dict, copy_) are rebuilt here as well;
+    entries of deleted weights are dropped."""
     from .params import weights_epoch
     epoch = weights_epoch()
     jobs, keys, dead = [], [], False
@@ -134,21 +134,26 @@ def repack_stale():
         if weight is None:
             dead = True
             continue
-        if not weight.requires_grad or tag[1] == epoch or tag[0] != weight._version:
+        if tag[0] == weight._version and (not weight.requires_grad or tag[1] == epoch):
+            continue
+        # stale by the optimizer's epoch OR because torch rewrote the tensor (load_state_dict / copy_: `_version`).  The second kind used to
+        # be left to the per-call path - which a REPLAYED graph never runs: a load_state_dict between two replays left the captured step
+        # convolving with the filters of before (tests/test_lfae_train.py::test_graphed_step_survives_foreign_work_between_replays).
+        if torch.is_tensor(geo):              # (the packed view was a COPY of a non-contiguous parameter: only the per-call path can rebuild it)
             continue
         w4 = _live_view(weight, geo)
-        if w4.data_ptr() != tag[2]:
+        if w4.device != packed.device or tuple(w4.shape) != tag[3]:
             continue
         jobs.append((w4, packed, key[1]))
-        keys.append(key)
+        keys.append((key, w4.data_ptr(), weight._version))
     if dead:
         _purge_dead_packs()
     if not jobs:
         return 0
     ops.pack_wino_weights_multi(jobs)
-    for key in keys:
+    for key, ptr, version in keys:
         ref, tag, packed, geo = _PACKS[key]
-        _PACKS[key] = (ref, (tag[0], epoch, tag[2], tag[3]), packed, geo)
+        _PACKS[key] = (ref, (version, epoch if ref().requires_grad else -1, ptr, tag[3]), packed, geo)
     return len(jobs)
 
 

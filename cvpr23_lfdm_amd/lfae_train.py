@@ -84,6 +84,22 @@ class _PadParam(Function):
 _PAD_BUFFERS = {}
 
 
+def refresh_pad_buffers():
+    """Bring every padded-parameter buffer up to date with its parameter (what _PadParam.forward does at its next use) - for callers that
+    REPLAY a captured forward: a replay runs no Python, so a parameter torch has rewritten since the capture (load_state_dict) would be
+    read through a stale buffer."""
+    for key, hit in list(_PAD_BUFFERS.items()):
+        p = hit[0]()
+        if p is None:
+            del _PAD_BUFFERS[key]
+            continue
+        tag = (p._version, P.weights_epoch() if p.requires_grad else -1, p.data_ptr())
+        if hit[2] != tag and hit[1].device == p.device:
+            with torch.no_grad():
+                hit[1][tuple(slice(0, n) for n in p.shape)].copy_(p)
+            hit[2] = tag
+
+
 def conv2d(x, weight, bias, padding, relu=False, residual=None):
     """nn.Conv2d (stride 1, square kernel) through the native kernels.  x: (N, C, H, W); returns a channels-last (N, O, H', W').
     Channel counts that are not multiples of 4 (RGB inputs, the region / mask / occlusion / RGB heads) are zero-padded (_PadParam).
@@ -618,6 +634,7 @@ class LFAETrainer:
             g["theta"].copy_(noise[0])
             if g["tps"] is not None:
                 g["tps"].copy_(noise[1])
+            refresh_pad_buffers()
             A.repack_stale()
             # autograd does not run on a replay: hand every parameter the gradient tensor the captured backward writes
             for p, gr in zip((p for grp in self.optimizer.param_groups for p in grp["params"]), g["grads"]):

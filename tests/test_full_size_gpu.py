@@ -96,14 +96,14 @@ def test_c4_training_step_t40(monkeypatch, fixture):
     assert_close(sub(m.real_vid_conf), T("real_vid_conf"), 1e-3, "pseudo-GT occlusion")
     st, pr = probes(m.real_vid_grid)
     assert_close(st.float(), T("grid_stats").float(), 1e-3, "flow statistics")
-    assert_close(pr.float(), T("grid_probes").float(), 2e-3, "flow projections")
+    assert_close(pr.float(), T("grid_probes").float(), 1e-3, "flow projections")
     assert bool((m.unet.null_cond_mask.cpu() == T("null_cond_mask")).all())
-    assert_close(sub(m.diffusion.pred_x0), T("pred_x0"), 2e-3, "pred_x0")
+    assert_close(sub(m.diffusion.pred_x0), T("pred_x0"), 1e-3, "pred_x0")
     st, pr = probes(m.diffusion.pred_x0)
-    assert_close(st.float(), T("pred_x0_stats").float(), 2e-3, "pred_x0 statistics")
-    assert_close(pr.float(), T("pred_x0_probes").float(), 3e-3, "pred_x0 projections")
+    assert_close(st.float(), T("pred_x0_stats").float(), 1e-3, "pred_x0 statistics")
+    assert_close(pr.float(), T("pred_x0_probes").float(), 1e-3, "pred_x0 projections")
     assert_close(m.real_out_vid[:, :, -1, ::2, ::2].cpu(), T("real_out_vid"), 1e-3, "real_out_vid")
-    assert_close(m.fake_out_vid[:, :, -1, ::2, ::2].cpu(), T("fake_out_vid"), 2e-3, "fake_out_vid")
+    assert_close(m.fake_out_vid[:, :, -1, ::2, ::2].cpu(), T("fake_out_vid"), 1e-3, "fake_out_vid")
     for k in ("loss", "rec_loss", "rec_warp_loss"):
         got, want = float(getattr(m, k)), float(g[k])
         record_margin(k, abs(got - want), abs(want), 1e-3)
@@ -122,8 +122,8 @@ def test_c4_training_step_t40(monkeypatch, fixture):
                        ("updated weight norm", abs(float(p.detach().double().norm()) - float(g["param_norm_after"][i])) / (float(g["param_norm_after"][i]) + 1e-12))):
             if e > worst[1]:
                 worst = ("%s of %s" % (tag, k), e)
-    record_margin("largest relative deviation over all parameter gradients / updated weights: " + worst[0], worst[1], 1.0, 5e-3)
-    assert worst[1] < 5e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
+    record_margin("largest relative deviation over all parameter gradients / updated weights: " + worst[0], worst[1], 1.0, 1e-3)
+    assert worst[1] < 1e-3, "largest deviation %.3e: %s" % (worst[1], worst[0])
 
 
 @pytest.mark.parametrize("fixture", ["sample_ddim10_c5_256", "sample_ddim50_c5_256", "sample_ddim50_c5_256_b4"])      # 10 steps, the configuration's own 50, and
@@ -147,3 +147,72 @@ def test_c5_natops_256_t40(fixture):                                            
     st, pr = probes(m.sample_out_vid)
     assert_close(st.float(), T("out_stats").float(), 1e-3, "video statistics")
     assert_close(pr.float(), T("out_probes").float(), 2e-3, "video projections")
+
+
+def test_c3_ddpm1000_full_schedule():
+    """BASELINE.json configs[2] END TO END: `p_sample_loop` (DM/modules/video_flow_diffusion.py:712-759) over ALL 1000 timesteps - the one
+    BASELINE sampler whose whole schedule had only been pinned by teacher-forced steps (test_c3_ddpm_steps_batch16) - at B = 2, T = 40,
+    32x32 latent, on the recorded noise tape the reference fixture was minted with (oracle/make_golden.py --full c3full), then the
+    40-frame LFAE decode.  Besides the final tensors the fixture holds the state x_t ENTERING t = 750 / 500 / 250 and statistics / random
+    projections of x_t every 50 steps: the error-vs-step curve goes to the parity log (profiles/*_parity_margins.json, and
+    profiles/r06_*_c3_drift.txt), so a miss would show where the drift enters.  Bar: 1e-3 (north star) on everything."""
+    g = gold("sample_ddpm1000_c3_b2")
+    b, t, s, hw, steps = int(g["b"]), int(g["t"]), int(g["s"]), int(g["hw"]), int(g["timesteps"])
+    m, _, _ = synth.build_flow_diffusion("cuda", img_size=s, num_frames=t, sampling_timesteps=steps, timesteps=steps)
+    assert not m.diffusion.is_ddim_sampling and steps == 1000
+    img, cond = synth.inputs(b, hw)
+    tape = synth.NoiseTape(int(g["noise_seed"]))
+    every, keep = int(g["every"]), [int(k) for k in g["keep"]]
+    seen, calls = {}, [0]
+
+    def source(shape):
+        # call 0 draws x_T; call k >= 1 draws the noise of the step at timestep steps - k, and the sampler's state buffer still holds the
+        # x_t ENTERING that step (one step per graph replay on a noise tape): what the reference's p_sample received
+        k = calls[0]
+        calls[0] += 1
+        step = steps - k
+        if k >= 1 and (step % every == 0 or step in keep):
+            x = next(iter(m.diffusion._plans.values()))["x"]
+            st, pr = probes(x)
+            seen[step] = (st, pr, x[:, :, ::8, ::4, ::4].cpu().clone() if step in keep else None)
+        return tape(shape)
+
+    m.diffusion.noise_source = source
+    m.set_sample_input(sample_img=img.cuda(), sample_text=cond.cuda())
+    m.sample_one_video(cond_scale=1.0)
+    assert calls[0] == steps + 1
+    T = lambda k: torch.from_numpy(g[k])
+    # ---- the drift curve first (recorded even if a later assertion fails): probes / statistics of x_t every `every` steps
+    curve = []
+    for step in sorted(seen, reverse=True):
+        st, pr, sub = seen[step]
+        e_st = float((st.float() - T("xt_stats_%d" % step).float()).abs().max())
+        e_pr = float((pr.float() - T("xt_probes_%d" % step).float()).abs().max())
+        scale = max(1.0, float(T("xt_probes_%d" % step).abs().max()))
+        record_margin("x_t projections entering t=%d" % step, e_pr, scale, 1e-3)
+        curve.append((step, e_st, e_pr, scale))
+    out = os.environ.get("LFDM_C3_DRIFT_OUT")
+    if out:
+        with open(out, "w") as f:
+            f.write("# DDPM-1000 (configs[2], B = 2, T = 40, 32x32): max |HIP - reference| of the per-sample statistics (mean, mean |x|, std) and of\n"
+                    "# 64 random unit-variance projections per sample of the sampler state x_t ENTERING timestep t; bar = 1e-3 * max(1, scale)\n"
+                    "# %6s %14s %14s %10s\n" % ("t", "err(stats)", "err(probes)", "scale"))
+            for step, e_st, e_pr, scale in curve:
+                f.write("  %6d %14.3e %14.3e %10.3f\n" % (step, e_st, e_pr, scale))
+    for step, e_st, e_pr, scale in curve:
+        assert e_st <= 1e-3 and e_pr <= 1e-3 * scale, "drift at t=%d: stats %.3e, projections %.3e (scale %.2f)" % (step, e_st, e_pr, scale)
+    for step in keep:
+        assert_close(seen[step][2], T("xt_%d" % step), 1e-3, "x_t entering t=%d (sub-tensor)" % step)
+    # ---- the end of the schedule and the decode
+    vf = torch.from_numpy(g["video_frames"]).long()
+    pred = torch.cat((m.sample_vid_grid, m.sample_vid_conf * 2 - 1), dim=1)
+    st, pr = probes(pred)
+    assert_close(st.float(), T("pred_stats").float(), 1e-3, "x_0 statistics after 1000 steps")
+    assert_close(pr.float(), T("pred_probes").float(), 1e-3, "x_0 projections after 1000 steps")
+    assert_close(m.sample_vid_grid[:, :, :, ::2, ::2].cpu(), T("sample_vid_grid"), 1e-3, "flow after 1000 steps")
+    assert_close(m.sample_vid_conf[:, :, :, ::2, ::2].cpu(), T("sample_vid_conf"), 1e-3, "occlusion after 1000 steps")
+    assert_close(m.sample_out_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_out_vid"), 1e-3, "frames")
+    assert_close(m.sample_warped_vid.cpu()[:, :, vf][..., ::2, ::2], T("sample_warped_vid"), 1e-3, "warped frames")
+    st, pr = probes(m.sample_out_vid)
+    assert_close(st.float(), T("out_stats").float(), 1e-3, "video statistics")
+    assert_close(pr.float(), T("out_probes").float(), 1e-3, "video projections")

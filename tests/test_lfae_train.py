@@ -33,7 +33,10 @@ def _build(kind, dev):
     return trainer, (mp, tp, hw, b)
 
 
-def _check(kind, dev, tol):
+def _check(kind, dev, tol, out_tol=None):
+    """tol: losses and gradient quantities (DESIGN.md section 4 says why those stay at 5e-3 on the GPU); out_tol: every generated tensor and
+    BatchNorm running statistic (default: tol)."""
+    out_tol = tol if out_tol is None else out_tol
     gold = np.load(os.path.join(GOLDEN, "lfae_train_%s.npz" % kind))
     trainer, (mp, tp, hw, b) = _build(kind, dev)
     src, drv, theta, tps = synth.lfae_train_inputs(b, hw, tp)
@@ -44,7 +47,7 @@ def _check(kind, dev, tol):
     for key, got in (("prediction", sub(gen["prediction"])), ("deformed", sub(gen["deformed"])), ("occlusion_map", gen["occlusion_map"]),
                      ("optical_flow", gen["optical_flow"]), ("driving_shift", gen["driving_region_params"]["shift"]),
                      ("driving_affine", gen["driving_region_params"]["affine"]), ("transformed_frame", sub(gen["transformed_frame"]))):
-        assert_close(got.detach().cpu(), torch.from_numpy(gold[key]), tol, key)
+        assert_close(got.detach().cpu(), torch.from_numpy(gold[key]), out_tol, key)
     nets = {"generator": trainer.generator, "region_predictor": trainer.region_predictor, "bg_predictor": trainer.bg_predictor}
     params = {n + "/" + k: p for n, net in nets.items() for k, p in net.named_parameters()}
     assert list(params) == [str(n) for n in gold["names"]]      # the reference's named_parameters() ORDER: its optimizer state (indexed by position) loads
@@ -73,7 +76,7 @@ def _check(kind, dev, tol):
             assert_close(params[key[5:]].grad.detach().cpu() / sc, ref / sc, 5 * tol, key)
         if key.startswith("bn/"):
             n, k = key[3:].split("/", 1)
-            assert_close(nets[n].state_dict()[k].cpu(), torch.from_numpy(gold[key]), tol, key)
+            assert_close(nets[n].state_dict()[k].cpu(), torch.from_numpy(gold[key]), out_tol, key)
     return worst
 
 
@@ -87,7 +90,7 @@ def test_lfae_train_step_tiny(backend):
 def test_lfae_train_step_mug128():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    _check("mug128", "cuda", 5e-3)
+    _check("mug128", "cuda", 5e-3, out_tol=1e-3)      # generated tensors / running statistics at the north star's 1e-3 (achieved: 1e-2 of that bar)
 
 
 def test_checkpoint_format_and_schedule():
@@ -243,9 +246,8 @@ def test_graphed_step_survives_foreign_work_between_replays():
     # (1) eval forward in between
     for t in (ta, tb):
         t.model.training = False                 # (ReconstructionModel is a plain object: `training` selects BatchNorm's running statistics)
-        with torch.no_grad():
-            src, drv = draw(b)
-            t.model({"source": src, "driving": drv}, transform_noise=ta.draw_transform_noise(b))
+        src, drv = draw(b)            # (no torch.no_grad(): the equivariance terms take autograd.grad of the transform inside the forward)
+        t.model({"source": src, "driving": drv}, transform_noise=ta.draw_transform_noise(b))
         t.model.training = True
     both(b)
     # (2) load_state_dict: same values, but torch bumps every _version -> every cached pack is stale by tag
