@@ -925,6 +925,7 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
         (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
       return false;
     const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+    if ((int64_t)pl.ksplit * M * p.coutp * 4 >= (1ll << 32) - 64) return false;      // (the slabs go through a buffer descriptor: 32-bit byte offsets)
     return (int64_t)p.tile_counters_len >= ((ntiles + 31) / 32) * (p.coutp / 32);
   }
   if (pl.kind != 1) return false;

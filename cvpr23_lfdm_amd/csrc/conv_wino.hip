@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   // (epilogue 4.7 -> measured in profiles/r02_*).  The plan only selects this schedule when float4 accesses are legal.
   // K groups: every group parks its planes in its own buffer; group 0 sums them while it reads and runs the epilogue alone
   float* const Ms = smem + kgrp * VSZ;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
+  // split-K slabs [ksplit][M][coutp] through a buffer descriptor with 32-bit byte offsets (splitk_fused checks the size)
+  const lfdm_buf slab_buf = lfdm_make_buf(FUSE && ksplit > 1 ? p.partial : nullptr, FUSE && ksplit > 1 ? (uint32_t)((int64_t)ksplit * M * p.coutp * 4) : 0u);
   const int e_tile = tid >> 3, e_c4 = tid & 7;
   float gs[NT][4], gq[NT][4];
 #pragma unroll
@@ -420,13 +422,10 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       for (int q = 0; q < 4; ++q) {
         const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
         if (ksplit > 1) {
-          float* dst = p.partial + ((int64_t)bz * M + orow) * p.coutp + co;
-          if (FUSE) {
-            unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
-            lfdm_agent_store_u64(d8, (unsigned long long)__float_as_uint(y[q].x) | ((unsigned long long)__float_as_uint(y[q].y) << 32));
-            lfdm_agent_store_u64(d8 + 1, (unsigned long long)__float_as_uint(y[q].z) | ((unsigned long long)__float_as_uint(y[q].w) << 32));
+          if (FUSE) {      // ONE 16-byte write-through store per float4 (round 6; two 8-byte agent-scope stores before: 2.7x the fabric time per byte)
+            lfdm_buf_store_f4_sc1(slab_buf, (uint32_t)((((int64_t)bz * M + orow) * p.coutp + co) * 4), y[q]);
           } else {
-            *reinterpret_cast<float4*>(dst) = y[q];
+            *reinterpret_cast<float4*>(p.partial + ((int64_t)bz * M + orow) * p.coutp + co) = y[q];
           }
         } else if (co < p.cout) {
           float4 v = make_float4(y[q].x + bb.x, y[q].y + bb.y, y[q].z + bb.z, y[q].w + bb.w);
@@ -452,6 +451,9 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   }
 #endif
   bool reduced_here = false;
+#if defined(LFDM_PROBE_NOTAIL) && LFDM_PROBE_NOTAIL == 1
+  if (FUSE && ksplit > 1) return;      // probe build only (tools/probe_wino_tail.sh; results WRONG): the launch without drain, ticket and reduce
+#endif
   if (FUSE && ksplit > 1) {
     __shared__ int s_last;
     LFDM_DRAIN_STORES();                                   // every storing wave: its slab words have left for memory
@@ -464,6 +466,9 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
     }
     __syncthreads();
     if (!s_last) return;
+#if defined(LFDM_PROBE_NOTAIL) && LFDM_PROBE_NOTAIL == 2
+    return;                            // probe build only: drain + ticket, but nobody reads the slabs back
+#endif
     reduced_here = true;
     const int co = n0 + 4 * e_c4;
     const int n = my_n;
@@ -480,33 +485,27 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
         res[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.residual) res[q] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.ldr + co);
       }
-      const int64_t zs2 = (M * p.coutp) / 2;                // slab stride in 8-byte words
-      const unsigned long long* src[4];
+      const uint32_t zs = (uint32_t)(M * p.coutp * 4);      // slab stride in bytes
+      uint32_t src[4];
       float4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        src[q] = reinterpret_cast<const unsigned long long*>(p.partial + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.coutp + co);
-      // four slabs x the thread's four pixels in flight per round (32 loads: one memory round trip for ksplit <= 4, two up to 8);
-      // summed z = 0, 1, ... per pixel (fixed order)
+      for (int q = 0; q < 4; ++q) src[q] = (uint32_t)(((orow0 + (q >> 1) * p.wq + (q & 1)) * p.coutp + co) * 4);
+      // four slabs x the thread's four pixels in flight per round (16 loads of 16 bytes, read past the L1: one memory round trip for
+      // ksplit <= 4, two up to 8); summed z = 0, 1, ... per pixel (fixed order)
       for (int z0 = 0; z0 < ksplit; z0 += 4) {
-        unsigned long long w[4][4][2];
+        float4 w[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool in = z0 + u < ksplit;
-            w[u][q][0] = in ? lfdm_agent_load_u64(src[q] + (int64_t)(z0 + u) * zs2) : 0ull;
-            w[u][q][1] = in ? lfdm_agent_load_u64(src[q] + (int64_t)(z0 + u) * zs2 + 1) : 0ull;
-          }
+          for (int q = 0; q < 4; ++q)
+            w[u][q] = lfdm_buf_load_f4_sc1(slab_buf, z0 + u < ksplit ? src[q] + (uint32_t)(z0 + u) * zs : LFDM_BUF_OOB);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (z0 + u < ksplit) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float ux = __uint_as_float((unsigned)(w[u][q][0] & 0xffffffffull)), uy = __uint_as_float((unsigned)(w[u][q][0] >> 32));
-              const float uz = __uint_as_float((unsigned)(w[u][q][1] & 0xffffffffull)), uw = __uint_as_float((unsigned)(w[u][q][1] >> 32));
-              if (z0 + u == 0) v[q] = make_float4(ux, uy, uz, uw);
-              else { v[q].x += ux; v[q].y += uy; v[q].z += uz; v[q].w += uw; }
+              if (z0 + u == 0) v[q] = w[u][q];
+              else { v[q].x += w[u][q].x; v[q].y += w[u][q].y; v[q].z += w[u][q].z; v[q].w += w[u][q].w; }
             }
           }
       }

@@ -93,6 +93,29 @@ __device__ __forceinline__ float2 lfdm_buf_load_f2(lfdm_buf b, uint32_t off) {
 #endif
 #define LFDM_BUF_OOB 0xFFFFFFF0u
 
+// 16-byte WRITE-THROUGH store / L1-bypassing load through a buffer descriptor (sc1: cdna_hip_programming.md Guideline 16 form R1 - the payload of
+// an in-launch hand-off between workgroups).  One 16-byte sc1 store is ONE fabric write; the same float4 as two 8-byte agent-scope atomic
+// stores costs 2.7x the time per byte (MI355X_MICROARCH.md, "stores of each flavour") and an 8-byte sc1 load runs at 0.54-0.70x the
+// 16-byte rate.  Ordering against the flag / ticket is the caller's: every storing wave drains (s_waitcnt vmcnt(0)) before the ticket.
+#if defined(LFDM_EMU_BUILD)
+static inline void lfdm_buf_store_f4_sc1(lfdm_buf b, uint32_t off, float4 v) {
+  if ((uint64_t)off + 16u <= (uint64_t)b.bytes) memcpy(const_cast<char*>(b.base) + off, &v, 16);
+}
+static inline float4 lfdm_buf_load_f4_sc1(lfdm_buf b, uint32_t off) { return lfdm_buf_load_f4(b, off); }
+#else
+__device__ __forceinline__ void lfdm_buf_store_f4_sc1(lfdm_buf b, uint32_t off, float4 v) {
+  lfdm_i32x4 d;
+  d.x = __float_as_int(v.x); d.y = __float_as_int(v.y); d.z = __float_as_int(v.z); d.w = __float_as_int(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, b, (int)off, 0, 16);          // aux 16 = sc1 on gfx940+
+}
+__device__ __forceinline__ float4 lfdm_buf_load_f4_sc1(lfdm_buf b, uint32_t off) {
+  const lfdm_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 16);
+  float4 f;
+  f.x = __int_as_float(v.x); f.y = __int_as_float(v.y); f.z = __int_as_float(v.z); f.w = __int_as_float(v.w);
+  return f;
+}
+#endif
+
 // Register-operand load pipelines.  hipcc (ROCm 7.2) undoes a source-level "load group g+1, multiply group g" loop whenever the loaded
 // values feed MFMAs straight from registers: the load is sunk across the back-edge to its use and every group pays the full memory
 // latency (attn_lowres.hip, first version: 18.6 us for 3 us of MFMA).  The loads of such loops are therefore issued by inline asm
