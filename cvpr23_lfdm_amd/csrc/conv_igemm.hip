@@ -821,14 +821,16 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     //  and measured in round 2, profiles/r02_n_tile16_sweep.txt: two-wave form slower everywhere; four-wave form -2..3 us at 16x16,
     //  +1..2 us at 32x32, equal at 4x4 / 8x8, +0.45 % end to end when selected below 512 workgroups - not worth a second kernel; removed)
     int k = 1;
-    // (LFDM_WINO_SLICE_CHUNKS / LFDM_WINO_SPLIT_MIN_CHUNKS: sweep knobs for the two constants below, read per call)
-    const char* e_sc = getenv("LFDM_WINO_SLICE_CHUNKS");
-    const char* e_mc = getenv("LFDM_WINO_SPLIT_MIN_CHUNKS");
-    // round 5: with the slabs reduced inside the launch (conv_wino.hip FUSE) the 8-chunk convolutions of the 16x16 level pay for two slices
-    // of four chunks as well (profiles/r05_t_sweep_wino_slices.txt: 280.2 -> 278.7 ms per video); 3 / 4 / 6 chunks per slice elsewhere lose
-    // (only for callers that hand in tile_counters - without the in-launch reduction the extra slices would buy a reduce launch)
-    const int min_chunks = e_mc && atoi(e_mc) > 0 ? atoi(e_mc) : (p.tile_counters ? 8 : 16);
-    const int slice_chunks = e_sc && atoi(e_sc) > 0 ? atoi(e_sc) : (nch < 16 ? 4 : 5);
+    // Slice length and the smallest reduction that is split (sweep knobs LFDM_WINO_SLICE_CHUNKS / LFDM_WINO_SPLIT_MIN_CHUNKS, read ONCE:
+    // tools/sweep_wino_slices.sh runs one process per setting).  Round 5: with the slabs reduced inside the launch (conv_wino.hip FUSE) the
+    // 8-chunk convolutions of the 16x16 level pay for two slices of four chunks (profiles/r05_t_sweep_wino_slices.txt; only for callers
+    // that hand in tile_counters - without the in-launch reduction the extra slices would buy a reduce launch).  Round 6: the slabs
+    // became 16-byte write-through accesses and four chunks per slice win at every depth (profiles/r06_i_sweep_wino_slices.txt: 274.3 ms
+    // per video against 275.0 with five chunks from 16 chunks on; 3 / 6 per slice lose).
+    static const int env_sc = [] { const char* e = getenv("LFDM_WINO_SLICE_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int env_mc = [] { const char* e = getenv("LFDM_WINO_SPLIT_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
+    const int min_chunks = env_mc > 0 ? env_mc : (p.tile_counters ? 8 : 16);
+    const int slice_chunks = env_sc > 0 ? env_sc : (p.tile_counters ? 4 : (nch < 16 ? 4 : 5));
     if (blocks < 512 && nch >= min_chunks) {
       // Split-K from tools/sweep_ksplit.sh (profiles/r02_c_ksplit_sweep.txt): a workgroup that is alone on its CU runs a
       // chunk in ~1.8 us (the matrix pipe needs 1.0), fixed costs are ~8 us per workgroup, and in the sampler the filters

@@ -358,6 +358,27 @@ __global__ __launch_bounds__(256) void conv_planar_in_mfma_kernel(
   // through (ky, kx, c) in the weight's own order by +1 with two selects (the first version interleaved the slots, k = 2*step + slot,
   // and spent ~700 cycles per step in divergent carry loops: 32 us for this kernel, no faster than the VALU form)
   const int half_k = Kp >> 1;
+  if (kh == 7 && kw == 7 && cin == 3) {
+    // The UNet's stem (7x7 over the three step-dependent channels, K = 147): every index of the walk is a compile-time constant - the
+    // generic loop below spends ~10 dependent VALU instructions and three LDS reads with computed addresses per step, which the 128
+    // matrix-pipe cycles of a step do not cover with one or two workgroups per CU (round 6: 31 -> see profiles/r06_k_*).  Fully unrolled:
+    // one select between the two k-slots' window offsets per step, LDS reads at immediate offsets the compiler can issue ahead.
+    constexpr int KH = 7, KW = 7, CIN = 3, WR = CPM_ROWS + KH - 1, WC = CPM_COLS + KW - 1, HALF = (KH * KW * CIN + 1) / 2;
+    const float* wbase = win + wave * WC + l31;
+    const float* bbase = ws + (khalf * HALF) * 64 + l31;
+#pragma unroll
+    for (int st = 0; st < HALF; ++st) {
+      const int k0 = st, k1 = HALF + st;
+      const int ky0 = k0 / (KW * CIN), kx0 = (k0 - ky0 * KW * CIN) / CIN, c0 = k0 - (ky0 * KW + kx0) * CIN;
+      const int ky1r = k1 / (KW * CIN), kx1 = (k1 - ky1r * KW * CIN) / CIN, c1 = k1 - (ky1r * KW + kx1) * CIN;
+      const int ky1 = ky1r < KH ? ky1r : KH - 1;                  // (index K of the odd K: any valid address, its filter row is zero)
+      const int o0 = (c0 * WR + ky0) * WC + kx0, o1 = (c1 * WR + ky1) * WC + kx1;
+      const float a = wbase[khalf ? o1 : o0];
+      const float b0 = bbase[st * 64], b1 = bbase[st * 64 + 32];
+      acc[0] = mfma_32x32x2(a, b0, acc[0]);
+      acc[1] = mfma_32x32x2(a, b1, acc[1]);
+    }
+  } else {
   int k = khalf * half_k;
   int ky = k / (kw * cin), kx = (k - ky * kw * cin) / cin, c = k - (ky * kw + kx) * cin;
   for (int st = 0; st < half_k; ++st, ++k) {
@@ -371,6 +392,7 @@ __global__ __launch_bounds__(256) void conv_planar_in_mfma_kernel(
     const bool kw_ = cw_ && kx + 1 == kw;
     kx = kw_ ? 0 : (cw_ ? kx + 1 : kx);
     ky = kw_ ? ky + 1 : ky;
+  }
   }
   const int oy = oy0 + wave;
   if (oy >= h) return;
