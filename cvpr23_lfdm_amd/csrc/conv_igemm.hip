@@ -922,7 +922,7 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
     // Winograd F(2x2): the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
     static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B knob)
     if (!on || pl.bn != 32 || pl.kgroups != 1 || p.groups > 1 || p.pool2 || p.gn_in_partial || p.cout != p.coutp || p.ldo % 4 != 0 ||
-        (((uintptr_t)p.out) & 15) != 0 || (((uintptr_t)p.partial) & 127) != 0 ||      // (slab rows of a column tile = whole 128-byte lines: lfdm_device.h)
+        (((uintptr_t)p.out) & 15) != 0 ||
         (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
         (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
       return false;
@@ -955,7 +955,9 @@ extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   const ConvPlan pl = make_plan(*p);
   if (pl.ksplit <= 1) return 0;
   const size_t rows = (size_t)p->n_img * p->hq * p->wq;
-  return ((size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * rows * p->coutp + (p->ln_wsum ? (size_t)pl.ksplit * rows * 2 : 0)) * sizeof(float);
+  // (+ 128: lfdm_conv2d_cl_f32 rounds the slab base up to a 128-byte boundary - the in-launch reduction needs every column tile's slab
+  //  rows to be whole cache lines, lfdm_device.h - so the caller's buffer may start anywhere and the plan never depends on its address)
+  return ((size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * rows * p->coutp + (p->ln_wsum ? (size_t)pl.ksplit * rows * 2 : 0)) * sizeof(float) + 128;
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
@@ -1010,6 +1012,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   p.ksplit = pl.ksplit;
   if (p.defer_reduce) { p.tile_counters = nullptr; p.tile_counters_len = 0; }      // raw slabs wanted: nobody reduces in the launch
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
+  if (p.partial && !p.defer_reduce) p.partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p.partial) + 127) & ~(uintptr_t)127);   // (slack: partial_bytes)
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (p.gn_partial) {
     const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;

@@ -179,7 +179,7 @@ __device__ __forceinline__ void lfdm_ticket_reset(unsigned* c) {
 // gfx950 because of how that target lowers and executes it (MI355X_MICROARCH.md, "inter-workgroup visibility": sc1 stores are written
 // through and acknowledged at memory before vmcnt drops; sc1 loads and atomics are served past the per-XCD L2s; observed untorn for 8-byte
 // granules) - hardware behaviour validated on gfx950 / ROCm 7.2, not an architectural guarantee.  Hence the compile-time guard below (the
-// library is built for gfx950 only, _build.py), the 128-byte alignment the launchers demand of slab buffers (two column tiles on different
+// library is built for gfx950 only, _build.py), the 128-byte boundary the launcher rounds every slab base up to (two column tiles on different
 // XCDs never share a cache line), and tests/test_ops_parity.py::test_wino_fused_reduce_stress (bit-equal to the separate reduce pass over
 // many launches under load).  A ticket array belongs to ONE stream: launches that share it must be ordered.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(LFDM_EMU_BUILD)

@@ -1353,14 +1353,17 @@ def test_wino_fused_reduce_stress():
             assert diff == 0, "launch %d rep %d: %d words differ from the reduce pass (s=%d cin=%d cout=%d n=%d ksplit=%d)" % (it, rep, diff, s, cin, cout, n, ks)
         torch.cuda.current_stream().wait_stream(side)
         assert int(counters.abs().sum()) == 0
-    # a misaligned slab buffer: the planner must not take the in-launch path (tile rows fall back to the reduce pass's 16)
+    # a slab buffer that starts anywhere: the library rounds its base up to a 128-byte boundary (lfdm_conv2d_partial_bytes carries the
+    # slack), so the plan never depends on the buffer's address and the result is the same
     x = torch.randn(16 * 16, 256, device=dev)
     wt = torch.randn(64, 256, 3, 3, device=dev) / 48
     w, ww = ops.pack_conv_weight(wt.cpu()).to(dev), ops.pack_wino_weight(wt)
-    pp, keep = ops.conv_params(x, w, 64, 3, 3, 16, 4, 4, weight_wino=ww, ksplit=4, tile_counters=counters)
-    pp.gn_partial = 1
-    slab = torch.empty(4 * 256 * 64 + 64, device=dev)
-    pp.partial = slab.data_ptr()
-    assert slab.data_ptr() % 128 == 0 and ops.conv_plan(pp)[0] == 128
-    pp.partial = slab.data_ptr() + 16
-    assert ops.conv_plan(pp)[0] == 16
+    pp, y = ops.conv_params(x, w, 64, 3, 3, 16, 4, 4, weight_wino=ww, ksplit=4, tile_counters=counters)
+    need = ops.conv_partial_floats(pp)
+    assert need >= 4 * 256 * 64 + 32
+    slab = torch.empty(need + 8, device=dev)
+    want = ops.conv2d_cl(x, w, 64, 3, 3, 16, 4, 4, weight_wino=ww, ksplit=4).clone()
+    for shift in (0, 4, 20):
+        pp.partial = slab.data_ptr() + 4 * shift
+        ops.conv_launch(pp)
+        assert int((y.view(torch.int32) != want.view(torch.int32)).sum()) == 0 and int(counters.abs().sum()) == 0
