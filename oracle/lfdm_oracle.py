@@ -224,13 +224,15 @@ def channel_layernorm(x, gamma, eps=1e-5):
 def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None, focus=None):
     """Attention.forward (:303-363).  tokens (..., n, C) - for the temporal form (b, h*w, f, C); w_qkv (768, C); w_out (C, 256);
     focus: None or the (b,) bool focus_present_mask (:313-317, :342-352: a focused sample attends only to itself)."""
-    qkv = tokens @ w_qkv.t()
-    q, k, v = qkv.chunk(3, dim=-1)
+    qkv = F.linear(tokens, w_qkv)                        # (nn.Linear in the reference; `tokens @ w.t()` took torch.matmul's expanded-weight
+    q, k, v = qkv.chunk(3, dim=-1)                       #  bmm path on the CPU: 0.5 s of a 1.7 s forward)
     if focus is not None and bool(focus.all()):          # :313-317: the values pass straight through to_out
-        return v @ w_out.t()
+        return F.linear(v, w_out)
 
     def heads(z):
-        return z.reshape(*z.shape[:-1], HEADS, DIM_HEAD).transpose(-2, -3)  # (..., h, n, d)
+        # (contiguous, as einops.rearrange leaves it in the reference: torch.bmm on a batch whose strides do not fold walks the 8 192
+        #  (pixel, head) pairs one by one - 0.6 s of a 1.7 s forward on the CPU)
+        return z.reshape(*z.shape[:-1], HEADS, DIM_HEAD).transpose(-2, -3).contiguous()  # (..., h, n, d)
 
     q, k, v = heads(q), heads(k), heads(v)
     q = q * (DIM_HEAD ** -0.5)
@@ -249,14 +251,14 @@ def softmax_attention(tokens, w_qkv, w_out, pos_bias=None, rotary=None, focus=No
     attn = sim.softmax(dim=-1)
     out = attn @ v                                   # (..., h, n, d)
     out = out.transpose(-2, -3).reshape(*tokens.shape[:-1], HIDDEN)
-    return out @ w_out.t()
+    return F.linear(out, w_out)
 
 
 def temporal_attention(x, sd, prefix, pos_bias, rotary, focus=None):
     """Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention))) (:397-399,413)."""
     b, c, f, h, w = x.shape
     normed = channel_layernorm(x, sd[prefix + "fn.norm.gamma"])
-    tokens = normed.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c)
+    tokens = normed.permute(0, 3, 4, 2, 1).reshape(b, h * w, f, c).contiguous()      # (a strided view otherwise: see softmax_attention)
     out = softmax_attention(tokens, sd[prefix + "fn.fn.fn.to_qkv.weight"],
                             sd[prefix + "fn.fn.fn.to_out.weight"], pos_bias, rotary, focus)
     out = out.reshape(b, h, w, f, c).permute(0, 4, 3, 1, 2)
@@ -267,7 +269,7 @@ def mid_spatial_attention(x, sd, prefix):
     """mid_spatial_attn: 'b c f h w' -> 'b f (h w) c', no rotary, no bias (:473-475)."""
     b, c, f, h, w = x.shape
     normed = channel_layernorm(x, sd[prefix + "fn.norm.gamma"])
-    tokens = normed.permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c)
+    tokens = normed.permute(0, 2, 3, 4, 1).reshape(b, f, h * w, c).contiguous()
     out = softmax_attention(tokens, sd[prefix + "fn.fn.fn.to_qkv.weight"],
                             sd[prefix + "fn.fn.fn.to_out.weight"])
     out = out.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
@@ -279,16 +281,16 @@ def spatial_linear_attention(x, sd, prefix):
     32-dim axis, k softmax over tokens, ctx = k v^T, out = ctx^T q, 1x1 out conv with bias."""
     b, c, f, h, w = x.shape
     normed = channel_layernorm(x, sd[prefix + "fn.norm.gamma"])
-    frames = normed.permute(0, 2, 1, 3, 4).reshape(b * f, c, h * w)
-    w_qkv = sd[prefix + "fn.fn.to_qkv.weight"].reshape(3 * HIDDEN, c)
-    qkv = torch.einsum("oc,bcn->bon", w_qkv, frames)
+    frames = normed.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    # (to_qkv / to_out are nn.Conv2d 1x1 in the reference (:246-247): the same ATen convolution here - as a broadcast einsum this was a
+    #  40-batch bmm with an expanded weight, 1.7x the reference's wall time for the whole forward, profiles/port_vs_reference_cpu.json)
+    qkv = F.conv2d(frames, sd[prefix + "fn.fn.to_qkv.weight"].reshape(3 * HIDDEN, c, 1, 1))
     q, k, v = [z.reshape(b * f, HEADS, DIM_HEAD, h * w) for z in qkv.chunk(3, dim=1)]
     q = q.softmax(dim=-2) * (DIM_HEAD ** -0.5)
     k = k.softmax(dim=-1)
     ctx = torch.einsum("bhdn,bhen->bhde", k, v)
-    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b * f, HIDDEN, h * w)
-    w_out = sd[prefix + "fn.fn.to_out.weight"].reshape(c, HIDDEN)
-    out = torch.einsum("oc,bcn->bon", w_out, out) + sd[prefix + "fn.fn.to_out.bias"].view(1, c, 1)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b * f, HIDDEN, h, w)
+    out = F.conv2d(out, sd[prefix + "fn.fn.to_out.weight"].reshape(c, HIDDEN, 1, 1), sd[prefix + "fn.fn.to_out.bias"])
     out = out.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
     return out + x
 
