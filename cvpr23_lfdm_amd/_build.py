@@ -52,8 +52,11 @@ def _run(cmd):
     return r.stdout
 
 
-def build_hip(force=False, verbose=False):
-    """hipcc -> liblfdm_hip.so (gfx950). One object per source so rebuilds are incremental."""
+def build_hip(force=False, verbose=False, knobs=False):
+    """hipcc -> liblfdm_hip.so (gfx950). One object per source so rebuilds are incremental.
+    knobs=True (`python -m cvpr23_lfdm_amd._build hip --knobs`): -DLFDM_TUNING_KNOBS - the sweep overrides of schedule constants
+    (csrc/lfdm_device.h lfdm_knob) read the environment; the shipped build compiles them to their defaults.  Forces a full rebuild."""
+    force = force or knobs or os.path.exists(os.path.join(PKG_DIR, "build", ".knobs"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(PKG_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -68,7 +71,7 @@ def build_hip(force=False, verbose=False):
     def compile_one(job):
         src, obj = job
         return _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
-                     "-o", obj, "-Wno-unused-result"])
+                     "-o", obj, "-Wno-unused-result"] + (["-DLFDM_TUNING_KNOBS"] if knobs else []))
 
     if todo:      # independent translation units: compile a few at a time
         from concurrent.futures import ThreadPoolExecutor
@@ -78,6 +81,11 @@ def build_hip(force=False, verbose=False):
                     print(out)
     if force or _stale(HIP_LIB, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    marker = os.path.join(objdir, ".knobs")          # a knob build must not survive as "the" library: the next plain build redoes everything
+    if knobs:
+        open(marker, "w").close()
+    elif os.path.exists(marker):
+        os.remove(marker)
     return HIP_LIB
 
 
@@ -106,6 +114,6 @@ def build_emu(force=False):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["hip"]
     if "hip" in which:
-        print(build_hip(force="--force" in which, verbose=True))
+        print(build_hip(force="--force" in which, verbose=True, knobs="--knobs" in which))
     if "emu" in which:
         print(build_emu(force="--force" in which))

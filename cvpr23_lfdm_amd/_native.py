@@ -133,13 +133,6 @@ _SIGNATURES = {
     "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
     "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
                                         f32, i32, C.c_void_p, sz, stream_t]),
-    "lfdm_groupnorm_splitk_ok": (i32, [i32, i32, i32]),
-    "lfdm_groupnorm_splitk_apply_cl_f32": (i32, [f32p, i32, C.c_longlong, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
-                                                 f32, i32, stream_t]),
-    "lfdm_groupnorm_splitk_coop_ok": (i32, [i32, i32, i32, i32, i32]),
-    "lfdm_groupnorm_splitk_coop_ws_bytes": (sz, [i32, i32, i32, i32]),
-    "lfdm_groupnorm_splitk_coop_cl_f32": (i32, [f32p, i32, C.c_longlong, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,
-                                                f32, i32, C.c_void_p, sz, stream_t]),
     "lfdm_groupnorm_apply_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p, f32, i32,
                                          f32p, i32, C.c_void_p, sz, stream_t]),
     "lfdm_layernorm_cl_f32": (i32, [f32p, f32p, i64, i32, f32p, f32, stream_t]),

@@ -526,7 +526,7 @@ int launch_fused(const float* x, int ldx, const float* wqkv, float* out, int bat
   const int64_t nseq = (int64_t)batch * hw;
   int hpb = 8;                                       // heads per workgroup: aim at >= 2048 workgroups
   while (hpb > 1 && nseq * (HEADS / hpb) < 2048) hpb >>= 1;
-  if (const char* e = getenv("LFDM_TATTN_HPB")) {    // experiment knob (tools/bench_attn.py)
+  if (const char* e = lfdm_knob("LFDM_TATTN_HPB")) {    // experiment knob (tools/bench_attn.py)
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4 || v == 8) hpb = v;
   }

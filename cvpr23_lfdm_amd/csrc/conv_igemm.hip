@@ -701,7 +701,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, bool fuse_reduce, hipStream_t stream);  // conv_wino.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, hipStream_t stream);  // conv_wino.hip
 int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
 int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream);         // conv_wino4.hip
 
@@ -717,7 +717,6 @@ struct ConvPlan {
                    // 4 = Winograd F(4x4,3x3), 512-pixel x 32-column tiles, batched shapes only (conv_wino4.hip)
   int bm, bn, ksplit;
   bool fast, simple;
-  int kgroups = 1;      // kind 2: K groups inside a workgroup (conv_wino.hip, template parameter G)
 };
 
 int conv_force() {   // debugging aid for tools/bench_conv.py: LFDM_CONV_FORCE=igemm|ksw
@@ -774,7 +773,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   // the K >= 256 ones with few output columns above it) and at M <= 1024 rows; with one K slice and thousands of rows the staged,
   // fully coalesced tiles are as fast or faster (its fragment-shaped loads cost four L1 line look-ups per 128-byte line).
   // LFDM_PW=0 disables it, LFDM_PW=2 takes it for every eligible geometry, LFDM_PW_MAXM bounds the row count.
-  static const long pw_max_m = [] { const char* e = getenv("LFDM_PW_MAXM"); return e ? atol(e) : 16384l; }();
+  static const long pw_max_m = [] { const char* e = lfdm_knob("LFDM_PW_MAXM"); return e ? atol(e) : 16384l; }();
   const char* pw_env = getenv("LFDM_PW");
   const int pw_mode = pw_env ? atoi(pw_env) : 1;
   const bool pw_ok = pw_mode != 0 && conv_force() < 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && !p.upsample && p.pad_y == 0 &&
@@ -804,17 +803,16 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.bm = 128;
     pl.bn = 32;
     const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
-    if (const char* e = getenv("LFDM_WINO_BN"))          // experiment knob (tools/bench_conv.py): 64-column workgroups
+    if (const char* e = getenv("LFDM_WINO_BN"))       // 64-column workgroups (tools/bench_conv.py, tests)
       if (e[0] == '6' && p.coutp % 64 == 0) pl.bn = 64;
     {
       // 64-column workgroups (half the patch loads / transforms per MFMA, two workgroups per CU) pay where every CU still gets
       // several of them: the batched shapes of training / throughput mode (B = 8 training step 157.0 -> 150.6 ms at >= 1536
       // workgroups = six per CU, 151.7 at 3072, 150.8 at 768: profiles/r02_u_bn64_train.txt), never the B = 1 sampler
       // (<= 640 such workgroups).  LFDM_WINO_BN64_MIN overrides the threshold, 0 disables.
-      static const long min_blocks64 = [] { const char* e = getenv("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1536l; }();
+      static const long min_blocks64 = [] { const char* e = lfdm_knob("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1536l; }();
       if (min_blocks64 > 0 && p.coutp % 64 == 0 && !(p.groups > 1) && ((ntiles + 31) / 32) * (p.coutp / 64) >= min_blocks64) pl.bn = 64;
     }
-    if (p.gn_in_partial) pl.bn = 32;                 // the fused input GroupNorm exists on the 32-column workgroup only
     const int64_t blocks = ((ntiles + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
     const int nch = cin / 16 / (p.groups > 1 ? p.groups : 1);      // chunks of one output channel's reduction
     // (16-tile workgroups on v_mfma_f32_16x16x4 - twice the workgroups at half the matrix work, half the split-K factor - were built
@@ -827,8 +825,8 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     // that hand in tile_counters - without the in-launch reduction the extra slices would buy a reduce launch).  Round 6: the slabs
     // became 16-byte write-through accesses and four chunks per slice win at every depth (profiles/r06_i_sweep_wino_slices.txt: 274.3 ms
     // per video against 275.0 with five chunks from 16 chunks on; 3 / 6 per slice lose).
-    static const int env_sc = [] { const char* e = getenv("LFDM_WINO_SLICE_CHUNKS"); return e ? atoi(e) : 0; }();
-    static const int env_mc = [] { const char* e = getenv("LFDM_WINO_SPLIT_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int env_sc = [] { const char* e = lfdm_knob("LFDM_WINO_SLICE_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int env_mc = [] { const char* e = lfdm_knob("LFDM_WINO_SPLIT_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
     const int min_chunks = env_mc > 0 ? env_mc : (p.tile_counters ? 8 : 16);
     const int slice_chunks = env_sc > 0 ? env_sc : (p.tile_counters ? 4 : (nch < 16 ? 4 : 5));
     if (blocks < 512 && nch >= min_chunks) {
@@ -840,32 +838,6 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       if (k > 8) k = 8;
       if (k < 1) k = 1;
     }
-    // K groups (round 4, conv_wino.hip: G wave groups per workgroup on interleaved chunks, accumulators merged through LDS).  Built against
-    // the per-chunk latency of workgroups that are alone on their CUs and MEASURED NEUTRAL (tools/bench_wino_kg.py with cold filters,
-    // profiles/r04_b_bench_wino_kg.txt: 512 -> 512 @4x4 G3 k3 35.6 us vs the plan's k6 34.9, 256 -> 256 @8x8 G3 k1 35.3 vs k3 31.6; end
-    // to end 306.3 vs 300.7 ms per video): two co-resident split-K workgroups already keep a CU's matrix pipe 2/3 busy in the K loop, what
-    // those launches lose is fixed cost (set-up, first patch, epilogue, reduce pass), which K groups do not remove.  Opt-in only:
-    // LFDM_WINO_KG = 2 / 3 forces that G, "auto" = G 3 with as little split-K as fills 256 CUs (read per call: tools / tests).
-    int kg = 1;
-    {
-      const char* e = getenv("LFDM_WINO_KG");
-      const int force = (e && e[0] >= '2' && e[0] <= '3') ? e[0] - '0' : 0;
-      const bool autok = e && e[0] == 'a';
-      const bool can = (pl.bn == 32 || force == 2) && !p.pool2 && !p.gn_in_partial;      // (64-column workgroups: two groups at most - registers)
-      if (can && force) {
-        kg = force;
-      } else if (can && autok && blocks <= 256) {
-        const int g = 3, min_ch = 3, max_ch = 8;
-        int kk = nch / (min_ch * g);
-        if (kk > 256 / blocks) kk = (int)(256 / blocks);
-        if (kk < 1) kk = 1;
-        if ((nch + kk * g - 1) / (kk * g) <= max_ch) {      // else: too long a slice per group for one workgroup per CU - the plain plan
-          kg = g;
-          k = kk;
-        }
-      }
-    }
-    pl.kgroups = kg;
     pl.ksplit = user_k >= 1 ? user_k : k;
     if (pl.ksplit > nch) pl.ksplit = nch;
     if (p.pool2) pl.ksplit = 1;                     // the pooled epilogue needs the finished sums
@@ -888,7 +860,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     pl.kind = 0;
     // 128x128 tiles only from two workgroups per CU up (round 4: the 320 / 480-workgroup launches of a B = 1 step - the merged output heads'
     // res_conv, the LayerNorm-fused qkv projections at 16x16 - run 128x64 tiles instead: 295.7 -> 293.0 ms per video, profiles/r04_f_*)
-    static const long wide_min = [] { const char* e = getenv("LFDM_IGEMM_WIDE_MIN"); return e ? atol(e) : 512l; }();
+    static const long wide_min = [] { const char* e = lfdm_knob("LFDM_IGEMM_WIDE_MIN"); return e ? atol(e) : 512l; }();
     const bool wide = p.coutp >= 128 && (M / 128) * (p.coutp / 128) >= wide_min;
     const bool small_m = M * (int64_t)((p.coutp + 63) / 64) < 128 * 512;
     pl.bm = wide ? 128 : (small_m ? 64 : 128);
@@ -914,14 +886,14 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   return pl;
 }
 
-// in-launch slab reduction: KSW schedule with enough zeroed tile counters
+// in-launch slab reduction (Winograd F(2x2) schedule, enough zeroed tile counters)
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
-  if (pl.ksplit <= 1 || !p.tile_counters || p.deconv4 || p.defer_reduce) return false;
+  if (pl.ksplit <= 1 || !p.tile_counters || p.deconv4) return false;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (pl.kind == 2) {
-    // Winograd F(2x2): the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
-    static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B knob)
-    if (!on || pl.bn != 32 || pl.kgroups != 1 || p.groups > 1 || p.pool2 || p.gn_in_partial || p.cout != p.coutp || p.ldo % 4 != 0 ||
+    // the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
+    static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B and bit-compare switch: tests)
+    if (!on || pl.bn != 32 || p.groups > 1 || p.pool2 || p.cout != p.coutp || p.ldo % 4 != 0 ||
         (((uintptr_t)p.out) & 15) != 0 ||
         (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
         (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
@@ -930,9 +902,7 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
     if ((int64_t)pl.ksplit * M * p.coutp * 4 >= (1ll << 32) - 64) return false;      // (the slabs go through a buffer descriptor: 32-bit byte offsets)
     return (int64_t)p.tile_counters_len >= ((ntiles + 31) / 32) * (p.coutp / 32);
   }
-  if (pl.kind != 1) return false;
-  const int64_t tiles = ((M + 159) / 160) * ((p.coutp + pl.bn - 1) / pl.bn);
-  return (int64_t)p.tile_counters_len >= tiles;
+  return false;
 }
 
 }  // namespace
@@ -994,25 +964,13 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
                    "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
   }
-  if (p.defer_reduce && (p.ln_wsum || p.deconv4 || p.residual || p.act != LFDM_ACT_NONE || p.gn_partial)) {
-    lfdm_set_error("conv2d: defer_reduce leaves the raw split-K slabs for lfdm_groupnorm_splitk_apply_cl_f32: no LayerNorm fold, deconv4, "
-                   "residual, activation or fused statistics");
+  if (p.gn_in_partial || p.defer_reduce) {
+    lfdm_set_error("conv2d: gn_in_* / defer_reduce are reserved since ABI 12 (the variants were measured slower and removed): pass NULL / 0");
     return LFDM_EINVAL;
   }
-  if (p.gn_in_partial) {
-    const int g = p.gn_in_groups;
-    if (pl.kind != 2 || p.c1 != 0 || p.upsample || p.pool2 || p.act != LFDM_ACT_NONE || g <= 0 || g > 64 || p.c0 % g != 0 || p.c0 > 1024 ||
-        p.gn_in_pixels <= 0 || p.gn_in_pixels % 128 != 0 || ((int64_t)p.n_img * p.hq * p.wq) % p.gn_in_pixels != 0 || p.gn_in_nchunk <= 0 ||
-        !p.gn_in_gamma || !p.gn_in_beta || (p.gn_in_ss && p.gn_in_ss_ld < 2 * p.c0)) {
-      lfdm_set_error("conv2d: gn_in_* (GroupNorm + SiLU of the input inside the convolution) needs the Winograd schedule (see lfdm_conv2d_schedule), one "
-                     "source, no upsample / pool / output activation, c0 <= 1024, c0 % groups == 0, pixels per sample % 128 == 0");
-      return LFDM_EINVAL;
-    }
-  }
   p.ksplit = pl.ksplit;
-  if (p.defer_reduce) { p.tile_counters = nullptr; p.tile_counters_len = 0; }      // raw slabs wanted: nobody reduces in the launch
   if (p.ksplit > 1 && !p.partial) { lfdm_set_error("conv2d: split-K needs the partial buffer (lfdm_conv2d_partial_bytes)"); return LFDM_EWORKSPACE; }
-  if (p.partial && !p.defer_reduce) p.partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p.partial) + 127) & ~(uintptr_t)127);   // (slack: partial_bytes)
+  if (p.partial) p.partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p.partial) + 127) & ~(uintptr_t)127);   // (slack: partial_bytes)
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
   if (p.gn_partial) {
     const int cg = p.gn_groups > 0 ? p.cout / p.gn_groups : 0;
@@ -1040,7 +998,7 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
-    rc = lfdm_conv_wino_launch(p, pl.bn, pl.kgroups, splitk_fused(pl, p), stream);
+    rc = lfdm_conv_wino_launch(p, pl.bn, splitk_fused(pl, p), stream);
   } else if (pl.kind == 3) {
     rc = lfdm_conv_pw_launch(p, stream);
   } else if (pl.kind == 4) {
@@ -1053,9 +1011,9 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     rc = lfdm_check_launch("conv_igemm");
   }
   if (rc) return rc;
-  if (p.ksplit > 1 && !splitk_fused(pl, p) && !p.defer_reduce) {
+  if (p.ksplit > 1 && !splitk_fused(pl, p)) {
     const dim3 rgrid((unsigned)((M + SPLITK_ROWS - 1) / SPLITK_ROWS), (unsigned)splitk_col_chunks(p, M), p.deconv4 ? 4 : 1);
-    static const bool vec_on = [] { const char* e = getenv("LFDM_REDUCE_VEC"); return !(e && e[0] == '0'); }();      // (A/B knob)
+    static const bool vec_on = [] { const char* e = lfdm_knob("LFDM_REDUCE_VEC"); return !(e && e[0] == '0'); }();      // (A/B knob)
     const bool vec = vec_on && p.ksplit <= 8 && !p.deconv4 && !p.ln_wsum && p.cout == p.coutp && p.ldo % 4 == 0 && (((uintptr_t)p.out) & 15) == 0 &&
                      p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq &&
                      (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (!p.residual || (p.ldr % 4 == 0 && (((uintptr_t)p.residual) & 15) == 0)) &&

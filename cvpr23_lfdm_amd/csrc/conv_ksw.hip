@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   // ---- cross-wave reduction + epilogue, one 32x32 tile at a time ----
   float* const scratch = smem;                     // [4 waves][32][LD]
   const int trow = tid >> 3, c4 = tid & 7;
-  const int ntiles = (int)(gridDim.x * gridDim.y);
-  const bool fuse = ksplit > 1 && p.tile_counters != nullptr && p.tile_counters_len >= ntiles && !p.deconv4;   // in-launch slab reduction
+  // (the in-launch slab reduction of the Winograd schedule was built here too - rounds 2 and 5 - and measured 0.9 ms per video SLOWER than
+  //  this schedule's four reduce launches: 4-40 workgroups whose last arriver walks up to ten tiles serially; removed in round 6)
   // (the host only selects this kernel when float4 epilogue accesses are legal)
   float gs[TN][4], gq[TN][4];
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   for (int j = 0; j < TN; ++j) {
     const int colbase = n0 + 32 * j + 4 * c4;
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && (ksplit == 1 || fuse) && colbase < p.cout) bias4[j] = *reinterpret_cast<const float4*>(p.bias + colbase);
+    if (p.bias && ksplit == 1 && colbase < p.cout) bias4[j] = *reinterpret_cast<const float4*>(p.bias + colbase);
   }
   auto out_row = [&](int i) -> int64_t {
     const int row = 32 * i + trow;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   };
   auto load_res = [&](int i, int j) -> float4 {
     const int colbase = n0 + 32 * j + 4 * c4;
-    if (p.residual && (ksplit == 1 || fuse) && s_img[32 * i + trow] >= 0 && colbase < p.cout)
+    if (p.residual && ksplit == 1 && s_img[32 * i + trow] >= 0 && colbase < p.cout)
       return *reinterpret_cast<const float4*>(p.residual + out_row(i) * p.ldr + colbase);
     return make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -264,14 +264,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
       if (img >= 0) {
         if (ksplit > 1) {
           if (colbase < p.coutp) {
-            float* dst = p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp + colbase;
-            if (fuse) {      // 8-byte agent-scope words: written through to memory - no cache-wide release before the ticket (conv_wino.hip FUSE)
-              unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
-              lfdm_agent_store_u64(d8, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32));
-              lfdm_agent_store_u64(d8 + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32));
-            } else {
-              *reinterpret_cast<float4*>(dst) = v;
-            }
+            *reinterpret_cast<float4*>(p.partial + ((int64_t)blockIdx.z * M + (m0 + row)) * p.coutp + colbase) = v;
           }
         } else if (colbase < p.cout) {
           const int64_t orow = out_row(i);
@@ -296,68 +289,6 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
   }
 
 
-  if (fuse) {
-    // ---- split-K: the workgroup that completes a tile's last slice reduces the slabs itself (no reduce launch) ----
-    LFDM_DRAIN_STORES();                              // every storing wave
-    __syncthreads();
-    int* const s_last = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      unsigned* cnt = p.tile_counters + (blockIdx.y * gridDim.x + blockIdx.x);
-      const bool last = lfdm_ticket_take(cnt) == (unsigned)(ksplit - 1);
-      if (last) lfdm_ticket_reset(cnt);               // ready for the next launch
-      s_last[0] = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last[0]) return;
-    float4 rnext = load_res(0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float4 rr = rnext;
-        {
-          const int t = i * TN + j + 1;
-          if (t < TM * TN) rnext = load_res(t / TN, t % TN);
-        }
-        const int row = 32 * i + trow;
-        const int colbase = n0 + 32 * j + 4 * c4;
-        if (s_img[row] >= 0 && colbase < p.cout) {
-          // slabs read past the non-coherent L2s (agent-scope loads, four slabs in flight); fixed order z = 0, 1, ...: bit-reproducible
-          const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.partial + ((int64_t)(m0 + row)) * p.coutp + colbase);
-          const int64_t zs2 = (M * p.coutp) / 2;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int z0 = 0; z0 < ksplit; z0 += 4) {
-            unsigned long long w[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const bool in = z0 + u < ksplit;
-              w[u][0] = in ? lfdm_agent_load_u64(src + (int64_t)(z0 + u) * zs2) : 0ull;
-              w[u][1] = in ? lfdm_agent_load_u64(src + (int64_t)(z0 + u) * zs2 + 1) : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (z0 + u < ksplit) {
-                v.x += __uint_as_float((unsigned)(w[u][0] & 0xffffffffull)); v.y += __uint_as_float((unsigned)(w[u][0] >> 32));
-                v.z += __uint_as_float((unsigned)(w[u][1] & 0xffffffffull)); v.w += __uint_as_float((unsigned)(w[u][1] >> 32));
-              }
-          }
-          const int64_t orow = out_row(i);
-          v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
-          if (p.gn_partial) {
-            gs[j][0] += v.x; gs[j][1] += v.y; gs[j][2] += v.z; gs[j][3] += v.w;
-            gq[j][0] += v.x * v.x; gq[j][1] += v.y * v.y; gq[j][2] += v.z * v.z; gq[j][3] += v.w * v.w;
-          }
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          if (ACT) {
-            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-          }
-          *reinterpret_cast<float4*>(p.out + orow * p.ldo + colbase) = v;
-        }
-      }
-    }
-  }
-
 #ifdef LFDM_KSW_TIMING
   tstamp[4] = __builtin_readcyclecounter();
   if (tid == 0 && p.partial && ksplit == 1) {
@@ -365,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_ksw_kernel(lfdm_conv_params p) {
     for (int i = 0; i < 5; ++i) dst[i] = tstamp[i];
   }
 #endif
-  if (p.gn_partial && (ksplit == 1 || fuse)) {
+  if (p.gn_partial && ksplit == 1) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll

@@ -49,38 +49,26 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // than the 112 us streaming pass it replaced - this K loop has no idle VALU slots (profiles/r02_ab_*).  The same activation
 // written as a SECOND OUTPUT of the producing convolution's epilogue (one more float4 store per pixel) cost 103 us per launch
 // for the same 112 us pass: no gain either, removed (profiles/r02_ac_*).
-// G = K groups per workgroup (round 4).  A launch with fewer workgroups than the chip has slots (the 16x16 / 8x8 / 4x4 levels of a
-// B = 1 step) leaves every workgroup ALONE on its CU: one wave per SIMD, nothing to run while a chunk's patches and filter fragments are
-// in flight - 2.8 us per chunk against 0.85 us of matrix-pipe time (profiles/r02_g_wino_phases.txt); more split-K slices buy that
-// overlap only through HBM slabs and a reduce launch.  With G > 1 the workgroup has G x 4 waves: group g runs chunks g, g + G, ... of the
-// workgroup's K slice on its own V buffer - G waves per SIMD, so one group's loads fly under the other groups' MFMAs - and the groups'
-// accumulators meet in LDS on the way into the output transform (the epilogue reads G x 8 planes instead of 8).  All groups run the same
-// trip count (one barrier pair per round); a group whose last chunk does not exist multiplies zero patches.
-// GNIN (round 4, lfdm_conv_params.gn_in_*): the input is the previous convolution's raw output; its GroupNorm + scale/shift + SiLU is applied to
-// the patches on their way into the transform (block1's norm inside block2's convolution: one launch less per ResnetBlock).  The
-// workgroup merges the statistics partials of its sample (double, fixed order - the arithmetic of gn_apply_kernel) while its first
-// patch / filter loads are in flight and keeps A[c], B[c] of its K slice in LDS.
+// Built, measured and REMOVED in round 6 (records: HISTORY.md rounds 4-6): K groups inside a workgroup (G x 4 waves on interleaved chunks,
+// accumulators merged through LDS: neutral, profiles/r04_b_bench_wino_kg.txt) and the input GroupNorm + SiLU applied to the patches on their
+// way into the transform (one launch less per ResnetBlock, ~10 us more per convolution: profiles/r04_d_*).
 // FUSE (round 5, lfdm_conv_params.tile_counters): split-K without a reduce launch.  Every slice's workgroup stores its 128 x 32 slab tile as
 // 8-byte agent-scope words (written through to memory: no cache-wide release), takes a ticket of its output tile, and the workgroup that draws
 // the tile's last ticket reads the ksplit slabs back past the non-coherent L2s (agent-scope loads: no acquire / invalidate), sums them in
 // slice order - bit-identical to conv_splitk_reduce_vec_kernel, whoever arrives last - and runs the epilogue (bias, GroupNorm partial sums,
 // residual, activation) itself.  The fence-based form of this hand-off (round 2, KSW schedule) measured neutral: its release wrote back the
 // XCD's whole L2 from every workgroup's tail - the cost found in the BatchNorm reduce (profiles/r05_p_bench_bn.txt, r05_q_*).
-template <bool ACT, int NT, bool POOL = false, int G = 1, bool GNIN = false, bool FUSE = false>
-__global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_wino_kernel(lfdm_conv_params p) {
-  static_assert(!FUSE || (NT == 1 && G == 1 && !POOL && !GNIN), "in-launch split-K reduction: the plain 32-column workgroup only");
+template <bool ACT, int NT, bool POOL = false, bool FUSE = false>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+  static_assert(!FUSE || (NT == 1 && !POOL), "in-launch split-K reduction: the plain 32-column workgroup only");
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
   constexpr int VSZ = 16 * WT * LD;
-  __shared__ __attribute__((aligned(16))) float smem[G * VSZ];   // V during the loop (one buffer per K group); >= 8*WT*LDM each for the epilogue planes
+  __shared__ __attribute__((aligned(16))) float smem[VSZ];   // V during the loop; >= 8*WT*LDM for the epilogue planes
   static_assert(VSZ >= 8 * WT * LDM, "epilogue planes must fit in the V buffer");
   __shared__ float s_gn[2][4][WNB];
-  constexpr int GIN_MAXC = 1024;
-  __shared__ __attribute__((aligned(16))) float s_gin[GNIN ? 2 * GIN_MAXC : 4];      // A[c] | B[c] of this workgroup's K slice
-  __shared__ float s_gstat[GNIN ? 128 : 4];                                          // mean | rstd per group
 
-  const int kgrp = G > 1 ? lfdm_uniform((int)(threadIdx.x >> 8)) : 0;      // K group of this wave (wave-uniform)
-  const int tid = G > 1 ? (int)(threadIdx.x & 255u) : (int)threadIdx.x;     // thread inside the group: every index below is per group
+  const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
 #ifdef LFDM_WINO_TIMING
@@ -237,103 +225,25 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   const int kc_last = kc_end - 1;
   auto clampc = [&](int c) { return c < kc_last ? c : kc_last; };     // re-fetching the last chunk is harmless
 
-  float* const Vs = smem + kgrp * VSZ;           // [16 pos][WT tiles][LD] of this K group
+  float* const Vs = smem;                        // [16 pos][WT tiles][LD]
 #ifdef LFDM_WINO_TIMING
   tstamp[1] = __builtin_readcyclecounter();
 #endif
-  // group g owns chunks kc_begin + g, + G, ...; every group runs `rounds` iterations (the barriers are workgroup wide): a chunk index
-  // past the slice reads zero patches (mask 0 -> out-of-range offsets) against the slice's last filter fragments
-  const int rounds = (kc_end - kc_begin + G - 1) / G;
-  const int kc0 = kc_begin + kgrp;
+  const int rounds = kc_end - kc_begin;
+  const int kc0 = kc_begin;
 #pragma unroll
   for (int pi = 0; pi < 4; ++pi) fetch_b(pi, clampc(kc0));
   {
-    fetch_patch(patch, clampc(kc0), (G == 1 || kc0 < kc_end) ? valid_mask : 0u);
-    if (GNIN) {
-      // (the loads above are in flight)  statistics of this tile block's sample: 32 lanes walk one group's chunks, as gn_apply_kernel does.
-      // ONE memory round trip for the whole prologue: gamma / beta / scale / shift of this thread's table entries are requested before the
-      // partial sums are walked (four chunk loads in flight), so only arithmetic and two barriers separate the loads from the first transform
-      const int groups = p.gn_in_groups, nchunk = p.gn_in_nchunk;
-      const int b = (int)((t0 < ntiles ? t0 : ntiles - 1) / (unsigned)(p.gn_in_pixels >> 2));      // (a tile = four pixels; host: pixels % 128 == 0)
-      const int c_lo = cbase + kc_begin * WKC, nslice = (kc_end - kc_begin) * WKC;
-      float t_g[4], t_b[4], t_sc[4], t_sh[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int lc = tid + 256 * j;
-        const int c = c_lo + (lc < nslice ? lc : 0);
-        t_g[j] = p.gn_in_gamma[c];
-        t_b[j] = p.gn_in_beta[c];
-        t_sc[j] = p.gn_in_ss ? p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + c] + 1.0f : 1.0f;
-        t_sh[j] = p.gn_in_ss ? p.gn_in_ss[(int64_t)b * p.gn_in_ss_ld + p.c0 + c] : 0.f;
-      }
-      const int sub = tid & 31;
-      for (int g0 = 0; g0 < groups; g0 += 8) {
-        const int g = g0 + (tid >> 5);
-        double sm = 0.0, sq = 0.0;
-        if (g < groups) {
-          const float2* src = reinterpret_cast<const float2*>(p.gn_in_partial) + ((int64_t)b * nchunk) * groups + g;
-          int k = sub;
-          for (; k + 96 < nchunk; k += 128) {
-            const float2 v0 = src[(int64_t)k * groups], v1 = src[(int64_t)(k + 32) * groups];
-            const float2 v2 = src[(int64_t)(k + 64) * groups], v3 = src[(int64_t)(k + 96) * groups];
-            sm += (double)v0.x; sq += (double)v0.y;
-            sm += (double)v1.x; sq += (double)v1.y;
-            sm += (double)v2.x; sq += (double)v2.y;
-            sm += (double)v3.x; sq += (double)v3.y;
-          }
-          for (; k < nchunk; k += 32) {
-            const float2 v = src[(int64_t)k * groups];
-            sm += (double)v.x;
-            sq += (double)v.y;
-          }
-        }
-        for (int msk = 16; msk >= 1; msk >>= 1) {
-          sm += __shfl_xor(sm, msk);
-          sq += __shfl_xor(sq, msk);
-        }
-        if (g < groups && sub == 0) {
-          const double n = (double)p.gn_in_pixels * (double)(p.c0 / groups);
-          const double mean = sm / n;
-          double var = sq / n - mean * mean;
-          if (var < 0.0) var = 0.0;
-          s_gstat[g] = (float)mean;
-          s_gstat[64 + g] = (float)(1.0 / sqrt(var + (double)p.gn_in_eps));
-        }
-      }
-      __syncthreads();
-      const int cg = p.c0 / groups;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int lc = tid + 256 * j;
-        if (lc < nslice) {
-          const int g = (c_lo + lc) / cg;
-          const float a = s_gstat[64 + g] * t_g[j];
-          s_gin[lc] = a * t_sc[j];
-          s_gin[GIN_MAXC + lc] = (t_b[j] - s_gstat[g] * a) * t_sc[j] + t_sh[j];
-        }
-      }
-      __syncthreads();
-    }
+    fetch_patch(patch, clampc(kc0), valid_mask);
     for (int r = 0; r < rounds; ++r) {
-      const int nxt_raw = kc0 + (r + 1) * G;
-      const int nxt = clampc(nxt_raw);
-      if (GNIN) {      // norm -> scale/shift -> SiLU of the in-image patch pixels (padding stays zero)
-        const int lc = (kc0 + r * G - kc_begin) * WKC + 2 * x_c2;
-        const float2 ga = *reinterpret_cast<const float2*>(s_gin + lc), gb = *reinterpret_cast<const float2*>(s_gin + GIN_MAXC + lc);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const bool in = (valid_mask >> q) & 1u;
-          patch[q].x = in ? silu_fast_(fmaf(patch[q].x, ga.x, gb.x)) : 0.f;
-          patch[q].y = in ? silu_fast_(fmaf(patch[q].y, ga.y, gb.y)) : 0.f;
-        }
-      }
+      const int nxt = clampc(kc0 + r + 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xform_part(patch, i, Vs);
 #ifdef LFDM_WINO_TIMING
       if (r == 0) tstamp[2] = __builtin_readcyclecounter();     // first patch arrived + transformed
 #endif
       __syncthreads();
-      fetch_patch(patch, nxt, (G == 1 || nxt_raw < kc_end) ? valid_mask : 0u);     // in flight under this round's MFMAs
+      fetch_patch(patch, nxt, valid_mask);     // in flight under this round's MFMAs
 #pragma unroll
       for (int pi = 0; pi < 4; ++pi) {
         float4 a0, a1;
@@ -352,8 +262,7 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
   // Read side: thread = (tile, 4 consecutive output channels): 8 ds_read_b128, then the 2x2 output pixels as float4 stores
   // (8 lanes cover a pixel's 128-byte row segment) - 4x fewer LDS / global instructions than one channel per lane
   // (epilogue 4.7 -> measured in profiles/r02_*).  The plan only selects this schedule when float4 accesses are legal.
-  // K groups: every group parks its planes in its own buffer; group 0 sums them while it reads and runs the epilogue alone
-  float* const Ms = smem + kgrp * VSZ;           // [8 = 2*i + j'][WT][LDM], one column tile at a time
+  float* const Ms = smem;                        // [8 = 2*i + j'][WT][LDM], one column tile at a time
   // split-K slabs [ksplit][M][coutp] through a buffer descriptor with 32-bit byte offsets (splitk_fused checks the size)
   const lfdm_buf slab_buf = lfdm_make_buf(FUSE && ksplit > 1 ? p.partial : nullptr, FUSE && ksplit > 1 ? (uint32_t)((int64_t)ksplit * M * p.coutp * 4) : 0u);
   const int e_tile = tid >> 3, e_c4 = tid & 7;
@@ -374,7 +283,7 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
     if (p.bias && ksplit == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
     const int n = my_n;                                 // e_tile == x_tile == tid >> 3
     const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
-    const bool live = n >= 0 && co < p.coutp && kgrp == 0;
+    const bool live = n >= 0 && co < p.coutp;
     float4 res[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                        // residual rows requested before the barrier
@@ -387,13 +296,6 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       float4 m[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) m[q] = *reinterpret_cast<const float4*>(Ms + (q * WT + e_tile) * LDM + 4 * e_c4);
-#pragma unroll
-      for (int g = 1; g < G; ++g)       // (kgrp == 0 here: Ms is buffer 0, the other groups' planes follow at VSZ strides)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(Ms + g * VSZ + (q * WT + e_tile) * LDM + 4 * e_c4);
-          m[q].x += t.x; m[q].y += t.y; m[q].z += t.z; m[q].w += t.w;
-        }
       float4 y[4];                   // y[i'][j'] = sum_i A^T[i'][i] T[i][j'],  m[2*i + j'] = T[i][j']
       y[0] = make_float4(m[0].x + m[2].x + m[4].x, m[0].y + m[2].y + m[4].y, m[0].z + m[2].z + m[4].z, m[0].w + m[2].w + m[4].w);
       y[1] = make_float4(m[1].x + m[3].x + m[5].x, m[1].y + m[3].y + m[5].y, m[1].z + m[3].z + m[5].z, m[1].w + m[3].w + m[5].w);
@@ -534,7 +436,7 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
           sv += __shfl_xor(sv, msk);
           qv += __shfl_xor(qv, msk);
         }
-        if (lane < 8 && kgrp == 0) {
+        if (lane < 8) {
           s_gn[0][wave][WN * ct + 4 * e_c4 + e] = sv;
           s_gn[1][wave][WN * ct + 4 * e_c4 + e] = qv;
         }
@@ -545,7 +447,7 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       // a group wider than the workgroup's columns (512 channels / 8 groups at the 4x4 level): the workgroup's sums are ONE of the
       // cg / WNB column parts of its group and go to their own chunk slot - chunk = tile block * parts + part; the consumer merges
       // (pixels / tile rows) * parts chunks per sample (host: lfdm_conv2d_plan's tile_rows, unet.py)
-      if (kgrp == 0 && tid == 0) {
+      if (tid == 0) {
         float sv = 0.f, qv = 0.f;
         for (int c = 0; c < WNB; ++c)
           for (int w4 = 0; w4 < 4; ++w4) {
@@ -560,7 +462,7 @@ __global__ __launch_bounds__(256 * G, G > 1 ? G : (NT == 1 ? 3 : 2)) void conv_w
       return;
     }
     const int gpt = WNB / cg;                     // groups inside this workgroup's columns (cg divides 32 or is a multiple of it: host check)
-    if (kgrp == 0 && tid < gpt && n0 + tid * cg < p.cout) {
+    if (tid < gpt && n0 + tid * cg < p.cout) {
       float sv = 0.f, qv = 0.f;
       for (int c = 0; c < cg; ++c)
         for (int w4 = 0; w4 < 4; ++w4) {
@@ -669,33 +571,13 @@ extern "C" int lfdm_pack_wino_weights_multi_f32(const lfdm_pack_wino_job* jobs, 
   return lfdm_check_launch("pack_wino_weights_multi");
 }
 
-// grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).  kgroups = G (1, 2, 3; 32-column tiles only).
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, int kgroups, bool fuse_reduce, hipStream_t stream) {
-  if (getenv("LFDM_WINO_TRACE") != nullptr) fprintf(stderr, "conv_wino: bn=%d ksplit=%d groups=%d kgroups=%d\n", bn, p.ksplit, p.groups, kgroups);   // which schedule ran: sweeps and tests
+// grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, hipStream_t stream) {
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (fuse_reduce) {                      // (splitk_fused, conv_igemm.hip: 32-column tiles, one K group, split-K; any activation at run time)
-    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 1, false, true>), grid, dim3(256), 0, stream, p);
-    return lfdm_check_launch("conv_wino");
-  }
-  if (p.gn_in_partial) {                  // (lfdm_conv2d_cl_f32 has checked: 32-column tiles, one K group, no output activation, no pool)
-    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 1, true>), grid, dim3(256), 0, stream, p);
-    return lfdm_check_launch("conv_wino");
-  }
-  if (kgroups == 2 && bn == 64 && !p.pool2) {      // 64 columns x two K groups: 250 VGPRs x two waves per SIMD
-    if (act) LFDM_LAUNCH((conv_wino_kernel<true, 2, false, 2>), grid, dim3(512), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<false, 2, false, 2>), grid, dim3(512), 0, stream, p);
-    return lfdm_check_launch("conv_wino");
-  }
-  if (kgroups > 1 && bn == 32 && !p.pool2) {
-    if (kgroups == 2) {
-      if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, 2>), grid, dim3(512), 0, stream, p);
-      else LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 2>), grid, dim3(512), 0, stream, p);
-    } else {
-      if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1, false, 3>), grid, dim3(768), 0, stream, p);
-      else LFDM_LAUNCH((conv_wino_kernel<false, 1, false, 3>), grid, dim3(768), 0, stream, p);
-    }
+  if (fuse_reduce) {                      // (splitk_fused, conv_igemm.hip: 32-column tiles, split-K; any activation at run time)
+    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, true>), grid, dim3(256), 0, stream, p);
     return lfdm_check_launch("conv_wino");
   }
   if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)

@@ -724,9 +724,9 @@ int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream) {
   const int gx = (int)((ntiles + W4T - 1) / W4T), ny = (p.coutp + W4N - 1) / W4N;
   const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny));
   // producer-wave priority (kernel argument `ablate`, bit 0): on by default, LFDM_W4_PRIO=0 switches it off (A/B: profiles/r04_w_wino4_stamps.txt)
-  static const int ablate = []() { const char* e = getenv("LFDM_W4_PRIO"); return e ? atoi(e) : 1; }();
+  static const int ablate = []() { const char* e = lfdm_knob("LFDM_W4_PRIO"); return e ? atoi(e) : 1; }();
   // staged flavour (unique pixels of an 8 x 4 tile block through LDS): whenever the tile grid allows; LFDM_W4_STAGED=0 keeps the direct one
-  static const bool staged_on = []() { const char* e = getenv("LFDM_W4_STAGED"); return !e || atoi(e) != 0; }();
+  static const bool staged_on = []() { const char* e = lfdm_knob("LFDM_W4_STAGED"); return !e || atoi(e) != 0; }();
   const bool act = p.act != LFDM_ACT_NONE;
   if (staged_on && (p.wq / 4) % 8 == 0 && (p.hq / 4) % 4 == 0) {
     if (p.upsample) {

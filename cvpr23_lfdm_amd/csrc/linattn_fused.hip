@@ -244,7 +244,7 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
   //  a single split left 5120 waves of 32 serial tiles for 3072 slots at B = 16, profiles/r04_t_other_configs.json)
   const int64_t pairs = (int64_t)n_frames * HEADS;
   int want = (int)((pairs <= 1536 ? 3072 : 4 * 3072 + pairs - 1) / pairs);
-  if (const char* e = getenv("LFDM_LINATTN_SPLITS")) want = atoi(e);      // experiment knob
+  if (const char* e = lfdm_knob("LFDM_LINATTN_SPLITS")) want = atoi(e);      // experiment knob
   if (want < 1) want = 1;
   if (want > 64) want = 64;
   if (want > tiles) want = tiles;

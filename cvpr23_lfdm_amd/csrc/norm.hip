@@ -389,8 +389,8 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
   const int64_t per_b = (int64_t)pixels * (channels / 4);
   // float4 per thread and threads per workgroup: two per thread in 256-thread workgroups measured best in rounds 1 and 2 for the
   // 64 ... 512-channel tensors with <= 8 groups; LFDM_GN_F4 / LFDM_GN_BLOCK override (tools/bench_gn.py sweeps them)
-  static const int env_f4 = [] { const char* e = getenv("LFDM_GN_F4"); return e ? atoi(e) : 0; }();
-  static const int env_nt = [] { const char* e = getenv("LFDM_GN_BLOCK"); return e ? atoi(e) : 0; }();
+  static const int env_f4 = [] { const char* e = lfdm_knob("LFDM_GN_F4"); return e ? atoi(e) : 0; }();
+  static const int env_nt = [] { const char* e = lfdm_knob("LFDM_GN_BLOCK"); return e ? atoi(e) : 0; }();
   int f4 = 2, nt = 256;
   // many partials: merge them in fewer, larger workgroups (tools/bench_gn.py sweep, profiles/r03_a_sweep_gn.txt: the merged output
   // heads' 21 MB tensor with 320 x 16 partials 33.1 -> 16.8 us at 1024 threads x 8 float4; 640 x 8 partials on 2.6 MB 6.5 -> 5.6 us at 512)
@@ -407,7 +407,7 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
   // XCD-affine run order (see the kernel): R = runs of nt float4 per 128-pixel tile block, a power of two; whole groups of 8R runs only
   int xcd_r = 0;
   {
-    const char* e = getenv("LFDM_GN_XCD");      // (read per call: A/B in tools)
+    const char* e = lfdm_knob("LFDM_GN_XCD");      // (read per call: A/B in tools)
     const int64_t blk_f4 = 128ll * (channels / 4);
     if (!(e && e[0] == '0') && blk_f4 % nt == 0) {
       const int64_t r = blk_f4 / nt;
@@ -426,328 +426,11 @@ void launch_gn_apply(const float* x, float* out, int batch, int pixels, int chan
 }
 
 
-// GroupNorm straight from split-K slabs: one workgroup per (group, sample) sums the slabs of its rows x channels into registers, reduces the
-// statistics (double), and writes y = silu(x * A[c] + B[c]) (+ residual).  1024 threads, GSK_MAX float4 per thread.
-constexpr int GSK_MAX = 20;
-__global__ __launch_bounds__(1024) void gn_splitk_apply_kernel(const float* __restrict__ partial, int ksplit, int64_t slab_stride, int coutp,
-                                                               const float* __restrict__ bias, float* __restrict__ out, int pixels,
-                                                               int channels, int groups, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, const float* __restrict__ scale_shift,
-                                                               int ss_ld, const float* __restrict__ residual, float eps, int silu) {
-  __shared__ double red_s[16], red_q[16];
-  __shared__ float s_stat[2];
-  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int cg = channels / groups, cg4 = cg >> 2;              // 1024 % cg4 == 0: a thread keeps its channel quad
-  const int items = pixels * cg4;
-  const int q = tid % cg4, c0 = g * cg + 4 * q;
-  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bb = *reinterpret_cast<const float4*>(bias + c0);
-  float4 v[GSK_MAX];
-  float ls = 0.f, lq = 0.f;
-#pragma unroll
-  for (int it = 0; it < GSK_MAX; ++it) {
-    const int i = tid + it * 1024;
-    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < items) {
-      const int64_t row = (int64_t)b * pixels + i / cg4;
-      const float* src = partial + row * coutp + c0;
-      float4 a = bb;
-      for (int z = 0; z < ksplit; ++z) {
-        const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)z * slab_stride);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-      }
-      v[it] = a;
-      ls += (a.x + a.y) + (a.z + a.w);
-      lq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-    }
-  }
-  double ds = (double)ls, dq = (double)lq;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    ds += __shfl_xor(ds, m);
-    dq += __shfl_xor(dq, m);
-  }
-  if ((tid & 63) == 0) {
-    red_s[tid >> 6] = ds;
-    red_q[tid >> 6] = dq;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double ts = 0.0, tq = 0.0;
-    for (int w = 0; w < 16; ++w) {
-      ts += red_s[w];
-      tq += red_q[w];
-    }
-    const double n = (double)pixels * (double)cg;
-    const double mean = ts / n;
-    double var = tq / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_stat[0] = (float)mean;
-    s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  const float mean = s_stat[0], rstd = s_stat[1];
-  float aa[4], ab[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = c0 + e;
-    const float a = rstd * gamma[c];
-    float bsh = beta[c] - mean * a, asc = a;
-    if (scale_shift) {
-      const float sc = scale_shift[(int64_t)b * ss_ld + c] + 1.0f;
-      const float sh = scale_shift[(int64_t)b * ss_ld + channels + c];
-      asc = a * sc;
-      bsh = bsh * sc + sh;
-    }
-    aa[e] = asc;
-    ab[e] = bsh;
-  }
-#pragma unroll
-  for (int it = 0; it < GSK_MAX; ++it) {
-    const int i = tid + it * 1024;
-    if (i < items) {
-      const int64_t row = (int64_t)b * pixels + i / cg4;
-      float4 y;
-      y.x = fmaf(v[it].x, aa[0], ab[0]);
-      y.y = fmaf(v[it].y, aa[1], ab[1]);
-      y.z = fmaf(v[it].z, aa[2], ab[2]);
-      y.w = fmaf(v[it].w, aa[3], ab[3]);
-      if (silu) {
-        y.x = siluf_(y.x);
-        y.y = siluf_(y.y);
-        y.z = siluf_(y.z);
-        y.w = siluf_(y.w);
-      }
-      if (residual) {
-        const float4 r = *reinterpret_cast<const float4*>(residual + row * channels + c0);
-        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
-      }
-      *reinterpret_cast<float4*>(out + row * channels + c0) = y;
-    }
-  }
-}
+// Built, measured and REMOVED in round 6 (records: HISTORY.md rounds 3-4): GroupNorm straight from the raw split-K slabs (one workgroup per
+// (group, sample): 8 workgroups pull 1 MB slabs at a tenth of the HBM rate) and the chip-wide cooperative reduce + statistics + apply launch
+// (+6.4 us per block against conv + reduce + apply, profiles/r04_p_gn_coop_ab.json).
 
-
-// ---- split-K reduce + GroupNorm statistics + apply in ONE launch, chip wide (round 4) ----
-// The low-resolution ResnetBlocks of a B = 1 step ran conv (split-K slabs) -> reduce pass (7 us) -> GroupNorm apply (5 us): two launches
-// that move a 1.3 MB tensor at a tenth of the HBM rate.  The one-workgroup-per-group form above has 8 workgroups pull the slabs (slower);
-// here the reduce pass's own grid - one workgroup per 16 rows x 64 channels, one float4 per thread - keeps its reduced values in
-// REGISTERS, publishes its (sum, sum of squares) of every group it touches as ONE 8-byte agent-scope granule, counts itself in on the
-// group's arrival counter, waits until all `need` workgroups of the (sample, group) have arrived (relaxed polls, bounded), sums the
-// granules in a fixed order (double: bit reproducible) and applies the normalisation to the values it still holds.  No fences: every
-// shared word is an 8- / 4-byte agent-scope atomic on both sides.  The last workgroup to LEAVE a group zeroes its two counters, so a
-// workspace zeroed once serves every later launch.  Correct for any placement; needs all workgroups co-resident (the launcher admits at
-// most 1024 = four per CU) - a timeout (2^20 polls) sets ws[0] and lets the launch finish rather than hang.
-constexpr int COOP_ROWS = 16, COOP_C4 = 16;       // 16 rows x 16 float4 columns = 256 threads, one item each
-template <int KS>
-__global__ __launch_bounds__(256) void gn_splitk_coop_kernel(const float* __restrict__ partial, int64_t slab_stride, int coutp,
-                                                             const float* __restrict__ bias, float* __restrict__ out, int pixels, int channels,
-                                                             int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ scale_shift, int ss_ld, const float* __restrict__ residual,
-                                                             float eps, int silu, unsigned* __restrict__ ws) {
-  __shared__ float s_ps[4][8], s_pq[4][8];        // per wave, per local group
-  __shared__ float s_mean[8], s_rstd[8];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = tid >> 4, q = tid & 15;           // row of the block, float4 column of the block
-  const int rb = blockIdx.x, cy = blockIdx.y;     // row block (over batch * pixels / 16), 64-channel column block
-  const int nrb = pixels / COOP_ROWS;             // row blocks per sample (pixels % 16 == 0: host)
-  const int b = rb / nrb, rbs = rb - b * nrb;
-  const int64_t row = (int64_t)rb * COOP_ROWS + r;
-  const int c = cy * 64 + 4 * q;
-  const int cg = channels / groups;               // 64 % cg == 0 or cg % 64 == 0 (host)
-  const int gpw = cg >= 64 ? 1 : 64 / cg;         // groups inside this workgroup's 64 channels
-  const int wpg = cg >= 64 ? cg / 64 : 1;         // column blocks per group
-  const int lg = cg >= 64 ? 0 : (4 * q) / cg;     // this thread's local group
-  const int g0 = (cy * 64) / cg;                  // first group of the workgroup
-  const int need = nrb * wpg;                     // workgroups per (sample, group)
-  // workspace: [0] timeout flag | per (sample, group): arrive, leave | granules [batch * groups][need]
-  unsigned* const cnt = ws + 4 + 2 * (b * groups + g0);
-  unsigned long long* const gran = reinterpret_cast<unsigned long long*>(ws + 4 + 2 * (gridDim.x / nrb) * groups) +
-                                   (int64_t)(b * groups + g0) * need + rbs * wpg + (cg >= 64 ? cy % wpg : 0);
-
-  // ---- reduce: all KS slab loads in flight, then the per-channel inputs of the apply ----
-  const float* pp = partial + row * coutp + c;
-  float4 v[KS];
-#pragma unroll
-  for (int z = 0; z < KS; ++z) v[z] = *reinterpret_cast<const float4*>(pp + z * slab_stride);
-  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), rr = bb, sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bb;
-  if (bias) bb = *reinterpret_cast<const float4*>(bias + c);
-  const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
-  if (scale_shift) {
-    sc = *reinterpret_cast<const float4*>(scale_shift + (int64_t)b * ss_ld + c);
-    sh = *reinterpret_cast<const float4*>(scale_shift + (int64_t)b * ss_ld + channels + c);
-    sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
-  }
-  if (residual) rr = *reinterpret_cast<const float4*>(residual + row * channels + c);
-  float4 x = v[0];
-#pragma unroll
-  for (int z = 1; z < KS; ++z) { x.x += v[z].x; x.y += v[z].y; x.z += v[z].z; x.w += v[z].w; }
-  x.x += bb.x; x.y += bb.y; x.z += bb.z; x.w += bb.w;
-  float ls = (x.x + x.y) + (x.z + x.w), lq = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-  // lanes of a wave: (row & 3) << 4 | q: sum over the rows (masks 16, 32) and over the quads of one group (masks < cg / 4)
-#pragma unroll
-  for (int m = 1; m <= 32; m <<= 1) {
-    const bool same_group = m >= 16 || m < (cg >= 64 ? 16 : cg / 4);
-    const float os = __shfl_xor(ls, m), oq = __shfl_xor(lq, m);
-    if (same_group) { ls += os; lq += oq; }
-  }
-  if ((lane >> 4) == 0 && (4 * q) % (cg >= 64 ? 64 : cg) == 0) {
-    s_ps[wave][lg] = ls;
-    s_pq[wave][lg] = lq;
-  }
-  __syncthreads();
-  if (tid < gpw) {       // publish: one granule per (workgroup, group), then count in
-    const float ts = (s_ps[0][tid] + s_ps[1][tid]) + (s_ps[2][tid] + s_ps[3][tid]);
-    const float tq = (s_pq[0][tid] + s_pq[1][tid]) + (s_pq[2][tid] + s_pq[3][tid]);
-    lfdm_agent_store_u64(gran + (int64_t)tid * need, ((unsigned long long)__float_as_uint(tq) << 32) | __float_as_uint(ts));
-    LFDM_DRAIN_STORES();
-    lfdm_ticket_take(cnt + 2 * tid);
-  }
-  // ---- wait for the whole (sample, group) cohort: one lane per group polls ----
-  if (tid < gpw) {
-    bool ok = true;
-    unsigned spins = 0;
-    while (lfdm_agent_load_u32(cnt + 2 * tid) < (unsigned)need) {
-      lfdm_sleep();
-      if (++spins > (1u << 20)) { ok = false; break; }
-    }
-    if (!ok) ws[0] = 1u;
-  }
-  __syncthreads();
-  // ---- statistics: wave w sums the granules of local groups w, w + 4 in a fixed order ----
-  for (int g = wave; g < gpw; g += 4) {
-    const unsigned long long* src = gran + (int64_t)g * need - (rbs * wpg + (cg >= 64 ? cy % wpg : 0));
-    double ds = 0.0, dq = 0.0;
-    for (int k = lane; k < need; k += 64) {
-      const unsigned long long u = lfdm_agent_load_u64(src + k);
-      ds += (double)__uint_as_float((unsigned)u);
-      dq += (double)__uint_as_float((unsigned)(u >> 32));
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      ds += __shfl_xor(ds, m);
-      dq += __shfl_xor(dq, m);
-    }
-    if (lane == 0) {
-      const double n = (double)pixels * (double)cg;
-      const double mean = ds / n;
-      double var = dq / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_mean[g] = (float)mean;
-      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  if (tid < gpw) {       // count out; the last one to leave re-arms the group's counters for the next launch
-    if (lfdm_ticket_take(cnt + 2 * tid + 1) == (unsigned)need - 1) {
-      lfdm_ticket_reset(cnt + 2 * tid);
-      lfdm_ticket_reset(cnt + 2 * tid + 1);
-    }
-  }
-  // ---- apply: y = silu(x * A[c] + B[c]) (+ residual), the arithmetic of gn_apply_kernel ----
-  const float mean = s_mean[lg], rstd = s_rstd[lg];
-  const float xs[4] = {x.x, x.y, x.z, x.w}, gs[4] = {ga.x, ga.y, ga.z, ga.w}, bs[4] = {be.x, be.y, be.z, be.w};
-  const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w}, rs[4] = {rr.x, rr.y, rr.z, rr.w};
-  float y[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float a = rstd * gs[e];
-    float bbv = bs[e] - mean * a, aa = a;
-    if (scale_shift) {
-      aa = a * scs[e];
-      bbv = bbv * scs[e] + shs[e];
-    }
-    float t = fmaf(xs[e], aa, bbv);
-    if (silu) t = siluf_(t);
-    y[e] = t + rs[e];
-  }
-  *reinterpret_cast<float4*>(out + row * channels + c) = make_float4(y[0], y[1], y[2], y[3]);
-}
 }  // namespace
-
-extern "C" int lfdm_groupnorm_splitk_ok(int pixels, int channels, int groups) {
-  if (pixels <= 0 || channels <= 0 || groups <= 0 || groups > 64 || channels % groups != 0) return 0;
-  const int cg = channels / groups;
-  if (cg % 4 != 0 || 1024 % (cg / 4) != 0) return 0;
-  return (int64_t)pixels * (cg / 4) <= (int64_t)GSK_MAX * 1024 ? 1 : 0;
-}
-
-extern "C" int lfdm_groupnorm_splitk_apply_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias,
-                                                  float* out, int batch, int pixels, int channels, int groups, const float* gamma,
-                                                  const float* beta, const float* scale_shift, int ss_ld, const float* residual,
-                                                  float eps, int apply_silu, lfdm_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!partial || !out || !gamma || !beta || ksplit < 1 || batch <= 0 || coutp < channels || coutp % 4 != 0 ||
-      slab_stride < (long long)batch * pixels * coutp || (scale_shift && ss_ld < 2 * channels) ||
-      !lfdm_groupnorm_splitk_ok(pixels, channels, groups) || (((uintptr_t)partial | (uintptr_t)out) & 15) != 0 ||
-      (bias && ((uintptr_t)bias & 15) != 0) || (residual && ((uintptr_t)residual & 15) != 0)) {
-    lfdm_set_error("groupnorm_splitk_apply: bad arguments (see lfdm_groupnorm_splitk_ok)");
-    return LFDM_EINVAL;
-  }
-  LFDM_LAUNCH(gn_splitk_apply_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(1024), 0, stream, partial, ksplit, (int64_t)slab_stride,
-              coutp, bias, out, pixels, channels, groups, gamma, beta, scale_shift, ss_ld, residual, eps, apply_silu);
-  return lfdm_check_launch("groupnorm_splitk_apply");
-}
-
-extern "C" int lfdm_groupnorm_splitk_coop_ok(int batch, int pixels, int channels, int groups, int ksplit) {
-  if (batch <= 0 || pixels <= 0 || channels <= 0 || groups <= 0 || groups > 64 || channels % groups != 0 || ksplit < 2 || ksplit > 8) return 0;
-  const int cg = channels / groups;
-  if (pixels % COOP_ROWS != 0 || channels % 64 != 0 || cg % 4 != 0 || !((cg <= 64 && 64 % cg == 0 && 64 / cg <= 8) || cg % 64 == 0)) return 0;
-  // every workgroup must be resident while its cohort gathers: at most four 256-thread workgroups per CU (MI355X_MICROARCH.md "Residency")
-  return (int64_t)batch * (pixels / COOP_ROWS) * (channels / 64) <= 1024 ? 1 : 0;
-}
-
-extern "C" size_t lfdm_groupnorm_splitk_coop_ws_bytes(int batch, int pixels, int channels, int groups) {
-  if (batch <= 0 || pixels <= 0 || channels <= 0 || groups <= 0 || channels % groups != 0) return 0;
-  const int cg = channels / groups;
-  const size_t need = (size_t)(pixels / COOP_ROWS) * (cg >= 64 ? cg / 64 : 1);
-  return (4 + 2 * (size_t)batch * groups) * sizeof(unsigned) + (size_t)batch * groups * need * sizeof(unsigned long long) + 16;
-}
-
-extern "C" int lfdm_groupnorm_splitk_coop_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias,
-                                                 float* out, int batch, int pixels, int channels, int groups, const float* gamma,
-                                                 const float* beta, const float* scale_shift, int ss_ld, const float* residual,
-                                                 float eps, int apply_silu, void* sync_ws, size_t sync_ws_bytes, lfdm_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!partial || !out || !gamma || !beta || !sync_ws || coutp < channels || coutp % 4 != 0 ||
-      slab_stride < (long long)batch * pixels * coutp || (scale_shift && (ss_ld < 2 * channels || ss_ld % 4 != 0)) ||
-      !lfdm_groupnorm_splitk_coop_ok(batch, pixels, channels, groups, ksplit) ||
-      (((uintptr_t)partial | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)sync_ws) & 15) != 0 || (slab_stride % 4) != 0 ||
-      (bias && ((uintptr_t)bias & 15) != 0) || (residual && ((uintptr_t)residual & 15) != 0) || (scale_shift && ((uintptr_t)scale_shift & 15) != 0)) {
-    lfdm_set_error("groupnorm_splitk_coop: bad arguments (see lfdm_groupnorm_splitk_coop_ok; 16-byte aligned pointers)");
-    return LFDM_EINVAL;
-  }
-  if (sync_ws_bytes < lfdm_groupnorm_splitk_coop_ws_bytes(batch, pixels, channels, groups)) {
-    lfdm_set_error("groupnorm_splitk_coop: sync workspace too small (lfdm_groupnorm_splitk_coop_ws_bytes; zero it ONCE before the first use)");
-    return LFDM_EWORKSPACE;
-  }
-#if defined(LFDM_EMU_BUILD)
-  // the fiber emulator runs the workgroups of a launch one after the other per OS thread: a workgroup that waits for its cohort would wait
-  // for ever.  The emulation build serves this entry point with the one-workgroup-per-group kernel (same arithmetic order per element,
-  // statistics summed in another order) so that callers can be exercised without a GPU; the cooperative kernel itself is tested on the GPU.
-  (void)sync_ws_bytes;
-  LFDM_LAUNCH(gn_splitk_apply_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(1024), 0, stream, partial, ksplit, (int64_t)slab_stride,
-              coutp, bias, out, pixels, channels, groups, gamma, beta, scale_shift, ss_ld, residual, eps, apply_silu);
-  return lfdm_check_launch("groupnorm_splitk_coop");
-#else
-  const dim3 grid((unsigned)(batch * (pixels / COOP_ROWS)), (unsigned)(channels / 64));
-  unsigned* ws = reinterpret_cast<unsigned*>(sync_ws);
-#define LFDM_COOP(KS) LFDM_LAUNCH(gn_splitk_coop_kernel<KS>, grid, dim3(256), 0, stream, partial, (int64_t)slab_stride, coutp, bias, out, pixels, channels, \
-                                  groups, gamma, beta, scale_shift, ss_ld, residual, eps, apply_silu, ws)
-  switch (ksplit) {
-    case 2: LFDM_COOP(2); break;
-    case 3: LFDM_COOP(3); break;
-    case 4: LFDM_COOP(4); break;
-    case 5: LFDM_COOP(5); break;
-    case 6: LFDM_COOP(6); break;
-    case 7: LFDM_COOP(7); break;
-    default: LFDM_COOP(8); break;
-  }
-#undef LFDM_COOP
-  return lfdm_check_launch("groupnorm_splitk_coop");
-#endif
-}
 
 extern "C" size_t lfdm_groupnorm_ws_bytes(int batch, int pixels, int channels) {
   const size_t partial = (size_t)batch * gn_num_chunks(pixels) * 64 * 2;

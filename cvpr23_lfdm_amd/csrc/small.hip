@@ -434,7 +434,7 @@ extern "C" int lfdm_conv_planar_in_cl_f32(const float* x, int batch, int cin, in
     return LFDM_EINVAL;
   }
   const int64_t total = (int64_t)batch * frames * h * w;
-  static const bool mfma_off = [] { const char* e = getenv("LFDM_STEM_MFMA"); return e && e[0] == '0'; }();
+  static const bool mfma_off = [] { const char* e = lfdm_knob("LFDM_STEM_MFMA"); return e && e[0] == '0'; }();
   const int tiles_x = (w + CPM_COLS - 1) / CPM_COLS, tiles_y = (h + CPM_ROWS - 1) / CPM_ROWS;
   const int64_t nblk = (int64_t)batch * frames * tiles_x * tiles_y;
   if (!mfma_off && cin <= 8 && kh <= 7 && kw <= 7 && (cout & 3) == 0 && ((((uintptr_t)wgt) & 15) == 0) && nblk < (1ll << 31)) {

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
 }
 
 bool attn_bwd_rows40_enabled() {          // experiment knob (tools/bench_attn_bwd.py): LFDM_ATTN_BWD_ROWS40=0 -> the 48-row / four-wave form
-  const char* e = getenv("LFDM_ATTN_BWD_ROWS40");
+  const char* e = lfdm_knob("LFDM_ATTN_BWD_ROWS40");
   return !(e && e[0] == '0');
 }
 

@@ -495,9 +495,9 @@ WgradPlan wgrad_plan(const lfdm_wgrad_params& p) {
         if (n_tiles >= 32) {
           // two workgroups per CU and no more: every further split is another 9 * cin * cout slab to write and re-read (sweep in
           // profiles/r05_d_bench_wgrad3.txt: 1024 / 2048 workgroups lose 10-25 % on the 128 ... 512-channel shapes)
-          const char* ew = getenv("LFDM_WGRAD3_WGS");      // experiment knob: workgroups aimed at
+          const char* ew = lfdm_knob("LFDM_WGRAD3_WGS");      // experiment knob: workgroups aimed at
           const int64_t want = ew ? atol(ew) : 512;
-          const char* ec = getenv("LFDM_WGRAD3_MAXSPLIT");
+          const char* ec = lfdm_knob("LFDM_WGRAD3_MAXSPLIT");
           const int64_t cap = ec ? atol(ec) : 256;
           int64_t s = (want + blocks - 1) / blocks;
           if (s > n_tiles / 8) s = n_tiles / 8;

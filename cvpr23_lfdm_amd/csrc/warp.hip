@@ -272,7 +272,7 @@ extern "C" int lfdm_warp_cl_f32(const lfdm_warp_params* pp, lfdm_stream_t stream
     return LFDM_EINVAL;
   }
   int r = (p.c % 16 == 0) ? 4 : (p.c % 8 == 0 ? 2 : 1);
-  if (const char* e = getenv("LFDM_WARP_R")) {      // experiment knob (bench.py warp object): lanes per pixel = C / (4 r)
+  if (const char* e = lfdm_knob("LFDM_WARP_R")) {      // experiment knob (bench.py warp object): lanes per pixel = C / (4 r)
     const int v = atoi(e);
     if ((v == 1 || v == 2 || v == 4) && p.c % (4 * v) == 0) r = v;
   }

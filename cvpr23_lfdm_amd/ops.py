@@ -284,8 +284,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, defer_reduce=False,
-                gn_in=None, weight_pw=None):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, weight_pw=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -347,25 +346,13 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         _chk(lib, weight_wino4)
         assert weight_wino is not None and weight_wino4.shape == (36, cin // 8, coutp, 8) and weight_wino4.is_contiguous()
         p.weight_wino4 = weight_wino4.data_ptr()
-    # gn_in = dict(partial, nchunk, pixels, gamma, beta, groups=8, scale_shift=None, eps=1e-5): src0 is the previous convolution's raw output;
-    # its GroupNorm + scale/shift + SiLU is applied inside this convolution's patch load (Winograd schedule only; lfdm_conv_params.gn_in_*)
     p.weight_pw = None
     if weight_pw is not None:          # the same 1x1 filter in operand order for the pointwise schedule (pack_pw_weight)
         _chk(lib, weight_pw)
         assert kh == 1 and kw == 1 and weight_pw.numel() == weight.numel() and weight_pw.is_contiguous()
         p.weight_pw = weight_pw.data_ptr()
-    p.gn_in_partial = None
     keep_gn = (weight_pw,)
-    if gn_in is not None:
-        gp, gg, gb, gss = gn_in["partial"], gn_in["gamma"], gn_in["beta"], gn_in.get("scale_shift")
-        _chk(lib, gp, gg, gb, gss)
-        assert src1 is None and gg.numel() == src0.shape[1] == gb.numel() and gp.is_contiguous()
-        p.gn_in_partial, p.gn_in_nchunk, p.gn_in_groups, p.gn_in_pixels = _p(gp), int(gn_in["nchunk"]), int(gn_in.get("groups", 8)), int(gn_in["pixels"])
-        p.gn_in_gamma, p.gn_in_beta, p.gn_in_ss = _p(gg), _p(gb), _p(gss)
-        p.gn_in_ss_ld = gss.stride(0) if gss is not None else 0
-        p.gn_in_eps = float(gn_in.get("eps", 1e-5))
-        keep_gn = (gp, gg, gb, gss)
-    p.defer_reduce = int(bool(defer_reduce))     # split-K slabs stay raw for groupnorm_splitk_apply_cl (no reduce launch)
+    p.gn_in_partial, p.defer_reduce = None, 0      # (reserved since ABI 12: must stay NULL / 0)
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
     p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4) + keep_gn   # keep the tensors alive with the struct
     return p, out
@@ -491,51 +478,6 @@ def groupnorm_apply_cl(x, batch, gamma, beta, partial, nchunk, *, groups=8, scal
                                               scale_shift.stride(0) if scale_shift is not None else 0,
                                               _p(residual), eps, int(silu), _p(partial), nchunk, _p(ws),
                                               ws.numel() * 4, _stream(lib)), "lfdm_groupnorm_apply_cl_f32")
-    return out
-
-
-def groupnorm_splitk_ok(pixels, channels, groups=8):
-    """Can groupnorm_splitk_apply_cl take this (sample, group) size in one workgroup (lfdm_groupnorm_splitk_ok)?"""
-    return bool(_lib().lfdm_groupnorm_splitk_ok(pixels, channels, groups))
-
-
-def groupnorm_splitk_coop_ok(batch, pixels, channels, groups, ksplit):
-    return bool(_lib().lfdm_groupnorm_splitk_coop_ok(batch, pixels, channels, groups, ksplit))
-
-
-def groupnorm_splitk_coop_ws(batch, pixels, channels, groups, device):
-    """Sync workspace of groupnorm_splitk_coop_cl: zeroed here ONCE; every launch leaves it zeroed."""
-    n = int(_lib().lfdm_groupnorm_splitk_coop_ws_bytes(batch, pixels, channels, groups))
-    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
-
-
-def groupnorm_splitk_coop_cl(partial, ksplit, slab_stride, coutp, bias, out, batch, gamma, beta, sync_ws, *, groups=8, scale_shift=None,
-                             residual=None, eps=1e-5, silu=True):
-    """GroupNorm (+ scale/shift, SiLU, residual) from the raw split-K slabs of the preceding convolution (conv_params(defer_reduce=True)),
-    chip wide: slab sum + bias + statistics + apply in ONE launch (lfdm_groupnorm_splitk_coop_cl_f32)."""
-    lib = _lib()
-    rows, ch = out.shape
-    _chk(lib, partial, bias, out, gamma, beta, scale_shift, residual, sync_ws)
-    assert out.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == out.shape))
-    lib.check(lib.lfdm_groupnorm_splitk_coop_cl_f32(_p(partial), ksplit, slab_stride, coutp, _p(bias), _p(out), batch, rows // batch, ch, groups,
-                                                    _p(gamma), _p(beta), _p(scale_shift), scale_shift.stride(0) if scale_shift is not None else 0,
-                                                    _p(residual), eps, int(silu), _p(sync_ws), sync_ws.numel() * 4, _stream(lib)),
-              "lfdm_groupnorm_splitk_coop_cl_f32")
-    return out
-
-
-def groupnorm_splitk_apply_cl(partial, ksplit, slab_stride, coutp, bias, out, batch, gamma, beta, *, groups=8, scale_shift=None,
-                              residual=None, eps=1e-5, silu=True):
-    """GroupNorm (+ scale/shift, SiLU, residual) straight from the raw split-K slabs of the preceding convolution
-    (conv_params(defer_reduce=True)): bias + slab sum + statistics + apply in ONE launch.  lfdm_groupnorm_splitk_apply_cl_f32."""
-    lib = _lib()
-    rows, ch = out.shape
-    _chk(lib, partial, bias, out, gamma, beta, scale_shift, residual)
-    assert out.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == out.shape))
-    lib.check(lib.lfdm_groupnorm_splitk_apply_cl_f32(_p(partial), ksplit, slab_stride, coutp, _p(bias), _p(out), batch, rows // batch, ch,
-                                                     groups, _p(gamma), _p(beta), _p(scale_shift),
-                                                     scale_shift.stride(0) if scale_shift is not None else 0, _p(residual), eps,
-                                                     int(silu), _stream(lib)), "lfdm_groupnorm_splitk_apply_cl_f32")
     return out
 
 

@@ -14,38 +14,22 @@ from . import ops
 from .params import ParamTree, build_tree, unet_spec, weights_epoch
 
 BERT_MODEL_DIM = 768
-# LFDM_LOWRES_ATTN=0: the low-resolution attention blocks as separate projection / core launches (A/B switch for profiling)
-_LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"
+# Default-on fusions keep ONE switch each for A/B profiling and for the bit-compare tests (LFDM_x=0 -> the separate launches):
+_LOWRES_ATTN = os.environ.get("LFDM_LOWRES_ATTN", "1") != "0"       # one-launch attention blocks at <= 64 pixels per frame
 # measured (tools/bench_attn_lowres.py, profiles/r03_f_bench_attn_lowres.txt): the one-launch kernels win at <= 64 pixels per frame
 # (4x4: 19 vs 31 us linear, 19 vs 26 temporal; 8x8: 33 vs 35 / 23 vs 29) and lose at 16x16 (69 vs 64 / 63 vs 52: 2048 workgroups of one
 # head each re-read the frame's rows eight times and hold 78-110 KB of LDS)
-_LOWRES_MAX_HW = int(os.environ.get("LFDM_LOWRES_MAX_HW", "64"))
-_RES_STREAM = os.environ.get("LFDM_RES_STREAM", "0") == "1"
-_GN_SPLITK = os.environ.get("LFDM_GN_SPLITK", "0") == "1"      # conv (split-K) -> GroupNorm without the reduce launch (ops.groupnorm_splitk_apply_cl)
-# ... the chip-wide form of it (ops.groupnorm_splitk_coop_cl, round 4): the reduce pass's grid keeps its values in registers and the
-# workgroups of a (sample, group) exchange their statistics through agent-scope granules.  Parity-green, bit reproducible - and SLOWER:
-# 298.3 vs 285.8 ms per video (profiles/r04_p_gn_coop_ab.json): the in-launch gather (publish, count in, poll, read 40-160 granules) costs
-# ~19 us where the reduce launch + apply launch cost 12.6 - a counter barrier is 7 us on this chip (MI355X_MICROARCH.md "barrier-counter"),
-# a kernel boundary 2.  Off by default; LFDM_GN_COOP=1 turns it on.
-_GN_COOP = os.environ.get("LFDM_GN_COOP", "0") == "1"
+_LOWRES_MAX_HW = 64
 # Split-K Winograd convolutions reduce their slabs inside the launch (lfdm_conv_params.tile_counters: fence-free hand-off, conv_wino.hip FUSE):
-# no conv_splitk_reduce launch behind the 8x8 / 4x4 convolutions of a B = 1 step.  LFDM_WINO_FUSE_REDUCE=0: the separate reduce pass.
+# no conv_splitk_reduce launch behind the 16x16 / 8x8 / 4x4 convolutions of a B = 1 step.  LFDM_WINO_FUSE_REDUCE=0: the separate reduce pass.
 _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
-# ... the same for the K-split-across-waves schedule: measured SLOWER (its four split-K launches per step have 4-40 workgroups whose last
-# arriver walks up to ten 32x32 tiles one after the other: 280.5 vs 279.6 ms per video, profiles/r05_s_fuse_reduce_ab.txt) - off
-_KSW_FUSE_REDUCE = os.environ.get("LFDM_KSW_FUSE_REDUCE", "0") == "1"
-_RES_STREAM_MAX_ROWS = int(os.environ.get("LFDM_RES_STREAM_MAX_ROWS", "16384"))
-# block1's GroupNorm + scale/shift + SiLU inside block2's Winograd convolution (lfdm_conv_params.gn_in_*): one launch less per ResnetBlock.
-# MEASURED SLOWER (round 4, profiles/r04_d_*): 146 instead of 165 launches per step, but every fused convolution takes ~10 us longer (the
-# statistics merge + A/B table sit in its prologue, the activation is recomputed for each of the 4 overlapping patches x column tiles) for
-# a 5-12 us launch saved: 304.2 vs 298.4 ms per video.  Off by default.  LFDM_GN_FUSE = 1 turns it on wherever the geometry allows;
-# LFDM_GN_FUSE_MAX_ROWS bounds the activation rows (B*T*S*S) it is used at.
-_GN_FUSE = os.environ.get("LFDM_GN_FUSE", "0") == "1"
-_GN_FUSE_MAX_ROWS = int(os.environ.get("LFDM_GN_FUSE_MAX_ROWS", str(1 << 30)))
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
-_TATTN_WIDE = os.environ.get("LFDM_TATTN_WIDE", "0") == "1"      # A/B: the channel-streaming fused kernel at C >= 128 where no one-launch form applies
+# Built, measured slower and REMOVED in round 6 (records in HISTORY.md, rounds 1-5): res_conv on a second stream (LFDM_RES_STREAM), GroupNorm
+# straight from the raw split-K slabs (LFDM_GN_SPLITK) and its chip-wide cooperative form (LFDM_GN_COOP), the in-launch slab reduction on
+# the KSW schedule (LFDM_KSW_FUSE_REDUCE), block1's GroupNorm inside block2's convolution (LFDM_GN_FUSE), the channel-streaming fused
+# temporal attention at C >= 128 (LFDM_TATTN_WIDE).
 
 
 def prob_mask_like(shape, prob, device):
@@ -330,7 +314,7 @@ class Unet3D(ParamTree):
         coutp = p.coutp
         sched = ops.conv_schedule(p) if (_WINO_FUSE_REDUCE and kw.get("deconv4") is None) else -1
         # (KSW: fused statistics need the group inside a 32-column tile - wider groups keep the reduce pass, whose statistics take any width)
-        if sched == 2 or (sched == 1 and _KSW_FUSE_REDUCE and (gn is None or 32 % (cout // (gn[1] if len(gn) > 1 else 8)) == 0)):
+        if sched == 2:
             counters = self._tile_counters(src0.device)
             p.tile_counters, p.tile_counters_len = counters.data_ptr(), counters.numel()
         if gn is not None:
@@ -345,17 +329,6 @@ class Unet3D(ParamTree):
             part = self._buf(scratch, 1, partial_floats)      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None
-        if (gn is not None and _GN_COOP and src0.is_cuda and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
-                coutp == cout and ops.groupnorm_splitk_coop_ok(gn[0], m // gn[0], cout, gn[1] if len(gn) > 1 else 8, ksplit)):
-            p.defer_reduce = 1
-            ops.conv_launch(p)
-            return y, ("coop", part, ksplit, m * coutp, coutp, bias)
-        if (gn is not None and _GN_SPLITK and ksplit > 1 and tile_rows != 160 and residual is None and not kw.get("act") and
-                ops.groupnorm_splitk_ok(m // gn[0], cout, gn[1] if len(gn) > 1 else 8)):
-            # the slabs stay raw: the GroupNorm launch sums them, adds the bias and normalises (one workgroup per (sample, group))
-            p.defer_reduce = 1
-            ops.conv_launch(p)
-            return y, ("slabs", part, ksplit, m * coutp, coutp, bias)
         if gn is not None:
             batch, groups = gn[0], (gn[1] if len(gn) > 1 else 8)
             pixels = m // batch
@@ -368,9 +341,7 @@ class Unet3D(ParamTree):
             in_reduce = ksplit > 1 and not fused and 256 % (coutp // 4) == 0 and coutp == cout    # ... from the split-K reduce pass (any group width)
             if pixels % tile_rows == 0 and cg % 4 == 0 and (in_tile or in_reduce):
                 nchunk = pixels // tile_rows * (parts if in_tile else 1)
-                # (a convolution that READS the previous statistics through gn_in writes its own into the other arena: its workgroups finish
-                #  - and store their partial sums - while others are still merging the input's)
-                stats = (self._buf("gn.partial2" if kw.get("gn_in") is not None else "gn.partial", batch * nchunk, 2 * groups), nchunk)
+                stats = (self._buf("gn.partial", batch * nchunk, 2 * groups), nchunk)
                 p.gn_partial, p.gn_groups, p.gn_pixels = stats[0].data_ptr(), groups, pixels
         ops.conv_launch(p)
         return (y, stats) if gn is not None else y
@@ -384,51 +355,13 @@ class Unet3D(ParamTree):
         return cur
 
     def _gn(self, x, batch, gamma, beta, stats, groups=8, **kw):
-        if stats is not None and stats[0] == "coop":
-            _, part, ksplit, slab_stride, coutp, bias = stats
-            key = (batch, x.shape[0] // batch, x.shape[1], groups)
-            ws = self._coop_ws.get(key) if getattr(self, "_coop_ws", None) else None
-            if ws is None or ws.device != x.device:
-                self._coop_ws = getattr(self, "_coop_ws", None) or {}
-                ws = self._coop_ws[key] = ops.groupnorm_splitk_coop_ws(batch, x.shape[0] // batch, x.shape[1], groups, x.device)
-                self._buf_gen += 1          # (a captured graph holds this pointer)
-            return ops.groupnorm_splitk_coop_cl(part, ksplit, slab_stride, coutp, bias, x, batch, gamma, beta, ws, groups=groups, **kw)
-        if stats is not None and stats[0] == "slabs":
-            _, part, ksplit, slab_stride, coutp, bias = stats
-            return ops.groupnorm_splitk_apply_cl(part, ksplit, slab_stride, coutp, bias, x, batch, gamma, beta, groups=groups, **kw)
         gws = self._buf("gn.ws", batch, 256 * 128 + 2 * 1024)
         if stats is not None:
             return ops.groupnorm_apply_cl(x, batch, gamma, beta, stats[0], stats[1], out=x, ws=gws, groups=groups, **kw)
         return ops.groupnorm_silu_cl(x, batch, gamma, beta, out=x, ws=gws, groups=groups, **kw)
 
-    def _gn_in(self, stats, batch, rows, channels, gamma, beta, sshift, ww, groups=8):
-        """Parameters of the fused input GroupNorm of the NEXT convolution (ops.conv_params gn_in=...), or None when the separate
-        GroupNorm launch has to run: statistics not available as partial sums, no Winograd form, a geometry the kernel refuses."""
-        if not _GN_FUSE or stats is None or stats[0] in ("slabs", "coop") or ww is None or rows > _GN_FUSE_MAX_ROWS:
-            return None
-        pixels = rows // batch
-        if pixels % 128 != 0 or channels > 1024 or channels % groups != 0 or channels % 16 != 0:
-            return None
-        return dict(partial=stats[0], nchunk=stats[1], pixels=pixels, gamma=gamma, beta=beta, groups=groups, scale_shift=sshift)
-
-    def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
-        return self._side
-
     def _resblock(self, pk, prefix, x, skip, batch, frames, s, ss, cout, outname):
         n_img, rows = batch * frames, batch * frames * s * s
-        # res_conv(x) does not depend on the block1 -> block2 chain.  LFDM_RES_STREAM=1: below the finest level, where a launch leaves
-        # most CUs idle, it runs on a second stream (a parallel branch of the captured graph) and the last GroupNorm kernel adds its
-        # result.  (Round 1 measured this slower with the projection as a staged kernel + split-K reduce pair; since round 3 it is one
-        # short pointwise launch - re-measured, see DESIGN.md.)
-        side, r = None, None
-        if _RES_STREAM and (prefix + "res.w") in pk and x.is_cuda and rows <= _RES_STREAM_MAX_ROWS:
-            side = self._side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                r = self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"],
-                               out=self._buf("rb.res", rows, cout), scratch="splitk.side")
         h1 = self._buf("rb.h1", rows, cout)
         _, st = self._conv(x, pk[prefix + "block1.proj.w"], cout, 3, n_img, s, src1=skip,
                            bias=pk[prefix + "block1.proj.b"], out=h1, gn=(batch,), ww=pk[prefix + "block1.proj.ww"])
@@ -436,17 +369,11 @@ class Unet3D(ParamTree):
         if ss is not None and (prefix + "ss_off") in pk:
             o = pk[prefix + "ss_off"]
             sshift = ss[:, o:o + 2 * cout]
-        gn_in = self._gn_in(st, batch, rows, cout, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], sshift, pk[prefix + "block2.proj.ww"])
-        if gn_in is None:
-            self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
+        self._gn(h1, batch, pk[prefix + "block1.norm.w"], pk[prefix + "block1.norm.b"], st, scale_shift=sshift)
         out = self._buf(outname, rows, cout)
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
-                           out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"], gn_in=gn_in)
+                           out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st, residual=r)
-            return out
         self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st,
                  residual=None if has_res else x)
         if has_res:
@@ -481,7 +408,7 @@ class Unet3D(ParamTree):
         if c == 64 and frames <= 64 and _TATTN_OUT:      # the whole block (LayerNorm, to_qkv, attention, to_out, residual) in one launch
             return ops.temporal_attention_fused_out_cl(x, pk[prefix + "qkv.wp"], pk[prefix + "out.wp"], batch, frames, s * s, bias=bias,
                                                        rot_cos=cos, rot_sin=sin, out=self._buf(outname, x.shape[0], c))
-        if (c == 64 or (_TATTN_WIDE and c % 64 == 0 and s * s > _LOWRES_MAX_HW)) and frames <= 64:
+        if c == 64 and frames <= 64:
             att = self._buf("at.o", x.shape[0], 256)
             ops.temporal_attention_fused_cl(x, pk[prefix + "qkv.wf"], batch, frames, s * s, bias=bias, rot_cos=cos,
                                             rot_sin=sin, out=att)
@@ -588,12 +515,10 @@ class Unet3D(ParamTree):
             h1 = self._buf("h.h1", rows, c2)
             _, st = self._conv(x, pk["heads.block1.w"], c2, 3, n_img, res, src1=r, bias=pk["heads.block1.b"], out=h1,
                                gn=(batch, 16), ww=pk["heads.block1.ww"])
-            gn_in = self._gn_in(st, batch, rows, c2, pk["heads.norm1.w"], pk["heads.norm1.b"], None, pk["heads.block2.ww"], groups=16)
-            if gn_in is None:
-                self._gn(h1, batch, pk["heads.norm1.w"], pk["heads.norm1.b"], st, groups=16)
+            self._gn(h1, batch, pk["heads.norm1.w"], pk["heads.norm1.b"], st, groups=16)
             y = self._buf("h.y", rows, c2)
             _, st = self._conv(h1, pk["heads.block2.ww"], c2, 3, n_img, res, bias=pk["heads.block2.b"], out=y,
-                               gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2, gn_in=gn_in)
+                               gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2)
             self._gn(y, batch, pk["heads.norm2.w"], pk["heads.norm2.b"], st, groups=16)
             if _HEADS_FOLD and x.shape[1] % 4 == 0 and r.shape[1] % 4 == 0 and x.shape[1] + r.shape[1] == pk["heads.fold.w"].shape[1]:
                 # the blocks' res_conv(cat(x, r)) folded into the linear heads: one 1x1 convolution launch less

@@ -93,12 +93,13 @@ typedef struct lfdm_conv_params {
      the row and writes rstd*(x.W' - mean*ln_wsum) - algebraically LayerNorm(x)*gamma followed by W. */
   const float* ln_wsum;
   float ln_eps;
-  /* Optional in-launch split-K reduction (Winograd F(2x2) schedule with 32-column workgroups, and the KSW schedule): tile_counters_len
-     zero-initialised words, at least one per output tile (lfdm_conv2d_plan's tile_rows - 128 / 160 - x 32/64 columns).  When given, the
+  /* Optional in-launch split-K reduction (Winograd F(2x2) schedule with 32-column workgroups): tile_counters_len
+     zero-initialised words, at least one per output tile (lfdm_conv2d_plan's tile_rows - 128 - x 32 columns).  When given, the
      workgroup that finishes a tile's last K slice sums the slabs in `partial` (slice order: bit-identical to the reduce pass) and runs the
      epilogue itself - no reduce launch; the counters are left at zero again.  NULL / too short / an unsupported geometry = separate reduce
-     pass (lfdm_conv2d_plan's tile_rows says which: 16 = reduce pass).  The slabs cross workgroups as 8-byte agent-scope words (written
-     through, read past the per-XCD L2s): no scope fence.  With tile_counters the Winograd plan also splits 8..15-chunk reductions.
+     pass (lfdm_conv2d_plan's tile_rows says which: 16 = reduce pass).  The slabs cross workgroups as 16-byte write-through (sc1) stores / L1-bypassing
+     loads through a buffer descriptor (the library rounds `partial` up to a 128-byte boundary; lfdm_conv2d_partial_bytes carries the slack):
+     no scope fence.  With tile_counters the Winograd plan also splits 8..15-chunk reductions.
      GroupNorm partial sums of a fused Winograd launch whose groups are wider than 32 channels occupy cg/32 chunk slots per tile block:
      chunk = tile block * (cg / 32) + column part. */
   unsigned int* tile_counters;
@@ -134,27 +135,16 @@ typedef struct lfdm_conv_params {
      512-pixel x 32-column workgroups (LFDM_WINO4_MIN; LFDM_WINO4=0 disables): the frozen-LFAE decode of a training step, throughput
      mode - never the B = 1 sampler.  Bias / residual / activation / virtual x2 upsample as in the F(2x2) schedule. */
   const float* weight_wino4;
-  /* Optional (ABI version 6): defer_reduce = 1 and a plan that splits K -> the reduce pass is NOT launched: `partial` keeps the raw slabs
-     [ksplit][M][coutp] (no bias) for lfdm_groupnorm_splitk_apply_cl_f32, which sums them, adds the bias and applies the GroupNorm in one
-     launch (the low-resolution ResnetBlocks of a B = 1 step: conv + reduce + apply -> conv + apply).  `out` is not written.  Needs no
-     residual / activation / fused statistics / LayerNorm fold / deconv4.  Ignored when the plan does not split K. */
+  /* RESERVED, must be 0 (ABI 6-11: defer_reduce - raw split-K slabs left for a GroupNorm launch that summed them; measured slower than
+     conv + reduce + apply and removed in ABI 12 together with lfdm_groupnorm_splitk_*). */
   int defer_reduce;
-  /* Optional (ABI version 8; Winograd schedule only - lfdm_conv2d_cl_f32 refuses it on a geometry that would run another schedule,
-     ask lfdm_conv2d_schedule first): the INPUT src0 is the raw output of the previous convolution, whose GroupNorm (+ per-sample
-     scale / shift) + SiLU has not been applied: gn_in_partial != NULL -> every patch element x[pixel][c] is read as
-     silu(x * A[c] + B[c]) with A, B folded from the (sum, sum of squares) partials of that tensor exactly like
-     lfdm_groupnorm_apply_cl_f32 does (gn_in_partial [batch * gn_in_nchunk][2 * gn_in_groups], merged in double in a fixed order by
-     every workgroup), gn_in_gamma / gn_in_beta [c0], optional gn_in_ss rows (scale | shift, 2 * c0 floats per sample, row stride
-     gn_in_ss_ld).  This is Block.forward's norm -> scale/shift -> act (video_flow_diffusion.py:199-212) of ResnetBlock.block1 moved
-     into block2's convolution: the sampler's block1 GroupNorm launches disappear.  Zero padding stays zero (the activation is
-     applied to in-image pixels only).  Needs one source (c1 == 0), no upsample, gn_in_pixels (pixels per sample) % 128 == 0,
-     c0 <= 1024, c0 % gn_in_groups == 0.  SiLU here is x * rcp(1 + exp2(-x log2 e)) on the hardware exponential / reciprocal
-     (within 3 ulp of the library's GroupNorm kernels). */
   /* Optional (ABI version 8): the SAME 1x1 filter as `weight`, for the pointwise schedule (3) only, in MFMA-operand order
      [ceil(K/32)][coutp/32][4 u][64 lanes = 32*kh + column][4 e] <- W[k = 32g + 8u + 4kh + e][32*ct + column]
      (cvpr23_lfdm_amd.ops.pack_pw_weight): every fragment load of conv_pw_kernel then reads one contiguous 1 KB.  Ignored by the other
      schedules (they read `weight`); NULL = the pointwise kernel reads `weight` as before. */
   const float* weight_pw;
+  /* RESERVED, must be NULL / 0 (ABI 8-11: gn_in_* - the INPUT's GroupNorm + SiLU applied inside the Winograd convolution's patch load;
+     ~10 us slower per convolution than the launch it saved, removed in ABI 12.  The fields keep the struct layout.) */
   const float* gn_in_partial;
   int gn_in_nchunk, gn_in_groups, gn_in_pixels;
   const float* gn_in_gamma;
@@ -203,29 +193,6 @@ int lfdm_groupnorm_apply_cl_f32(const float* x, float* out, int batch, int pixel
                                 const float* scale_shift, int ss_ld, const float* residual,
                                 float eps, int apply_silu, const float* partial, int nchunk,
                                 void* ws, size_t ws_bytes, lfdm_stream_t stream);
-
-/* GroupNorm (+ scale/shift, SiLU, residual as above) straight from the split-K slabs of the preceding convolution
- * (lfdm_conv_params.defer_reduce): x[row][c] = bias[c] + sum_z partial[z * slab_stride + row * coutp + c] is formed in registers, the
- * statistics of a (sample, group) are reduced inside ONE workgroup (grid = groups x batch, 1024 threads, <= 20 float4 per thread:
- * lfdm_groupnorm_splitk_ok), so neither the reduce launch nor a statistics pass exists.  out: (batch*pixels, channels) rows, ldo = channels. */
-int lfdm_groupnorm_splitk_ok(int pixels, int channels, int groups);
-int lfdm_groupnorm_splitk_apply_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias, float* out,
-                                       int batch, int pixels, int channels, int groups, const float* gamma, const float* beta,
-                                       const float* scale_shift, int ss_ld, const float* residual, float eps, int apply_silu,
-                                       lfdm_stream_t stream);
-/* The same operation spread over the CHIP (ABI version 8): the split-K reduce pass's own grid (one workgroup per 16 rows x 64 channels) keeps the
- * reduced values in registers, exchanges (sum, sum of squares) granules and arrival counts through `sync_ws` with agent-scope atomics (no
- * fences, any workgroup placement) and applies the normalisation - conv + reduce + apply becomes conv + ONE launch.  lfdm_groupnorm_splitk_coop_ok:
- * pixels % 16 == 0, channels % 64 == 0, group width dividing 64 (at most 8 groups per 64 channels) or a multiple of 64, 2 <= ksplit <= 8 and at
- * most 1024 workgroups (all must be co-resident while a group's cohort gathers).  sync_ws: lfdm_groupnorm_splitk_coop_ws_bytes, ZEROED ONCE by
- * the caller before its first use; every launch leaves it zeroed for the next.  ((unsigned*)sync_ws)[0] != 0 afterwards = a workgroup gave up
- * waiting (2^20 polls) - the result is then invalid. */
-int lfdm_groupnorm_splitk_coop_ok(int batch, int pixels, int channels, int groups, int ksplit);
-size_t lfdm_groupnorm_splitk_coop_ws_bytes(int batch, int pixels, int channels, int groups);
-int lfdm_groupnorm_splitk_coop_cl_f32(const float* partial, int ksplit, long long slab_stride, int coutp, const float* bias, float* out,
-                                      int batch, int pixels, int channels, int groups, const float* gamma, const float* beta,
-                                      const float* scale_shift, int ss_ld, const float* residual, float eps, int apply_silu,
-                                      void* sync_ws, size_t sync_ws_bytes, lfdm_stream_t stream);
 
 /* Channel LayerNorm (gamma only, biased variance): video_flow_diffusion.py:170-179. */
 int lfdm_layernorm_cl_f32(const float* x, float* out, int64_t rows, int channels,

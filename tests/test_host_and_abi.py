@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     assert len(declared) >= 25
     assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
     lib = _native.NativeLibrary(path, "hip")          # getattr on every symbol; raises if one is missing
-    assert lib.lfdm_abi_version() == 11         # 11: BatchNorm segments; 10: LFAE stage-1 training glue; 9: lfdm_wgrad_params.dw_layout / .dbias, lfdm_multi_linear_*; 8: lfdm_conv_params.gn_in_*; 7: lfdm_calib_mfma_f32; 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2; 4: *_lowres_cl_f32; 5: .weight_wino4; 6: .defer_reduce
+    assert lib.lfdm_abi_version() == 12         # 12: defer_reduce / gn_in_* reserved, lfdm_groupnorm_splitk_* removed; 11: BatchNorm segments; 10: LFAE stage-1 training glue; 9: lfdm_wgrad_params.dw_layout / .dbias, lfdm_multi_linear_*; 8: lfdm_conv_params.gn_in_*; 7: lfdm_calib_mfma_f32; 2: lfdm_conv_params.deconv4 / .groups, heads ld; 3: .pool2; 4: *_lowres_cl_f32; 5: .weight_wino4; 6: .defer_reduce
     nm = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True).stdout
     for sym in declared:
         assert re.search(r"\bT %s\b" % sym, nm), sym

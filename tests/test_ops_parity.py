@@ -319,88 +319,6 @@ def test_conv2d_winograd_grouped(backend, case):
         assert_close(got[..., 1].float(), (y * y).sum(-1).float(), TOL, "gn sumsq")
 
 
-@pytest.mark.parametrize("case", [dict(b=2, pixels=40, c=128, ksplit=3, ss=True, res=False), dict(b=1, pixels=640, c=512, ksplit=6, ss=True, res=True),
-                                  dict(b=3, pixels=96, c=64, ksplit=1, ss=False, res=True, silu=False),
-                                  dict(b=1, pixels=2560, c=256, ksplit=3, ss=False, res=False, gpu_only=True)],
-                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
-def test_groupnorm_from_splitk_slabs(backend, case):
-    """lfdm_groupnorm_splitk_apply_cl_f32: bias + sum of the raw split-K slabs + GroupNorm(8) + scale/shift + SiLU + residual in one launch
-    (the conv -> reduce -> apply triple of the low-resolution ResnetBlocks without its middle launch) against F.group_norm."""
-    dev = backend
-    if case.get("gpu_only") and not big(dev):
-        pytest.skip("full-size shapes run on the GPU")
-    b, pixels, c, ks = case["b"], case["pixels"], case["c"], case["ksplit"]
-    coutp = (c + 31) // 32 * 32
-    rows = b * pixels
-    slabs = rnd(ks, rows, coutp, seed=1)
-    bias = rnd(c, seed=2)
-    gamma, beta = rnd(c, seed=3) + 1.0, rnd(c, seed=4)
-    ss = rnd(b, 2 * c, seed=5) * 0.5 if case["ss"] else None
-    res = rnd(rows, c, seed=6) if case["res"] else None
-    x = slabs[:, :, :c].double().sum(0).float() + bias                       # (rows, c) CL
-    xr = x.view(b, pixels, c).permute(0, 2, 1)                               # (b, c, pixels)
-    ref = F.group_norm(xr, 8, gamma, beta, eps=1e-5)
-    if ss is not None:
-        ref = ref * (ss[:, :c].unsqueeze(-1) + 1) + ss[:, c:].unsqueeze(-1)
-    if case.get("silu", True):
-        ref = F.silu(ref)
-    ref = ref.permute(0, 2, 1).reshape(rows, c)
-    if res is not None:
-        ref = ref + res
-    assert ops.groupnorm_splitk_ok(pixels, c, 8)
-    out = torch.full((rows, c), float("nan"), device=dev)
-    ops.groupnorm_splitk_apply_cl(slabs.to(dev), ks, rows * coutp, coutp, bias.to(dev), out, b, gamma.to(dev), beta.to(dev),
-                                  scale_shift=None if ss is None else ss.to(dev), residual=None if res is None else res.to(dev),
-                                  silu=case.get("silu", True))
-    assert_close(out.cpu(), ref, TOL, "groupnorm from split-K slabs")
-    assert not ops.groupnorm_splitk_ok(10240, 128, 8)                         # 16x16 x 40 frames: too many elements for one workgroup
-
-
-@pytest.mark.parametrize("case", [dict(b=2, pixels=48, c=128, ksplit=3, ss=True, res=False), dict(b=1, pixels=640, c=512, ksplit=6, ss=True, res=True),
-                                  dict(b=3, pixels=96, c=64, ksplit=2, ss=False, res=True, silu=False),          # eight groups inside one 64-channel block
-                                  dict(b=1, pixels=2560, c=256, ksplit=3, ss=False, res=False, gpu_only=True),   # the 8x8 level: 640 workgroups
-                                  dict(b=2, pixels=160, c=1024, ksplit=8, ss=True, res=True, gpu_only=True)],    # groups wider than a column block
-                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
-def test_groupnorm_splitk_coop(backend, case):
-    """lfdm_groupnorm_splitk_coop_cl_f32: the same conv -> GroupNorm seam as above, chip wide: the reduce grid keeps its values in registers, the
-    workgroups of a (sample, group) exchange statistics through agent-scope granules + arrival counters (on the emulation build the entry
-    point runs the one-workgroup-per-group kernel: the cooperative kernel needs co-resident workgroups).  Launched three times on ONE
-    workspace that is zeroed once: every launch must leave it re-armed; results must be bit-identical from launch to launch."""
-    dev = backend
-    if case.get("gpu_only") and not big(dev):
-        pytest.skip("full-size shapes run on the GPU")
-    b, pixels, c, ks = case["b"], case["pixels"], case["c"], case["ksplit"]
-    coutp, rows = c, b * pixels
-    slabs = rnd(ks, rows, coutp, seed=1)
-    bias = rnd(c, seed=2)
-    gamma, beta = rnd(c, seed=3) + 1.0, rnd(c, seed=4)
-    ss = rnd(b, 2 * c, seed=5) * 0.5 if case["ss"] else None
-    res = rnd(rows, c, seed=6) if case["res"] else None
-    x = slabs.double().sum(0).float() + bias
-    ref = F.group_norm(x.view(b, pixels, c).permute(0, 2, 1), 8, gamma, beta, eps=1e-5)
-    if ss is not None:
-        ref = ref * (ss[:, :c].unsqueeze(-1) + 1) + ss[:, c:].unsqueeze(-1)
-    if case.get("silu", True):
-        ref = F.silu(ref)
-    ref = ref.permute(0, 2, 1).reshape(rows, c)
-    if res is not None:
-        ref = ref + res
-    assert ops.groupnorm_splitk_coop_ok(b, pixels, c, 8, ks)
-    assert not ops.groupnorm_splitk_coop_ok(1, 40960, 64, 8, 2)               # 32x32 x 40 frames: 2560 workgroups cannot all be resident
-    ws = ops.groupnorm_splitk_coop_ws(b, pixels, c, 8, dev)
-    outs = []
-    for _ in range(3):
-        out = torch.full((rows, c), float("nan"), device=dev)
-        ops.groupnorm_splitk_coop_cl(slabs.to(dev), ks, rows * coutp, coutp, bias.to(dev), out, b, gamma.to(dev), beta.to(dev), ws,
-                                     scale_shift=None if ss is None else ss.to(dev), residual=None if res is None else res.to(dev),
-                                     silu=case.get("silu", True))
-        outs.append(out.cpu())
-    assert_close(outs[0], ref, TOL, "cooperative groupnorm from split-K slabs")
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), "not reproducible from launch to launch"
-    if dev != "cpu":
-        assert int(ws[:4 + 2 * b * 8].cpu().abs().sum()) == 0, "a launch left its counters dirty or a workgroup timed out (ws[0])"
-
-
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,with_ss", [(64, True), (128, False), (512, True)])
 def test_groupnorm_silu(backend, c, with_ss):
@@ -440,12 +358,12 @@ def test_groupnorm_apply_many_partials(backend, groups, nchunk, c):
     assert_close(out.cpu().view(b, pixels, c), ref, TOL, "groupnorm apply, %d groups / %d chunks" % (groups, nchunk))
 
 
-@pytest.mark.parametrize("ksplit", [1, 3, -3, 512])
+@pytest.mark.parametrize("ksplit", [1, 3, 512])
 def test_conv_fused_groupnorm_stats(backend, ksplit):
     """conv epilogue (or the split-K reduce) emits the GroupNorm partial sums; finalize+apply must equal
     conv -> group_norm."""
     dev = backend
-    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else ((2, 5, 8, 32, 64) if ksplit >= 0 else (2, 5, 8, 64, 64))
+    b, t, s, cin, cout = (1, 40, 32, 64, 64) if big(dev) else (2, 5, 8, 32, 64)
     if ksplit == 512:       # 64-channel groups (C_out = 512, the 4x4 level): statistics come from the split-K reduce pass
         b, t, s, cin, cout, ksplit = (1, 40, 4, 256, 512, 4) if big(dev) else (2, 2, 4, 64, 512, 2)
     x = rnd(b, cin, t, s, s, seed=1)
@@ -457,12 +375,9 @@ def test_conv_fused_groupnorm_stats(backend, ksplit):
     ref = F.silu(ref * (ss[:, :cout].view(b, cout, 1, 1, 1) + 1) + ss[:, cout:].view(b, cout, 1, 1, 1)) + res
     w = ops.pack_conv_weight(wt).to(dev)
     xs = unet_to_cl(x).to(dev)
-    counters = torch.zeros(512, dtype=torch.int32, device=dev) if ksplit < 0 else None   # -3: split-K reduced in-launch
-    ksplit = abs(ksplit)
+    counters = None      # (the in-launch reduction exists on the Winograd schedule only: test_conv_winograd_splitk_reduced_in_launch)
     pp, _ = ops.conv_params(xs, w, cout, 3, 3, b * t, s, s, bias=bias.to(dev), ksplit=ksplit, tile_counters=counters)
     rows_per_tile, ks = ops.conv_plan(pp)
-    if counters is not None:
-        assert rows_per_tile == 160
     pixels = t * s * s
     assert ks == ksplit and pixels % rows_per_tile == 0, (ks, rows_per_tile)
     nchunk = pixels // rows_per_tile
@@ -472,60 +387,6 @@ def test_conv_fused_groupnorm_stats(backend, ksplit):
     out = ops.groupnorm_apply_cl(h, b, gamma.to(dev), beta.to(dev), partial, nchunk, scale_shift=ss.to(dev),
                                  residual=unet_to_cl(res).to(dev))
     assert_close(unet_from_cl(out.cpu(), b, t, s, s), ref, TOL, "fused gn stats")
-
-
-@pytest.mark.parametrize("case", [
-    dict(b=2, n=8, h=8, w=8, cin=32, cout=64, nchunk=2),                          # two samples x 256 pixels, scale/shift rows
-    dict(b=1, n=4, h=8, w=8, cin=64, cout=40, nchunk=1, ksplit=2, ss=False),      # split-K slices build only their part of the A / B table
-    dict(b=2, n=16, h=4, w=4, cin=48, cout=32, nchunk=4, residual=True),          # 4x4 images: half of every patch is zero padding
-    dict(b=1, n=2, h=16, w=8, cin=64, cout=64, nchunk=2, groups=2, gn_groups=16),  # the merged output heads: grouped convolution, 16 norm groups
-    dict(b=1, n=40, h=32, w=32, cin=64, cout=64, nchunk=320, gpu_only=True),
-    dict(b=1, n=40, h=4, w=4, cin=512, cout=512, nchunk=40, ksplit=6, gpu_only=True),
-], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-def test_conv_winograd_gn_in(backend, case, monkeypatch):
-    """lfdm_conv_params.gn_in_*: GroupNorm + (scale+1, shift) + SiLU of the INPUT applied inside the Winograd convolution's patch load
-    (ResnetBlock.block1's norm / act inside block2's convolution, video_flow_diffusion.py:199-212, 226-234) against
-    conv2d(silu(group_norm(x) * (scale + 1) + shift)); the statistics arrive as (sum, sum of squares) partials like the producing
-    convolution writes them."""
-    dev = backend
-    if case.get("gpu_only") and not big(dev):
-        pytest.skip("full-size shapes run on the GPU")
-    monkeypatch.setenv("LFDM_WINO", "1")
-    b, n, h, w, cin, cout, nchunk = (case[k] for k in ("b", "n", "h", "w", "cin", "cout", "nchunk"))
-    cgroups, gg = case.get("groups", 1), case.get("gn_groups", 8)
-    x = rnd(n, cin, h, w, seed=1) * 1.5 + 0.3
-    wt = rnd(cout, cin // cgroups, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9 / cgroups))
-    bias, gamma, beta = rnd(cout, seed=3), rnd(cin, seed=4) * 0.3 + 1, rnd(cin, seed=5) * 0.3
-    ss = rnd(b, 2 * cin, seed=6) * 0.3 if case.get("ss", True) else None
-    pixels = n // b * h * w
-    xcl = to_cl(x)                                                # (n*h*w, cin), frames of one sample contiguous
-    xs = xcl.view(b, pixels, cin)
-    xn = F.group_norm(xs.permute(0, 2, 1), gg, gamma, beta, eps=1e-5).permute(0, 2, 1)
-    if ss is not None:
-        xn = xn * (ss[:, None, :cin] + 1) + ss[:, None, cin:]
-    act = from_cl(F.silu(xn).reshape(n * h * w, cin), n, h, w)
-    ref = F.conv2d(act, wt, bias, padding=1, groups=cgroups)
-    res = rnd(*ref.shape, seed=8) if case.get("residual") else None
-    if res is not None:
-        ref = ref + res
-    xg = xs.view(b, nchunk, pixels // nchunk, gg, cin // gg)
-    partial = torch.stack([xg.sum(dim=(2, 4)), (xg * xg).sum(dim=(2, 4))], dim=-1).contiguous().view(b * nchunk, 2 * gg).to(dev)
-    gn_in = dict(partial=partial, nchunk=nchunk, pixels=pixels, gamma=gamma.to(dev), beta=beta.to(dev), groups=gg,
-                 scale_shift=None if ss is None else ss.to(dev))
-    if cgroups > 1:
-        ww = ops.pack_wino_weight_grouped([wt[g * (cout // cgroups):(g + 1) * (cout // cgroups)].to(dev) for g in range(cgroups)])
-        wd = ww
-    else:
-        wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
-    kw = dict(bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), ksplit=case.get("ksplit", 1), weight_wino=ww,
-              groups=cgroups, gn_in=gn_in)
-    pp, _ = ops.conv_params(xcl.to(dev), wd, cout, 3, 3, n, h, w, **kw)
-    assert ops._lib().lfdm_conv2d_schedule(ctypes.byref(pp)) == 2
-    out = ops.conv2d_cl(xcl.to(dev), wd, cout, 3, 3, n, h, w, **kw)
-    assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "Winograd convolution with the input GroupNorm + SiLU fused")
-    # the geometry checks: two sources / an upsampled input / an output activation are refused, not mis-computed
-    with pytest.raises(RuntimeError):
-        ops.conv2d_cl(xcl.to(dev), wd, cout, 3, 3, n, h, w, **dict(kw, act=1))
 
 
 @pytest.mark.parametrize("c", [64, 128, 512])
@@ -991,22 +852,15 @@ def test_conv2d_smalln(backend, cin, k, h, w):
     dict(cin=64, cout=64, n=40, h=32, w=32, gpu_only=True, gn=True),
     dict(cin=512, cout=512, n=40, h=4, w=4, gpu_only=True),
 ], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
-@pytest.mark.parametrize("bn", ["32", "64", "32-kg2", "32-kg3", "32-auto", "64-kg2"], ids=["n32", "n64", "n32kg2", "n32kg3", "n32auto", "n64kg2"])
+@pytest.mark.parametrize("bn", ["32", "64"], ids=["n32", "n64"])
 def test_conv2d_winograd(backend, case, bn, monkeypatch):
     """Winograd F(2x2,3x3) schedule (conv_wino.hip; LFDM_WINO=0 disables it) against F.conv2d, incl. the XCD-aware
-    tile order of the low-resolution levels and the K-group workgroups (G = 2 / 3 wave groups on interleaved chunks, merged in LDS;
-    `auto` = the plan's own choice of G and split-K)."""
+    tile order of the low-resolution levels, with 32- and 64-column workgroups."""
     dev = backend
     if case.get("gpu_only") and not big(dev):
         pytest.skip("full-size shapes run on the GPU")
     monkeypatch.setenv("LFDM_WINO", "1")
-    bn, _, kg = bn.partition("-")
-    monkeypatch.setenv("LFDM_WINO_KG", {"": "0", "kg2": "2", "kg3": "3"}.get(kg, ""))
-    if kg == "auto":
-        monkeypatch.setenv("LFDM_WINO_KG", "auto")
-        case = dict(case)
-        case.pop("ksplit", None)                    # the plan chooses split-K as well
-    monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (experiment knob)
+    monkeypatch.setenv("LFDM_WINO_BN", bn)          # 64: two column tiles per workgroup where coutp % 64 == 0 (test hook: the plan takes them from 1536 workgroups on)
     cin, cout, n, h, w = (case[x] for x in ("cin", "cout", "n", "h", "w"))
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(cin * 9))
@@ -1028,7 +882,7 @@ def test_conv2d_winograd(backend, case, bn, monkeypatch):
         src0, src1 = xs[:, :s].contiguous(), xs[:, s:].contiguous()
     wd, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
     kw = dict(src1=src1, bias=bias.to(dev), residual=None if res is None else to_cl(res).to(dev), act=act,
-              ksplit=case.get("ksplit", 0 if kg == "auto" else 1), weight_wino=ww, upsample=up)
+              ksplit=case.get("ksplit", 1), weight_wino=ww, upsample=up)
     pp, _ = ops.conv_params(src0, wd, cout, 3, 3, n, h, w, **kw)
     rows, ks = ops.conv_plan(pp)
     assert rows == (128 if ks == 1 else 16), "the Winograd plan was not selected"
@@ -1230,7 +1084,7 @@ def test_conv2d_winograd_random_geometries(backend, seed, monkeypatch):
         split = rnd_.choice([0, 16]) if cin > 16 else 0
         monkeypatch.setenv("LFDM_WINO", "1")
         monkeypatch.setenv("LFDM_WINO_BN", rnd_.choice(["32", "64"]))
-        monkeypatch.setenv("LFDM_WINO_KG", rnd_.choice(["0", "2", "3", "3"]))       # K groups per workgroup (0 = one group)
+        rnd_.choice(["0", "2", "3", "3"])              # (the draw of the removed K-group variants: keeps the seeded geometry sequence of earlier rounds)
         x = rnd(n, cin, h, w, seed=10 * seed + trial)
         wt = rnd(cout, cin, 3, 3, seed=77 + trial, scale=1.0 / math.sqrt(cin * 9))
         bias = rnd(cout, seed=5)

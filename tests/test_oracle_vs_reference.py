@@ -184,45 +184,60 @@ def test_p_losses_tensor_cond_quirk_is_stated(monkeypatch):
     assert seen["none_cond_mask"] == [True]
 
 
+_CALIB_SCRIPT = r"""
+import json, os, sys, time
+import torch
+sys.path.insert(0, %(oracle)r); sys.path.insert(0, %(tests)r)
+import reference_loader
+ref = reference_loader.load_reference()
+import lfdm_oracle as O
+import synth
+b, t, s = 1, 40, 32
+m = ref.vfdm.FlowDiffusion(img_size=s, num_frames=t, sampling_timesteps=100, is_train=False, config_pth=synth.CONFIG, pretrained_pth="")
+usd = synth.unet_state()
+m.unet.load_state_dict(usd)
+m.eval()
+dsd = {"denoise_fn." + k: v for k, v in usd.items()}
+x, tt, cond = synth.unet_inputs(b, t, s, seed=12)
+t_ref, t_port = [], []
+with torch.no_grad():
+    want = m.unet(x, tt, cond=cond, null_cond_prob=0.)            # warm-up of both (thread pools, allocator) = one more parity check
+    got = O.unet_forward(dsd, x, tt, cond)
+    err = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
+    for _ in range(%(reps)d):
+        t0 = time.perf_counter(); m.unet(x, tt, cond=cond, null_cond_prob=0.); t_ref.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); O.unet_forward(dsd, x, tt, cond); t_port.append(time.perf_counter() - t0)
+print("CALIB " + json.dumps({"shape": [b, 259, t, s, s], "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "rel_err": err,
+      "reference_s_per_unet_forward": [round(v, 3) for v in t_ref], "port_s_per_unet_forward": [round(v, 3) for v in t_port],
+      "port_over_reference": round(min(t_port) / min(t_ref), 3)}))
+"""
+
+
 def test_port_speed_is_calibrated_against_the_reference():
     """bench.py's `cpu_baseline` times the PORT (oracle/lfdm_oracle.py: /root/reference does not travel to the GPU box).  This pins what that
     number means: the reference's own `Unet3D.forward` and the port's `unet_forward` on the SAME cores, same C2-shape input (B = 1, 259
-    channels, 40 frames, 32x32), interleaved, best of three each - the port must be within +-15 % of the reference.  LFDM_WRITE_CALIB=1
-    writes the pair to profiles/port_vs_reference_cpu.json, which bench.py quotes as `cpu_baseline.port_over_reference`."""
+    channels, 40 frames, 32x32), interleaved, best of five each, in a FRESH interpreter (a process that has run other tests - emulator
+    threads, changed thread pools - skews the two differently) - the port must be within +-15 % of the reference (one retry: the container's
+    eight cores are shared).  LFDM_WRITE_CALIB=1 writes the pair to profiles/port_vs_reference_cpu.json, which bench.py quotes as
+    `cpu_baseline.port_over_reference`."""
     import json
     import os
-    import time
-    import lfdm_oracle as O
-    import synth
-    ref = reference_loader.load_reference()
-    b, t, s = 1, 40, 32
-    m = ref.vfdm.FlowDiffusion(img_size=s, num_frames=t, sampling_timesteps=100, is_train=False, config_pth=synth.CONFIG, pretrained_pth="")
-    usd = synth.unet_state()
-    m.unet.load_state_dict(usd)
-    m.eval()
-    dsd = {"denoise_fn." + k: v for k, v in usd.items()}
-    x, tt, cond = synth.unet_inputs(b, t, s, seed=12)
-    threads = torch.get_num_threads()
-    t_ref, t_port = [], []
-    with torch.no_grad():
-        want = m.unet(x, tt, cond=cond, null_cond_prob=0.)            # warm-up of both (thread pools, allocator) = one more parity check
-        got = O.unet_forward(dsd, x, tt, cond)
-        assert float((got - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
-        for _ in range(3):
-            t0 = time.perf_counter()
-            m.unet(x, tt, cond=cond, null_cond_prob=0.)
-            t_ref.append(time.perf_counter() - t0)
-            t0 = time.perf_counter()
-            O.unet_forward(dsd, x, tt, cond)
-            t_port.append(time.perf_counter() - t0)
-    ratio = min(t_port) / min(t_ref)
-    rec = {"shape": [b, 259, t, s, s], "threads": threads, "host_cpus": os.cpu_count(), "reference_s_per_unet_forward": [round(v, 3) for v in t_ref],
-           "port_s_per_unet_forward": [round(v, 3) for v in t_port], "port_over_reference": round(ratio, 3),
-           "what": "best-of-3 wall time of ONE UNet forward at the C2 shape: the unmodified reference (DM/modules/video_flow_diffusion.py Unet3D.forward) vs "
-                   "oracle/lfdm_oracle.py unet_forward, same process, same torch threads, interleaved (tests/test_oracle_vs_reference.py)"}
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _CALIB_SCRIPT % {"oracle": os.path.join(root, "oracle"), "tests": os.path.join(root, "tests"), "reps": 5}
+    rec = None
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("CALIB ")][-1][6:])
+        assert rec["rel_err"] < 2e-4
+        if 0.85 <= rec["port_over_reference"] <= 1.15:
+            break
+    rec["what"] = ("best-of-5 wall time of ONE UNet forward at the C2 shape: the unmodified reference (DM/modules/video_flow_diffusion.py Unet3D.forward) vs "
+                   "oracle/lfdm_oracle.py unet_forward, same fresh process, same torch threads, interleaved (tests/test_oracle_vs_reference.py)")
     print(json.dumps(rec))
     if os.environ.get("LFDM_WRITE_CALIB") == "1":
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         with open(os.path.join(root, "profiles", "port_vs_reference_cpu.json"), "w") as f:
             json.dump(rec, f, indent=1)
-    assert 0.85 <= ratio <= 1.15, rec
+    assert 0.85 <= rec["port_over_reference"] <= 1.15, rec
