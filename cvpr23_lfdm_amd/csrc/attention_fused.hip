@@ -216,7 +216,11 @@ __device__ __forceinline__ void tattn_heads(const float* __restrict__ x, int ldx
     float qf[NT][8], kf[NT][8];
     {
       // four weight-row fragments (q/k x two feature tiles), all loads issued before the first MFMA; the NT token
-      // tiles of a fragment are independent accumulator chains and are interleaved step by step
+      // tiles of a fragment are independent accumulator chains and are interleaved step by step.
+      // (Round 6, measured and NOT kept: the head's 24 fragment loads as a hand-counted asm pipeline - 16 up front, the v fragments under
+      //  the k projections, rotary moved behind the v projection: +1.9 ms per video, profiles/r06_n_tattn_asm_pipeline_ab.txt.  The ISA
+      //  hipcc emits here already runs the loads one to two quads (12-24 MFMAs) ahead of their use; the weight stream is not what
+      //  the launch waits for.)
       float wa[4][CQ];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

@@ -69,6 +69,9 @@ __device__ __forceinline__ void load_wfrag(const float* __restrict__ wp, int whi
 // per feature row), so the split length no longer costs registers: the launcher sizes the splits for ONE round of waves on the chip (the
 // fixed 64-token splits gave 5120 waves for 3072 slots at 32x32 - a second, two-thirds-empty round - and 16 partials per (frame, head)
 // for the merge pass).  The rescale factor lives per LANE (feature d = l31) while the context rows live per REGISTER: 16 shuffles per tile.
+// Round 6, measured and NOT kept: the units (frame, head, tile) as ONE linear sequence cut into equal pieces per wave - exactly ten units per
+// SIMD at 32x32 x 40 frames instead of 2.5 waves per SIMD, pieces crossing (frame, head) boundaries: +1.6 ms per video at five units per wave,
+// equal at four (profiles/r06_m_linattn_ctx_balanced_ab.txt) - the pass does not wait for its busiest SIMD.
 __global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* __restrict__ x, int ldx,
                                                                   const float* __restrict__ wqkv, int hw, float eps,
                                                                   float* __restrict__ part, int split_tok) {
