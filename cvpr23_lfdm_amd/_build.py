@@ -75,7 +75,7 @@ def build_hip(force=False, verbose=False, knobs=False):
 
     if todo:      # independent translation units: compile a few at a time
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(6, len(todo), os.cpu_count() or 1)) as pool:
+        with ThreadPoolExecutor(max_workers=max(1, min(16, len(todo), (os.cpu_count() or 1) - 2))) as pool:
             for out in pool.map(compile_one, todo):
                 if verbose and out.strip():
                     print(out)

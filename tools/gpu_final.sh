@@ -3,8 +3,12 @@
 # command under its own timeout.  Outputs under gpurun_out/$TAG (copy what should be judged into profiles/ as ${TAG}_*, and put the tag + the
 # counter file into profiles/LATEST: bench.py quotes them beside its live figures).
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+# a CLEAN build of the library on this box first (every object recompiled, hipcc --offload-arch=gfx950): the evidence below is of a library
+# built from the sources in this tree, not of the one that travelled with the snapshot
+( time timeout 1500 python -m cvpr23_lfdm_amd._build hip --force ) > $O/clean_build.txt 2>&1; echo "clean build rc=$?" >> $O/clean_build.txt; tail -n 5 $O/clean_build.txt
+python -c "from cvpr23_lfdm_amd import _build; print('build fingerprint', _build.source_fingerprint())" >> $O/clean_build.txt
 rm -f $O/parity.jsonl
-LFDM_PARITY_LOG=$O/parity.jsonl timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -n 4 $O/pytest_gpu.txt
+LFDM_C3_DRIFT_OUT=$O/c3_ddpm1000_drift.txt LFDM_PARITY_LOG=$O/parity.jsonl timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -n 4 $O/pytest_gpu.txt
 timeout 60 python tools/parity_margins.py $O/parity.jsonl $O/parity_margins.json | tail -n 3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt
 # (the CPU baseline leg is left to the driver's own bench run: ~2 minutes of host time that the evidence run does not need)
