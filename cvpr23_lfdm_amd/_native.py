@@ -154,6 +154,7 @@ _SIGNATURES = {
     "lfdm_conv2d_smalln_cl_f32": (i32, [f32p, i32, i32, i32, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, stream_t]),
     "lfdm_linear_attention_fused_ws_bytes": (sz, [i32, i32]),
     "lfdm_linear_attention_fused_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, i32, i32, f32, C.c_void_p, sz, stream_t]),
+    "lfdm_linear_attention_fused_out_cl_f32": (i32, [f32p, i32, i32, f32p, f32p, f32p, f32p, i32, i32, i32, f32, C.c_void_p, sz, stream_t]),
     "lfdm_linear_attention_ws_bytes": (sz, [i32]),
     "lfdm_linear_attention_cl_f32": (i32, [f32p, f32p, i32, i32, C.c_void_p, sz, stream_t]),
     "lfdm_linear_small_f32": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, i32, stream_t]),

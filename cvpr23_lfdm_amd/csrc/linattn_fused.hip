@@ -221,6 +221,108 @@ __global__ __launch_bounds__(64, 2) void linattn_fused_out_kernel(const float* _
   }
 }
 
+
+// ---- C': output + to_out + bias + residual in one pass (round 6; lfdm_linear_attention_fused_out_cl_f32) ----
+// The separate to_out projection of a C = 64 block was a 25 us launch that re-read the 42 MB attention output pass C had just written in
+// 128-byte pieces.  Here a workgroup of four waves owns one 32-token tile of a frame; wave w runs heads 2w, 2w + 1:
+//   Q^T = Wq xhat^T as in pass C (lane = token, registers = 16 features), softmax over the features,
+//   O^T[e][tok] = sum_d ctx[d][e] q~[tok][d]  - pass C's product with the operands exchanged: the accumulator then has lane = token, registers =
+//     features e(half, r), which IS the B operand (column = token, k = e) of
+//   Y^T[c][tok] += sum_e Wout[c][32 h + e] O^T[e][tok]   (A = Wout rows in operand order, two 32-channel row blocks).
+// The four waves' partial Y^T (their two heads each) meet in LDS ([wave][token][64 + 4] floats: a lane's registers (r & 3) are four consecutive
+// channels = one 16-byte store), and 256 threads finish out[tok][c] = x[tok][c] + bias[c] + sum of the four partials as float4 rows.
+// wout arrives packed (ops.pack_linattn_out_weight): [8 heads][2 row blocks][4 quads][64 lanes = 32 kh + c_local][4] <- Wout[32 cb + c_local][32 h + 8 quad + 4 kh + e].
+constexpr int LDY = C + 4;
+__global__ __launch_bounds__(256, 2) void linattn_fused_out2_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wqkv,
+                                                                    const float* __restrict__ wout, const float* __restrict__ bias_out,
+                                                                    const float* __restrict__ ctx, int hw, float eps, float* __restrict__ out,
+                                                                    int ldo) {
+  __shared__ __attribute__((aligned(16))) float s_y[4 * 32 * LDY];
+  const int tid = threadIdx.x;
+  const int wave = lfdm_uniform(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  const int f = blockIdx.y;
+  const int n0 = blockIdx.x * 32;
+  const int n = n0 + l31;
+  float xf[CH];                                            // B operand of Q^T = Wq xhat^T: lane = token
+  load_xhat(x + ((int64_t)f * hw + (n < hw ? n : 0)) * ldx, n < hw, kh, eps, xf);
+  f32x16 yT[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yT[cb][r] = 0.f;
+#pragma unroll 1
+  for (int h = 2 * wave; h < 2 * wave + 2; ++h) {
+    float wq[CH];
+    load_wfrag(wqkv, 0, h, lane, wq);                      // A operand: lane = feature d
+    f32x16 q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) q = mfma_32x32x2(wq[s], xf[s], q);
+    // lane = token; q[r] = feature d(kh, r) = (r&3) + 8*(r>>2) + 4*kh : softmax over the 32 features
+    float m = q[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, q[r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      q[r] = expf(q[r] - m);
+      sum += q[r];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = LA_SCALE / sum;
+    // O^T[e][tok]: A = ctx[d(kh, r)][e = l31] (lane = row e), B = q~ (lane = column tok, k = d(kh, r))
+    const float* cb_ = ctx + ((int64_t)f * HEADS + h) * DH * DH + l31;
+    f32x16 oT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT = mfma_32x32x2(cb_[((r & 3) + 8 * (r >> 2) + 4 * kh) * DH], q[r] * inv, oT);
+    // lane = token; oT[r] = O^T[e(kh, r)][tok].  Y^T[c][tok] += Wout[c][32 h + e] O^T[e][tok]: A = Wout fragment (lane = row c), B = oT
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float* wsrc = wout + ((int64_t)((h * 2 + cb) * 4) * 64 + lane) * 4;
+      float4 wo[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) wo[qd] = *reinterpret_cast<const float4*>(wsrc + 256 * qd);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        yT[cb] = mfma_32x32x2(wo[qd].x, oT[4 * qd + 0], yT[cb]);
+        yT[cb] = mfma_32x32x2(wo[qd].y, oT[4 * qd + 1], yT[cb]);
+        yT[cb] = mfma_32x32x2(wo[qd].z, oT[4 * qd + 2], yT[cb]);
+        yT[cb] = mfma_32x32x2(wo[qd].w, oT[4 * qd + 3], yT[cb]);
+      }
+    }
+  }
+  // lane (tok = l31, half kh): yT[cb][r] = Y^T[c = 32 cb + (r&3) + 8 (r>>2) + 4 kh][tok] over this wave's two heads
+  float* ys = s_y + (wave * 32 + l31) * LDY;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(ys + 32 * cb + 8 * g + 4 * kh) = make_float4(yT[cb][4 * g], yT[cb][4 * g + 1], yT[cb][4 * g + 2], yT[cb][4 * g + 3]);
+  __syncthreads();
+  const int tok = tid >> 3, c8 = (tid & 7) * 8;
+  if (n0 + tok < hw) {
+    const int64_t row = (int64_t)f * hw + n0 + tok;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c8 + 4 * j;
+      float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+      const float4 b4 = bias_out ? *reinterpret_cast<const float4*>(bias_out + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const float4 u = *reinterpret_cast<const float4*>(s_y + (w4 * 32 + tok) * LDY + c);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      *reinterpret_cast<float4*>(out + row * ldo + c) = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw) {
@@ -228,19 +330,10 @@ extern "C" size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw) {
   return ((size_t)n_frames * HEADS * nsplit * PART + (size_t)n_frames * HEADS * DH * DH) * sizeof(float);
 }
 
-extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
-                                                  int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
-                                                  lfdm_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || hw > 64 * 64 || channels != C || ldx < C || ldx % 4 != 0 ||
-      (((uintptr_t)x | (uintptr_t)wqkv) & 15) || (int64_t)n_frames * HEADS > 0x7fffffff) {
-    lfdm_set_error("linear_attention_fused: needs C == 64 and 16-byte aligned rows");
-    return LFDM_EINVAL;
-  }
-  if (!ws || ws_bytes < lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) {
-    lfdm_set_error("linear_attention_fused: workspace too small");
-    return LFDM_EWORKSPACE;
-  }
+namespace {
+// passes A + B: context partials and their merge; *ctx_out = the merged contexts inside the workspace
+void launch_ctx_and_merge(const float* x, int ldx, const float* wqkv, int n_frames, int hw, float ln_eps, void* ws, float** ctx_out,
+                          hipStream_t stream) {
   // splits of whole 32-token tiles, as many as fit ONE round of waves (3 per SIMD: 3072), at most 64 (the merge kernel's table)
   const int tiles = (hw + 31) / 32;
   // (batched shapes - more (frame, head) pairs than half a round - get at least four rounds of waves instead of one long wave per pair:
@@ -257,9 +350,49 @@ extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int c
   float* ctx = part + (size_t)n_frames * HEADS * ((hw + SPLIT_TOK - 1) / SPLIT_TOK) * PART;
   LFDM_LAUNCH(linattn_fused_ctx_kernel, dim3(n_frames * HEADS, nsplit), dim3(64), 0, stream, x, ldx, wqkv, hw, ln_eps, part, split_tok);
   LFDM_LAUNCH(linattn_fused_merge_kernel, dim3(n_frames * HEADS), dim3(256), 0, stream, (const float*)part, nsplit, ctx);
+  *ctx_out = ctx;
+}
+}  // namespace
+
+extern "C" int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
+                                                  int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
+                                                  lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wqkv || !out || n_frames <= 0 || hw <= 0 || hw > 64 * 64 || channels != C || ldx < C || ldx % 4 != 0 ||
+      (((uintptr_t)x | (uintptr_t)wqkv) & 15) || (int64_t)n_frames * HEADS > 0x7fffffff) {
+    lfdm_set_error("linear_attention_fused: needs C == 64 and 16-byte aligned rows");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) {
+    lfdm_set_error("linear_attention_fused: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  float* ctx = nullptr;
+  launch_ctx_and_merge(x, ldx, wqkv, n_frames, hw, ln_eps, ws, &ctx, stream);
   const int64_t otiles = (int64_t)((hw + 31) / 32) * n_frames;
   const int hgroups = otiles >= 4096 ? 1 : (otiles >= 2048 ? 2 : 4);
   LFDM_LAUNCH(linattn_fused_out_kernel, dim3((hw + 31) / 32, n_frames, hgroups), dim3(64), 0, stream, x, ldx, wqkv,
               (const float*)ctx, hw, ln_eps, out);
   return lfdm_check_launch("linear_attention_fused");
+}
+
+extern "C" int lfdm_linear_attention_fused_out_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wout,
+                                                      const float* bias_out, float* out, int ldo, int n_frames, int hw, float ln_eps,
+                                                      void* ws, size_t ws_bytes, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !wqkv || !wout || !out || out == x || n_frames <= 0 || hw <= 0 || hw > 64 * 64 || channels != C || ldx < C || ldx % 4 != 0 || ldo < C ||
+      ldo % 4 != 0 || (((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)wout | (uintptr_t)out | (uintptr_t)bias_out) & 15) ||
+      (int64_t)n_frames * HEADS > 0x7fffffff || n_frames > 65535) {
+    lfdm_set_error("linear_attention_fused_out: needs C == 64, 16-byte aligned rows, out != x, <= 65535 frames");
+    return LFDM_EINVAL;
+  }
+  if (!ws || ws_bytes < lfdm_linear_attention_fused_ws_bytes(n_frames, hw)) {
+    lfdm_set_error("linear_attention_fused_out: workspace too small");
+    return LFDM_EWORKSPACE;
+  }
+  float* ctx = nullptr;
+  launch_ctx_and_merge(x, ldx, wqkv, n_frames, hw, ln_eps, ws, &ctx, stream);
+  LFDM_LAUNCH(linattn_fused_out2_kernel, dim3((hw + 31) / 32, n_frames), dim3(256), 0, stream, x, ldx, wqkv, wout, bias_out, (const float*)ctx, hw,
+              ln_eps, out, ldo);
+  return lfdm_check_launch("linear_attention_fused_out");
 }

@@ -211,6 +211,25 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
                                                              unsigned* __restrict__ ticket, int32_t* advance_dev) {
   __shared__ unsigned s_part[256], s_res[4];
   const int b = blockIdx.y;
+  float* xb = x + (int64_t)b * n;
+  const float* eb = eps + (int64_t)b * n;
+  const float* nb = noise ? noise + (int64_t)b * n : nullptr;
+  const float* x0b = x0buf + (int64_t)b * n;
+  float* x0o = x0_out ? x0_out + (int64_t)b * n : nullptr;
+  // The first PRE elements of this thread (all of them at the C2 latent: 122 880 / (60 x 256) = 8) are requested BEFORE the histograms are
+  // searched: five scans with barriers stand between the kernel's start and the threshold, the operands' round trip runs under them (round 6).
+  constexpr int PRE = 8;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  float p_x0[PRE], p_e[PRE], p_x[PRE], p_n[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int64_t i = i0 + k * stride;
+    const bool in = i < n;
+    p_x0[k] = in ? x0b[i] : 0.f;
+    p_e[k] = in ? eb[i] : 0.f;
+    p_x[k] = in ? xb[i] : 0.f;
+    p_n[k] = (in && nb) ? nb[i] : 0.f;
+  }
   float s = 1.0f;                       // rk.frac < 0: static clipping, x0.clamp(-1, 1) (use_dynamic_thres=False, :729-732)
   if (rk.frac >= 0.f) {
     s = resolve_quantile(hists + (int64_t)b * HIST_PER_SAMPLE, rk, s_part, s_res);
@@ -218,12 +237,19 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(float* __restrict__
   }
   const float* c = coef + (int64_t)(*step_dev) * 6;
   const float k_x0 = c[2], k_eps = c[3], k_x = c[4], k_noise = c[5];
-  float* xb = x + (int64_t)b * n;
-  const float* eb = eps + (int64_t)b * n;
-  const float* nb = noise ? noise + (int64_t)b * n : nullptr;
-  const float* x0b = x0buf + (int64_t)b * n;
-  float* x0o = x0_out ? x0_out + (int64_t)b * n : nullptr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int64_t i = i0 + k * stride;
+    if (i < n) {
+      float x0 = fminf(fmaxf(p_x0[k], -s), s) / s;
+      if (x0o) x0o[i] = x0;
+      float v = k_x0 * x0 + k_eps * p_e[k];
+      if (k_x != 0.f) v += k_x * p_x[k];
+      if (k_noise != 0.f && nb) v += k_noise * p_n[k];
+      xb[i] = v;
+    }
+  }
+  for (int64_t i = i0 + PRE * stride; i < n; i += stride) {
     float x0 = x0b[i];
     x0 = fminf(fmaxf(x0, -s), s) / s;
     if (x0o) x0o[i] = x0;

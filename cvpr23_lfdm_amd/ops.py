@@ -582,6 +582,34 @@ def linear_attention_fused_cl(x, wqkv, n_frames, hw, *, eps=1e-5, out=None, ws=N
     return out
 
 
+def pack_linattn_out_weight(wout):
+    """(64, 256) to_out weight of SpatialLinearAttention -> the MFMA-operand order of lfdm_linear_attention_fused_out_cl_f32:
+    [8 heads][2 row blocks][4 quads][64 lanes = 32*kh + c_local][4]  <-  Wout[32*cb + c_local][32*h + 8*quad + 4*kh + e]."""
+    w = wout.float().reshape(64, 256)
+    # rows: cb(2) c_local(32); columns: h(8) quad(4) kh(2) e(4)  ->  h cb quad (kh c_local) e
+    return w.reshape(2, 32, 8, 4, 2, 4).permute(2, 0, 3, 4, 1, 5).contiguous().view(8, 2, 4, 64, 4)
+
+
+def linear_attention_fused_out_cl(x, wqkv, wout, bias_out, n_frames, hw, *, eps=1e-5, out=None, ws=None):
+    """The whole Residual(PreNorm(SpatialLinearAttention)) block at C == 64: out = x + to_out(linear_attention(LayerNorm(x))) + bias;
+    wqkv = pack_linattn_weights(W_qkv * gamma), wout = pack_linattn_out_weight(W_out)."""
+    lib = _lib()
+    _chk(lib, x, wqkv, wout, bias_out, out, ws)
+    assert x.shape[1] == 64 and wqkv.shape == (3, 8, 8, 64, 4) and wqkv.is_contiguous() and wout.shape == (8, 2, 4, 64, 4) and wout.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape[0], 64, dtype=torch.float32, device=x.device)
+    assert out.data_ptr() != x.data_ptr()
+    need = lib.lfdm_linear_attention_fused_ws_bytes(n_frames, hw)
+    if ws is not None:
+        ws = ws.reshape(-1)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    lib.check(lib.lfdm_linear_attention_fused_out_cl_f32(_p(x), x.stride(0), x.shape[1], _p(wqkv), _p(wout), _p(bias_out), _p(out), out.stride(0),
+                                                         n_frames, hw, eps, _p(ws), ws.numel() * 4, _stream(lib)),
+              "lfdm_linear_attention_fused_out_cl_f32")
+    return out
+
+
 def linear_attention_lowres_cl(x, wqkv, wsum, n_frames, hw, *, eps=1e-5, out=None):
     """LayerNorm + to_qkv + linear attention core in ONE launch (low-resolution levels: hw <= 64 or 192 < hw <= 256 pixels per frame,
     C % 64 == 0); wqkv (768, C) with gamma folded, wsum (768,) = its row sums (pack_ln_conv_weight)."""

@@ -25,6 +25,7 @@ _LOWRES_MAX_HW = 64
 _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
+_LINATTN_OUT = os.environ.get("LFDM_LINATTN_OUT", "1") != "0"      # to_out + bias + residual inside the fused linear attention's output pass at C = 64
 _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
 # Built, measured slower and REMOVED in round 6 (records in HISTORY.md, rounds 1-5): res_conv on a second stream (LFDM_RES_STREAM), GroupNorm
 # straight from the raw split-K slabs (LFDM_GN_SPLITK) and its chip-wide cooperative form (LFDM_GN_COOP), the in-launch slab reduction on
@@ -186,6 +187,7 @@ class Unet3D(ParamTree):
             pk[prefix + "qkv.wf"] = (wq.reshape(wq.shape[0], -1) * gam.reshape(1, -1)).contiguous()      # (see temporal)
             if wq.shape[1] == 64:      # the fused three-launch form at C = 64: weight fragments in MFMA-operand order
                 pk[prefix + "qkv.wp"] = ops.pack_linattn_weights(pk[prefix + "qkv.wf"])
+                pk[prefix + "out.wp"] = ops.pack_linattn_out_weight(g(prefix + "fn.fn.to_out.weight").reshape(64, 256))
             pk[prefix + "qkv.w"], pk[prefix + "qkv.wsum"] = ops.pack_ln_conv_weight(wq, gam)
             pk[prefix + "out.w"] = ops.pack_conv_weight(g(prefix + "fn.fn.to_out.weight"))
             pk[prefix + "out.b"] = g(prefix + "fn.fn.to_out.bias")
@@ -434,6 +436,10 @@ class Unet3D(ParamTree):
 
     def _linear_attn(self, pk, prefix, x, batch, frames, s, c, outname):
         n_img = batch * frames
+        if c == 64 and _LINATTN_OUT:      # the whole block in three launches: context partials, merge, output + to_out + bias + residual
+            ws = self._buf("la.wsf", 1, ops.linear_attention_fused_ws_floats(n_img, s * s))
+            return ops.linear_attention_fused_out_cl(x, pk[prefix + "qkv.wp"], pk[prefix + "out.wp"], pk[prefix + "out.b"], n_img, s * s,
+                                                     out=self._buf(outname, x.shape[0], c), ws=ws)
         if c == 64:
             att = self._buf("at.o", x.shape[0], 256)
             ws = self._buf("la.wsf", 1, ops.linear_attention_fused_ws_floats(n_img, s * s))

@@ -369,6 +369,15 @@ size_t lfdm_linear_attention_fused_ws_bytes(int n_frames, int hw);
 int lfdm_linear_attention_fused_cl_f32(const float* x, int ldx, int channels, const float* wqkv, float* out,
                                        int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
                                        lfdm_stream_t stream);
+/* ... and the WHOLE block Residual(PreNorm(SpatialLinearAttention)) at C == 64 (ABI version 12; video_flow_diffusion.py:170-189, :240-265 incl. to_out,
+ * its bias and the residual add): out[row][c] = x[row][c] + bias_out[c] + sum_k attention(LayerNorm(x))[row][k] Wout[c][k], rows of 64 with stride ldo,
+ * out != x.  The 256-column attention output is never written: the output pass keeps O^T in accumulator registers as the B operand of the to_out
+ * product (one launch and 84 MB of traffic less than lfdm_linear_attention_fused_cl_f32 + a 1x1 convolution at 40 frames of 32x32).  wout: the
+ * (64, 256) to_out weight in MFMA-operand order [8 heads][2 row blocks][4 quads][64 lanes = 32*kh + c_local][4] <- Wout[32*cb + c_local][32*h + 8*quad + 4*kh + e]
+ * (cvpr23_lfdm_amd.ops.pack_linattn_out_weight); bias_out (64,) or NULL; same workspace as above. */
+int lfdm_linear_attention_fused_out_cl_f32(const float* x, int ldx, int channels, const float* wqkv, const float* wout, const float* bias_out,
+                                           float* out, int ldo, int n_frames, int hw, float ln_eps, void* ws, size_t ws_bytes,
+                                           lfdm_stream_t stream);
 
 /* The same two blocks - PreNorm LayerNorm + to_qkv + attention core, without to_out - as ONE launch for the low-resolution levels
  * (C % 64 == 0 channels, a few hundred to a few thousand rows), where separate projection / reduce / core launches sit at their

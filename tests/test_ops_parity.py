@@ -755,6 +755,19 @@ def test_linear_attention_fused(backend, hw):
     wf = (wq * gamma.reshape(1, -1)).contiguous()
     out = ops.linear_attention_fused_cl(x.reshape(-1, c).to(dev), ops.pack_linattn_weights(wf).to(dev), nf, hw)
     assert_close(out.cpu(), ref, TOL, "fused LN + qkv + linear attention")
+    # ... and the whole block in three launches: + to_out (1x1 convolution with bias) + residual (lfdm_linear_attention_fused_out_cl_f32); a ragged
+    # last token tile at hw = 16 / 144, a strided output
+    wo = rnd(c, 256, seed=4, scale=1.0 / 16)
+    bo = rnd(c, seed=5)
+    ref2 = x.reshape(-1, c) + ref @ wo.t() + bo
+    wide = torch.full((nf * hw, c + 8), 7.0, device=dev)
+    got = ops.linear_attention_fused_out_cl(x.reshape(-1, c).to(dev), ops.pack_linattn_weights(wf).to(dev), ops.pack_linattn_out_weight(wo).to(dev),
+                                            bo.to(dev), nf, hw, out=wide[:, :c])
+    assert_close(got.cpu(), ref2, TOL, "fused LN + qkv + linear attention + to_out + residual")
+    assert float(wide[:, c:].min()) == 7.0 and float(wide[:, c:].max()) == 7.0            # nothing written past the 64 columns
+    got2 = ops.linear_attention_fused_out_cl(x.reshape(-1, c).to(dev), ops.pack_linattn_weights(wf).to(dev), ops.pack_linattn_out_weight(wo).to(dev),
+                                             None, nf, hw)
+    assert_close(got2.cpu(), ref2 - bo, TOL, "... without bias")
 
 
 @pytest.mark.parametrize("c,hw,nf", [(512, 16, 3), (256, 64, 2), (128, 36, 2), (192, 9, 5), (128, 256, 2), (64, 200, 2), (512, 16, 40), (256, 64, 40),
