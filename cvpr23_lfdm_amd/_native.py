@@ -166,6 +166,8 @@ _SIGNATURES = {
                                          i32, stream_t]),
     "lfdm_heads_res_cl_to_planar_f32": (i32, [f32p, f32p, i32, i32, f32p, f32p, f32p, f32p, f32p, i32, i32, f32p, i32, i32, f32p, f32p, i32, i32,
                                               i32, stream_t]),
+    "lfdm_heads_gn_res_cl_to_planar_f32": (i32, [f32p, i32, i32, f32p, i32, i32, f32p, f32p, f32, f32p, f32p, f32p, f32p, f32p, i32, i32, f32p, i32, i32,
+                                                 f32p, f32p, i32, i32, i32, stream_t]),
     "lfdm_sampler_ws_bytes": (sz, [i32, i64]),
     "lfdm_sampler_ws_init": (i32, [C.c_void_p, sz, i32, i64, stream_t]),
     "lfdm_sampler_step_f32": (i32, [f32p, f32p, f32p, f32p, i32, i64, f32p, C.c_void_p, f32, i32,

@@ -208,6 +208,129 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ y_
   ob[2 * fhw] = s2 + b_occ[0];
 }
 
+// The output heads with the LAST GroupNorm folded in (round 6; lfdm_heads_gn_res_cl_to_planar_f32).  The merged heads block ends in
+// conv -> GroupNorm(16 groups over 2C channels) + SiLU -> [1x1 heads + folded res_conv] (unet.py run_trunk): the GroupNorm apply was a launch of
+// its own that wrote 21 MB for the heads kernel to read back.  Here a workgroup merges the statistics partials of its sample exactly as
+// gn_apply_kernel does (double, fixed order), keeps A[c], B[c] in LDS and normalises + activates each value on its way into the three dot products.
+// Eight lanes share a pixel row: lane (row r8 = lane >> 3, segment = lane & 7) walks the float4 columns segment, segment + 8, ... of the row
+// (one 128-byte line per eight lanes and load instruction - the one-thread-per-row kernel above touches 64 different lines per instruction), the three
+// partial sums meet through three xor-shuffles.
+__global__ __launch_bounds__(256) void heads_gn_kernel(const float* __restrict__ y, int ld, int channels,
+                                                       const float* __restrict__ partial, int nchunk, int groups,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       const float* __restrict__ w_flow, const float* __restrict__ b_flow,
+                                                       const float* __restrict__ w_occ, const float* __restrict__ b_occ,
+                                                       const float* __restrict__ x0, int ld0, int c0, const float* __restrict__ x1, int ld1, int c1,
+                                                       const float* __restrict__ w_extra, float* __restrict__ out, int frames, int hw, int rows_per_wg) {
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ __attribute__((aligned(16))) float s_a[512], s_b[512];
+  __shared__ __attribute__((aligned(16))) float wl[3 * 512];                 // per channel of y: the two flow weights | the occlusion weight (0 where not used)
+  __shared__ __attribute__((aligned(16))) float we[3 * 512];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int c2 = 2 * channels;                                                // channels of y: [flow C | occlusion C]
+  const int pixels = frames * hw;
+  // ---- statistics of this sample: gn_apply_kernel's merge (32 lanes walk one group's chunks, four loads in flight, k ascending) ----
+  {
+    const int lpg = 32, gpp = 256 / lpg, sub = tid & (lpg - 1);
+    for (int g0 = 0; g0 < groups; g0 += gpp) {
+      const int g = g0 + tid / lpg;
+      double sm = 0.0, sq = 0.0;
+      if (g < groups) {
+        const float2* src = reinterpret_cast<const float2*>(partial) + ((int64_t)b * nchunk) * groups + g;
+        int k = sub;
+        for (; k + 3 * lpg < nchunk; k += 4 * lpg) {
+          const float2 v0 = src[(int64_t)k * groups], v1 = src[(int64_t)(k + lpg) * groups];
+          const float2 v2 = src[(int64_t)(k + 2 * lpg) * groups], v3 = src[(int64_t)(k + 3 * lpg) * groups];
+          sm += (double)v0.x; sq += (double)v0.y;
+          sm += (double)v1.x; sq += (double)v1.y;
+          sm += (double)v2.x; sq += (double)v2.y;
+          sm += (double)v3.x; sq += (double)v3.y;
+        }
+        for (; k < nchunk; k += lpg) {
+          const float2 v = src[(int64_t)k * groups];
+          sm += (double)v.x;
+          sq += (double)v.y;
+        }
+      }
+      for (int m = lpg >> 1; m >= 1; m >>= 1) {
+        sm += __shfl_xor(sm, m);
+        sq += __shfl_xor(sq, m);
+      }
+      if (g < groups && sub == 0) {
+        const double n = (double)pixels * (double)(c2 / groups);
+        const double mean = sm / n;
+        double var = sq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+  }
+  for (int i = tid; i < c2; i += 256) {                                       // head weights per y channel
+    wl[i] = i < channels ? w_flow[i] : 0.f;
+    wl[512 + i] = i < channels ? w_flow[channels + i] : 0.f;
+    wl[1024 + i] = i < channels ? 0.f : w_occ[i - channels];
+  }
+  const int ce = c0 + c1;
+  for (int i = tid; i < 3 * ce; i += 256) we[(i / ce) * 512 + (i % ce)] = w_extra[i];
+  __syncthreads();
+  const int cg = c2 / groups;
+  for (int c = tid; c < c2; c += 256) {
+    const int g = c / cg;
+    const float a = s_rstd[g] * gamma[c];
+    s_a[c] = a;
+    s_b[c] = beta[c] - s_mean[g] * a;
+  }
+  __syncthreads();
+  const int r8 = tid >> 3, seg = tid & 7;
+  const float bf0 = b_flow[0], bf1 = b_flow[1], bo = b_occ[0];
+  const int64_t fhw = (int64_t)frames * hw;
+  for (int p0 = 0; p0 < rows_per_wg; p0 += 32) {
+    const int pix = blockIdx.x * rows_per_wg + p0 + r8;                       // pixel of the sample (frame-major)
+    if (pix >= pixels) break;                                                 // (whole 8-lane groups leave together)
+    const int64_t row = (int64_t)b * pixels + pix;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const float4* yr = reinterpret_cast<const float4*>(y + row * ld);
+    for (int k = seg; k < c2 / 4; k += 8) {
+      const float4 v = yr[k];
+      const float4 a = *reinterpret_cast<const float4*>(s_a + 4 * k), d = *reinterpret_cast<const float4*>(s_b + 4 * k);
+      const float4 w0 = *reinterpret_cast<const float4*>(wl + 4 * k), w1 = *reinterpret_cast<const float4*>(wl + 512 + 4 * k);
+      const float4 w2 = *reinterpret_cast<const float4*>(wl + 1024 + 4 * k);
+      const float t0 = siluf_(fmaf(v.x, a.x, d.x)), t1 = siluf_(fmaf(v.y, a.y, d.y)), t2 = siluf_(fmaf(v.z, a.z, d.z)), t3 = siluf_(fmaf(v.w, a.w, d.w));
+      s0 += (t0 * w0.x + t1 * w0.y) + (t2 * w0.z + t3 * w0.w);
+      s1 += (t0 * w1.x + t1 * w1.y) + (t2 * w1.z + t3 * w1.w);
+      s2 += (t0 * w2.x + t1 * w2.y) + (t2 * w2.z + t3 * w2.w);
+    }
+#pragma unroll
+    for (int src = 0; src < 2; ++src) {
+      const int cs = src == 0 ? c0 : c1, base = src == 0 ? 0 : c0;
+      if (cs == 0) continue;
+      const float4* xr = reinterpret_cast<const float4*>(src == 0 ? x0 + row * ld0 : x1 + row * ld1);
+      for (int k = seg; k < cs / 4; k += 8) {
+        const float4 v = xr[k];
+        const float4 w0 = *reinterpret_cast<const float4*>(we + base + 4 * k), w1 = *reinterpret_cast<const float4*>(we + 512 + base + 4 * k);
+        const float4 w2 = *reinterpret_cast<const float4*>(we + 1024 + base + 4 * k);
+        s0 += (v.x * w0.x + v.y * w0.y) + (v.z * w0.z + v.w * w0.w);
+        s1 += (v.x * w1.x + v.y * w1.y) + (v.z * w1.z + v.w * w1.w);
+        s2 += (v.x * w2.x + v.y * w2.y) + (v.z * w2.z + v.w * w2.w);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m <= 4; m <<= 1) {
+      s0 += __shfl_xor(s0, m);
+      s1 += __shfl_xor(s1, m);
+      s2 += __shfl_xor(s2, m);
+    }
+    if (seg == 0) {
+      const int t = pix / hw, px = pix - t * hw;
+      float* ob = out + (int64_t)b * 3 * fhw + (int64_t)t * hw + px;
+      ob[0] = s0 + bf0;
+      ob[fhw] = s1 + bf1;
+      ob[2 * fhw] = s2 + bo;
+    }
+  }
+}
+
 // out[b][i] = step_table[*step][i] + batch_base[b][i]
 __global__ __launch_bounds__(256) void step_cond_kernel(const float* __restrict__ step_table,
                                                         const float* __restrict__ batch_base,
@@ -481,6 +604,26 @@ extern "C" int lfdm_heads_res_cl_to_planar_f32(const float* y_flow, const float*
   LFDM_LAUNCH(heads_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y_flow, y_occ, channels, ld, w_flow, b_flow,
               w_occ, b_occ, out, batch, frames, hw, x0, ld0, c0, x1 ? x1 : x0, ld1, c1, w_extra);
   return lfdm_check_launch("heads_res");
+}
+
+extern "C" int lfdm_heads_gn_res_cl_to_planar_f32(const float* y, int ld, int channels, const float* partial, int nchunk, int groups,
+                                                  const float* gamma, const float* beta, float eps, const float* w_flow, const float* b_flow,
+                                                  const float* w_occ, const float* b_occ, const float* x0, int ld0, int c0, const float* x1, int ld1,
+                                                  int c1, const float* w_extra, float* out, int batch, int frames, int hw, lfdm_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int c2 = 2 * channels;
+  if (!y || !partial || !gamma || !beta || !w_flow || !b_flow || !w_occ || !b_occ || !out || !x0 || !w_extra || channels <= 0 || c2 > 512 ||
+      channels % 4 != 0 || ld < c2 || ld % 4 != 0 || batch <= 0 || batch > 65535 || frames <= 0 || hw <= 0 || nchunk <= 0 || groups <= 0 || groups > 64 ||
+      c2 % groups != 0 || c0 <= 0 || c0 % 4 != 0 || ld0 < c0 || ld0 % 4 != 0 || c1 < 0 || c1 % 4 != 0 ||
+      (c1 > 0 && (!x1 || ld1 < c1 || ld1 % 4 != 0)) || c0 + c1 > 512 || (((uintptr_t)y | (uintptr_t)x0 | (uintptr_t)x1) & 15) != 0) {
+    lfdm_set_error("heads_gn_res: bad arguments (2C <= 512 and % groups == 0, C % 4 == 0, c0 + c1 <= 512, 16-byte aligned rows, <= 65535 samples)");
+    return LFDM_EINVAL;
+  }
+  const int64_t pixels = (int64_t)frames * hw;
+  const int rows_per_wg = pixels >= 32768 ? 128 : 32;                         // four passes per workgroup once that still leaves >= 256 workgroups per sample
+  LFDM_LAUNCH(heads_gn_kernel, dim3((unsigned)((pixels + rows_per_wg - 1) / rows_per_wg), (unsigned)batch), dim3(256), 0, stream, y, ld, channels, partial,
+              nchunk, groups, gamma, beta, eps, w_flow, b_flow, w_occ, b_occ, x0, ld0, c0, x1 ? x1 : x0, ld1, c1, w_extra, out, frames, hw, rows_per_wg);
+  return lfdm_check_launch("heads_gn_res");
 }
 
 extern "C" int lfdm_pack_conv_weight_f32(const float* w, int n_o, int n_i, int taps, int64_t stride_o, int64_t stride_i,

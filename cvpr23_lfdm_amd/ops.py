@@ -771,6 +771,24 @@ def heads_res_cl_to_planar(y_flow, y_occ, w_flow, b_flow, w_occ, b_occ, x0, x1, 
     return out
 
 
+def heads_gn_res_cl_to_planar(y, partial, nchunk, gamma, beta, w_flow, b_flow, w_occ, b_occ, x0, x1, w_extra, batch, frames, hw, *, groups=16,
+                              eps=1e-5, out=None):
+    """heads_res_cl_to_planar with the preceding GroupNorm + SiLU folded in: y (rows, 2C) = the RAW second convolution of the merged heads block,
+    partial / nchunk = its fused statistics, gamma / beta (2C,) (lfdm_heads_gn_res_cl_to_planar_f32)."""
+    lib = _lib()
+    _chk(lib, y, partial, gamma, beta, w_flow, b_flow, w_occ, b_occ, x0, x1, w_extra, out)
+    ch = y.shape[1] // 2
+    c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
+    assert y.stride(1) == 1 and y.shape[1] == 2 * ch and gamma.numel() == 2 * ch == beta.numel() and partial.is_contiguous()
+    assert w_extra.shape == (3, c0 + c1) and w_extra.is_contiguous() and x0.stride(1) == 1 and w_flow.numel() == 2 * ch and w_occ.numel() == ch
+    if out is None:
+        out = torch.empty(batch, 3, frames, hw, dtype=torch.float32, device=y.device)
+    lib.check(lib.lfdm_heads_gn_res_cl_to_planar_f32(_p(y), y.stride(0), ch, _p(partial), nchunk, groups, _p(gamma), _p(beta), eps, _p(w_flow), _p(b_flow),
+                                                     _p(w_occ), _p(b_occ), _p(x0), x0.stride(0), c0, _p(x1), x1.stride(0) if x1 is not None else 0, c1,
+                                                     _p(w_extra), _p(out), batch, frames, hw, _stream(lib)), "lfdm_heads_gn_res_cl_to_planar_f32")
+    return out
+
+
 def sampler_ws(batch, n, device):
     """Workspace of sampler_step / abs_quantile, initialised (lfdm_sampler_ws_init: histograms + end-of-step ticket cleared)."""
     lib = _lib()

@@ -26,6 +26,7 @@ _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 _LINATTN_OUT = os.environ.get("LFDM_LINATTN_OUT", "1") != "0"      # to_out + bias + residual inside the fused linear attention's output pass at C = 64
+_HEADS_GN = os.environ.get("LFDM_HEADS_GN", "1") != "0"            # the heads block's last GroupNorm + SiLU inside the heads kernel
 _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
 # Built, measured slower and REMOVED in round 6 (records in HISTORY.md, rounds 1-5): res_conv on a second stream (LFDM_RES_STREAM), GroupNorm
 # straight from the raw split-K slabs (LFDM_GN_SPLITK) and its chip-wide cooperative form (LFDM_GN_COOP), the in-launch slab reduction on
@@ -525,8 +526,15 @@ class Unet3D(ParamTree):
             y = self._buf("h.y", rows, c2)
             _, st = self._conv(h1, pk["heads.block2.ww"], c2, 3, n_img, res, bias=pk["heads.block2.b"], out=y,
                                gn=(batch, 16), ww=pk["heads.block2.ww"], groups=2)
+            fold = _HEADS_FOLD and x.shape[1] % 4 == 0 and r.shape[1] % 4 == 0 and x.shape[1] + r.shape[1] == pk["heads.fold.w"].shape[1]
+            if fold and _HEADS_GN and st is not None and c2 <= 512:
+                # ... and the block's last GroupNorm + SiLU applied by the heads kernel itself on the raw convolution output: one launch and
+                # 2 x 21 MB of traffic less at 40 frames of 32x32
+                return ops.heads_gn_res_cl_to_planar(y, st[0], st[1], pk["heads.norm2.w"], pk["heads.norm2.b"], pk["final_conv.1.w"],
+                                                     pk["heads.fold.bf"], pk["occlusion_map.1.w"], pk["heads.fold.bo"], x, r, pk["heads.fold.w"],
+                                                     batch, frames, res * res, groups=16, out=out)
             self._gn(y, batch, pk["heads.norm2.w"], pk["heads.norm2.b"], st, groups=16)
-            if _HEADS_FOLD and x.shape[1] % 4 == 0 and r.shape[1] % 4 == 0 and x.shape[1] + r.shape[1] == pk["heads.fold.w"].shape[1]:
+            if fold:
                 # the blocks' res_conv(cat(x, r)) folded into the linear heads: one 1x1 convolution launch less
                 return ops.heads_res_cl_to_planar(y[:, :dim], y[:, dim:], pk["final_conv.1.w"], pk["heads.fold.bf"], pk["occlusion_map.1.w"],
                                                   pk["heads.fold.bo"], x, r, pk["heads.fold.w"], batch, frames, res * res, out=out)

@@ -268,6 +268,16 @@ int lfdm_heads_res_cl_to_planar_f32(const float* y_flow, const float* y_occ, int
                                     const float* b_flow, const float* w_occ, const float* b_occ, const float* x0, int ld0, int c0,
                                     const float* x1, int ld1, int c1, const float* w_extra, float* out, int batch, int frames,
                                     int hw, lfdm_stream_t stream);
+/* ... with the block's LAST GroupNorm folded in (ABI version 12): y (rows, >= 2*channels) is the RAW output of the merged heads block's second
+ * convolution, columns [flow C | occlusion C]; every value is read as silu(y * A[c] + B[c]) with A, B folded from that tensor's (sum, sum of squares)
+ * partials exactly like lfdm_groupnorm_apply_cl_f32 does (partial [batch * nchunk][2 * groups], merged in double in a fixed order; gamma / beta
+ * [2*channels]; no scale / shift) - the GroupNorm launch between the convolution and the heads, and the 21 MB it wrote and the heads read back at
+ * 40 frames of 32x32, disappear.  Otherwise as lfdm_heads_res_cl_to_planar_f32 (w_flow (2, C), w_occ (1, C), b_* incl. the folded res_conv bias,
+ * w_extra (3, c0 + c1)).  video_flow_diffusion.py:199-212 (Block.forward's norm + act), :493-509, :583-586. */
+int lfdm_heads_gn_res_cl_to_planar_f32(const float* y, int ld, int channels, const float* partial, int nchunk, int groups,
+                                       const float* gamma, const float* beta, float eps, const float* w_flow, const float* b_flow,
+                                       const float* w_occ, const float* b_occ, const float* x0, int ld0, int c0, const float* x1, int ld1,
+                                       int c1, const float* w_extra, float* out, int batch, int frames, int hw, lfdm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sampler step (GaussianDiffusion.ddim_sample :791-827 / p_sample :737-746): predict x0

@@ -538,6 +538,40 @@ def test_conv_planar_in_and_heads(backend):
     assert_close(out.cpu().reshape(b, 3, t, s, s), ref, TOL, "heads")
 
 
+@pytest.mark.parametrize("case", [dict(b=2, t=3, s=8, nchunk=3), dict(b=1, t=2, s=4, nchunk=1), dict(b=1, t=40, s=32, nchunk=320, gpu_only=True)],
+                         ids=lambda c: "-".join("%s%s" % kv for kv in c.items()))
+def test_heads_with_groupnorm_folded(backend, case):
+    """lfdm_heads_gn_res_cl_to_planar_f32: the merged heads block's last GroupNorm(16 groups over 2C channels) + SiLU applied by the heads kernel on
+    the RAW convolution output (statistics as chunked (sum, sum of squares) partials, like the producing convolution writes them), the two
+    1x1 heads and the folded res_conv term - against group_norm -> silu -> the same linear maps (video_flow_diffusion.py:199-212, :493-509)."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shape runs on the GPU")
+    b, t, s, nchunk = case["b"], case["t"], case["s"], case["nchunk"]
+    ch, c0, c1, groups = 64, 64, 64, 16
+    pixels = t * s * s
+    y = rnd(b * pixels, 2 * ch, seed=1) * 1.7 + 0.4
+    x0, x1 = rnd(b * pixels, c0, seed=2), rnd(b * pixels, c1, seed=3)
+    gamma, beta = rnd(2 * ch, seed=4) * 0.3 + 1, rnd(2 * ch, seed=5) * 0.3
+    wf, bf, wo, bo = rnd(2, ch, seed=7, scale=0.2), rnd(2, seed=8), rnd(1, ch, seed=9, scale=0.2), rnd(1, seed=10)
+    we = rnd(3, c0 + c1, seed=11, scale=0.1)
+    ys = y.view(b, pixels, 2 * ch)
+    yn = F.silu(F.group_norm(ys.permute(0, 2, 1), groups, gamma, beta, eps=1e-5).permute(0, 2, 1)).reshape(b * pixels, 2 * ch)
+    xe = torch.cat((x0, x1), dim=1)
+    ref = torch.stack((yn[:, :ch] @ wf[0] + bf[0] + xe @ we[0], yn[:, :ch] @ wf[1] + bf[1] + xe @ we[1], yn[:, ch:] @ wo[0] + bo[0] + xe @ we[2]), dim=1)
+    ref = ref.view(b, t, s * s, 3).permute(0, 3, 1, 2)                                         # planar (B, 3, T, HW)
+    assert pixels % nchunk == 0
+    yg = ys.view(b, nchunk, pixels // nchunk, groups, 2 * ch // groups)
+    partial = torch.stack([yg.sum(dim=(2, 4)), (yg * yg).sum(dim=(2, 4))], dim=-1).contiguous().view(b * nchunk, 2 * groups)
+    out = ops.heads_gn_res_cl_to_planar(y.to(dev), partial.to(dev), nchunk, gamma.to(dev), beta.to(dev), wf.to(dev), bf.to(dev), wo.to(dev), bo.to(dev),
+                                        x0.to(dev), x1.to(dev), we.to(dev), b, t, s * s, groups=groups)
+    assert_close(out.cpu(), ref, TOL, "heads with the last GroupNorm folded in")
+    # ... and equal to the two-launch path it replaces
+    act = ops.groupnorm_apply_cl(y.clone().to(dev), b, gamma.to(dev), beta.to(dev), partial.to(dev), nchunk, groups=groups)
+    two = ops.heads_res_cl_to_planar(act[:, :ch], act[:, ch:], wf.to(dev), bf.to(dev), wo.to(dev), bo.to(dev), x0.to(dev), x1.to(dev), we.to(dev), b, t, s * s)
+    assert_close(out.cpu(), two.cpu(), 1e-5, "fused vs GroupNorm apply + heads")
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [97, 3 * 4 * 8 * 8, 122880])
 def test_abs_quantile(backend, n):
