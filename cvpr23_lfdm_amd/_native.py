@@ -50,6 +50,9 @@ class ConvParams(C.Structure):
         ("gn_in_nchunk", i32), ("gn_in_groups", i32), ("gn_in_pixels", i32),
         ("gn_in_gamma", f32p), ("gn_in_beta", f32p), ("gn_in_ss", f32p),
         ("gn_in_ss_ld", i32), ("gn_in_eps", f32),
+        ("res_gn_partial", f32p),
+        ("res_gn_nchunk", i32), ("res_gn_groups", i32), ("res_gn_pixels", i32),
+        ("res_gn_gamma", f32p), ("res_gn_beta", f32p), ("res_gn_eps", f32),
     ]
 
 

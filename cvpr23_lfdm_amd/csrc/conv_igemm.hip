@@ -877,7 +877,8 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   }
   if (pl.ksplit > nchunks) pl.ksplit = nchunks;
   if (pl.ksplit < 1) pl.ksplit = 1;
-  if (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1)) {      // see above: where the staged schedules would split K, or few rows
+  // (res_gn_*: the residual's GroupNorm + SiLU in the epilogue exists on the pointwise schedule only - it takes every eligible geometry then)
+  if (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1 || p.res_gn_partial)) {      // see above: where the staged schedules would split K, or few rows
     pl.kind = 3;
     pl.bm = 32;
     pl.bn = 32;
@@ -963,6 +964,15 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
     lfdm_set_error("conv2d: pool2 exists on the Winograd schedule only (3x3, stride 1, zero pad 1, even size, C % 16 == 0): out = (hq/2, wq/2), "
                    "an output activation, no residual / fused GroupNorm / split-K - see lfdm_conv2d_schedule");
     return LFDM_EINVAL;
+  }
+  if (p.res_gn_partial) {
+    const int g = p.res_gn_groups;
+    if (pl.kind != 3 || !p.residual || g <= 0 || g > 64 || p.cout % g != 0 || (p.cout / g) % 4 != 0 || p.res_gn_pixels <= 0 || p.res_gn_pixels % 32 != 0 ||
+        ((int64_t)p.n_img * p.hq * p.wq) % p.res_gn_pixels != 0 || p.res_gn_nchunk <= 0 || !p.res_gn_gamma || !p.res_gn_beta) {
+      lfdm_set_error("conv2d: res_gn_* (GroupNorm + SiLU of the residual in the epilogue) needs the pointwise schedule (see lfdm_conv2d_schedule), a residual, "
+                     "cout % groups == 0 with groups of a multiple of 4 channels, pixels per sample % 32 == 0");
+      return LFDM_EINVAL;
+    }
   }
   if (p.gn_in_partial || p.defer_reduce) {
     lfdm_set_error("conv2d: gn_in_* / defer_reduce are reserved since ABI 12 (the variants were measured slower and removed): pass NULL / 0");

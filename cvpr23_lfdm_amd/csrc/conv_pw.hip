@@ -25,6 +25,9 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   constexpr int LD = 36;               // scratch row stride (floats): conflict-free b128 reads
   __shared__ __attribute__((aligned(16))) float scratch[4 * 32 * LD];
   __shared__ float s_ln[2][4][32];     // fused LayerNorm: [sum | sum of squares][wave][row]
+  constexpr int BN = (4 / KW) * TN * 32;                         // columns of this workgroup
+  __shared__ __attribute__((aligned(16))) float s_ga[BN], s_gb[BN];      // res_gn_*: A[c] | B[c] of the workgroup's columns
+  __shared__ float s_gstat[2][64];
 
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index is uniform, but derived from threadIdx the compiler cannot know it: every buffer load whose descriptor or
@@ -87,6 +90,60 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   };
 
   fetch(0);
+  if (p.res_gn_partial) {
+    // (round 6) the residual is a RAW convolution output: its GroupNorm + SiLU is applied in the epilogue.  Statistics of this row tile's sample,
+    // merged as gn_apply_kernel does (32 lanes walk one group's chunks, k ascending, double) while the first operand group is in flight; only the
+    // groups that cover this workgroup's columns are merged.
+    const int groups = p.res_gn_groups, nchunk = p.res_gn_nchunk, cg = p.cout / groups;
+    const int b = m0 / p.res_gn_pixels;
+    const int g_lo = n0 / cg;
+    const int g_hi = (((n0 + BN < p.cout ? n0 + BN : p.cout) - 1) / cg);
+    const int sub = tid & 31;
+    for (int g0 = g_lo; g0 <= g_hi; g0 += 8) {
+      const int g = g0 + (tid >> 5);
+      double sm = 0.0, sq = 0.0;
+      if (g <= g_hi) {
+        const float2* src = reinterpret_cast<const float2*>(p.res_gn_partial) + ((int64_t)b * nchunk) * groups + g;
+        int k = sub;
+        for (; k + 96 < nchunk; k += 128) {
+          const float2 v0 = src[(int64_t)k * groups], v1 = src[(int64_t)(k + 32) * groups];
+          const float2 v2 = src[(int64_t)(k + 64) * groups], v3 = src[(int64_t)(k + 96) * groups];
+          sm += (double)v0.x; sq += (double)v0.y;
+          sm += (double)v1.x; sq += (double)v1.y;
+          sm += (double)v2.x; sq += (double)v2.y;
+          sm += (double)v3.x; sq += (double)v3.y;
+        }
+        for (; k < nchunk; k += 32) {
+          const float2 v = src[(int64_t)k * groups];
+          sm += (double)v.x;
+          sq += (double)v.y;
+        }
+      }
+      for (int msk = 16; msk >= 1; msk >>= 1) {
+        sm += __shfl_xor(sm, msk);
+        sq += __shfl_xor(sq, msk);
+      }
+      if (g <= g_hi && sub == 0) {
+        const double n = (double)p.res_gn_pixels * (double)cg;
+        const double mean = sm / n;
+        double var = sq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_gstat[0][g - g_lo] = (float)mean;
+        s_gstat[1][g - g_lo] = (float)(1.0 / sqrt(var + (double)p.res_gn_eps));
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      const int col = n0 + c;
+      if (col < p.cout) {
+        const int g = col / cg - g_lo;
+        const float a = s_gstat[1][g] * p.res_gn_gamma[col];
+        s_ga[c] = a;
+        s_gb[c] = p.res_gn_beta[col] - s_gstat[0][g] * a;
+      }
+    }
+    // (the table is read after the epilogue's first barrier)
+  }
   for (int g = 0; g < ng; ++g) {
     float4 a[4], b[4][TN];
 #pragma unroll
@@ -177,7 +234,13 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
         v.z = rstd * (v.z - mean * ws.z); v.w = rstd * (v.w - mean * ws.w);
       }
       {
-        const float4 bb = pre_b[g * TN + j], rr = pre_r[g * TN + j];
+        const float4 bb = pre_b[g * TN + j];
+        float4 rr = pre_r[g * TN + j];
+        if (p.res_gn_partial) {
+          const float4 ga = *reinterpret_cast<const float4*>(s_ga + col - n0), gb = *reinterpret_cast<const float4*>(s_gb + col - n0);
+          rr.x = siluf_(fmaf(rr.x, ga.x, gb.x)); rr.y = siluf_(fmaf(rr.y, ga.y, gb.y));
+          rr.z = siluf_(fmaf(rr.z, ga.z, gb.z)); rr.w = siluf_(fmaf(rr.w, ga.w, gb.w));
+        }
         v.x += bb.x + rr.x; v.y += bb.y + rr.y; v.z += bb.z + rr.z; v.w += bb.w + rr.w;
       }
       if (p.act) {

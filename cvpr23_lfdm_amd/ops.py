@@ -284,7 +284,7 @@ def pack_planar_in_weight(w):
 def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=None, pad=None, stride=1,
                 upsample=False, reflect=False, residual=None, act=ACT_NONE, out=None, hq=None, wq=None,
                 ho=None, wo=None, out_scale=1, out_off=(0, 0), ksplit=0, ln_wsum=None, ln_eps=1e-5,
-                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, weight_pw=None):
+                tile_counters=None, weight_wino=None, deconv4=None, groups=1, pool2=False, weight_wino4=None, weight_pw=None, res_gn=None):
     """Fills an lfdm_conv_params struct (allocating `out` if needed); returns (params, out).
     ksplit=0 lets the library choose (conv_plan reports the choice)."""
     lib = _lib()
@@ -353,6 +353,16 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
         p.weight_pw = weight_pw.data_ptr()
     keep_gn = (weight_pw,)
     p.gn_in_partial, p.defer_reduce = None, 0      # (reserved since ABI 12: must stay NULL / 0)
+    # res_gn = dict(partial, nchunk, pixels, gamma, beta, groups=8, eps=1e-5): `residual` is a RAW convolution output whose GroupNorm + SiLU is
+    # applied in this (pointwise) convolution's epilogue (lfdm_conv_params.res_gn_*)
+    p.res_gn_partial = None
+    if res_gn is not None:
+        gp, gg, gb = res_gn["partial"], res_gn["gamma"], res_gn["beta"]
+        _chk(lib, gp, gg, gb)
+        assert residual is not None and gg.numel() == cout == gb.numel() and gp.is_contiguous()
+        p.res_gn_partial, p.res_gn_nchunk, p.res_gn_groups, p.res_gn_pixels = _p(gp), int(res_gn["nchunk"]), int(res_gn.get("groups", 8)), int(res_gn["pixels"])
+        p.res_gn_gamma, p.res_gn_beta, p.res_gn_eps = _p(gg), _p(gb), float(res_gn.get("eps", 1e-5))
+        keep_gn = keep_gn + (gp, gg, gb)
     p.pool2 = int(bool(pool2))          # Winograd schedule only (the library refuses it elsewhere): the 2x2 average pool behind conv -> act
     p._keep = (src0, src1, weight, bias, residual, out, ln_wsum, tile_counters, weight_wino, deconv4, weight_wino4) + keep_gn   # keep the tensors alive with the struct
     return p, out

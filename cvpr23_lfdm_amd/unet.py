@@ -26,6 +26,7 @@ _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 _LINATTN_OUT = os.environ.get("LFDM_LINATTN_OUT", "1") != "0"      # to_out + bias + residual inside the fused linear attention's output pass at C = 64
+_RES_GN = os.environ.get("LFDM_RES_GN", "1") != "0"                # block2's GroupNorm + SiLU inside the res_conv launch (blocks that change their channel count)
 _HEADS_GN = os.environ.get("LFDM_HEADS_GN", "1") != "0"            # the heads block's last GroupNorm + SiLU inside the heads kernel
 _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
 # Built, measured slower and REMOVED in round 6 (records in HISTORY.md, rounds 1-5): res_conv on a second stream (LFDM_RES_STREAM), GroupNorm
@@ -377,6 +378,15 @@ class Unet3D(ParamTree):
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
                            out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
+        if has_res and _RES_GN and st is not None and rows <= 16384 and (rows // batch) % 32 == 0 and cout % 32 == 0:
+            # h + res_conv(x) with block2's GroupNorm + SiLU applied to the RAW `out` in the res_conv launch's epilogue (pointwise schedule;
+            # lfdm_conv_params.res_gn_*): no GroupNorm launch for the blocks that change their channel count
+            res_gn = dict(partial=st[0], nchunk=st[1], pixels=rows // batch, gamma=pk[prefix + "block2.norm.w"], beta=pk[prefix + "block2.norm.b"], groups=8)
+            try:
+                return self._conv(x, pk[prefix + "res.w"], cout, 1, n_img, s, src1=skip, bias=pk[prefix + "res.b"], residual=out, out=out,
+                                  res_gn=res_gn)
+            except RuntimeError:
+                pass          # (a geometry the pointwise schedule does not take - M > 16 384 rows: the separate GroupNorm launch below)
         self._gn(out, batch, pk[prefix + "block2.norm.w"], pk[prefix + "block2.norm.b"], st,
                  residual=None if has_res else x)
         if has_res:

@@ -152,6 +152,18 @@ typedef struct lfdm_conv_params {
   const float* gn_in_ss;
   int gn_in_ss_ld;
   float gn_in_eps;
+  /* Optional (ABI version 12; pointwise schedule 3 only - ask lfdm_conv2d_schedule with the fields set: a geometry that schedule cannot take is
+     refused): `residual` is the RAW output of a convolution whose GroupNorm + SiLU has not been applied: res_gn_partial != NULL -> the epilogue adds
+     silu(r * A[c] + B[c]) instead of r, with A, B folded from that tensor's (sum, sum of squares) partials exactly like lfdm_groupnorm_apply_cl_f32
+     does (res_gn_partial [batch * res_gn_nchunk][2 * res_gn_groups], merged in double in a fixed order; res_gn_gamma / res_gn_beta [cout]; no scale /
+     shift).  This is ResnetBlock.forward's `h + res_conv(x)` (video_flow_diffusion.py:226-238) with block2's norm + act folded into the res_conv launch:
+     the GroupNorm launch of every ResnetBlock that changes its channel count disappears.  Needs res_gn_pixels (pixels per sample) % 32 == 0 and
+     cout % res_gn_groups == 0; out may alias residual (every thread reads the elements it writes). */
+  const float* res_gn_partial;
+  int res_gn_nchunk, res_gn_groups, res_gn_pixels;
+  const float* res_gn_gamma;
+  const float* res_gn_beta;
+  float res_gn_eps;
 } lfdm_conv_params;
 
 int lfdm_conv2d_cl_f32(const lfdm_conv_params* p, lfdm_stream_t stream);

@@ -164,6 +164,42 @@ def test_conv_pointwise(backend, case, monkeypatch):
     assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv, LFDM_PW=0")
 
 
+@pytest.mark.parametrize("case", [dict(c0=64, c1=0, cout=128, b=2, t=2, hw=(4, 4), nchunk=2), dict(c0=256, c1=256, cout=256, b=1, t=5, hw=(8, 8), nchunk=5),
+                                  dict(c0=512, c1=512, cout=512, b=1, t=40, hw=(4, 4), nchunk=10, big=True), dict(c0=64, c1=0, cout=128, b=1, t=40, hw=(16, 16), nchunk=80, big=True)],
+                         ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_pointwise_residual_groupnorm(backend, case):
+    """lfdm_conv_params.res_gn_*: ResnetBlock.forward's `h + res_conv(x)` (video_flow_diffusion.py:226-238) with block2's GroupNorm + SiLU folded into
+    the res_conv launch - the residual operand is the RAW convolution output, its statistics arrive as chunked (sum, sum of squares) partials -
+    against conv1x1(cat(x0, x1)) + bias + silu(group_norm(raw)); out aliases the residual, as the sampler uses it."""
+    dev = backend
+    if case.get("big") and not big(dev):
+        pytest.skip("full-size shape runs on the GPU")
+    c0, c1, cout, b, t, nchunk = (case[k] for k in ("c0", "c1", "cout", "b", "t", "nchunk"))
+    h, w = case["hw"]
+    n, pixels = b * t, t * h * w
+    x = rnd(n, c0 + c1, h, w, seed=1)
+    wt = rnd(cout, c0 + c1, 1, 1, seed=2, scale=1.0 / math.sqrt(c0 + c1))
+    bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) * 0.3 + 1, rnd(cout, seed=5) * 0.3
+    raw = rnd(n * h * w, cout, seed=6) * 1.5 + 0.2                                     # channels-last rows of the raw block2 convolution
+    rs = raw.view(b, pixels, cout)
+    act = F.silu(F.group_norm(rs.permute(0, 2, 1), 8, gamma, beta, eps=1e-5).permute(0, 2, 1)).reshape(n * h * w, cout)
+    ref = to_cl(F.conv2d(x, wt, bias)) + act
+    rg = rs.view(b, nchunk, pixels // nchunk, 8, cout // 8)
+    partial = torch.stack([rg.sum(dim=(2, 4)), (rg * rg).sum(dim=(2, 4))], dim=-1).contiguous().view(b * nchunk, 16)
+    xs = to_cl(x).to(dev)
+    src0, src1 = (xs, None) if not c1 else (xs[:, :c0].contiguous(), xs[:, c0:].contiguous())
+    out = raw.clone().to(dev)
+    res_gn = dict(partial=partial.to(dev), nchunk=nchunk, pixels=pixels, gamma=gamma.to(dev), beta=beta.to(dev), groups=8)
+    kw = dict(src1=src1, bias=bias.to(dev), residual=out, out=out, res_gn=res_gn)
+    pp, _ = ops.conv_params(src0, ops.pack_conv_weight(wt).to(dev), cout, 1, 1, n, h, w, **kw)
+    assert ops.conv_schedule(pp) == 3
+    got = ops.conv2d_cl(src0, ops.pack_conv_weight(wt).to(dev), cout, 1, 1, n, h, w, **kw)
+    assert_close(got.cpu(), ref, TOL, "1x1 convolution + GroupNorm + SiLU of the raw residual")
+    with pytest.raises(RuntimeError):            # a 3x3 convolution cannot take it: refused, not mis-computed
+        ops.conv2d_cl(src0, ops.pack_conv_weight(rnd(cout, c0 + c1, 3, 3, seed=9)).to(dev), cout, 3, 3, n, h, w, **kw)
+
+
+
 def test_conv_pointwise_plan():
     """Where the planner takes schedule 3 by itself (no launch: lfdm_conv2d_schedule only reads the geometry): every 1x1 projection
     of the 4x4 level, above it the ones the LDS-staged schedules would split K for; never with fused GroupNorm statistics."""
