@@ -779,7 +779,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   const bool pw_ok = pw_mode != 0 && conv_force() < 0 && p.kh == 1 && p.kw == 1 && p.stride == 1 && !p.upsample && p.pad_y == 0 &&
                      p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
                      p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
-                     M <= pw_max_m && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
+                     (M <= pw_max_m || (p.res_gn_partial && M <= 65536)) && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
   // F(4x4,3x3) (conv_wino4.hip): an opt-in of the caller (weight_wino4 given: its fp32 error is ~4e-6 of the output scale against
   // ~1e-6 for F(2x2)) and only where every CU gets several of its one-per-CU workgroups - the batched shapes of training / throughput
   // mode.  LFDM_WINO4=0 disables it, LFDM_WINO4_MIN overrides the workgroup-count threshold.

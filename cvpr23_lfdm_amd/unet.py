@@ -26,6 +26,7 @@ _WINO_FUSE_REDUCE = os.environ.get("LFDM_WINO_FUSE_REDUCE", "1") != "0"
 # to_out + the residual add inside the fused temporal-attention launch at C = 64 (ops.temporal_attention_fused_out_cl); LFDM_TATTN_OUT=0: separate
 _TATTN_OUT = os.environ.get("LFDM_TATTN_OUT", "1") != "0"
 _LINATTN_OUT = os.environ.get("LFDM_LINATTN_OUT", "1") != "0"      # to_out + bias + residual inside the fused linear attention's output pass at C = 64
+_RES_GN_MAX_ROWS = 65536         # (the pointwise schedule takes a res_gn launch up to this many rows: the level-0 res_conv of a B = 1 step included, -0.7 ms)
 _RES_GN = os.environ.get("LFDM_RES_GN", "1") != "0"                # block2's GroupNorm + SiLU inside the res_conv launch (blocks that change their channel count)
 _HEADS_GN = os.environ.get("LFDM_HEADS_GN", "1") != "0"            # the heads block's last GroupNorm + SiLU inside the heads kernel
 _HEADS_FOLD = os.environ.get("LFDM_HEADS_FOLD", "1") != "0"      # the output heads' res_conv folded into the 1x1 heads (exact by linearity)
@@ -378,7 +379,7 @@ class Unet3D(ParamTree):
         _, st = self._conv(h1, pk[prefix + "block2.proj.w"], cout, 3, n_img, s, bias=pk[prefix + "block2.proj.b"],
                            out=out, gn=(batch,), ww=pk[prefix + "block2.proj.ww"])
         has_res = (prefix + "res.w") in pk
-        if has_res and _RES_GN and st is not None and rows <= 16384 and (rows // batch) % 32 == 0 and cout % 32 == 0:
+        if has_res and _RES_GN and st is not None and rows <= _RES_GN_MAX_ROWS and (rows // batch) % 32 == 0 and cout % 32 == 0:
             # h + res_conv(x) with block2's GroupNorm + SiLU applied to the RAW `out` in the res_conv launch's epilogue (pointwise schedule;
             # lfdm_conv_params.res_gn_*): no GroupNorm launch for the blocks that change their channel count
             res_gn = dict(partial=st[0], nchunk=st[1], pixels=rows // batch, gamma=pk[prefix + "block2.norm.w"], beta=pk[prefix + "block2.norm.b"], groups=8)
