@@ -780,6 +780,14 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
                      p.pad_x == 0 && pl.fast && fits32 && vec_ok && user_k <= 1 && !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 &&
                      p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 && p.ho == p.hq && p.wo == p.wq && p.hq == p.hi && p.wq == p.wi &&
                      (M <= pw_max_m || (p.res_gn_partial && M <= 65536)) && (!p.ln_wsum || (p.c1 == 0 && (((uintptr_t)p.ln_wsum) & 15) == 0)) && !p.tile_counters;
+  // ... and its gather form (round 6) for the Downsample convolutions: 4x4 / stride 2 / zero pad over one source, K = 16 C a multiple of 128,
+  // K <= 2048, M <= 16 384 output rows (the KSW schedule + its reduce launch: 28 us for 1.3 GFLOP at every level of a B = 1 step; measured in the
+  // step: 19.9 / 22.2 us at the first two levels, but 34.0 us for the 256-channel one - 160 workgroups walking K = 4096 - which stays on KSW)
+  const bool pwg_ok = pw_mode != 0 && conv_force() < 0 && p.kh == 4 && p.kw == 4 && p.stride == 2 && !p.upsample && p.pad_mode == 0 && p.c1 == 0 &&
+                      p.c0 % 32 == 0 && (16 * p.c0) % 128 == 0 && 16 * p.c0 <= 2048 && p.ld0 % 4 == 0 && (((uintptr_t)p.src0) & 15) == 0 && fits32 && vec_ok && user_k <= 1 &&
+                      !p.gn_partial && !p.deconv4 && !(p.groups > 1) && !p.pool2 && p.out_scale == 1 && p.out_off_y == 0 && p.out_off_x == 0 &&
+                      p.ho == p.hq && p.wo == p.wq && !p.ln_wsum && !p.res_gn_partial && M <= pw_max_m && !p.tile_counters &&
+                      (int64_t)p.n_img * p.hi * p.wi < (1ll << 31) - (1 << 20);
   // F(4x4,3x3) (conv_wino4.hip): an opt-in of the caller (weight_wino4 given: its fp32 error is ~4e-6 of the output scale against
   // ~1e-6 for F(2x2)) and only where every CU gets several of its one-per-CU workgroups - the batched shapes of training / throughput
   // mode.  LFDM_WINO4=0 disables it, LFDM_WINO4_MIN overrides the workgroup-count threshold.
@@ -878,7 +886,7 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   if (pl.ksplit > nchunks) pl.ksplit = nchunks;
   if (pl.ksplit < 1) pl.ksplit = 1;
   // (res_gn_*: the residual's GroupNorm + SiLU in the epilogue exists on the pointwise schedule only - it takes every eligible geometry then)
-  if (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1 || p.res_gn_partial)) {      // see above: where the staged schedules would split K, or few rows
+  if (pwg_ok || (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1 || p.res_gn_partial))) {      // see above: where the staged schedules would split K, or few rows
     pl.kind = 3;
     pl.bm = 32;
     pl.bn = 32;

@@ -19,7 +19,12 @@
 
 namespace {
 
-template <int TN, int KW, bool LN>
+// GATHER (round 6): the same register-operand GEMM for a kh x kw / any-stride / zero-padded convolution over ONE source with C % 32 == 0 - the
+// Downsample convolutions (4x4, stride 2) of a B = 1 step, which the K-split-across-waves schedule ran as 23 us + a 5 us reduce launch for 1.3 GFLOP.
+// k = tap * C + c in the filter's own order; a 32-deep K group lies inside one tap, so a group's A fragments are 16 contiguous bytes of the lane's
+// output pixel's input pixel (iy0 + ky, ix0 + kx) - a uniform (ky, kx) per group, a per-lane validity bit per tap (out of the image = out-of-range
+// offset = zeros).  Nothing else changes: no im2col, no LDS staging, no split-K slabs.
+template <int TN, int KW, bool LN, bool GATHER = false>
 __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx, int ny) {
   constexpr int NW = 4 / KW;           // wavefronts along N
   constexpr int LD = 36;               // scratch row stride (floats): conflict-free b128 reads
@@ -41,13 +46,14 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   const int M = p.n_img * p.hq * p.wq;
   const int m0 = bx * 32;
   const int n0 = by * (NW * TN * 32);
-  const int K = p.c0 + p.c1;
+  const int K = GATHER ? p.kh * p.kw * p.c0 : p.c0 + p.c1;
   const int kw_len = K / KW;           // this wave's K slice: [wk*kw_len, +kw_len), a multiple of 32
   const int kbeg = wk * kw_len;
   const int ng = kw_len >> 5;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((int64_t)(M - 1) * p.ld0 + p.c0) * 4));
+  const int64_t in_rows = GATHER ? (int64_t)p.n_img * p.hi * p.wi : (int64_t)M;
+  const lfdm_buf buf0 = lfdm_make_buf(p.src0, (uint32_t)(((in_rows - 1) * p.ld0 + p.c0) * 4));
   const lfdm_buf buf1 = p.c1 > 0 ? lfdm_make_buf(p.src1, (uint32_t)(((int64_t)(M - 1) * p.ld1 + p.c1) * 4)) : buf0;
   // weight_pw (round 4): the same filter in MFMA-operand order [K/32][coutp/32][4 u][64 lanes = 32*kh + column][4] - one contiguous 1 KB
   // per fragment load instead of a 16-byte piece of each of 32 columns' 128-byte rows (four times the L1 line look-ups per byte)
@@ -56,6 +62,18 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   const uint32_t ustride = wpk ? 1024u : 32u;
   const int row = m0 + l31;
   const bool row_ok = row < M;
+  // GATHER: this lane's output pixel -> the corner of its input window and one validity bit per tap
+  int g_pix0 = 0;
+  unsigned g_valid = 0;
+  if (GATHER && row_ok) {
+    const int ox = row % p.wq, t1 = row / p.wq;
+    const int oy = t1 % p.hq, n = t1 / p.hq;
+    const int iy0 = oy * p.stride - p.pad_y, ix0 = ox * p.stride - p.pad_x;
+    g_pix0 = (n * p.hi + iy0) * p.wi + ix0;
+    for (int ky = 0; ky < p.kh; ++ky)
+      for (int kx = 0; kx < p.kw; ++kx)
+        if (iy0 + ky >= 0 && iy0 + ky < p.hi && ix0 + kx >= 0 && ix0 + kx < p.wi) g_valid |= 1u << (ky * p.kw + kx);
+  }
   const uint32_t a_off0 = row_ok ? ((uint32_t)row * (uint32_t)p.ld0 + 4u * kh) * 4u : LFDM_BUF_OOB;
   const uint32_t a_off1 = row_ok ? ((uint32_t)row * (uint32_t)p.ld1 + 4u * kh) * 4u : LFDM_BUF_OOB;
   uint32_t b_off[TN];
@@ -76,13 +94,20 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
   float4 ra[4], rb[4][TN];
   auto fetch = [&](int g) {
     const int kk = kbeg + 32 * g;
-    const bool second = kk >= p.c0;
+    const bool second = !GATHER && kk >= p.c0;
     const lfdm_buf buf = second ? buf1 : buf0;
-    const uint32_t abase = second ? a_off1 + (uint32_t)(kk - p.c0) * 4u : a_off0 + (uint32_t)kk * 4u;
+    uint32_t abase = second ? a_off1 + (uint32_t)(kk - p.c0) * 4u : a_off0 + (uint32_t)kk * 4u;
+    bool a_ok = row_ok;
+    if (GATHER) {
+      const int tap = kk / p.c0, cch = kk - tap * p.c0;             // (uniform)
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      a_ok = (g_valid >> tap) & 1u;
+      abase = ((uint32_t)(g_pix0 + ky * p.wi + kx) * (uint32_t)p.ld0 + (uint32_t)cch + 4u * kh) * 4u;
+    }
     const uint32_t wbase = (uint32_t)(kk >> 5) * wgroup_bytes;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ra[u] = lfdm_buf_load_f4(buf, row_ok ? abase + 32u * u : LFDM_BUF_OOB);
+      ra[u] = lfdm_buf_load_f4(buf, a_ok ? abase + 32u * u : LFDM_BUF_OOB);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         rb[u][j] = lfdm_buf_load_f4(bufw, b_off[j] == LFDM_BUF_OOB ? LFDM_BUF_OOB : wbase + b_off[j] + ustride * u);
@@ -255,6 +280,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
 template <int TN, int KW>
 void launch_pw(const lfdm_conv_params& p, int gx, int ny, hipStream_t stream) {
   const dim3 grid((unsigned)(((gx + 7) / 8) * 8 * ny)), block(256);
+  if (p.kh * p.kw > 1) {                 // (the gather form: K over all four waves, one or two column tiles per wave - lfdm_conv_pw_shape)
+    if constexpr (TN <= 2 && KW == 4) LFDM_LAUNCH((conv_pw_kernel<TN, 4, false, true>), grid, block, 0, stream, p, gx, ny);
+    return;
+  }
   if (p.ln_wsum) LFDM_LAUNCH((conv_pw_kernel<TN, KW, true>), grid, block, 0, stream, p, gx, ny);
   else LFDM_LAUNCH((conv_pw_kernel<TN, KW, false>), grid, block, 0, stream, p, gx, ny);
 }
@@ -269,8 +298,13 @@ int env_int(const char* name, int dflt) {
 // Tile shape for a geometry the caller has already checked (1x1, stride 1, C % 32 == 0, float4-legal epilogue):
 // K across KW wavefronts when the slices stay multiples of 32; the widest column tile that still leaves >= 256 workgroups.
 void lfdm_conv_pw_shape(const lfdm_conv_params& p, int* tn, int* kw) {
-  const int K = p.c0 + p.c1;
+  const int K = p.kh * p.kw > 1 ? p.kh * p.kw * p.c0 : p.c0 + p.c1;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  if (p.kh * p.kw > 1) {                 // gather form (the plan has checked K % 128 == 0): 64-column workgroups while >= 256 of them remain
+    *tn = (p.coutp % 64 == 0 && ((M + 31) / 32) * (p.coutp / 64) >= 256) ? 2 : 1;
+    *kw = 4;
+    return;
+  }
   // (two sources: the source is selected per 32-deep K group and c0 % 32 == 0, so a slice only has to be a multiple of 32)
   int k = K % 128 == 0 ? 4 : K % 64 == 0 ? 2 : 1;
   const int fk = env_int("LFDM_PW_KW", 0);

@@ -349,7 +349,7 @@ def conv_params(src0, weight, cout, kh, kw, n_img, hi, wi, *, src1=None, bias=No
     p.weight_pw = None
     if weight_pw is not None:          # the same 1x1 filter in operand order for the pointwise schedule (pack_pw_weight)
         _chk(lib, weight_pw)
-        assert kh == 1 and kw == 1 and weight_pw.numel() == weight.numel() and weight_pw.is_contiguous()
+        assert weight_pw.numel() == weight.numel() and weight_pw.is_contiguous()      # (1x1, or the gather form of the 4x4 / stride-2 Downsample)
         p.weight_pw = weight_pw.data_ptr()
     keep_gn = (weight_pw,)
     p.gn_in_partial, p.defer_reduce = None, 0      # (reserved since ABI 12: must stay NULL / 0)

@@ -307,7 +307,8 @@ class Unet3D(ParamTree):
         #  fence pair, KSW schedule - neutral; the fence-free form on the Winograd schedule is `_WINO_FUSE_REDUCE` below)
         """One lfdm_conv2d_cl_f32 launch; tile shape / split-K come from the library's plan.
         gn = (batch,) asks for fused GroupNorm statistics; then returns (out, (partial, nchunk) or None)."""
-        if k == 1 and self._pk is not None and w.dim() == 3 and w.shape[1] % 32 == 0 and not kw.get("deconv4"):
+        if ((k == 1 or (k == 4 and kw.get("stride") == 2)) and self._pk is not None and w.dim() == 3 and w.shape[1] % 32 == 0 and
+                not kw.get("deconv4")):
             # 1x1 projections: the operand-order pack for the pointwise schedule, built once per weight pack
             cache = self._pk.setdefault("_pw", {})
             wpw = cache.get(w.data_ptr())

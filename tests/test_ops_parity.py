@@ -164,6 +164,35 @@ def test_conv_pointwise(backend, case, monkeypatch):
     assert_close(from_cl(out.cpu(), n, h, w), ref, TOL, "pointwise conv, LFDM_PW=0")
 
 
+@pytest.mark.parametrize("case", [dict(c=32, n=3, h=6, w=10), dict(c=64, n=2, h=8, w=8, residual=True), dict(c=128, n=5, h=4, w=4, act=3),
+                                  dict(c=64, n=40, h=32, w=32, big=True), dict(c=128, n=40, h=16, w=16, big=True)],
+                         ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_downsample_gather(backend, case):
+    """The Downsample convolution (4x4, stride 2, zero pad 1; video_flow_diffusion.py Downsample = Conv3d(dim, dim, (1, 4, 4), (1, 2, 2), (0, 1, 1))) on the
+    gather form of the pointwise schedule (conv_pw.hip GATHER: no im2col, no split-K): the planner picks schedule 3, image borders, a ragged
+    last row tile, residual and activation in the epilogue - against F.conv2d."""
+    dev = backend
+    if case.get("big") and not big(dev):
+        pytest.skip("full-size shape runs on the GPU")
+    c, n, h, w = case["c"], case["n"], case["h"], case["w"]
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, c, 4, 4, seed=2, scale=1.0 / math.sqrt(16 * c))
+    bias = rnd(c, seed=3)
+    ref = F.conv2d(x, wt, bias, stride=2, padding=1)
+    res = rnd(*ref.shape, seed=4) if case.get("residual") else None
+    if res is not None:
+        ref = ref + res
+    if case.get("act") == 3:
+        ref = F.silu(ref)
+    wd = ops.pack_conv_weight(wt).to(dev)
+    kw = dict(bias=bias.to(dev), pad=(1, 1), stride=2, residual=None if res is None else to_cl(res).to(dev), act=case.get("act", 0))
+    for wpw in (None, ops.pack_pw_weight(wd)):
+        pp, _ = ops.conv_params(to_cl(x).to(dev), wd, c, 4, 4, n, h, w, weight_pw=wpw, **kw)
+        assert ops.conv_schedule(pp) == 3 and ops.conv_plan(pp)[1] == 1
+        out = ops.conv2d_cl(to_cl(x).to(dev), wd, c, 4, 4, n, h, w, weight_pw=wpw, **kw)
+        assert_close(from_cl(out.cpu(), n, h // 2, w // 2), ref, TOL, "Downsample on the gather form, operand-order pack %s" % (wpw is not None))
+
+
 @pytest.mark.parametrize("case", [dict(c0=64, c1=0, cout=128, b=2, t=2, hw=(4, 4), nchunk=2), dict(c0=256, c1=256, cout=256, b=1, t=5, hw=(8, 8), nchunk=5),
                                   dict(c0=512, c1=512, cout=512, b=1, t=40, hw=(4, 4), nchunk=10, big=True), dict(c0=64, c1=0, cout=128, b=1, t=40, hw=(16, 16), nchunk=80, big=True)],
                          ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
