@@ -231,10 +231,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #endif
   const int rounds = kc_end - kc_begin;
   const int kc0 = kc_begin;
-#pragma unroll
-  for (int pi = 0; pi < 4; ++pi) fetch_b(pi, clampc(kc0));
   {
+    // (patch BEFORE the filter fragments, as inside the loop: loads retire in order, and with the same order on both ways into the loop
+    // header the wait for the patch there is vmcnt(8) - the eight fragment loads stay in flight under the input transform.  With the
+    // fragments first the header got vmcnt(0): every round then waited for the fragment loads issued at the very end of the round before.)
     fetch_patch(patch, clampc(kc0), valid_mask);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) fetch_b(pi, clampc(kc0));
     for (int r = 0; r < rounds; ++r) {
       const int nxt = clampc(kc0 + r + 1);
 #pragma unroll

@@ -30,7 +30,7 @@ for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8),
     pp, _ = ops.conv_params(x, w, cout, 3, 3, frames, s, s, out=o, weight_wino=ww)
     rows, ks = ops.conv_plan(pp)
     if ks > 1:
-        part = torch.empty(ks * m * w.shape[1], device="cuda")
+        part = torch.empty(ops.conv_partial_floats(pp), device="cuda")
         pp.partial = part.data_ptr()
     stamps = torch.zeros(16384 * 6, dtype=torch.int64, device="cuda")
     pp.tile_counters, pp.tile_counters_len = stamps.data_ptr(), 0
