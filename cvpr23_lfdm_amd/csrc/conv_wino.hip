@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
 #ifdef LFDM_WINO_TIMING
-  // probe build only (tools/probe_wino_phases.py): cycle stamps of every workgroup go to p.tile_counters (unused by this schedule)
+  // probe build only (tools/probe_wino_phases.py): cycle stamps of every workgroup go behind the first 64 K words of p.tile_counters
   unsigned long long tstamp[6];
   tstamp[0] = __builtin_readcyclecounter();
   const unsigned long long wall0 = wall_clock64();
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   tstamp[4] = __builtin_readcyclecounter();
   tstamp[5] = wall_clock64() - wall0;
   if (threadIdx.x == 0 && p.tile_counters) {
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.tile_counters) +
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.tile_counters + 65536) +      // (behind the 64 K ticket words)
                               ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
     for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
   }

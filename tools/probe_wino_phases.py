@@ -16,11 +16,11 @@ if "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
                            "-amdgpu-mfma-vgpr-form", "-DLFDM_WINO_TIMING", "-o", out] + sorted(glob.glob(os.path.join(csrc, "*.hip"))))
     sys.exit(0)
-os.environ["LFDM_HIP_LIB"] = out
+os.environ["LFDM_HIP_LIB"] = os.environ.get("LFDM_PROBE_LIB", out)
 import torch  # noqa: E402
 from cvpr23_lfdm_amd import ops  # noqa: E402
 
-for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8), (512, 512, 4), (256, 256, 32)):
+for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8), (512, 256, 8), (512, 512, 4), (1024, 512, 4), (256, 256, 32)):
     frames = 40
     m = frames * s * s
     x = torch.randn(m, cin, device="cuda")
@@ -28,12 +28,13 @@ for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8),
     w, ww = ops.pack_conv_weight(raw), ops.pack_wino_weight(raw)
     o = torch.empty(m, cout, device="cuda")
     pp, _ = ops.conv_params(x, w, cout, 3, 3, frames, s, s, out=o, weight_wino=ww)
+    buf = torch.zeros(32768 + 16384 * 6, dtype=torch.int64, device="cuda")      # 64 K ticket words, then six stamps per workgroup
+    stamps = buf[32768:]
+    pp.tile_counters, pp.tile_counters_len = buf.data_ptr(), 65536               # (the sampler's plan: split-K reduced inside the launch)
     rows, ks = ops.conv_plan(pp)
     if ks > 1:
-        part = torch.empty(ops.conv_partial_floats(pp), device="cuda")
+        part = torch.empty(max(1, ops.conv_partial_floats(pp)), device="cuda")
         pp.partial = part.data_ptr()
-    stamps = torch.zeros(16384 * 6, dtype=torch.int64, device="cuda")
-    pp.tile_counters, pp.tile_counters_len = stamps.data_ptr(), 0
     for _ in range(3):
         ops.conv_launch(pp)
     torch.cuda.synchronize()
