@@ -288,8 +288,8 @@ void launch_pw(const lfdm_conv_params& p, int gx, int ny, hipStream_t stream) {
   else LFDM_LAUNCH((conv_pw_kernel<TN, KW, false>), grid, block, 0, stream, p, gx, ny);
 }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
+int env_int(const char* name, int dflt) {      // (sweep constants: read in `--knobs` builds only - lfdm_knob)
+  const char* e = lfdm_knob(name);
   return e ? atoi(e) : dflt;
 }
 
