@@ -132,6 +132,7 @@ _SIGNATURES = {
     "lfdm_conv2d_cl_f32": (i32, [C.POINTER(ConvParams), stream_t]),
     "lfdm_conv2d_partial_bytes": (sz, [C.POINTER(ConvParams)]),
     "lfdm_conv2d_plan": (i32, [C.POINTER(ConvParams), C.POINTER(i32), C.POINTER(i32)]),
+    "lfdm_conv2d_plan_slabs": (i32, [C.POINTER(ConvParams)]),
     "lfdm_conv2d_schedule": (i32, [C.POINTER(ConvParams)]),
     "lfdm_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
     "lfdm_groupnorm_silu_cl_f32": (i32, [f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, i32, f32p,

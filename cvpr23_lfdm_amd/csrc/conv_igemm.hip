@@ -701,7 +701,7 @@ void launch_conv(const lfdm_conv_params& p, bool fast, bool simple, dim3 grid, h
 }  // namespace
 
 int lfdm_conv_ksw_launch(const lfdm_conv_params& p, int bn, hipStream_t stream);   // conv_ksw.hip
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, hipStream_t stream);  // conv_wino.hip
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, int bal_whole, hipStream_t stream);  // conv_wino.hip
 int lfdm_conv_pw_launch(const lfdm_conv_params& p, hipStream_t stream);            // conv_pw.hip
 int lfdm_conv_wino4_launch(const lfdm_conv_params& p, hipStream_t stream);         // conv_wino4.hip
 
@@ -709,6 +709,7 @@ namespace {
 
 struct ConvPlan;
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p);
+int wino_balance(const ConvPlan& pl, const lfdm_conv_params& p, int* extra_slabs);
 
 struct ConvPlan {
   int kind;        // 0 = 2x2-wave tiles (this file), 1 = K-split-across-waves 160-row tiles (conv_ksw.hip),
@@ -914,6 +915,36 @@ bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
   return false;
 }
 
+// Balanced Winograd launch (conv_wino.hip, round 6): a launch of exactly 640 (tile, K slice) jobs - every 3x3 convolution of a B = 1 sampler step but
+// two - leaves 128 CUs with three workgroups and 128 with two; the launch then runs 512 whole jobs and both halves of the other 128 (768 workgroups =
+// three per CU, two whole + one half each).  Needs what the in-launch reduction needs (ticket words, 16-byte-legal epilogue) plus slabs for
+// ksplit + *extra_slabs slices; returns the number of whole jobs (512) or 0.  The caller opts in by handing in tile_counters AND a partial buffer
+// of lfdm_conv2d_partial_bytes - a binding that sizes nothing for ksplit = 1 plans keeps the plain launch.
+int wino_balance(const ConvPlan& pl, const lfdm_conv_params& p, int* extra_slabs) {
+  if (extra_slabs) *extra_slabs = 0;
+  static const bool on = [] { const char* e = getenv("LFDM_WINO_BALANCE"); return !(e && e[0] == '0'); }();      // (A/B and bit-compare switch)
+  static const bool fuse_on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();
+  if (!on || !fuse_on || pl.kind != 2 || pl.bn != 32 || !p.tile_counters || p.deconv4 || p.groups > 1 || p.pool2 || p.cout != p.coutp || p.ldo % 4 != 0 ||
+      (((uintptr_t)p.out) & 15) != 0 || (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
+      (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
+    return 0;
+  if (pl.ksplit > 1 && !splitk_fused(pl, p)) return 0;
+  const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+  const int64_t T = ((ntiles + 31) / 32) * (p.coutp / 32);
+  const int whole = 512, jobs = 640;
+  if (T * pl.ksplit != jobs || (int64_t)p.tile_counters_len < T) return 0;
+  const int nch = (p.c0 + p.c1) / 16;
+  if (nch / pl.ksplit < 2) return 0;                                   // every slice can be halved
+  // slice z of the tile at position tl of a slice layer has job id z * T + tl; ids >= whole are halved: the last tile (tl = T - 1) has the most
+  const int z_first = T - 1 >= whole ? 0 : (int)((whole - (T - 1) + T - 1) / T);
+  const int extra = pl.ksplit - z_first;
+  if (extra < 1) return 0;
+  const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
+  if ((int64_t)(pl.ksplit + extra) * M * p.coutp * 4 >= (1ll << 32) - 64) return 0;
+  if (extra_slabs) *extra_slabs = extra;
+  return whole;
+}
+
 }  // namespace
 
 extern "C" int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit) {
@@ -932,11 +963,21 @@ extern "C" int lfdm_conv2d_schedule(const lfdm_conv_params* p) {
 extern "C" size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p) {
   if (!p) return 0;
   const ConvPlan pl = make_plan(*p);
-  if (pl.ksplit <= 1) return 0;
+  int extra = 0;
+  wino_balance(pl, *p, &extra);            // (balanced Winograd launch: one more slab per halved K slice of a tile - also where ksplit is 1)
+  if (pl.ksplit <= 1 && extra == 0) return 0;
   const size_t rows = (size_t)p->n_img * p->hq * p->wq;
   // (+ 128: lfdm_conv2d_cl_f32 rounds the slab base up to a 128-byte boundary - the in-launch reduction needs every column tile's slab
   //  rows to be whole cache lines, lfdm_device.h - so the caller's buffer may start anywhere and the plan never depends on its address)
-  return ((size_t)pl.ksplit * (p->deconv4 ? 4 : 1) * rows * p->coutp + (p->ln_wsum ? (size_t)pl.ksplit * rows * 2 : 0)) * sizeof(float) + 128;
+  return ((size_t)(pl.ksplit + extra) * (p->deconv4 ? 4 : 1) * rows * p->coutp + (p->ln_wsum ? (size_t)pl.ksplit * rows * 2 : 0)) * sizeof(float) + 128;
+}
+
+extern "C" int lfdm_conv2d_plan_slabs(const lfdm_conv_params* p) {
+  if (!p) return LFDM_EINVAL;
+  const ConvPlan pl = make_plan(*p);
+  int extra = 0;
+  wino_balance(pl, *p, &extra);
+  return pl.ksplit + extra;
 }
 
 extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stream_) {
@@ -1016,7 +1057,8 @@ extern "C" int lfdm_conv2d_cl_f32(const lfdm_conv_params* pp, lfdm_stream_t stre
   if (pl.kind == 1) {
     rc = lfdm_conv_ksw_launch(p, pl.bn, stream);
   } else if (pl.kind == 2) {
-    rc = lfdm_conv_wino_launch(p, pl.bn, splitk_fused(pl, p), stream);
+    const int bal = p.partial ? wino_balance(pl, p, nullptr) : 0;
+    rc = lfdm_conv_wino_launch(p, pl.bn, bal > 0 || splitk_fused(pl, p), bal, stream);
   } else if (pl.kind == 3) {
     rc = lfdm_conv_pw_launch(p, stream);
   } else if (pl.kind == 4) {

@@ -59,7 +59,7 @@ constexpr int LDM = WN + 4;       // LDS row stride of the half-transformed M pl
 // residual, activation) itself.  The fence-based form of this hand-off (round 2, KSW schedule) measured neutral: its release wrote back the
 // XCD's whole L2 from every workgroup's tail - the cost found in the BatchNorm reduce (profiles/r05_p_bench_bn.txt, r05_q_*).
 template <bool ACT, int NT, bool POOL = false, bool FUSE = false>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p) {
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_conv_params p, int bal_whole) {
   static_assert(!FUSE || (NT == 1 && !POOL), "in-launch split-K reduction: the plain 32-column workgroup only");
   constexpr int WNB = WN * NT;      // output channels per workgroup
   constexpr int LD = LDV;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const int l31 = lane & 31, kh = lane >> 5;
 #ifdef LFDM_WINO_TIMING
   // probe build only (tools/probe_wino_phases.py): cycle stamps of every workgroup go behind the first 64 K words of p.tile_counters
-  unsigned long long tstamp[6];
+  unsigned long long tstamp[8];
   tstamp[0] = __builtin_readcyclecounter();
   const unsigned long long wall0 = wall_clock64();
 #endif
@@ -86,14 +86,32 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   // default order puts the column tiles of one tile block on one XCD (gridDim.x % 8 == 0: they share the input patches).
   // Where the Winograd filters outweigh the input (16*coutp*cin vs pixels*cin floats: the 8x8 / 4x4 levels) it is the
   // filter slice that must not be fetched into all eight L2s: XCD k then owns the column tiles k, k+8, ...
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if ((gridDim.y & 7u) == 0 && 16ll * p.coutp > (int64_t)p.n_img * p.hi * p.wi) {     // (physical input pixels)
-    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned j = L >> 3, ny8 = gridDim.y >> 3;
+  // BALANCED launch (round 6, FUSE only, bal_whole > 0): a launch of 640 (tile, K slice) jobs puts three workgroups on 128 CUs and two on the other 128
+  // (the dispatcher deals ids i, i + 256, i + 512 to one CU: tools/probe_wino_phases.py --placement), and the CUs with three set the launch's time.  Here
+  // the grid is ONE dimension of bal_whole + 2 * (jobs - bal_whole) = 768 ids: ids < bal_whole (512) run a whole job, the others HALF the K range of one
+  // of the remaining 128 jobs - every CU gets two whole jobs and one half (10 chunk units instead of 12 / 8).  A halved job adds one slab to its tile; the
+  // tile's ticket counts ksplit + (halved slices of the tile) arrivals.  v = the id the job would have had in the (gx, gy, ksplit) grid, and
+  // v = id (mod 8): a job stays on the XCD the tile order below wants it on.
+  unsigned gx = gridDim.x, gy = gridDim.y;
+  unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  int half = -1;                                         // 0 / 1: this workgroup runs the first / second half of its job's chunks
+  if (FUSE && bal_whole > 0) {
+    gx = (unsigned)(((int64_t)p.n_img * (p.hq >> 1) * (p.wq >> 1) + WT - 1) / WT);
+    gy = (unsigned)((p.coutp + WNB - 1) / WNB);
+    if (L >= (unsigned)bal_whole) {
+      const unsigned t = L - (unsigned)bal_whole, q = t >> 3;
+      L = (unsigned)bal_whole + 8u * (q >> 1) + (t & 7u);
+      half = (int)(q & 1u);
+    }
+  }
+  const unsigned T = gx * gy;                            // tiles of one K slice
+  unsigned bx = L % gx, by = (L / gx) % gy, bz = L / T;
+  if ((gy & 7u) == 0 && 16ll * p.coutp > (int64_t)p.n_img * p.hi * p.wi) {     // (physical input pixels)
+    const unsigned j = L >> 3, ny8 = gy >> 3;
     by = (L & 7u) + 8u * (j % ny8);
     const unsigned rest = j / ny8;
-    bx = rest % gridDim.x;
-    bz = rest / gridDim.x;
+    bx = rest % gx;
+    bz = rest / gx;
   }
   const unsigned t0 = bx * WT;
   const int n0 = by * WNB;
@@ -106,8 +124,21 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const int cbase = grp * cin;                                       // first input channel of the group
   const int nchunks_all = cin / WKC;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-  const int kc_begin = (int)((int64_t)nchunks_all * bz / ksplit);
-  const int kc_end = (int)((int64_t)nchunks_all * (bz + 1) / ksplit);
+  int kc_begin = (int)((int64_t)nchunks_all * bz / ksplit);
+  int kc_end = (int)((int64_t)nchunks_all * (bz + 1) / ksplit);
+  // slabs of this workgroup's tile and the one it writes: ksplit, or (balanced) one more per halved slice of the tile - slice z of the tile whose
+  // position inside a slice layer is tl has id z * T + tl, and ids >= bal_whole are the halved ones
+  int nslab = ksplit, my_slab = (int)bz;
+  if (FUSE && bal_whole > 0) {
+    const int tl = (int)(L % T);
+    const int z_first = tl >= bal_whole ? 0 : (bal_whole - tl + (int)T - 1) / (int)T;      // the tile's first halved slice
+    if (z_first < ksplit) nslab = ksplit + (ksplit - z_first);
+    if (half >= 0) {
+      const int mid = (kc_begin + kc_end) >> 1;
+      if (half == 0) kc_end = mid;
+      else { kc_begin = mid; my_slab = ksplit + ((int)bz - z_first); }
+    }
+  }
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
 
   // every thread derives the coordinates of ITS tile (tid >> 3 - the same tile in the input transform and in the epilogue)
@@ -267,7 +298,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   // (epilogue 4.7 -> measured in profiles/r02_*).  The plan only selects this schedule when float4 accesses are legal.
   float* const Ms = smem;                        // [8 = 2*i + j'][WT][LDM], one column tile at a time
   // split-K slabs [ksplit][M][coutp] through a buffer descriptor with 32-bit byte offsets (splitk_fused checks the size)
-  const lfdm_buf slab_buf = lfdm_make_buf(FUSE && ksplit > 1 ? p.partial : nullptr, FUSE && ksplit > 1 ? (uint32_t)((int64_t)ksplit * M * p.coutp * 4) : 0u);
+  const lfdm_buf slab_buf = lfdm_make_buf(FUSE && nslab > 1 ? p.partial : nullptr, FUSE && nslab > 1 ? (uint32_t)((int64_t)nslab * M * p.coutp * 4) : 0u);
   const int e_tile = tid >> 3, e_c4 = tid & 7;
   float gs[NT][4], gq[NT][4];
 #pragma unroll
@@ -283,7 +314,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #pragma unroll
     for (int e = 0; e < 4; ++e) gs[ct][e] = gq[ct][e] = 0.f;
     float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && ksplit == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
+    if (p.bias && nslab == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
     const int n = my_n;                                 // e_tile == x_tile == tid >> 3
     const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
     const bool live = n >= 0 && co < p.coutp;
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                        // residual rows requested before the barrier
       res[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live && ksplit == 1 && p.residual && co < p.cout)
+      if (live && nslab == 1 && p.residual && co < p.cout)
         res[q] = *reinterpret_cast<const float4*>(p.residual + (orow0 + (q >> 1) * p.wq + (q & 1)) * p.ldr + co);
     }
     __syncthreads();
@@ -326,9 +357,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t orow = orow0 + (q >> 1) * p.wq + (q & 1);
-        if (ksplit > 1) {
+        if (nslab > 1) {
           if (FUSE) {      // ONE 16-byte write-through store per float4 (round 6; two 8-byte agent-scope stores before: 2.7x the fabric time per byte)
-            lfdm_buf_store_f4_sc1(slab_buf, (uint32_t)((((int64_t)bz * M + orow) * p.coutp + co) * 4), y[q]);
+            lfdm_buf_store_f4_sc1(slab_buf, (uint32_t)((((int64_t)my_slab * M + orow) * p.coutp + co) * 4), y[q]);
           } else {
             *reinterpret_cast<float4*>(p.partial + ((int64_t)bz * M + orow) * p.coutp + co) = y[q];
           }
@@ -349,23 +380,25 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
 #ifdef LFDM_WINO_TIMING
   tstamp[4] = __builtin_readcyclecounter();
   tstamp[5] = wall_clock64() - wall0;
+  tstamp[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID | XCC_ID
+  tstamp[7] = wall0;                                                   // (100 MHz wall clock at entry: which workgroups started together)
   if (threadIdx.x == 0 && p.tile_counters) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.tile_counters + 65536) +      // (behind the 64 K ticket words)
-                              ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
-    for (int i = 0; i < 6; ++i) dst[i] = tstamp[i];
+                              ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;      // (hardware id order)
+    for (int i = 0; i < 8; ++i) dst[i] = tstamp[i];
   }
 #endif
   bool reduced_here = false;
 #if defined(LFDM_PROBE_NOTAIL) && LFDM_PROBE_NOTAIL == 1
-  if (FUSE && ksplit > 1) return;      // probe build only (tools/probe_wino_tail.sh; results WRONG): the launch without drain, ticket and reduce
+  if (FUSE && nslab > 1) return;      // probe build only (tools/probe_wino_tail.sh; results WRONG): the launch without drain, ticket and reduce
 #endif
-  if (FUSE && ksplit > 1) {
+  if (FUSE && nslab > 1) {
     __shared__ int s_last;
     LFDM_DRAIN_STORES();                                   // every storing wave: its slab words have left for memory
     __syncthreads();
     if (tid == 0) {
-      unsigned* cnt = p.tile_counters + ((int64_t)by * gridDim.x + bx);
-      const bool last = lfdm_ticket_take(cnt) == (unsigned)(ksplit - 1);
+      unsigned* cnt = p.tile_counters + ((int64_t)by * gx + bx);
+      const bool last = lfdm_ticket_take(cnt) == (unsigned)(nslab - 1);
       if (last) lfdm_ticket_reset(cnt);                   // ready for the next launch
       s_last = last ? 1 : 0;
     }
@@ -397,16 +430,16 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       for (int q = 0; q < 4; ++q) src[q] = (uint32_t)(((orow0 + (q >> 1) * p.wq + (q & 1)) * p.coutp + co) * 4);
       // four slabs x the thread's four pixels in flight per round (16 loads of 16 bytes, read past the L1: one memory round trip for
       // ksplit <= 4, two up to 8); summed z = 0, 1, ... per pixel (fixed order)
-      for (int z0 = 0; z0 < ksplit; z0 += 4) {
+      for (int z0 = 0; z0 < nslab; z0 += 4) {
         float4 w[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            w[u][q] = lfdm_buf_load_f4_sc1(slab_buf, z0 + u < ksplit ? src[q] + (uint32_t)(z0 + u) * zs : LFDM_BUF_OOB);
+            w[u][q] = lfdm_buf_load_f4_sc1(slab_buf, z0 + u < nslab ? src[q] + (uint32_t)(z0 + u) * zs : LFDM_BUF_OOB);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (z0 + u < ksplit) {
+          if (z0 + u < nslab) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if (z0 + u == 0) v[q] = w[u][q];
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
       }
     }
   }
-  if (p.gn_partial && (ksplit == 1 || reduced_here)) {
+  if (p.gn_partial && (nslab == 1 || reduced_here)) {
     // per-channel sums over the workgroup's 32 tiles: lanes with equal e_c4 (stride 8) inside the wave, then the four waves
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
@@ -575,20 +608,25 @@ extern "C" int lfdm_pack_wino_weights_multi_f32(const lfdm_pack_wino_job* jobs, 
 }
 
 // grid (tile blocks, column tiles, ksplit).  Called by lfdm_conv2d_cl_f32 (conv_igemm.hip).
-int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, hipStream_t stream) {
+int lfdm_conv_wino_launch(const lfdm_conv_params& p, int bn, bool fuse_reduce, int bal_whole, hipStream_t stream) {
   const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
   const dim3 grid((unsigned)((ntiles + WT - 1) / WT), (unsigned)((p.coutp + bn - 1) / bn), p.ksplit > 1 ? p.ksplit : 1);
   const bool act = p.act != LFDM_ACT_NONE;
-  if (fuse_reduce) {                      // (splitk_fused, conv_igemm.hip: 32-column tiles, split-K; any activation at run time)
-    LFDM_LAUNCH((conv_wino_kernel<false, 1, false, true>), grid, dim3(256), 0, stream, p);
+  if (fuse_reduce) {                      // (splitk_fused / wino_balance, conv_igemm.hip: 32-column tiles; any activation at run time)
+    if (bal_whole > 0) {                  // balanced: whole jobs first, then the two halves of each remaining job (see the kernel)
+      const unsigned jobs = grid.x * grid.y * grid.z;
+      LFDM_LAUNCH((conv_wino_kernel<false, 1, false, true>), dim3((unsigned)bal_whole + 2u * (jobs - (unsigned)bal_whole)), dim3(256), 0, stream, p, bal_whole);
+    } else {
+      LFDM_LAUNCH((conv_wino_kernel<false, 1, false, true>), grid, dim3(256), 0, stream, p, 0);
+    }
     return lfdm_check_launch("conv_wino");
   }
   if (p.pool2 && act) {                   // (the pooled form follows an output activation in every caller: lfdm_conv2d_cl_f32 checks)
-    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p);
-    else LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p);
-  } else if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p);
-  else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p);
-  else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p);
-  else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p);
+    if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<true, 2, true>), grid, dim3(256), 0, stream, p, 0);
+    else LFDM_LAUNCH((conv_wino_kernel<true, 1, true>), grid, dim3(256), 0, stream, p, 0);
+  } else if (bn == 64 && act) LFDM_LAUNCH((conv_wino_kernel<true, 2>), grid, dim3(256), 0, stream, p, 0);
+  else if (bn == 64) LFDM_LAUNCH((conv_wino_kernel<false, 2>), grid, dim3(256), 0, stream, p, 0);
+  else if (act) LFDM_LAUNCH((conv_wino_kernel<true, 1>), grid, dim3(256), 0, stream, p, 0);
+  else LFDM_LAUNCH((conv_wino_kernel<false, 1>), grid, dim3(256), 0, stream, p, 0);
   return lfdm_check_launch("conv_wino");
 }

@@ -373,6 +373,11 @@ def conv_partial_floats(p):
     return _lib().lfdm_conv2d_partial_bytes(C.byref(p)) // 4
 
 
+def conv_plan_slabs(p):
+    """Slabs per output tile the launch will sum (lfdm_conv2d_plan_slabs): ksplit, or more for a balanced Winograd launch."""
+    return _lib().lfdm_conv2d_plan_slabs(C.byref(p))
+
+
 class WinogradUnavailable(RuntimeError):
     pass
 
@@ -406,9 +411,8 @@ def conv2d_cl(src0, weight, cout, kh, kw, n_img, hi, wi, *, partial=None, gn_par
                                   "run the pooling as a launch of its own")
     if gn_partial is not None:      # before the plan is asked for: the pointwise schedule has no fused statistics
         p.gn_partial, p.gn_groups, p.gn_pixels = _p(gn_partial), gn_groups, gn_pixels
-    _, ks = conv_plan(p)
-    if ks > 1:
-        need = conv_partial_floats(p)
+    need = conv_partial_floats(p)          # (also non-zero for a ksplit = 1 plan that balances its Winograd launch: lfdm_hip.h, tile_counters)
+    if need > 0:
         if partial is None or partial.numel() < need:
             partial = torch.empty(need, dtype=torch.float32, device=src0.device)
         p.partial = _p(partial)

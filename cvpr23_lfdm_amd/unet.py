@@ -328,10 +328,11 @@ class Unet3D(ParamTree):
         tile_rows, ksplit = ops.conv_plan(p)
         # (sized while the placeholder is still set: the slab buffer must belong to the plan the launch will re-derive with the real
         # gn_partial - without it schedules 3 / 4 would plan ksplit = 1 and size it 0)
-        partial_floats = ops.conv_partial_floats(p) if ksplit > 1 else 0
+        # (asked for ksplit = 1 plans too: the balanced Winograd launch halves the K range of 128 of a launch's 640 jobs and needs slabs for those)
+        partial_floats = ops.conv_partial_floats(p) if (ksplit > 1 or sched == 2) else 0
         p.gn_partial = None
         m = n_img * p.hq * p.wq
-        if ksplit > 1:
+        if partial_floats > 0:
             part = self._buf(scratch, 1, partial_floats)      # slabs (+ LayerNorm row statistics)
             p.partial = part.data_ptr()
         stats = None

@@ -100,6 +100,11 @@ typedef struct lfdm_conv_params {
      pass (lfdm_conv2d_plan's tile_rows says which: 16 = reduce pass).  The slabs cross workgroups as 16-byte write-through (sc1) stores / L1-bypassing
      loads through a buffer descriptor (the library rounds `partial` up to a 128-byte boundary; lfdm_conv2d_partial_bytes carries the slack):
      no scope fence.  With tile_counters the Winograd plan also splits 8..15-chunk reductions.
+     BALANCED launch (round 6): with tile_counters AND a `partial` buffer of lfdm_conv2d_partial_bytes, a Winograd launch of exactly 640
+     (tile, K slice) workgroups - three on half of the 256 CUs, two on the others - runs as 512 whole jobs + both halves of the other 128
+     (768 workgroups: two whole + one half per CU); a halved slice adds one slab to its tile, so lfdm_conv2d_partial_bytes may be non-zero for a
+     plan with ksplit = 1 and lfdm_conv2d_plan_slabs reports ksplit + the extra slabs.  The slabs are still summed in one fixed order (run-to-run
+     identical results), but not the order of the plain launch: equal to it within fp32 rounding, not bit for bit.  LFDM_WINO_BALANCE=0 disables.
      GroupNorm partial sums of a fused Winograd launch whose groups are wider than 32 channels occupy cg/32 chunk slots per tile block:
      chunk = tile block * (cg / 32) + column part. */
   unsigned int* tile_counters;
@@ -178,8 +183,11 @@ int lfdm_conv2d_plan(const lfdm_conv_params* p, int* tile_rows, int* ksplit);
  * video_flow_diffusion.py:224,246-247,300-301 - 32-row tiles, never split-K; LFDM_PW=0 in the environment disables it), 4 = Winograd
  * F(4x4,3x3) (conv_wino4: reads weight_wino4 only; batched shapes, see lfdm_conv_params.weight_wino4), < 0 = error */
 int lfdm_conv2d_schedule(const lfdm_conv_params* p);
-/* bytes of `partial` needed (0 when the plan does not split K) */
+/* bytes of `partial` needed (0 when the plan neither splits K nor balances the launch - see tile_counters) */
 size_t lfdm_conv2d_partial_bytes(const lfdm_conv_params* p);
+/* slabs per output tile the launch will sum when it is handed `partial`: ksplit, or more for a balanced Winograd launch (tile_counters);
+ * 1 = no slabs.  (A binding that compares two plans bit for bit asks this to know whether they sum in the same order.) */
+int lfdm_conv2d_plan_slabs(const lfdm_conv_params* p);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(G) over (C/G, T, H, W) + optional (scale+1, shift) + SiLU, channels-last.

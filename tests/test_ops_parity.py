@@ -1275,6 +1275,59 @@ def test_conv_winograd_splitk_reduced_in_launch(backend, case):
     assert torch.equal(outs[0], outs[1]), "in-launch reduction must equal the reduce pass bit for bit"
 
 
+@pytest.mark.parametrize("case", [
+    dict(t=40, s=4, cin=512, cout=512),                    # 80 tiles x ksplit 8: slices 6 (tiles 32 ..) and 7 halved - nine / ten slabs per tile
+    dict(t=40, s=8, cin=256, cout=256, gpu_only=True),      # 160 tiles x ksplit 4
+    dict(t=40, s=16, cin=128, cout=128, gpu_only=True),     # 320 tiles x ksplit 2
+    dict(t=40, s=32, cin=64, cout=64, gpu_only=True),       # 640 tiles, ksplit 1: the level-0 convolutions of a B = 1 step
+    dict(t=40, s=32, cin=128, cout=64, c1=64, gpu_only=True),
+], ids=lambda c: "-".join("%s%s" % (k, v) for k, v in c.items()))
+def test_conv_winograd_balanced_launch(backend, case):
+    """A Winograd launch of exactly 640 (tile, K slice) jobs runs as 512 whole jobs + both halves of the other 128 when it is handed tile_counters and
+    a partial buffer (conv_wino.hip, lfdm_hip.h tile_counters): equal to torch and to the plain launch within fp32 rounding, identical from run to run,
+    ticket words back at zero, GroupNorm statistics intact."""
+    dev = backend
+    if case.get("gpu_only") and not big(dev):
+        pytest.skip("full-size shapes run on the GPU")
+    t, s, cin, cout = (case[k] for k in ("t", "s", "cin", "cout"))
+    c1 = case.get("c1", 0)
+    x = rnd(t, cin, s, s, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * cin))
+    bias, gamma, beta = rnd(cout, seed=3), rnd(cout, seed=4) + 1, rnd(cout, seed=5)
+    res = rnd(t, cout, s, s, seed=7)
+    conv = F.conv2d(x, wt, bias, padding=1)
+    xs = to_cl(x).to(dev)
+    src0, src1 = (xs, None) if not c1 else (xs[:, :cin - c1].contiguous(), xs[:, cin - c1:].contiguous())
+    w, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
+    counters = torch.zeros(1024, dtype=torch.int32, device=dev)
+    kw = dict(src1=src1, bias=bias.to(dev), weight_wino=ww, residual=to_cl(res).to(dev))
+    pp, _ = ops.conv_params(src0, w, cout, 3, 3, t, s, s, tile_counters=counters, **kw)
+    assert ops.conv_schedule(pp) == 2
+    pp.gn_partial = 1
+    rows, ks = ops.conv_plan(pp)
+    slabs = ops.conv_plan_slabs(pp)
+    tiles = (t * s * s // 4 + 31) // 32 * (cout // 32)
+    assert tiles * ks == 640 and slabs > ks and rows == 128, (tiles, ks, slabs, rows)
+    assert ops.conv_partial_floats(pp) >= slabs * t * s * s * cout
+    pixels, groups = t * s * s, 8
+    cg = cout // groups
+    nchunk = pixels // 128 * max(1, cg // 32)
+    plain = ops.conv2d_cl(src0, w, cout, 3, 3, t, s, s, **kw).clone()               # no ticket words: the plain launch (+ reduce pass)
+    outs = []
+    for rep in range(3):
+        partial = torch.zeros(nchunk, 2 * groups, device=dev)
+        y = ops.conv2d_cl(src0, w, cout, 3, 3, t, s, s, tile_counters=counters, gn_partial=partial, gn_groups=groups, gn_pixels=pixels, **kw)
+        assert int(counters.abs().sum()) == 0
+        outs.append(y.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "fixed summation order: identical from run to run"
+    assert_close(from_cl(outs[0].cpu(), t, s, s), conv + res, TOL, "balanced winograd launch")
+    assert_close(outs[0].cpu(), plain.cpu(), 2e-6, "balanced against the plain launch")
+    h = outs[0] - to_cl(res).to(dev)                          # the statistics describe conv + bias
+    gn = ops.groupnorm_apply_cl(h.clone(), 1, gamma.to(dev), beta.to(dev), partial, nchunk, groups=groups, silu=False)
+    ref = F.group_norm(conv.view(1, t, cout, s, s).permute(0, 2, 1, 3, 4), groups, gamma, beta, eps=1e-5)
+    assert_close(gn.cpu().view(1, t, s, s, cout).permute(0, 4, 1, 2, 3), ref, 5 * TOL, "group norm from the balanced launch's partial sums")
+
+
 @pytest.mark.gpu
 def test_wino_fused_reduce_stress():
     """The fence-free in-launch split-K hand-off (conv_wino.hip FUSE; csrc/lfdm_device.h states what it rests on) under UNEVEN load: 60 launches
@@ -1306,6 +1359,8 @@ def test_wino_fused_reduce_stress():
         kw = dict(bias=bias, weight_wino=ww, ksplit=ks, residual=res, act=3 if it % 3 == 0 else 0)
         pp, _ = ops.conv_params(x, w, cout, 3, 3, n, s, s, tile_counters=counters, **kw)
         if ops.conv_schedule(pp) != 2 or ops.conv_plan(pp)[1] != ks:
+            continue
+        if ops.conv_plan_slabs(pp) != ks:                   # a 640-job launch is balanced (halved slices: another summation order) - its own test
             continue
         plain = ops.conv2d_cl(x, w, cout, 3, 3, n, s, s, **kw).clone()
         side.wait_stream(torch.cuda.current_stream())

@@ -28,12 +28,12 @@ for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8),
     w, ww = ops.pack_conv_weight(raw), ops.pack_wino_weight(raw)
     o = torch.empty(m, cout, device="cuda")
     pp, _ = ops.conv_params(x, w, cout, 3, 3, frames, s, s, out=o, weight_wino=ww)
-    buf = torch.zeros(32768 + 16384 * 6, dtype=torch.int64, device="cuda")      # 64 K ticket words, then six stamps per workgroup
+    buf = torch.zeros(32768 + 16384 * 8, dtype=torch.int64, device="cuda")      # 64 K ticket words, then eight stamps per workgroup
     stamps = buf[32768:]
     pp.tile_counters, pp.tile_counters_len = buf.data_ptr(), 65536               # (the sampler's plan: split-K reduced inside the launch)
     rows, ks = ops.conv_plan(pp)
-    if ks > 1:
-        part = torch.empty(max(1, ops.conv_partial_floats(pp)), device="cuda")
+    if ops.conv_partial_floats(pp) > 0:                                           # (also the balanced ksplit = 1 launches)
+        part = torch.empty(ops.conv_partial_floats(pp), device="cuda")
         pp.partial = part.data_ptr()
     for _ in range(3):
         ops.conv_launch(pp)
@@ -44,8 +44,9 @@ for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8),
         ops.conv_launch(pp)
     e1.record()
     torch.cuda.synchronize()
-    st = stamps.cpu().view(-1, 6)
-    st = st[st[:, 0] > 0].double()
+    raw = stamps.cpu().view(-1, 8)
+    raw = raw[raw[:, 0] > 0]
+    st = raw.double()
     span_cyc = st[:, 4] - st[:, 0]
     tick = float((st[:, 5] * 0.01).sum() / span_cyc.sum())           # us per cycle (wall clock = 100 MHz)
     ph = (st[:, 1:5] - st[:, 0:4]).mean(dim=0) * tick
@@ -54,3 +55,18 @@ for cin, cout, s in ((64, 64, 32), (128, 64, 32), (128, 128, 16), (256, 256, 8),
           "epilogue %.2f | workgroup life %.2f us (max %.2f) | %.3f GHz" % (
               cin, cout, s, ks, st.shape[0], nchunk, e0.elapsed_time(e1) * 100, ph[0], ph[1], ph[2], float(ph[2]) / max(1, nchunk), ph[3],
               float(span_cyc.mean()) * tick, float(span_cyc.max()) * tick, 1e-3 / tick))
+    if "--placement" in sys.argv:
+        # where the dispatcher put the workgroups: HW_ID (cu_id bits 11:8, sh_id 12, se_id 15:13) | XCC_ID << 32, in linear workgroup-id order
+        hw = raw[:, 6]
+        cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (((hw >> 32) & 0xF) << 8)
+        ids, counts = torch.unique(cu, return_counts=True)
+        hist = torch.bincount(counts)
+        print("      placement: %d CUs used; workgroups per CU -> number of CUs: %s" % (ids.numel(), {int(k): int(v) for k, v in enumerate(hist) if v}))
+        print("      first 24 workgroups (linear id): (xcc, se, sh, cu) = %s" % [(int((h >> 32) & 0xF), int((h >> 13) & 7), int((h >> 12) & 1), int((h >> 8) & 0xF)) for h in hw[:24]])
+        same = [int((cu == cu[i]).nonzero().flatten().tolist().__len__()) for i in range(4)]
+        print("      workgroups sharing a CU with workgroup 0: ids %s" % (cu == cu[0]).nonzero().flatten().tolist())
+        print("      workgroups sharing a CU with workgroup 1: ids %s" % (cu == cu[1]).nonzero().flatten().tolist())
+        life = (raw[:, 4] - raw[:, 0]).double() * tick
+        for n in sorted(set(counts.tolist())):
+            sel = torch.isin(cu, ids[counts == n])
+            print("      CUs with %d workgroups: mean workgroup life %.2f us, K loop %.2f us" % (n, float(life[sel].mean()), float(((raw[:, 3] - raw[:, 2]).double() * tick)[sel].mean())))
