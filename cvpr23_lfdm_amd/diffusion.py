@@ -151,6 +151,25 @@ class GaussianDiffusion(nn.Module):
                 draws.append(True)      # p_sample draws on every step, also at t == 0 (:743)
         return times, torch.stack(rows).float().contiguous(), draws
 
+    def _step_tables_on(self, ddim, dev):
+        """(times, coefficient table on `dev`, timestep table on `dev`, draws) of `_step_tables`, kept per schedule.  The tables are functions of
+        the registered buffers only, but building them reads every buffer back to the host - a device-to-host copy, i.e. a host synchronisation
+        at the start of EVERY video: the host could never run ahead of the GPU, and its own work between two videos (these 100 iterations of
+        scalar tensor arithmetic, the next video's launches) ran with the GPU idle - 2.3-3.8 ms of a 258 ms video in the kernel trace
+        (profiles/r06_af_video_gaps.txt).  Cached on (schedule, every buffer's version counter and address); an instance-level replacement of
+        `_step_tables` (the teacher-forced tests) is never cached."""
+        if "_step_tables" in self.__dict__:
+            times, coef, draws = self._step_tables(ddim)
+            return times, coef.to(dev), torch.tensor(times, dtype=torch.int32, device=dev), draws
+        key = (bool(ddim), self.sampling_timesteps, float(self.ddim_sampling_eta), self.num_timesteps, str(dev),
+               tuple((k, v._version, v.data_ptr()) for k, v in self.named_buffers(recurse=False)))
+        hit = self.__dict__.get("_tables_cache")
+        if hit is None or hit[0] != key:
+            times, coef, draws = self._step_tables(ddim)
+            hit = (key, times, coef.to(dev), torch.tensor(times, dtype=torch.int32, device=dev), draws)
+            self.__dict__["_tables_cache"] = hit
+        return hit[1], hit[2], hit[3], hit[4]
+
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
     def sample(self, fea, cond=None, cond_scale=1., batch_size=16):
@@ -176,7 +195,7 @@ class GaussianDiffusion(nn.Module):
         dev = next(unet.parameters()).device
         batch, ch, frames, s, _ = shape
         n = ch * frames * s * s
-        times, coef, draws = self._step_tables(ddim)
+        times, coef_dev, t_table, draws = self._step_tables_on(ddim, dev)
         steps = len(times)
 
         # ---- per-call constants -------------------------------------------------------------
@@ -185,7 +204,6 @@ class GaussianDiffusion(nn.Module):
             raise ValueError("fea batch %d != cond batch %d" % (fea.shape[0], batch))
         fea_cl = ops.planar_to_cl(fea.reshape(batch, fea.shape[1], s * s), batch, fea.shape[1], s * s)
         fea_term = unet.fea_term(pk, fea_cl, batch, s)
-        t_table = torch.tensor(times, dtype=torch.int32, device=dev)
         temb_steps = unet.time_embedding(pk, t_table, steps)
         variants = []           # (per-sample cond part) for each UNet pass of a step
         if unet.has_cond:
@@ -203,7 +221,6 @@ class GaussianDiffusion(nn.Module):
         else:
             step_part = ops.linear_small(temb_steps, pk["cond.w"], pk["cond.b"], act_in=ops.ACT_SILU)
             variants.append(torch.zeros(batch, pk["cond.n"], device=dev))
-        coef_dev = coef.to(dev)
 
         # ---- static step state ----------------------------------------------------------------
         key = (batch, frames, s, len(variants), float(cond_scale), bool(ddim), steps, id(pk))
