@@ -818,8 +818,10 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
       // 64-column workgroups (half the patch loads / transforms per MFMA, two workgroups per CU) pay where every CU still gets
       // several of them: the batched shapes of training / throughput mode (B = 8 training step 157.0 -> 150.6 ms at >= 1536
       // workgroups = six per CU, 151.7 at 3072, 150.8 at 768: profiles/r02_u_bn64_train.txt), never the B = 1 sampler
-      // (<= 640 such workgroups).  LFDM_WINO_BN64_MIN overrides the threshold, 0 disables.
-      static const long min_blocks64 = [] { const char* e = lfdm_knob("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1536l; }();
+      // (<= 640 such workgroups).  LFDM_WINO_BN64_MIN (--knobs builds) overrides the threshold, 0 disables.
+      // (round 6: 1280 - the LFAE decoder's 256 -> 256 convolutions over 40 frames of 32x32, 320 x 4 such workgroups, twelve per video: -0.5 ms per video,
+      //  profiles/r06_aj_bn64_decode_ab.txt; the training step measured the same at 768 and 1536)
+      static const long min_blocks64 = [] { const char* e = lfdm_knob("LFDM_WINO_BN64_MIN"); return e ? atol(e) : 1280l; }();
       if (min_blocks64 > 0 && p.coutp % 64 == 0 && !(p.groups > 1) && ((ntiles + 31) / 32) * (p.coutp / 64) >= min_blocks64) pl.bn = 64;
     }
     const int64_t blocks = ((ntiles + 31) / 32) * ((p.coutp + pl.bn - 1) / pl.bn);
