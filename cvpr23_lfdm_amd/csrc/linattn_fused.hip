@@ -31,25 +31,45 @@ constexpr int SPLIT_TOK = 32;           // smallest context split (one token til
 constexpr int PART = DH * DH + 2 * DH;  // floats per partial: ctx[32][32] | m[32] | s[32]
 constexpr float LA_SCALE = 0.17677669529663687f;
 
-// xhat fragment of one token: lane (token l31 of the tile, half kh) holds channels CH*kh .. CH*kh + CH-1, normalised
-__device__ __forceinline__ void load_xhat(const float* __restrict__ xrow, bool ok, int kh, float eps, float (&xf)[CH]) {
+// xhat fragment of one token: lane (token l31 of the tile, half kh) holds channels CH*kh .. CH*kh + CH-1, normalised.  `xrow` is ALWAYS a valid
+// row (the callers clamp the token index) and is loaded unconditionally; !ok only zeroes the result.  (Round 6: behind `if (ok)` every one of the
+// eight 16-byte loads got a branch of its own and, in the context pass's tile loop, an s_waitcnt vmcnt(0) right behind it - eight memory round
+// trips in a row per 32-token tile where one was meant.)
+__device__ __forceinline__ void load_xraw(const float* __restrict__ xrow, int kh, float4 (&raw)[CH / 4]) {
+#pragma unroll
+  for (int q = 0; q < CH / 4; ++q) raw[q] = *reinterpret_cast<const float4*>(xrow + CH * kh + 4 * q);
+}
+__device__ __forceinline__ void xhat_stats(const float4 (&raw)[CH / 4], float eps, float& mean, float& rstd) {
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int q = 0; q < CH / 4; ++q) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) v = *reinterpret_cast<const float4*>(xrow + CH * kh + 4 * q);
-    xf[4 * q] = v.x; xf[4 * q + 1] = v.y; xf[4 * q + 2] = v.z; xf[4 * q + 3] = v.w;
+    const float4 v = raw[q];
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   s1 += __shfl_xor(s1, 32);
   s2 += __shfl_xor(s2, 32);
-  const float mean = s1 * (1.0f / (float)C);
+  mean = s1 * (1.0f / (float)C);
   float var = s2 * (1.0f / (float)C) - mean * mean;
   if (var < 0.f) var = 0.f;
-  const float rstd = 1.0f / sqrtf(var + eps);
+  rstd = 1.0f / sqrtf(var + eps);
+}
+__device__ __forceinline__ void xhat_apply(const float4 (&raw)[CH / 4], bool ok, float mean, float rstd, float (&xf)[CH]) {
 #pragma unroll
-  for (int s = 0; s < CH; ++s) xf[s] = ok ? (xf[s] - mean) * rstd : 0.f;
+  for (int q = 0; q < CH / 4; ++q) {
+    const float4 v = raw[q];
+    xf[4 * q] = ok ? (v.x - mean) * rstd : 0.f;
+    xf[4 * q + 1] = ok ? (v.y - mean) * rstd : 0.f;
+    xf[4 * q + 2] = ok ? (v.z - mean) * rstd : 0.f;
+    xf[4 * q + 3] = ok ? (v.w - mean) * rstd : 0.f;
+  }
+}
+__device__ __forceinline__ void load_xhat(const float* __restrict__ xrow, bool ok, int kh, float eps, float (&xf)[CH]) {
+  float4 raw[CH / 4];
+  float mean, rstd;
+  load_xraw(xrow, kh, raw);
+  xhat_stats(raw, eps, mean, rstd);
+  xhat_apply(raw, ok, mean, rstd, xf);
 }
 
 // Weight fragment of one (q | k | v, head): lane (feature l31, k-slot kh) holds W[which*256 + head*32 + l31][CH*kh .. CH*kh + CH-1].
@@ -89,6 +109,9 @@ __global__ __launch_bounds__(64, 3) void linattn_fused_ctx_kernel(const float* _
   f32x16 ctx;
 #pragma unroll
   for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+  // (Round 6, tried: the NEXT tile's rows requested before this tile's products.  hipcc sinks such loads to their first use behind the back-edge; pinned
+  //  there by a use behind the products, the 32 extra live registers push the kernel over its 168 and the loads end up behind the last MFMAs anyway.
+  //  What is kept: the tile's eight loads are unconditional and in flight TOGETHER - one round trip per tile instead of six to eight.)
   for (int t0 = n0; t0 < n1; t0 += 32) {
     const int n = t0 + l31;
     float xf[CH];
