@@ -103,6 +103,9 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
       }
     }
   };
+  // BATCH (round 6): the unit's table loads - rotary factors, relative-position bias - are requested in batches in front of the work that hides them instead
+  // of one by one at their use; not for the two instantiations that are at the register limit already (48 rows x 48, 64 x 64: the batches spill there)
+  constexpr bool BATCH = LROWS < LP || LP <= 32;
   constexpr bool PREFETCH = LP <= 48;          // (64 tokens - the mid spatial attention of the 256x256 configuration, a handful of sequences - is at the register limit already: rows fetched at the top of the unit as before)
   if (PREFETCH) fetch((int64_t)blockIdx.x * WPB + wave);
 
@@ -116,14 +119,25 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
 
     // ---- stage Q (scaled + rotary), K (rotary), V, dO ----
     {
+      // rotary factors of this lane's rows / feature pairs, requested together (round 6: each of the twelve 8-byte loads sat behind
+      // `if (rot_cos && t < L)` with an s_waitcnt vmcnt(0) of its own - twelve L2 round trips in a row per (sequence, head))
+      float2 rcos[NR], rsin[NR];
+      if (BATCH) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int t = rr + 8 * i, tt = t < L ? t : 0;
+          rcos[i] = rot_cos ? *reinterpret_cast<const float2*>(rot_cos + tt * 16 + 2 * c4) : make_float2(1.f, 1.f);
+          rsin[i] = rot_cos ? *reinterpret_cast<const float2*>(rot_sin + tt * 16 + 2 * c4) : make_float2(0.f, 0.f);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int t = rr + 8 * i;
         float4 q = qv[i], k = kv[i];
         q.x *= ATT_SCALE; q.y *= ATT_SCALE; q.z *= ATT_SCALE; q.w *= ATT_SCALE;
         if (rot_cos && t < L) {
-          const float c0 = rot_cos[t * 16 + 2 * c4], s0 = rot_sin[t * 16 + 2 * c4];
-          const float c1 = rot_cos[t * 16 + 2 * c4 + 1], s1 = rot_sin[t * 16 + 2 * c4 + 1];
+          const float c0 = BATCH ? rcos[i].x : rot_cos[t * 16 + 2 * c4], s0 = BATCH ? rsin[i].x : rot_sin[t * 16 + 2 * c4];
+          const float c1 = BATCH ? rcos[i].y : rot_cos[t * 16 + 2 * c4 + 1], s1 = BATCH ? rsin[i].y : rot_sin[t * 16 + 2 * c4 + 1];
           float4 qr, kr;
           qr.x = q.x * c0 - q.y * s0; qr.y = q.y * c0 + q.x * s0;
           qr.z = q.z * c1 - q.w * s1; qr.w = q.w * c1 + q.z * s1;
@@ -140,16 +154,33 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
         *reinterpret_cast<float4*>(Gs + t * SV + 4 * c4) = gv[i];
       }
     }
-    if (PREFETCH && base + (int64_t)gridDim.x * WPB < units) fetch(unit + (int64_t)gridDim.x * WPB);       // in flight under this unit's GEMMs
-    lfdm_wave_lds_sync();
-
-    // ---- S = Q K^T, dP = dO V^T ----
+    // The relative-position bias is the INITIAL value of the score accumulators (round 6): its 4 NT^2 loads are requested together, in front of the
+    // next unit's prefetch (loads retire in order: behind it, the first MFMA's wait for the bias would also wait for the prefetched rows), and the
+    // products accumulate on top.  Before, each value was loaded behind `else if (bias && row < L)` inside the softmax and used at once: 36 dependent
+    // L1 / L2 round trips per (sequence, head).
     f32x4 p[NT][NT], dp[NT][NT];
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        const int col = tj * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ti * 16 + lq * 4 + r;
+          const bool in = BATCH && bias && row < L && col < L;
+          const float bv = (BATCH && bias) ? bias[((int64_t)head * L + (row < L ? row : 0)) * L + (col < L ? col : 0)] : 0.f;
+          p[ti][tj][r] = in ? bv : 0.f;
+        }
+      }
+    if (PREFETCH && base + (int64_t)gridDim.x * WPB < units) fetch(unit + (int64_t)gridDim.x * WPB);       // in flight under this unit's GEMMs
+    lfdm_wave_lds_sync();
+
+    // ---- S = Q K^T (+ bias), dP = dO V^T ----
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        f32x4 acc = p[ti][tj], acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < DH / 4; ++s) {
           const float a = Qs[rowc(ti * 16 + l15) * SQ + 4 * s + lq];
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
           const int col = tj * 16 + l15;
           float v = p[ti][tj][r];
           if (col >= L) v = -3.0e38f;
-          else if (bias && row < L) v += bias[((int64_t)head * L + row) * L + col];
+          else if (!BATCH && bias && row < L) v += bias[((int64_t)head * L + row) * L + col];
           p[ti][tj][r] = v;
           m = fmaxf(m, v);
         }
@@ -251,6 +282,19 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
     for (int ti = 0; ti < NT; ++ti) {
       f32x4 oq[2], ok[2];
       oq[0] = oq[1] = ok[0] = ok[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the tile's sixteen rotary factors are requested in front of its MFMAs (they were loaded one by one at their use, each behind a wait)
+      float urc[4][2], urs[4][2];
+      if (BATCH && rot_cos) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = ti * 16 + lq * 4 + r, tt = t < L ? t : 0;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            urc[r][hh] = rot_cos[tt * 16 + ((16 * hh + l15) >> 1)];
+            urs[r][hh] = rot_sin[tt * 16 + ((16 * hh + l15) >> 1)];
+          }
+        }
+      }
 #pragma unroll
       for (int s = 0; s < LROWS / 4; ++s) {      // (tokens >= LROWS do not exist; rows in [L, LROWS) hold zeros)
         const float aq = Ps[rowc(ti * 16 + l15) * SP + 4 * s + lq];      // dS[i][j = 4s+lq]
@@ -272,7 +316,7 @@ __global__ __launch_bounds__(64 * WPB) void attention_bwd_kernel(
             // feature d = 16*hh + l15; pair index d>>1; even lane holds x, odd lane holds y of the pair
             const float gq_o = __shfl_xor(gq, 1), gk_o = __shfl_xor(gk, 1);
             const int tt = t < L ? t : 0;
-            const float c = rot_cos[tt * 16 + ((16 * hh + l15) >> 1)], sn = rot_sin[tt * 16 + ((16 * hh + l15) >> 1)];
+            const float c = BATCH ? urc[r][hh] : rot_cos[tt * 16 + ((16 * hh + l15) >> 1)], sn = BATCH ? urs[r][hh] : rot_sin[tt * 16 + ((16 * hh + l15) >> 1)];
             if ((l15 & 1) == 0) {          // dx = gx*c + gy*s
               gq = gq * c + gq_o * sn;
               gk = gk * c + gk_o * sn;
