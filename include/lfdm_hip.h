@@ -483,7 +483,8 @@ int lfdm_pack_conv_weight_f32(const float* w, int n_o, int n_i, int taps, int64_
 /* Convolution with at most 4 output channels on v_mfma_f32_4x4x1 (sixteen 4x4 blocks per instruction, lane = output
  * pixel): the LFAE generator's final Conv2d(64 -> 3, 7x7) + sigmoid (LFAE/modules/generator.py:54,161-162).
  * x: CL rows (n_img*h*w, cin) stride ldx; wgt: [k*k][cin][4] (tap-major, filters innermost, zero padded to 4);
- * bias: 4 floats or NULL; out: CL rows stride ldo (only `cout` columns are written); stride 1, zero padding k/2. */
+ * bias: 4 floats or NULL; out: CL rows stride ldo (only `cout` columns are written); stride 1, zero padding k/2.
+ * x and wgt 16-byte aligned, ldx % 4 == 0, cin % 16 == 0, odd k <= 7 (LFDM_EINVAL otherwise). */
 int lfdm_conv2d_smalln_cl_f32(const float* x, int ldx, int cin, int n_img, int h, int w, const float* wgt,
                               const float* bias, float* out, int ldo, int cout, int k, int act,
                               lfdm_stream_t stream);
