@@ -301,6 +301,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
   const lfdm_buf slab_buf = lfdm_make_buf(FUSE && nslab > 1 ? p.partial : nullptr, FUSE && nslab > 1 ? (uint32_t)((int64_t)nslab * M * p.coutp * 4) : 0u);
   const int e_tile = tid >> 3, e_c4 = tid & 7;
   float gs[NT][4], gq[NT][4];
+  float4 yown[4];                    // (FUSE) this workgroup's own contribution to its thread's four pixels: the reducer does not read its own slab back
+#pragma unroll
+  for (int q = 0; q < 4; ++q) yown[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     if (ct > 0) __syncthreads();    // the previous column tile's planes have been consumed
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
         if (nslab > 1) {
           if (FUSE) {      // ONE 16-byte write-through store per float4 (round 6; two 8-byte agent-scope stores before: 2.7x the fabric time per byte)
             lfdm_buf_store_f4_sc1(slab_buf, (uint32_t)((((int64_t)my_slab * M + orow) * p.coutp + co) * 4), y[q]);
+            yown[q] = y[q];
           } else {
             *reinterpret_cast<float4*>(p.partial + ((int64_t)bz * M + orow) * p.coutp + co) = y[q];
           }
@@ -436,14 +440,16 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            w[u][q] = lfdm_buf_load_f4_sc1(slab_buf, z0 + u < nslab ? src[q] + (uint32_t)(z0 + u) * zs : LFDM_BUF_OOB);
+            w[u][q] = lfdm_buf_load_f4_sc1(slab_buf, (z0 + u < nslab && z0 + u != my_slab) ? src[q] + (uint32_t)(z0 + u) * zs : LFDM_BUF_OOB);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (z0 + u < nslab) {
+            const bool mine = z0 + u == my_slab;          // (the same bits this workgroup stored: the sum is the one every other arrival order gives)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              if (z0 + u == 0) v[q] = w[u][q];
-              else { v[q].x += w[u][q].x; v[q].y += w[u][q].y; v[q].z += w[u][q].z; v[q].w += w[u][q].w; }
+              const float4 t = mine ? yown[q] : w[u][q];
+              if (z0 + u == 0) v[q] = t;
+              else { v[q].x += t.x; v[q].y += t.y; v[q].z += t.z; v[q].w += t.w; }
             }
           }
       }
