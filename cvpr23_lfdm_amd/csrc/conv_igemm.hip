@@ -709,6 +709,7 @@ namespace {
 
 struct ConvPlan;
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p);
+bool wino_fuse_geometry_ok(const lfdm_conv_params& p, int bn);
 int wino_balance(const ConvPlan& pl, const lfdm_conv_params& p, int* extra_slabs);
 
 struct ConvPlan {
@@ -838,8 +839,9 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
     // per video against 275.0 with five chunks from 16 chunks on; 3 / 6 per slice lose).
     static const int env_sc = [] { const char* e = lfdm_knob("LFDM_WINO_SLICE_CHUNKS"); return e ? atoi(e) : 0; }();
     static const int env_mc = [] { const char* e = lfdm_knob("LFDM_WINO_SPLIT_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
-    const int min_chunks = env_mc > 0 ? env_mc : (p.tile_counters ? 8 : 16);
-    const int slice_chunks = env_sc > 0 ? env_sc : (p.tile_counters ? 4 : (nch < 16 ? 4 : 5));
+    const bool fuse = wino_fuse_geometry_ok(p, pl.bn);      // (not merely "ticket words were handed in")
+    const int min_chunks = env_mc > 0 ? env_mc : (fuse ? 8 : 16);
+    const int slice_chunks = env_sc > 0 ? env_sc : (fuse ? 4 : (nch < 16 ? 4 : 5));
     if (blocks < 512 && nch >= min_chunks) {
       // Split-K from tools/sweep_ksplit.sh (profiles/r02_c_ksplit_sweep.txt): a workgroup that is alone on its CU runs a
       // chunk in ~1.8 us (the matrix pipe needs 1.0), fixed costs are ~8 us per workgroup, and in the sampler the filters
@@ -898,23 +900,25 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   return pl;
 }
 
+// what the in-launch slab reduction of the Winograd schedule needs apart from a split plan: the plain 32-column workgroup (conv_wino_kernel FUSE), an epilogue
+// that stores whole float4 columns of real channels, enough zeroed ticket words.  make_plan asks this BEFORE it takes the finer slices that only pay with the
+// in-launch reduction (advisor, round 5: ticket words handed in for a launch the fused path then refuses bought extra slabs and a reduce launch).
+bool wino_fuse_geometry_ok(const lfdm_conv_params& p, int bn) {
+  static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B and bit-compare switch: tests)
+  if (!on || !p.tile_counters || p.deconv4 || bn != 32 || p.groups > 1 || p.pool2 || p.cout != p.coutp || p.ldo % 4 != 0 ||
+      (((uintptr_t)p.out) & 15) != 0 ||
+      (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
+      (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
+    return false;
+  const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
+  return (int64_t)p.tile_counters_len >= ((ntiles + 31) / 32) * (p.coutp / 32);
+}
+
 // in-launch slab reduction (Winograd F(2x2) schedule, enough zeroed tile counters)
 bool splitk_fused(const ConvPlan& pl, const lfdm_conv_params& p) {
-  if (pl.ksplit <= 1 || !p.tile_counters || p.deconv4) return false;
+  if (pl.ksplit <= 1 || pl.kind != 2 || !wino_fuse_geometry_ok(p, pl.bn)) return false;
   const int64_t M = (int64_t)p.n_img * p.hq * p.wq;
-  if (pl.kind == 2) {
-    // the plain 32-column workgroup (conv_wino_kernel FUSE); the tail stores whole float4 columns of real channels
-    static const bool on = [] { const char* e = getenv("LFDM_WINO_FUSE_REDUCE"); return !(e && e[0] == '0'); }();      // (A/B and bit-compare switch: tests)
-    if (!on || pl.bn != 32 || p.groups > 1 || p.pool2 || p.cout != p.coutp || p.ldo % 4 != 0 ||
-        (((uintptr_t)p.out) & 15) != 0 ||
-        (p.bias && (((uintptr_t)p.bias) & 15) != 0) ||
-        (p.residual && (p.ldr % 4 != 0 || (((uintptr_t)p.residual) & 15) != 0)))
-      return false;
-    const int64_t ntiles = (int64_t)p.n_img * (p.hq / 2) * (p.wq / 2);
-    if ((int64_t)pl.ksplit * M * p.coutp * 4 >= (1ll << 32) - 64) return false;      // (the slabs go through a buffer descriptor: 32-bit byte offsets)
-    return (int64_t)p.tile_counters_len >= ((ntiles + 31) / 32) * (p.coutp / 32);
-  }
-  return false;
+  return (int64_t)pl.ksplit * M * p.coutp * 4 < (1ll << 32) - 64;      // (the slabs go through a buffer descriptor: 32-bit byte offsets)
 }
 
 // Balanced Winograd launch (conv_wino.hip, round 6): a launch of exactly 640 (tile, K slice) jobs - every 3x3 convolution of a B = 1 sampler step but

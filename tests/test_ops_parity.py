@@ -1275,6 +1275,22 @@ def test_conv_winograd_splitk_reduced_in_launch(backend, case):
     assert torch.equal(outs[0], outs[1]), "in-launch reduction must equal the reduce pass bit for bit"
 
 
+def test_conv_winograd_plan_splits_finer_only_for_the_fused_reduction(backend):
+    """The four-chunk slices / the split of 8..15-chunk reductions exist for the in-launch reduction: ticket words that the fused path will refuse
+    (too few of them, an epilogue it cannot run) must leave the plan of a caller without ticket words (advisor, round 5)."""
+    dev = backend
+    t, s, cin, cout = 8, 8, 128, 64                          # 8 chunks: split only with the in-launch reduction
+    x = torch.zeros(t * s * s, cin, device=dev)
+    wt = torch.zeros(cout, cin, 3, 3)
+    w, ww = ops.pack_conv_weight(wt).to(dev), ops.pack_wino_weight(wt.to(dev))
+    plain, _ = ops.conv_params(x, w, cout, 3, 3, t, s, s, weight_wino=ww)
+    enough, _ = ops.conv_params(x, w, cout, 3, 3, t, s, s, weight_wino=ww, tile_counters=torch.zeros(64, dtype=torch.int32, device=dev))
+    short, _ = ops.conv_params(x, w, cout, 3, 3, t, s, s, weight_wino=ww, tile_counters=torch.zeros(1, dtype=torch.int32, device=dev))
+    assert ops.conv_schedule(plain) == 2
+    assert ops.conv_plan(plain)[1] == 1 and ops.conv_plan(enough)[1] == 2
+    assert ops.conv_plan(short) == ops.conv_plan(plain) and ops.conv_partial_floats(short) == 0
+
+
 @pytest.mark.parametrize("case", [
     dict(t=40, s=4, cin=512, cout=512),                    # 80 tiles x ksplit 8: slices 6 (tiles 32 ..) and 7 halved - nine / ten slabs per tile
     dict(t=40, s=8, cin=256, cout=256, gpu_only=True),      # 160 tiles x ksplit 4
