@@ -110,6 +110,17 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
       if (rb) pre_r[k] = rb[i];
     }
   }
+  // ... and so are this thread's per-channel parameters (round 6): read behind the merge's barrier they were one more dependent round trip of every launch
+  constexpr int PREC = 2;            // channels tid, tid + NT (C <= 512 with 256 threads); further ones are read in place
+  float p_g[PREC], p_b[PREC], p_sc[PREC], p_sh[PREC];
+#pragma unroll
+  for (int j = 0; j < PREC; ++j) {
+    const int c = tid + j * NT, cc = c < channels ? c : 0;
+    p_g[j] = gamma[cc];
+    p_b[j] = beta[cc];
+    p_sc[j] = scale_shift ? scale_shift[(int64_t)b * ss_ld + cc] : 0.f;
+    p_sh[j] = scale_shift ? scale_shift[(int64_t)b * ss_ld + channels + cc] : 0.f;
+  }
   // (a coalesced float2 walk with one thread per (chunk, group) item + an LDS tree was measured: 9.2 vs 9.1 us at 320 chunks and
   // 8.0 vs 6.8 us at 32 - the extra barrier costs more than the strided loads; removed)
   // LPG lanes walk one group's chunks: a whole wavefront per group once the workgroup has 64 threads per group
@@ -156,19 +167,23 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(
   }
   __syncthreads();
   const int cg = channels / groups;
-  for (int c = tid; c < channels; c += NT) {
-    const int g = c / cg;
-    const float a = s_rstd[g] * gamma[c];
-    float bb = beta[c] - s_mean[g] * a;
-    float aa = a;
-    if (scale_shift) {
-      const float sc = scale_shift[(int64_t)b * ss_ld + c] + 1.0f;
-      const float sh = scale_shift[(int64_t)b * ss_ld + channels + c];
-      aa = a * sc;
-      bb = bb * sc + sh;
+  {
+    int j = 0;
+    for (int c = tid; c < channels; c += NT, ++j) {
+      const int g = c / cg;
+      const bool pre = j < PREC;
+      const float a = s_rstd[g] * (pre ? (j == 0 ? p_g[0] : p_g[1]) : gamma[c]);
+      float bb = (pre ? (j == 0 ? p_b[0] : p_b[1]) : beta[c]) - s_mean[g] * a;
+      float aa = a;
+      if (scale_shift) {
+        const float sc = (pre ? (j == 0 ? p_sc[0] : p_sc[1]) : scale_shift[(int64_t)b * ss_ld + c]) + 1.0f;
+        const float sh = pre ? (j == 0 ? p_sh[0] : p_sh[1]) : scale_shift[(int64_t)b * ss_ld + channels + c];
+        aa = a * sc;
+        bb = bb * sc + sh;
+      }
+      s_a[c] = aa;
+      s_b[c] = bb;
     }
-    s_a[c] = aa;
-    s_b[c] = bb;
   }
   __syncthreads();
   int k = 0;
