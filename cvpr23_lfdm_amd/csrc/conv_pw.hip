@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
     const int g_lo = n0 / cg;
     const int g_hi = (((n0 + BN < p.cout ? n0 + BN : p.cout) - 1) / cg);
     const int sub = tid & 31;
+    // (this thread's gamma / beta are requested before the merge, not behind its barrier: BN <= 256 columns, one per thread)
+    const int pcol = n0 + tid;
+    const bool pcol_ok = tid < BN && pcol < p.cout;
+    const float pre_gamma = p.res_gn_gamma[pcol_ok ? pcol : 0], pre_beta = p.res_gn_beta[pcol_ok ? pcol : 0];
     for (int g0 = g_lo; g0 <= g_hi; g0 += 8) {
       const int g = g0 + (tid >> 5);
       double sm = 0.0, sq = 0.0;
@@ -158,14 +162,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(lfdm_conv_params p, int gx
       }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      const int col = n0 + c;
-      if (col < p.cout) {
-        const int g = col / cg - g_lo;
-        const float a = s_gstat[1][g] * p.res_gn_gamma[col];
-        s_ga[c] = a;
-        s_gb[c] = p.res_gn_beta[col] - s_gstat[0][g] * a;
-      }
+    if (pcol_ok) {
+      const int g = pcol / cg - g_lo;
+      const float a = s_gstat[1][g] * pre_gamma;
+      s_ga[tid] = a;
+      s_gb[tid] = pre_beta - s_gstat[0][g] * a;
     }
     // (the table is read after the epilogue's first barrier)
   }

@@ -229,6 +229,14 @@ __global__ __launch_bounds__(256) void heads_gn_kernel(const float* __restrict__
   const int tid = threadIdx.x, b = blockIdx.y;
   const int c2 = 2 * channels;                                                // channels of y: [flow C | occlusion C]
   const int pixels = frames * hw;
+  // (round 6) everything the prologue reads that does NOT depend on the statistics - the thread's head weights, extra-term weights, gamma / beta - is
+  // requested HERE, in front of the merge, instead of in loops behind it (each of those was a dependent round trip of its own)
+  const int ce = c0 + c1;
+  const bool pi_ok = tid < c2;
+  const float pw_f0 = (pi_ok && tid < channels) ? w_flow[tid] : 0.f, pw_f1 = (pi_ok && tid < channels) ? w_flow[channels + tid] : 0.f;
+  const float pw_oc = (pi_ok && tid >= channels) ? w_occ[tid - channels] : 0.f;
+  const float pe0 = tid < 3 * ce ? w_extra[tid] : 0.f, pe1 = tid + 256 < 3 * ce ? w_extra[tid + 256] : 0.f;
+  const float pre_gamma = gamma[pi_ok ? tid : 0], pre_beta = beta[pi_ok ? tid : 0];
   // ---- statistics of this sample: gn_apply_kernel's merge (32 lanes walk one group's chunks, four loads in flight, k ascending) ----
   {
     const int lpg = 32, gpp = 256 / lpg, sub = tid & (lpg - 1);
@@ -267,19 +275,19 @@ __global__ __launch_bounds__(256) void heads_gn_kernel(const float* __restrict__
     }
   }
   for (int i = tid; i < c2; i += 256) {                                       // head weights per y channel
-    wl[i] = i < channels ? w_flow[i] : 0.f;
-    wl[512 + i] = i < channels ? w_flow[channels + i] : 0.f;
-    wl[1024 + i] = i < channels ? 0.f : w_occ[i - channels];
+    const bool pre = i == tid;
+    wl[i] = pre ? pw_f0 : (i < channels ? w_flow[i] : 0.f);
+    wl[512 + i] = pre ? pw_f1 : (i < channels ? w_flow[channels + i] : 0.f);
+    wl[1024 + i] = pre ? pw_oc : (i < channels ? 0.f : w_occ[i - channels]);
   }
-  const int ce = c0 + c1;
-  for (int i = tid; i < 3 * ce; i += 256) we[(i / ce) * 512 + (i % ce)] = w_extra[i];
+  for (int i = tid; i < 3 * ce; i += 256) we[(i / ce) * 512 + (i % ce)] = i == tid ? pe0 : (i == tid + 256 ? pe1 : w_extra[i]);
   __syncthreads();
   const int cg = c2 / groups;
   for (int c = tid; c < c2; c += 256) {
     const int g = c / cg;
-    const float a = s_rstd[g] * gamma[c];
+    const float a = s_rstd[g] * (c == tid ? pre_gamma : gamma[c]);
     s_a[c] = a;
-    s_b[c] = beta[c] - s_mean[g] * a;
+    s_b[c] = (c == tid ? pre_beta : beta[c]) - s_mean[g] * a;
   }
   __syncthreads();
   const int r8 = tid >> 3, seg = tid & 7;
