@@ -169,6 +169,47 @@ __global__ __launch_bounds__(256) void linattn_fused_merge_kernel(const float* _
   const float* base = part + (int64_t)blockIdx.x * nsplit * PART;
   // (round 4: every loop over the splits is unrolled by four - a load per trip paid one L2 round trip per split, 16 of them in a row at
   //  32x32: 12.6 us for a kernel that moves 22 MB)
+  if (nsplit <= 8) {
+    // (round 6) the sampler's shape - eight splits or fewer: everything the thread will read is requested at once - its four context elements of every
+    // split and (threads < 32) the splits' maxima and sums - instead of in three dependent phases (maxima -> weights | barrier | weighted sum)
+    constexpr int PS = 8;
+    float cv[4][PS], pm[PS], psum[PS];
+#pragma unroll
+    for (int p = 0; p < PS; ++p) {
+      const int pc = p < nsplit ? p : nsplit - 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cv[e][p] = base[(int64_t)pc * PART + tid + 256 * e];
+      pm[p] = base[(int64_t)pc * PART + DH * DH + (tid & (DH - 1))];
+      psum[p] = base[(int64_t)pc * PART + DH * DH + DH + (tid & (DH - 1))];
+    }
+    if (tid < DH) {
+      float mm = -3.0e38f;
+#pragma unroll
+      for (int p = 0; p < PS; ++p)
+        if (p < nsplit) mm = fmaxf(mm, pm[p]);
+      float den = 0.f, w[PS];
+#pragma unroll
+      for (int p = 0; p < PS; ++p) {
+        w[p] = p < nsplit ? expf(pm[p] - mm) : 0.f;
+        den += w[p] * psum[p];
+      }
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int p = 0; p < PS; ++p)
+        if (p < nsplit) s_w[p][tid] = w[p] * inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = tid + 256 * e, d = i >> 5;
+      float acc = 0.f;
+#pragma unroll
+      for (int p = 0; p < PS; ++p)
+        if (p < nsplit) acc += s_w[p][d] * cv[e][p];
+      ctx_out[(int64_t)blockIdx.x * DH * DH + i] = acc;
+    }
+    return;
+  }
   if (tid < DH) {
     float mm = -3.0e38f;
 #pragma unroll 4
