@@ -355,6 +355,14 @@ __global__ __launch_bounds__(64 * NW, 2) void temporal_attn_fused_out_kernel(con
     const float* arow = o_lds + tr * OUT_LD;
     const float* brow = wout + ((int64_t)ct * (OUT_LD / 16) * 64 + lane) * 4;      // packed [ct][S][lane][4]: one contiguous 1 KB per load
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc;      // two chains: the 40-cycle dependent latency of 16x16x4 exceeds its 32-cycle issue
+    // the tile's residual values are requested in front of its 128 MFMAs (round 6: loaded behind `if (tok < L)` at the store, they were a
+    // dependent round trip at the end of every tile)
+    float xr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = ti * 16 + 4 * lq + r;
+      xr[r] = x[(row0 + (int64_t)(tok < L ? tok : L - 1) * hw) * ldx + ct * 16 + l15];
+    }
 #pragma unroll 4
     for (int S = 0; S < OUT_LD / 16; S += 2) {
       const float4 a = *reinterpret_cast<const float4*>(arow + (((4 * S + lq) ^ (tr & 15)) << 2));
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, 2) void temporal_attn_fused_out_kernel(con
       const int tok = ti * 16 + 4 * lq + r;
       if (tok < L) {
         const int64_t row = row0 + (int64_t)tok * hw;
-        out[row * ldo + ct * 16 + l15] = acc[r] + x[row * ldx + ct * 16 + l15];
+        out[row * ldo + ct * 16 + l15] = acc[r] + xr[r];
       }
     }
   }
