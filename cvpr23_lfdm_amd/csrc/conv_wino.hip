@@ -176,6 +176,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     for (int py = 0; py < 4; ++py)
       if ((rows >> py) & 1u) valid_mask |= cols << (4 * py);
   }
+  // the epilogue's bias (unsplit tiles add it themselves) is requested HERE, under the whole K loop, not at the epilogue's start
+  float4 bias_pre[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int co = n0 + WN * ct + 4 * (tid & 7);
+    bias_pre[ct] = (NT == 1 && p.bias && nslab == 1 && co < p.cout) ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }                                    // (NT = 2 is at its register limit: it reads the bias in the epilogue as before)
   float2 patch[16];
   auto fetch_patch = [&](float2 (&patch)[16], int chunk, unsigned vmask) {
     int cc = chunk * WKC + cbase;
@@ -316,8 +323,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv_wino_kernel(lfdm_co
     const int co = n0 + WN * ct + 4 * e_c4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) gs[ct][e] = gq[ct][e] = 0.f;
-    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && nslab == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
+    float4 bb = bias_pre[ct];
+    if (NT > 1 && p.bias && nslab == 1 && co < p.cout) bb = *reinterpret_cast<const float4*>(p.bias + co);
     const int n = my_n;                                 // e_tile == x_tile == tid >> 3
     const int64_t orow0 = ((int64_t)n * p.hq + 2 * my_ty) * p.wq + 2 * my_tx;
     const bool live = n >= 0 && co < p.coutp;
