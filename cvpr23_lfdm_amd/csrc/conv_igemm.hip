@@ -891,7 +891,11 @@ ConvPlan make_plan(const lfdm_conv_params& p) {
   if (pl.ksplit > nchunks) pl.ksplit = nchunks;
   if (pl.ksplit < 1) pl.ksplit = 1;
   // (res_gn_*: the residual's GroupNorm + SiLU in the epilogue exists on the pointwise schedule only - it takes every eligible geometry then)
-  if (pwg_ok || (pw_ok && (pw_mode == 2 || M <= 1024 || pl.ksplit > 1 || p.res_gn_partial))) {      // see above: where the staged schedules would split K, or few rows
+  // (round 6: without a LayerNorm fold the pointwise schedule also takes the 10 240-row projections of the 16x16 level - to_out after the attention cores,
+  //  128 workgroups on the K-split-across-waves schedule; with the fold it is 2.4 ms per video slower there: profiles/r06_au_*, r06_bg_*)
+  //  (only the narrow ones, K <= 256 into <= 128 columns: at K = N = 512 and 5 120 rows - the 4x4 level of a B = 8 training step - the staged schedules win)
+  const int64_t pw_rows = (!p.ln_wsum && p.c0 + p.c1 <= 256 && p.coutp <= 128) ? 10240 : 1024;
+  if (pwg_ok || (pw_ok && (pw_mode == 2 || M <= pw_rows || pl.ksplit > 1 || p.res_gn_partial))) {      // see above: where the staged schedules would split K, or few rows
     pl.kind = 3;
     pl.bm = 32;
     pl.bn = 32;
