@@ -61,6 +61,27 @@ def test_sampler_tables_match_oracle():
     assert torch.equal(coef[0, 2], sched["posterior_mean_coef1"][999])
 
 
+def test_sampler_tables_are_kept_per_schedule_and_follow_the_buffers():
+    """`_step_tables_on` (the tables of `_step_tables` on the sampling device, kept between videos so that no per-video host read-back synchronises with
+    the GPU): the same objects for the same schedule, rebuilt when a registered buffer is written (load_state_dict, an edited schedule), when the
+    schedule changes, and never cached for an instance-level replacement of `_step_tables` (the teacher-forced tests)."""
+    from cvpr23_lfdm_amd import GaussianDiffusion
+    d = GaussianDiffusion(torch.nn.Identity(), image_size=8, num_frames=4, timesteps=50, sampling_timesteps=10, loss_type="l2")
+    t1, c1, tt1, dr1 = d._step_tables_on(True, torch.device("cpu"))
+    t2, c2, tt2, dr2 = d._step_tables_on(True, torch.device("cpu"))
+    assert c1 is c2 and tt1 is tt2 and t1 == t2 and tt1.tolist() == t1
+    ref_t, ref_c, _ = d._step_tables(True)
+    assert torch.equal(c1, ref_c) and t1 == ref_t
+    d.sqrt_recip_alphas_cumprod.mul_(2.0)                    # an in-place write bumps the buffer's version counter
+    t3, c3, _, _ = d._step_tables_on(True, torch.device("cpu"))
+    assert c3 is not c1 and torch.equal(c3, d._step_tables(True)[1]) and not torch.equal(c3, c1)
+    t4, c4, _, _ = d._step_tables_on(False, torch.device("cpu"))
+    assert len(t4) == 50 and c4 is not c3
+    d._step_tables = lambda ddim: ([7], torch.zeros(1, 6), [True])
+    t5, c5, tt5, _ = d._step_tables_on(True, torch.device("cpu"))
+    assert t5 == [7] and tt5.tolist() == [7] and "_tables_cache" in d.__dict__ and d.__dict__["_tables_cache"][1] != [7]
+
+
 def test_state_dict_layout_and_roundtrip():
     from cvpr23_lfdm_amd import FlowDiffusion
     m = FlowDiffusion(img_size=8, num_frames=4, sampling_timesteps=5, is_train=True, config_pth=synth.CONFIG)
